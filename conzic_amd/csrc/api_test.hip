@@ -1,0 +1,216 @@
+// Kernel-level parity hooks of include/conzic_hip.h (czc_test_*): run ONE kernel on host data.
+// Used only by tests/ (-m gpu) to compare each HIP kernel with the CPU oracle.
+#include <vector>
+#include <cstring>
+
+#include "../../include/conzic_hip.h"
+#include "kernels.h"
+#include "bridge_hash.h"
+
+using namespace czc;
+
+namespace {
+
+struct DevPool {
+  std::vector<void*> ptrs;
+  ~DevPool() { for (void* p : ptrs) (void)hipFree(p); }
+  void* alloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) return nullptr;
+    ptrs.push_back(p);
+    return p;
+  }
+  void* up(const void* src, size_t bytes) {
+    void* p = alloc(bytes);
+    if (p && src && hipMemcpy(p, src, bytes, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    return p;
+  }
+};
+
+#define T_HIP(expr)                                                                                   \
+  do {                                                                                                \
+    hipError_t _h = (expr);                                                                           \
+    if (_h != hipSuccess) {                                                                           \
+      snprintf(czc::g_err, sizeof(czc::g_err), "%s:%d %s -> %s", __FILE__, __LINE__, #expr,           \
+               hipGetErrorString(_h));                                                                \
+      return CZC_ERR_HIP;                                                                             \
+    }                                                                                                 \
+  } while (0)
+#define T_CHECK(expr) do { int _r = (expr); if (_r) return _r; } while (0)
+#define T_PTR(p) do { if (!(p)) { snprintf(czc::g_err, sizeof(czc::g_err), "device allocation/copy failed"); return CZC_ERR_HIP; } } while (0)
+
+// fp32 host -> device buffer in precision `prec`
+void* up_act(DevPool& pool, int prec, const float* src, size_t n) {
+  float* f = (float*)pool.up(src, n * 4);
+  if (!f) return nullptr;
+  if (prec == PREC_F32) return f;
+  void* a = pool.alloc(n * 2);
+  if (!a) return nullptr;
+  if (launch_convert(prec, f, a, (long)n, nullptr)) return nullptr;
+  return a;
+}
+
+__global__ void act_to_f32_kernel(const bf16_t* src, float* dst, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] = bf2f(src[i]);
+}
+
+int down_act(DevPool& pool, int prec, const void* src, size_t n, float* host) {
+  const float* f = (const float*)src;
+  if (prec == PREC_BF16) {
+    float* t = (float*)pool.alloc(n * 4);
+    T_PTR(t);
+    hipLaunchKernelGGL(act_to_f32_kernel, dim3(1024), dim3(256), 0, nullptr, (const bf16_t*)src, t, (long)n);
+    f = t;
+  }
+  T_HIP(hipMemcpy(host, f, n * 4, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int czc_test_gemm(int precision, int M, int N, int K, const float* A, const float* W, const float* bias,
+                  const float* resid, int act, float* C) {
+  DevPool pool;
+  void* dA = up_act(pool, precision, A, (size_t)M * K); T_PTR(dA);
+  void* dW = up_act(pool, precision, W, (size_t)N * K); T_PTR(dW);
+  float* dB = bias ? (float*)pool.up(bias, (size_t)N * 4) : nullptr;
+  float* dR = resid ? (float*)pool.up(resid, (size_t)M * N * 4) : nullptr;
+  float* dC = (float*)pool.alloc((size_t)M * N * 4); T_PTR(dC);
+  GemmArgs g;
+  g.A = dA; g.lda = K; g.W = dW; g.ldw = K; g.bias = dB; g.resid = dR; g.ldr = N; g.out_act = nullptr;
+  g.out_f32 = dC; g.ldc = N; g.M = M; g.N = N; g.K = K; g.act = act;
+  T_CHECK(launch_gemm(precision, g, nullptr));
+  T_HIP(hipDeviceSynchronize());
+  T_HIP(hipMemcpy(C, dC, (size_t)M * N * 4, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int czc_test_layernorm(int precision, int M, int H, const float* x, const float* gamma, const float* beta, float eps,
+                       float* y) {
+  DevPool pool;
+  float* dx = (float*)pool.up(x, (size_t)M * H * 4); T_PTR(dx);
+  float* dg = (float*)pool.up(gamma, (size_t)H * 4); T_PTR(dg);
+  float* db = (float*)pool.up(beta, (size_t)H * 4); T_PTR(db);
+  void* dy = pool.alloc((size_t)M * H * 4); T_PTR(dy);
+  T_CHECK(launch_layernorm(precision, dx, nullptr, dg, db, eps, M, H, dy, nullptr, nullptr));
+  T_HIP(hipDeviceSynchronize());
+  T_CHECK(down_act(pool, precision, dy, (size_t)M * H, y));
+  return 0;
+}
+
+int czc_test_attention(int precision, int n_seq, const int32_t* seq_len, int heads, int causal, float scale,
+                       const float* qkv, float* out) {
+  DevPool pool;
+  std::vector<int> off(n_seq + 1, 0);
+  int mx = 0;
+  for (int i = 0; i < n_seq; ++i) { off[i + 1] = off[i] + seq_len[i]; mx = seq_len[i] > mx ? seq_len[i] : mx; }
+  const size_t M = off[n_seq];
+  const int Hd = heads * 64;
+  void* dq = up_act(pool, precision, qkv, M * 3 * Hd); T_PTR(dq);
+  int* doff = (int*)pool.up(off.data(), (n_seq + 1) * 4); T_PTR(doff);
+  int* dlen = (int*)pool.up(seq_len, n_seq * 4); T_PTR(dlen);
+  void* dout = pool.alloc(M * Hd * 4); T_PTR(dout);
+  T_CHECK(launch_attention(precision, dq, doff, dlen, 0, n_seq, mx, heads, causal, scale, dout, nullptr));
+  T_HIP(hipDeviceSynchronize());
+  T_CHECK(down_act(pool, precision, dout, M * Hd, out));
+  return 0;
+}
+
+int czc_test_topk(int B, int V, int K, const float* logits, const float* mask, float temperature, int dot_id,
+                  int dot_allowed, float* probs, int32_t* idxs, int32_t* cand) {
+  DevPool pool;
+  float* dl = (float*)pool.up(logits, (size_t)B * V * 4); T_PTR(dl);
+  float* dm = (float*)pool.up(mask, (size_t)V * 4); T_PTR(dm);
+  float* dp = (float*)pool.alloc((size_t)B * K * 4); T_PTR(dp);
+  int* di = (int*)pool.alloc((size_t)B * K * 4); T_PTR(di);
+  int* dc = (int*)pool.alloc((size_t)B * K * 4); T_PTR(dc);
+  T_CHECK(launch_softmax_mask_topk(dl, B, V, K, dm, temperature, dot_id, dot_allowed, dp, di, dc, nullptr));
+  T_HIP(hipDeviceSynchronize());
+  T_HIP(hipMemcpy(probs, dp, (size_t)B * K * 4, hipMemcpyDeviceToHost));
+  T_HIP(hipMemcpy(idxs, di, (size_t)B * K * 4, hipMemcpyDeviceToHost));
+  if (cand) T_HIP(hipMemcpy(cand, dc, (size_t)B * K * 4, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int czc_test_bridge(const czc_bridge_tables* t, const czc_config* cfg, int n_rows, int T, const int32_t* rows,
+                    int32_t* clip_ids, int32_t* clip_len) {
+  (void)cfg;
+  DevPool pool;
+  BridgeDev bd;
+  const size_t nbytes = t->piece_off[t->bert_vocab];
+  bd.bert_vocab = t->bert_vocab;
+  bd.piece_off = (const uint32_t*)pool.up(t->piece_off, (size_t)(t->bert_vocab + 1) * 4); T_PTR(bd.piece_off);
+  bd.piece_bytes = (const uint8_t*)pool.up(t->piece_bytes, nbytes ? nbytes : 1); T_PTR(bd.piece_bytes);
+  bd.piece_class = (const uint8_t*)pool.up(t->piece_class, nbytes ? nbytes : 1); T_PTR(bd.piece_class);
+  bd.piece_flags = (const uint8_t*)pool.up(t->piece_flags, (size_t)t->bert_vocab); T_PTR(bd.piece_flags);
+  bd.byte_sym = (const int*)pool.up(t->byte_sym, 256 * 4); T_PTR(bd.byte_sym);
+  bd.byte_sym_eow = (const int*)pool.up(t->byte_sym_eow, 256 * 4); T_PTR(bd.byte_sym_eow);
+  size_t cap = 1024;
+  while (cap < (size_t)t->n_merges * 2 + 2) cap <<= 1;
+  std::vector<unsigned long long> keys(cap, ~0ull), vals(cap, 0ull);
+  for (int r = 0; r < t->n_merges; ++r) {
+    const unsigned long long key = ((unsigned long long)(unsigned)t->merge_left[r] << 32) | (unsigned)t->merge_right[r];
+    unsigned h = bridge_hash(key) & (unsigned)(cap - 1);
+    bool dup = false;
+    while (keys[h] != ~0ull) {
+      if (keys[h] == key) { dup = true; break; }
+      h = (h + 1) & (unsigned)(cap - 1);
+    }
+    if (dup) continue;
+    keys[h] = key;
+    vals[h] = ((unsigned long long)(unsigned)r << 32) | (unsigned)t->merge_out[r];
+  }
+  bd.hkeys = (const unsigned long long*)pool.up(keys.data(), cap * 8); T_PTR(bd.hkeys);
+  bd.hvals = (const unsigned long long*)pool.up(vals.data(), cap * 8); T_PTR(bd.hvals);
+  bd.hmask = (unsigned)(cap - 1);
+  bd.bos_id = t->bos_id;
+  bd.eos_id = t->eos_id;
+  int* drows = (int*)pool.up(rows, (size_t)n_rows * T * 4); T_PTR(drows);
+  int* dids = (int*)pool.alloc((size_t)n_rows * CZC_CLIP_MAX_LEN * 4); T_PTR(dids);
+  int* dlen = (int*)pool.alloc((size_t)n_rows * 4); T_PTR(dlen);
+  int* dovf = (int*)pool.alloc(4); T_PTR(dovf);
+  T_HIP(hipMemset(dovf, 0, 4));
+  T_CHECK(launch_bridge(bd, drows, n_rows, T, -1, nullptr, 1, nullptr, 0, dids, dlen, nullptr, nullptr, dovf, nullptr));
+  T_HIP(hipDeviceSynchronize());
+  int ovf = 0;
+  T_HIP(hipMemcpy(&ovf, dovf, 4, hipMemcpyDeviceToHost));
+  T_HIP(hipMemcpy(clip_ids, dids, (size_t)n_rows * CZC_CLIP_MAX_LEN * 4, hipMemcpyDeviceToHost));
+  T_HIP(hipMemcpy(clip_len, dlen, (size_t)n_rows * 4, hipMemcpyDeviceToHost));
+  if (ovf) { snprintf(czc::g_err, sizeof(czc::g_err), "bridge overflow on %d rows", ovf); return CZC_ERR_OVERFLOW; }
+  return 0;
+}
+
+int czc_test_combine(int B, int K, int D, const float* text_feat, const float* img_embeds, float logit_scale,
+                     const float* probs, const float* senti_raw, const float* repeats, const czc_hyper* hp,
+                     float* clip_score, float* clip_ref, float* final_score, int32_t* best) {
+  DevPool pool;
+  const size_t bk = (size_t)B * K;
+  float* dt = (float*)pool.up(text_feat, bk * D * 4); T_PTR(dt);
+  float* di = (float*)pool.up(img_embeds, (size_t)B * D * 4); T_PTR(di);
+  float* din = (float*)pool.alloc((size_t)B * D * 4); T_PTR(din);
+  float* dp = (float*)pool.up(probs, bk * 4); T_PTR(dp);
+  float* ds = senti_raw ? (float*)pool.up(senti_raw, bk * 4) : nullptr;
+  float* dr = repeats ? (float*)pool.up(repeats, bk * 4) : nullptr;
+  int* dcand = (int*)pool.alloc(bk * 4); T_PTR(dcand);
+  T_HIP(hipMemset(dcand, 0, bk * 4));
+  float* o1 = (float*)pool.alloc(bk * 4); float* o2 = (float*)pool.alloc(bk * 4); float* o3 = (float*)pool.alloc(bk * 4);
+  int* ob = (int*)pool.alloc((size_t)B * 4); float* oc = (float*)pool.alloc((size_t)B * 4);
+  T_PTR(o1); T_PTR(o2); T_PTR(o3); T_PTR(ob); T_PTR(oc);
+  T_CHECK(launch_l2_normalize(di, B, D, din, nullptr));
+  CombineArgs a;
+  a.text_feat = dt; a.img_n = din; a.logit_scale_exp = expf(logit_scale); a.probs = dp; a.cand = dcand;
+  a.senti_raw = ds; a.repeats = dr; a.alpha = hp->alpha; a.beta = hp->beta; a.gamma = hp->gamma;
+  a.use_senti = hp->use_sentiment && ds && dr; a.B = B; a.K = K; a.D = D; a.clip_score = o1; a.clip_ref = o2;
+  a.final_score = o3; a.best = ob; a.best_cos = oc; a.inp = nullptr; a.T = 0; a.gen_idx = 0;
+  T_CHECK(launch_combine(a, nullptr));
+  T_HIP(hipDeviceSynchronize());
+  T_HIP(hipMemcpy(clip_score, o1, bk * 4, hipMemcpyDeviceToHost));
+  T_HIP(hipMemcpy(clip_ref, o2, bk * 4, hipMemcpyDeviceToHost));
+  T_HIP(hipMemcpy(final_score, o3, bk * 4, hipMemcpyDeviceToHost));
+  T_HIP(hipMemcpy(best, ob, (size_t)B * 4, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,182 @@
+// On-device text bridge: BERT WordPiece ids -> CLIP byte-level BPE ids, no host strings.
+//
+// Replaces, per step, `tokenizer.batch_decode(topk_inp_batch, skip_special_tokens=True)`
+// (gen_utils.py:75) followed by `CLIPTokenizer(text_list, padding=True, max_length=77,
+// truncation=True)` (clip/clip.py:71-74), i.e. 51,200 Python/Rust string round trips per step at
+// B=256, K=200.  One thread per candidate row does, entirely on integers/bytes:
+//   1. WordPiece decode with clean-up: specials dropped, '##' pieces glued, a space before every
+//      other piece unless the clean-up rules remove it (tokenizers decoders::wordpiece);
+//   2. CLIP pre-split  's|'t|'re|'ve|'m|'ll|'d|\p{L}+|\p{N}|[^\s\p{L}\p{N}]+  over per-byte
+//      character classes precomputed on the host (pieces are NFC + lower-cased there);
+//   3. byte-level BPE with '</w>' suffix: lowest-rank adjacent pair first, leftmost on ties,
+//      merges looked up in an open-addressing hash table (L2-resident, 2 MB);
+//   4. <|startoftext|> ... <|endoftext|>, truncated to 77.
+// It also produces the two sentiment-path extras that only need the row ids: the repeat count
+// (control_gen_utils.py:53) and the per-token lexicon sum (stand-in for sentiments_classifer.py:30).
+// All scratch (512 B text + 512 B classes + 64 symbols per thread) lives in LDS.
+#include "kernels.h"
+#include "bridge_hash.h"
+
+namespace czc {
+
+constexpr int BR_THREADS = 64;
+constexpr int BR_MAXB = 512;   // == CZC_BRIDGE_MAX_BYTES
+constexpr int BR_MAXSYM = 64;  // longest pre-split chunk in bytes
+constexpr int BR_LEN = 77;
+
+__device__ __forceinline__ bool merge_lookup(const BridgeDev& bd, int l, int r, unsigned& rank, int& out) {
+  const unsigned long long key = ((unsigned long long)(unsigned)l << 32) | (unsigned)r;
+  unsigned h = bridge_hash(key) & bd.hmask;
+  for (;;) {
+    const unsigned long long k = bd.hkeys[h];
+    if (k == key) {
+      const unsigned long long v = bd.hvals[h];
+      rank = (unsigned)(v >> 32);
+      out = (int)(v & 0xFFFFFFFFu);
+      return true;
+    }
+    if (k == ~0ull) return false;
+    h = (h + 1) & bd.hmask;
+  }
+}
+
+__global__ __launch_bounds__(BR_THREADS) void bridge_kernel(BridgeDev bd, const int* inp, int B, int T, int gen_idx,
+                                                            const int* cand, int K, const float* lexicon, int negative,
+                                                            int* clip_ids, int* clip_len, float* senti_raw,
+                                                            float* repeats, int* overflow) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char br_lds[];
+  unsigned char* txt = br_lds + (size_t)threadIdx.x * BR_MAXB;
+  unsigned char* cls = br_lds + (size_t)BR_THREADS * BR_MAXB + (size_t)threadIdx.x * BR_MAXB;
+  int* sym = (int*)(br_lds + (size_t)2 * BR_THREADS * BR_MAXB) + threadIdx.x * BR_MAXSYM;
+
+  const long row = (long)blockIdx.x * BR_THREADS + threadIdx.x;
+  if (row >= (long)B * K) return;
+  const int b = (int)(row / K);
+  const int cid = cand ? cand[row] : -1;
+
+  // ---- 1. decode to bytes ------------------------------------------------------------------
+  int n = 0;
+  bool first = true, ovf = false;
+  float senti = 0.f;
+  int rep = 0;
+  for (int t = 0; t < T; ++t) {
+    const int id = (cand && t == gen_idx) ? cid : inp[b * T + t];
+    if (cand && id == cid) ++rep;
+    const unsigned fl = bd.piece_flags[id];
+    if (fl & 1u) continue;  // special token: skipped
+    if (lexicon) senti += lexicon[id];
+    const unsigned o0 = bd.piece_off[id], o1 = bd.piece_off[id + 1];
+    int need = (int)(o1 - o0) + 2;
+    if (n + need > BR_MAXB) { ovf = true; break; }
+    if (first) {
+      if (fl & 2u) {  // a leading '##' piece keeps its prefix (decode_chain: i == 0 untouched)
+        txt[n] = '#'; cls[n] = 2 | 4; ++n;
+        txt[n] = '#'; cls[n] = 2 | 4; ++n;
+      }
+    } else if (!(fl & 6u)) {
+      txt[n] = ' '; cls[n] = 3 | 4; ++n;
+    }
+    for (unsigned o = o0; o < o1; ++o) {
+      txt[n] = bd.piece_bytes[o];
+      cls[n] = bd.piece_class[o];
+      ++n;
+    }
+    first = false;
+  }
+
+  // ---- 2-4. pre-split, BPE, emit -------------------------------------------------------------
+  int* outp = clip_ids + row * BR_LEN;
+  int nt = 0;  // text tokens emitted (cap 75)
+  outp[0] = bd.bos_id;
+  int i = 0;
+  while (i < n && nt < BR_LEN - 2) {
+    const int c = cls[i] & 3;
+    if (c == 3) { ++i; continue; }
+    int j = 0;
+    if (txt[i] == '\'' && i + 1 < n) {
+      const unsigned char c1 = txt[i + 1];
+      if (c1 == 's' || c1 == 't' || c1 == 'm' || c1 == 'd') j = i + 2;
+      else if (i + 2 < n) {
+        const unsigned char c2 = txt[i + 2];
+        if ((c1 == 'r' && c2 == 'e') || (c1 == 'v' && c2 == 'e') || (c1 == 'l' && c2 == 'l')) j = i + 3;
+      }
+    }
+    if (j == 0) {
+      j = i + 1;
+      if (c == 0) { while (j < n && (cls[j] & 3) == 0) ++j; }
+      else if (c == 1) { while (j < n && !(cls[j] & 4)) ++j; }          // exactly one \p{N} character
+      else { while (j < n && (cls[j] & 3) == 2) ++j; }
+    }
+    int m = j - i;
+    if (m > BR_MAXSYM) { ovf = true; m = BR_MAXSYM; }
+    for (int q = 0; q < m; ++q) sym[q] = bd.byte_sym[txt[i + q]];
+    sym[m - 1] = bd.byte_sym_eow[txt[i + m - 1]];
+    // BPE: merge the lowest-ranked adjacent pair (leftmost on ties) until none applies
+    while (m > 1) {
+      unsigned best = 0xFFFFFFFFu;
+      int bi = -1, bo = 0;
+      for (int q = 0; q + 1 < m; ++q) {
+        unsigned rk; int o;
+        if (merge_lookup(bd, sym[q], sym[q + 1], rk, o) && rk < best) { best = rk; bi = q; bo = o; }
+      }
+      if (bi < 0) break;
+      sym[bi] = bo;
+      for (int q = bi + 1; q + 1 < m; ++q) sym[q] = sym[q + 1];
+      --m;
+    }
+    for (int q = 0; q < m && nt < BR_LEN - 2; ++q) outp[1 + nt++] = sym[q];
+    i = j;
+  }
+  outp[1 + nt] = bd.eos_id;
+  for (int q = nt + 2; q < BR_LEN; ++q) outp[q] = bd.eos_id;
+  clip_len[row] = nt + 2;
+  if (senti_raw) senti_raw[row] = negative ? -senti : senti;
+  if (repeats) repeats[row] = (float)(rep - 1);
+  if (ovf) atomicAdd(overflow, 1);
+}
+
+int launch_bridge(const BridgeDev& bd, const int* inp, int B, int T, int gen_idx, const int* cand, int K,
+                  const float* lexicon, int negative, int* clip_ids, int* clip_len, float* senti_raw, float* repeats,
+                  int* overflow_flag, hipStream_t st) {
+  const long rows = (long)B * K;
+  if (rows <= 0) return 0;
+  const size_t shmem = (size_t)BR_THREADS * (2 * BR_MAXB + BR_MAXSYM * 4);
+  CZC_HIP_CHECK(hipFuncSetAttribute((const void*)bridge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+  hipLaunchKernelGGL(bridge_kernel, dim3(cdiv(rows, BR_THREADS)), dim3(BR_THREADS), shmem, st, bd, inp, B, T, gen_idx,
+                     cand, K, lexicon, negative, clip_ids, clip_len, senti_raw, repeats, overflow_flag);
+  CZC_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// ---- exclusive scan of sequence lengths --------------------------------------------------------
+__global__ __launch_bounds__(1024) void scan_kernel(const int* len, int n, int* off, int* totals) {
+  __shared__ int part[1024];
+  __shared__ int pmax[1024];
+  const int tid = threadIdx.x;
+  const int per = (n + 1023) / 1024;
+  const int lo = tid * per, hi = min(n, lo + per);
+  int s = 0, mx = 0;
+  for (int i = lo; i < hi; ++i) { s += len[i]; mx = max(mx, len[i]); }
+  part[tid] = s;
+  pmax[tid] = mx;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const int v = tid >= o ? part[tid - o] : 0;
+    const int w = tid >= o ? pmax[tid - o] : 0;
+    __syncthreads();
+    part[tid] += v;
+    pmax[tid] = max(pmax[tid], w);
+    __syncthreads();
+  }
+  int run = part[tid] - s;
+  for (int i = lo; i < hi; ++i) { off[i] = run; run += len[i]; }
+  if (tid == 1023) { off[n] = part[1023]; totals[0] = part[1023]; totals[1] = pmax[1023]; }
+}
+
+int launch_scan(const int* len, int n, int* off, int* totals, hipStream_t st) {
+  hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, len, n, off, totals);
+  CZC_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+}  // namespace czc

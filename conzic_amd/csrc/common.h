@@ -1,0 +1,71 @@
+// Shared device/host helpers for the gfx950 kernels of the polishing engine.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+namespace czc {
+
+typedef unsigned short bf16_t;  // raw bf16 storage
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+__host__ __device__ __forceinline__ float bf2f(bf16_t h) {
+  union { uint32_t u; float f; } c;
+  c.u = ((uint32_t)h) << 16;
+  return c.f;
+}
+// round-to-nearest-even, NaN preserved
+__host__ __device__ __forceinline__ bf16_t f2bf(float f) {
+  union { uint32_t u; float f; } c;
+  c.f = f;
+  uint32_t u = c.u;
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+// activation storage type per engine precision
+template <typename T> struct Act;
+template <> struct Act<bf16_t> {
+  __device__ static __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
+  __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+};
+template <> struct Act<float> {
+  __device__ static __forceinline__ float ld(const float* p) { return *p; }
+  __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ float quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+enum { ACT_NONE = 0, ACT_QUICK_GELU = 1, ACT_GELU_ERF = 2 };
+enum { PREC_BF16 = 0, PREC_F32 = 1 };
+
+#define CZC_HIP_CHECK(expr)                                                                      \
+  do {                                                                                           \
+    hipError_t _e = (expr);                                                                      \
+    if (_e != hipSuccess) {                                                                      \
+      snprintf(czc::g_err, sizeof(czc::g_err), "%s:%d %s -> %s", __FILE__, __LINE__, #expr,      \
+               hipGetErrorString(_e));                                                           \
+      return 2;                                                                                  \
+    }                                                                                            \
+  } while (0)
+
+extern char g_err[512];
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace czc

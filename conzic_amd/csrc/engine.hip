@@ -1,0 +1,811 @@
+// Engine: frozen-weight residency, workspace, the three tower forwards and the polishing
+// step/generate loops behind the C ABI of include/conzic_hip.h.
+//
+// One engine = one GPU = one HIP stream.  Weights are resident for the engine's lifetime
+// (bf16 GEMM operands + fp32 LayerNorm/bias/embedding tables: ~0.75 GB of the 288 GB HBM);
+// activations live in a grow-only workspace sized by the packed CLIP row count of the step.
+#include <map>
+#include <string>
+#include <vector>
+#include <cmath>
+#include <cstring>
+
+#include "../../include/conzic_hip.h"
+#include "kernels.h"
+#include "bridge_hash.h"
+
+namespace czc {
+char g_err[512] = {0};
+}
+using namespace czc;
+
+namespace {
+
+struct Tensor {
+  float* p = nullptr;
+  std::vector<int64_t> shape;
+  size_t numel = 0;
+};
+
+struct LayerW {
+  void* qkv_w = nullptr; float* qkv_b = nullptr;
+  void* o_w = nullptr; float* o_b = nullptr;
+  float *ln1_g = nullptr, *ln1_b = nullptr;
+  void* fc1_w = nullptr; float* fc1_b = nullptr;
+  void* fc2_w = nullptr; float* fc2_b = nullptr;
+  float *ln2_g = nullptr, *ln2_b = nullptr;
+};
+
+struct Buf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+
+struct ProfKind {
+  std::vector<hipEvent_t> ev;  // start/stop pairs
+  size_t used = 0;
+  double flops = 0;
+  int64_t launches = 0;
+};
+
+}  // namespace
+
+struct czc_engine {
+  czc_config cfg;
+  int dev = 0;
+  hipStream_t st = nullptr;
+  char err[512] = {0};
+  bool finalized = false;
+  size_t esz = 2;  // bytes per activation element
+
+  std::map<std::string, Tensor> w;
+  std::vector<LayerW> bert, ctext, cvis;
+  // extra processed weights
+  void* mlm_dense_w = nullptr; void* decoder_w = nullptr; void* tproj_w = nullptr; void* vproj_w = nullptr;
+  void* patch_w = nullptr;
+
+  std::map<std::string, Buf> ws;
+  float* d_mask = nullptr; int mask_vocab = 0;
+  float* d_lex = nullptr;
+  BridgeDev bd; bool has_bridge = false;
+  std::vector<void*> bridge_allocs;
+  float* d_img_n = nullptr; int img_B = 0;
+  float logit_scale_exp = 1.f;
+  int* h_totals = nullptr;  // pinned: [0]=rows [1]=max len [2]=overflow
+  int last_BT = 0;
+
+  bool prof = false;
+  std::map<std::string, ProfKind> pk;
+  int64_t stat_clip_rows = 0, stat_clip_seqs = 0, stat_bert_rows = 0, stat_steps = 0;
+};
+
+namespace {
+
+#define E_CHECK(expr)                                                                         \
+  do {                                                                                        \
+    int _r = (expr);                                                                          \
+    if (_r) {                                                                                 \
+      if (!e->err[0]) snprintf(e->err, sizeof(e->err), "%s", czc::g_err);                     \
+      return _r;                                                                              \
+    }                                                                                         \
+  } while (0)
+
+#define E_HIP(expr)                                                                           \
+  do {                                                                                        \
+    hipError_t _h = (expr);                                                                   \
+    if (_h != hipSuccess) {                                                                   \
+      snprintf(e->err, sizeof(e->err), "%s:%d %s -> %s", __FILE__, __LINE__, #expr,           \
+               hipGetErrorString(_h));                                                        \
+      return CZC_ERR_HIP;                                                                     \
+    }                                                                                         \
+  } while (0)
+
+int fail(czc_engine* e, int code, const char* fmt, const char* a = "") {
+  snprintf(e->err, sizeof(e->err), fmt, a);
+  return code;
+}
+
+int ensure(czc_engine* e, const char* name, size_t bytes, void** out) {
+  Buf& b = e->ws[name];
+  if (b.bytes < bytes) {
+    if (b.p) {
+      E_HIP(hipStreamSynchronize(e->st));
+      E_HIP(hipFree(b.p));
+    }
+    size_t want = bytes + bytes / 4 + 256;
+    E_HIP(hipMalloc(&b.p, want));
+    b.bytes = want;
+  }
+  *out = b.p;
+  return 0;
+}
+
+struct ProfScope {
+  czc_engine* e;
+  ProfKind* k = nullptr;
+  ProfScope(czc_engine* e_, const char* kind, double flops) : e(e_) {
+    if (!e->prof) return;
+    k = &e->pk[kind];
+    if (k->used + 2 > k->ev.size()) {
+      for (int i = 0; i < 2; ++i) {
+        hipEvent_t ev;
+        if (hipEventCreate(&ev) != hipSuccess) { k = nullptr; return; }
+        k->ev.push_back(ev);
+      }
+    }
+    k->flops += flops;
+    k->launches += 1;
+    (void)hipEventRecord(k->ev[k->used], e->st);
+  }
+  ~ProfScope() {
+    if (!k) return;
+    (void)hipEventRecord(k->ev[k->used + 1], e->st);
+    k->used += 2;
+  }
+};
+
+const Tensor* find(czc_engine* e, const std::string& n) {
+  auto it = e->w.find(n);
+  return it == e->w.end() ? nullptr : &it->second;
+}
+
+int need(czc_engine* e, const std::string& n, size_t numel, float** out) {
+  const Tensor* t = find(e, n);
+  if (!t) return fail(e, CZC_ERR_STATE, "missing tensor %s", n.c_str());
+  if (t->numel != numel) return fail(e, CZC_ERR_STATE, "tensor %s has the wrong size", n.c_str());
+  *out = t->p;
+  return 0;
+}
+
+// GEMM operand in engine precision (new allocation); frees nothing
+int to_act(czc_engine* e, const float* src, size_t numel, void** out) {
+  void* p = nullptr;
+  E_HIP(hipMalloc(&p, numel * e->esz));
+  E_CHECK(launch_convert(e->cfg.precision, src, p, (long)numel, e->st));
+  *out = p;
+  return 0;
+}
+
+int build_layers(czc_engine* e, std::vector<LayerW>& L, int n_layers, int H, int I, bool bert_style,
+                 const std::string& prefix) {
+  L.resize(n_layers);
+  for (int n = 0; n < n_layers; ++n) {
+    LayerW& l = L[n];
+    std::string p = prefix + std::to_string(n);
+    std::string q, k, v, o, ln1, fc1, fc2, ln2;
+    if (bert_style) {
+      q = p + ".attention.self.query"; k = p + ".attention.self.key"; v = p + ".attention.self.value";
+      o = p + ".attention.output.dense"; ln1 = p + ".attention.output.LayerNorm";
+      fc1 = p + ".intermediate.dense"; fc2 = p + ".output.dense"; ln2 = p + ".output.LayerNorm";
+    } else {
+      q = p + ".self_attn.q_proj"; k = p + ".self_attn.k_proj"; v = p + ".self_attn.v_proj";
+      o = p + ".self_attn.out_proj"; ln1 = p + ".layer_norm1";
+      fc1 = p + ".mlp.fc1"; fc2 = p + ".mlp.fc2"; ln2 = p + ".layer_norm2";
+    }
+    float *qw, *kw, *vw, *qb, *kb, *vb, *t;
+    E_CHECK(need(e, q + ".weight", (size_t)H * H, &qw));
+    E_CHECK(need(e, k + ".weight", (size_t)H * H, &kw));
+    E_CHECK(need(e, v + ".weight", (size_t)H * H, &vw));
+    E_CHECK(need(e, q + ".bias", H, &qb));
+    E_CHECK(need(e, k + ".bias", H, &kb));
+    E_CHECK(need(e, v + ".bias", H, &vb));
+    E_HIP(hipMalloc(&l.qkv_w, (size_t)3 * H * H * e->esz));
+    char* base = (char*)l.qkv_w;
+    E_CHECK(launch_convert(e->cfg.precision, qw, base, (long)H * H, e->st));
+    E_CHECK(launch_convert(e->cfg.precision, kw, base + (size_t)H * H * e->esz, (long)H * H, e->st));
+    E_CHECK(launch_convert(e->cfg.precision, vw, base + (size_t)2 * H * H * e->esz, (long)H * H, e->st));
+    E_HIP(hipMalloc((void**)&l.qkv_b, (size_t)3 * H * 4));
+    E_HIP(hipMemcpyAsync(l.qkv_b, qb, (size_t)H * 4, hipMemcpyDeviceToDevice, e->st));
+    E_HIP(hipMemcpyAsync(l.qkv_b + H, kb, (size_t)H * 4, hipMemcpyDeviceToDevice, e->st));
+    E_HIP(hipMemcpyAsync(l.qkv_b + 2 * H, vb, (size_t)H * 4, hipMemcpyDeviceToDevice, e->st));
+    E_CHECK(need(e, o + ".weight", (size_t)H * H, &t)); E_CHECK(to_act(e, t, (size_t)H * H, &l.o_w));
+    E_CHECK(need(e, o + ".bias", H, &l.o_b));
+    E_CHECK(need(e, ln1 + ".weight", H, &l.ln1_g)); E_CHECK(need(e, ln1 + ".bias", H, &l.ln1_b));
+    E_CHECK(need(e, fc1 + ".weight", (size_t)I * H, &t)); E_CHECK(to_act(e, t, (size_t)I * H, &l.fc1_w));
+    E_CHECK(need(e, fc1 + ".bias", I, &l.fc1_b));
+    E_CHECK(need(e, fc2 + ".weight", (size_t)H * I, &t)); E_CHECK(to_act(e, t, (size_t)H * I, &l.fc2_w));
+    E_CHECK(need(e, fc2 + ".bias", H, &l.fc2_b));
+    E_CHECK(need(e, ln2 + ".weight", H, &l.ln2_g)); E_CHECK(need(e, ln2 + ".bias", H, &l.ln2_b));
+  }
+  return 0;
+}
+
+int gemm(czc_engine* e, const char* kind, const void* A, int lda, const void* W, int ldw, const float* bias,
+         const float* resid, int ldr, void* out_act, float* out_f32, int ldc, int M, int N, int K, int act) {
+  GemmArgs g;
+  g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.resid = resid; g.ldr = ldr;
+  g.out_act = out_act; g.out_f32 = out_f32; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.act = act;
+  ProfScope ps(e, kind, 2.0 * M * (double)N * K);
+  E_CHECK(launch_gemm(e->cfg.precision, g, e->st));
+  return 0;
+}
+
+// ---- pre-LN transformer stack shared by the CLIP text and vision towers -----------------------
+// x_f32 [M,H] residual stream (updated in place); packed sequences described by off/len or fixed_T
+int clip_stack(czc_engine* e, const char* gk, std::vector<LayerW>& L, float* x, int M, int H, int I, int heads,
+               float eps, const int* off, const int* len, int fixed_T, int n_seq, int max_len, int causal) {
+  const int P = e->cfg.precision;
+  void *y, *qkv, *ctx, *hbuf;
+  E_CHECK(ensure(e, "cs_y", (size_t)M * H * e->esz, &y));
+  E_CHECK(ensure(e, "cs_qkv", (size_t)M * 3 * H * e->esz, &qkv));
+  E_CHECK(ensure(e, "cs_ctx", (size_t)M * H * e->esz, &ctx));
+  E_CHECK(ensure(e, "cs_h", (size_t)M * I * e->esz, &hbuf));
+  const float scale = 1.0f / sqrtf(64.0f);
+  for (size_t n = 0; n < L.size(); ++n) {
+    LayerW& l = L[n];
+    { ProfScope ps(e, "rowops", 0); E_CHECK(launch_layernorm(P, x, nullptr, l.ln1_g, l.ln1_b, eps, M, H, y, nullptr, e->st)); }
+    E_CHECK(gemm(e, gk, y, H, l.qkv_w, H, l.qkv_b, nullptr, 0, qkv, nullptr, 3 * H, M, 3 * H, H, ACT_NONE));
+    { ProfScope ps(e, "attention", 0);
+      E_CHECK(launch_attention(P, qkv, off, len, fixed_T, n_seq, max_len, heads, causal, scale, ctx, e->st)); }
+    E_CHECK(gemm(e, gk, ctx, H, l.o_w, H, l.o_b, x, H, nullptr, x, H, M, H, H, ACT_NONE));
+    { ProfScope ps(e, "rowops", 0); E_CHECK(launch_layernorm(P, x, nullptr, l.ln2_g, l.ln2_b, eps, M, H, y, nullptr, e->st)); }
+    E_CHECK(gemm(e, gk, y, H, l.fc1_w, H, l.fc1_b, nullptr, 0, hbuf, nullptr, I, M, I, H, ACT_QUICK_GELU));
+    E_CHECK(gemm(e, gk, hbuf, I, l.fc2_w, I, l.fc2_b, x, H, nullptr, x, H, M, H, I, ACT_NONE));
+  }
+  return 0;
+}
+
+// ---- BERT encoder (post-LN) on [B*T] rows: leaves the final hidden state in ws "b_x" ----------
+int bert_forward(czc_engine* e, const int* d_inp, int B, int T) {
+  const czc_config& c = e->cfg;
+  const int P = c.precision, M = B * T, H = c.bert_hidden, I = c.bert_inter;
+  void *xa, *qkv, *ctx, *hbuf; float *x, *tmp;
+  E_CHECK(ensure(e, "b_x", (size_t)M * H * 4, (void**)&x));
+  E_CHECK(ensure(e, "b_tmp", (size_t)M * H * 4, (void**)&tmp));
+  E_CHECK(ensure(e, "b_xa", (size_t)M * H * e->esz, &xa));
+  E_CHECK(ensure(e, "b_qkv", (size_t)M * 3 * H * e->esz, &qkv));
+  E_CHECK(ensure(e, "b_ctx", (size_t)M * H * e->esz, &ctx));
+  E_CHECK(ensure(e, "b_h", (size_t)M * I * e->esz, &hbuf));
+  float *word, *pos, *typ, *g, *b;
+  E_CHECK(need(e, "bert.embeddings.word_embeddings.weight", (size_t)c.bert_vocab * H, &word));
+  E_CHECK(need(e, "bert.embeddings.position_embeddings.weight", (size_t)c.bert_max_pos * H, &pos));
+  E_CHECK(need(e, "bert.embeddings.token_type_embeddings.weight", (size_t)2 * H, &typ));
+  E_CHECK(need(e, "bert.embeddings.LayerNorm.weight", H, &g));
+  E_CHECK(need(e, "bert.embeddings.LayerNorm.bias", H, &b));
+  { ProfScope ps(e, "rowops", 0);
+    E_CHECK(launch_bert_embed(P, d_inp, B, T, H, word, pos, typ, g, b, c.bert_eps, xa, x, e->st)); }
+  const float scale = 1.0f / sqrtf(64.0f);
+  for (int n = 0; n < c.bert_layers; ++n) {
+    LayerW& l = e->bert[n];
+    E_CHECK(gemm(e, "gemm_bert", xa, H, l.qkv_w, H, l.qkv_b, nullptr, 0, qkv, nullptr, 3 * H, M, 3 * H, H, ACT_NONE));
+    { ProfScope ps(e, "attention", 0);
+      E_CHECK(launch_attention(P, qkv, nullptr, nullptr, T, B, T, c.bert_heads, 0, scale, ctx, e->st)); }
+    E_CHECK(gemm(e, "gemm_bert", ctx, H, l.o_w, H, l.o_b, x, H, nullptr, tmp, H, M, H, H, ACT_NONE));
+    { ProfScope ps(e, "rowops", 0); E_CHECK(launch_layernorm(P, tmp, nullptr, l.ln1_g, l.ln1_b, c.bert_eps, M, H, xa, x, e->st)); }
+    E_CHECK(gemm(e, "gemm_bert", xa, H, l.fc1_w, H, l.fc1_b, nullptr, 0, hbuf, nullptr, I, M, I, H, ACT_GELU_ERF));
+    E_CHECK(gemm(e, "gemm_bert", hbuf, I, l.fc2_w, I, l.fc2_b, x, H, nullptr, tmp, H, M, H, I, ACT_NONE));
+    { ProfScope ps(e, "rowops", 0); E_CHECK(launch_layernorm(P, tmp, nullptr, l.ln2_g, l.ln2_b, c.bert_eps, M, H, xa, x, e->st)); }
+  }
+  e->stat_bert_rows += M;
+  e->last_BT = M;
+  return 0;
+}
+
+// MLM head on row gen_idx of every sequence -> logits fp32 [B,V] in ws "b_logits"
+int mlm_head(czc_engine* e, int B, int T, int gen_idx, float** logits_out) {
+  const czc_config& c = e->cfg;
+  const int P = c.precision, H = c.bert_hidden, V = c.bert_vocab;
+  float* x = (float*)e->ws["b_x"].p;
+  int* idx; float *gx, *t32, *logits; void *ga, *ta;
+  E_CHECK(ensure(e, "h_idx", (size_t)B * 4, (void**)&idx));
+  E_CHECK(ensure(e, "h_gx", (size_t)B * H * 4, (void**)&gx));
+  E_CHECK(ensure(e, "h_ga", (size_t)B * H * e->esz, &ga));
+  E_CHECK(ensure(e, "h_t32", (size_t)B * H * 4, (void**)&t32));
+  E_CHECK(ensure(e, "h_ta", (size_t)B * H * e->esz, &ta));
+  E_CHECK(ensure(e, "b_logits", (size_t)B * V * 4, (void**)&logits));
+  float *db, *g, *b, *bias;
+  E_CHECK(need(e, "cls.predictions.transform.dense.bias", H, &db));
+  E_CHECK(need(e, "cls.predictions.transform.LayerNorm.weight", H, &g));
+  E_CHECK(need(e, "cls.predictions.transform.LayerNorm.bias", H, &b));
+  E_CHECK(need(e, "cls.predictions.bias", V, &bias));
+  { ProfScope ps(e, "rowops", 0);
+    E_CHECK(launch_make_row_index(idx, B, T, gen_idx, e->st));
+    E_CHECK(launch_gather_rows_f32(x, idx, B, H, gx, e->st));
+    E_CHECK(launch_convert(P, gx, ga, (long)B * H, e->st)); }
+  E_CHECK(gemm(e, "gemm_bert", ga, H, e->mlm_dense_w, H, db, nullptr, 0, nullptr, t32, H, B, H, H, ACT_GELU_ERF));
+  { ProfScope ps(e, "rowops", 0); E_CHECK(launch_layernorm(P, t32, nullptr, g, b, c.bert_eps, B, H, ta, nullptr, e->st)); }
+  E_CHECK(gemm(e, "gemm_bert", ta, H, e->decoder_w, H, bias, nullptr, 0, nullptr, logits, V, B, V, H, ACT_NONE));
+  *logits_out = logits;
+  return 0;
+}
+
+// CLIP text tower on packed sequences (clip/clip.py:78-83): ids [n_seq,77] + len -> feat fp32 [n_seq, proj]
+int clip_text_forward(czc_engine* e, const int* cids, const int* clen, const int* coff, int* eidx, int n_seq, int M,
+                      int max_len, float** feat_out) {
+  const czc_config& c = e->cfg;
+  const int P = c.precision;
+  const int H = c.clip_hidden;
+  float *x, *feat, *tok, *pos, *fg, *fb; void* pa;
+  E_CHECK(ensure(e, "c_x", (size_t)M * H * 4, (void**)&x));
+  E_CHECK(ensure(e, "c_pa", (size_t)n_seq * H * e->esz, &pa));
+  E_CHECK(ensure(e, "c_feat", (size_t)n_seq * c.clip_proj * 4, (void**)&feat));
+  E_CHECK(need(e, "text_model.embeddings.token_embedding.weight", (size_t)c.clip_vocab * H, &tok));
+  E_CHECK(need(e, "text_model.embeddings.position_embedding.weight", (size_t)c.clip_max_pos * H, &pos));
+  E_CHECK(need(e, "text_model.final_layer_norm.weight", H, &fg));
+  E_CHECK(need(e, "text_model.final_layer_norm.bias", H, &fb));
+  { ProfScope ps(e, "rowops", 0);
+    E_CHECK(launch_clip_embed(cids, CZC_CLIP_MAX_LEN, coff, clen, n_seq, max_len, H, tok, pos, x, e->st)); }
+  E_CHECK(clip_stack(e, "gemm_clip_text", e->ctext, x, M, H, c.clip_inter, c.clip_heads, c.clip_eps, coff, clen, 0,
+                     n_seq, max_len, 1));
+  { ProfScope ps(e, "rowops", 0);
+    E_CHECK(launch_eos_index(coff, clen, n_seq, eidx, e->st));
+    E_CHECK(launch_layernorm(P, x, eidx, fg, fb, c.clip_eps, n_seq, H, pa, nullptr, e->st)); }
+  E_CHECK(gemm(e, "gemm_clip_text", pa, H, e->tproj_w, H, nullptr, nullptr, 0, nullptr, feat, c.clip_proj, n_seq,
+               c.clip_proj, H, ACT_NONE));
+
+  *feat_out = feat;
+  return 0;
+}
+
+// one position-step on the device-resident d_inp (gen_utils.py:66-81)
+int step_device(czc_engine* e, int* d_inp, int B, int T, int gen_idx, int n_mask, int dot_allowed, int K,
+                const czc_hyper* hp) {
+  const czc_config& c = e->cfg;
+  if (!e->finalized) return fail(e, CZC_ERR_STATE, "weights not finalized%s");
+  if (c.bert_layers <= 0) return fail(e, CZC_ERR_STATE, "this engine was created without the BERT tower%s");
+  if (!e->d_mask) return fail(e, CZC_ERR_STATE, "token mask not set%s");
+  if (!e->has_bridge) return fail(e, CZC_ERR_STATE, "bridge tables not set%s");
+  if (!e->d_img_n || e->img_B != B) return fail(e, CZC_ERR_STATE, "image embeds not set for this batch size%s");
+  if (T > CZC_MAX_BERT_LEN || gen_idx < 0 || gen_idx >= T || K > CZC_MAX_TOPK)
+    return fail(e, CZC_ERR_ARG, "step: bad T/gen_idx/K%s");
+  if (hp->use_sentiment && !e->d_lex) return fail(e, CZC_ERR_STATE, "sentiment path needs a lexicon%s");
+  const int P = c.precision;
+  const int n_seq = B * K;
+
+  if (n_mask > 0) {
+    E_CHECK(launch_mask_positions(d_inp, B, T, gen_idx, n_mask, c.mask_id, e->st));
+    E_CHECK(bert_forward(e, d_inp, B, T));
+  } else if (e->last_BT != B * T) {
+    return fail(e, CZC_ERR_STATE, "n_mask=0 needs a previous forward of the same shape%s");
+  }
+  float* logits;
+  E_CHECK(mlm_head(e, B, T, gen_idx, &logits));
+
+  float *probs, *senti, *reps; int *idxs, *cand, *cids, *clen, *coff, *totals, *eidx;
+  E_CHECK(ensure(e, "s_probs", (size_t)n_seq * 4, (void**)&probs));
+  E_CHECK(ensure(e, "s_idxs", (size_t)n_seq * 4, (void**)&idxs));
+  E_CHECK(ensure(e, "s_cand", (size_t)n_seq * 4, (void**)&cand));
+  E_CHECK(ensure(e, "s_cids", (size_t)n_seq * CZC_CLIP_MAX_LEN * 4, (void**)&cids));
+  E_CHECK(ensure(e, "s_clen", (size_t)n_seq * 4, (void**)&clen));
+  E_CHECK(ensure(e, "s_coff", (size_t)(n_seq + 1) * 4, (void**)&coff));
+  E_CHECK(ensure(e, "s_tot", 16, (void**)&totals));
+  E_CHECK(ensure(e, "s_eidx", (size_t)n_seq * 4, (void**)&eidx));
+  E_CHECK(ensure(e, "s_senti", (size_t)n_seq * 4, (void**)&senti));
+  E_CHECK(ensure(e, "s_reps", (size_t)n_seq * 4, (void**)&reps));
+  { ProfScope ps(e, "topk", 0);
+    E_CHECK(launch_softmax_mask_topk(logits, B, c.bert_vocab, K, e->d_mask, hp->temperature, c.dot_id, dot_allowed,
+                                     probs, idxs, cand, e->st)); }
+  E_HIP(hipMemsetAsync(totals, 0, 16, e->st));
+  { ProfScope ps(e, "bridge", 0);
+    E_CHECK(launch_bridge(e->bd, d_inp, B, T, gen_idx, cand, K, hp->use_sentiment ? e->d_lex : nullptr, hp->negative,
+                          cids, clen, senti, reps, totals + 2, e->st));
+    E_CHECK(launch_scan(clen, n_seq, coff, totals, e->st)); }
+  E_HIP(hipMemcpyAsync(e->h_totals, totals, 12, hipMemcpyDeviceToHost, e->st));
+  E_HIP(hipStreamSynchronize(e->st));  // the one host round trip per step (the reference has one too, gen_utils.py:81)
+  const int M = e->h_totals[0], max_len = e->h_totals[1];
+  if (e->h_totals[2]) return fail(e, CZC_ERR_OVERFLOW, "text bridge overflow (row text > CZC_BRIDGE_MAX_BYTES)%s");
+  if (max_len > c.clip_max_pos) return fail(e, CZC_ERR_ARG, "CLIP sequence longer than max_position_embeddings%s");
+
+  float* feat;
+  E_CHECK(clip_text_forward(e, cids, clen, coff, eidx, n_seq, M, max_len, &feat));
+
+  float *cscore, *cref, *fin, *bcos; int* best;
+  E_CHECK(ensure(e, "s_cscore", (size_t)n_seq * 4, (void**)&cscore));
+  E_CHECK(ensure(e, "s_cref", (size_t)n_seq * 4, (void**)&cref));
+  E_CHECK(ensure(e, "s_fin", (size_t)n_seq * 4, (void**)&fin));
+  E_CHECK(ensure(e, "s_best", (size_t)B * 4, (void**)&best));
+  E_CHECK(ensure(e, "s_bcos", (size_t)B * 4, (void**)&bcos));
+  CombineArgs a;
+  a.text_feat = feat; a.img_n = e->d_img_n; a.logit_scale_exp = e->logit_scale_exp; a.probs = probs; a.cand = cand;
+  a.senti_raw = senti; a.repeats = reps; a.alpha = hp->alpha; a.beta = hp->beta; a.gamma = hp->gamma;
+  a.use_senti = hp->use_sentiment; a.B = B; a.K = K; a.D = c.clip_proj; a.clip_score = cscore; a.clip_ref = cref;
+  a.final_score = fin; a.best = best; a.best_cos = bcos; a.inp = d_inp; a.T = T; a.gen_idx = gen_idx;
+  { ProfScope ps(e, "combine", 0); E_CHECK(launch_combine(a, e->st)); }
+  e->stat_clip_rows += M;
+  e->stat_clip_seqs += n_seq;
+  e->stat_steps += 1;
+  return 0;
+}
+
+int copy_out(czc_engine* e, void* dst, const char* ws_name, size_t bytes) {
+  if (!dst) return 0;
+  E_HIP(hipMemcpyAsync(dst, e->ws[ws_name].p, bytes, hipMemcpyDefault, e->st));
+  return 0;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+int czc_version(void) { return 100; }
+
+const char* czc_last_error(const czc_engine* e) { return e ? e->err : czc::g_err; }
+
+int czc_create(const czc_config* cfg, int device_id, czc_engine** out) {
+  if (!cfg || !out) { snprintf(czc::g_err, sizeof(czc::g_err), "czc_create: null argument"); return CZC_ERR_ARG; }
+  if (cfg->bert_hidden != cfg->bert_heads * 64 || cfg->clip_hidden != cfg->clip_heads * 64 ||
+      cfg->vis_hidden != cfg->vis_heads * 64) {
+    snprintf(czc::g_err, sizeof(czc::g_err), "czc_create: head_dim must be 64 for all towers");
+    return CZC_ERR_ARG;
+  }
+  if (cfg->precision != CZC_PREC_BF16 && cfg->precision != CZC_PREC_F32) {
+    snprintf(czc::g_err, sizeof(czc::g_err), "czc_create: unknown precision");
+    return CZC_ERR_ARG;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    snprintf(czc::g_err, sizeof(czc::g_err), "czc_create: no HIP device visible (the engine has no CPU fallback)");
+    return CZC_ERR_HIP;
+  }
+  if (device_id < 0 || device_id >= ndev) {
+    snprintf(czc::g_err, sizeof(czc::g_err), "czc_create: device %d out of range", device_id);
+    return CZC_ERR_ARG;
+  }
+  czc_engine* e = new czc_engine();
+  e->cfg = *cfg;
+  e->dev = device_id;
+  e->esz = cfg->precision == CZC_PREC_BF16 ? 2 : 4;
+  if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&e->st) != hipSuccess ||
+      hipHostMalloc((void**)&e->h_totals, 64) != hipSuccess) {
+    snprintf(czc::g_err, sizeof(czc::g_err), "czc_create: stream/host allocation failed");
+    delete e;
+    return CZC_ERR_HIP;
+  }
+  memset(&e->bd, 0, sizeof(e->bd));
+  *out = e;
+  return CZC_OK;
+}
+
+int czc_destroy(czc_engine* e) {
+  if (!e) return CZC_OK;
+  (void)hipSetDevice(e->dev);
+  (void)hipStreamSynchronize(e->st);
+  for (auto& kv : e->w) if (kv.second.p) (void)hipFree(kv.second.p);
+  auto free_layers = [](std::vector<LayerW>& L) {
+    for (auto& l : L) { (void)hipFree(l.qkv_w); (void)hipFree(l.qkv_b); (void)hipFree(l.o_w); (void)hipFree(l.fc1_w); (void)hipFree(l.fc2_w); }
+  };
+  free_layers(e->bert); free_layers(e->ctext); free_layers(e->cvis);
+  (void)hipFree(e->mlm_dense_w); (void)hipFree(e->decoder_w); (void)hipFree(e->tproj_w); (void)hipFree(e->vproj_w);
+  (void)hipFree(e->patch_w);
+  for (auto& kv : e->ws) if (kv.second.p) (void)hipFree(kv.second.p);
+  for (void* p : e->bridge_allocs) (void)hipFree(p);
+  (void)hipFree(e->d_mask); (void)hipFree(e->d_lex); (void)hipFree(e->d_img_n);
+  for (auto& kv : e->pk) for (hipEvent_t ev : kv.second.ev) (void)hipEventDestroy(ev);
+  if (e->h_totals) (void)hipHostFree(e->h_totals);
+  (void)hipStreamDestroy(e->st);
+  delete e;
+  return CZC_OK;
+}
+
+int czc_load_tensor(czc_engine* e, const char* name, int dtype, int ndim, const int64_t* shape, const void* src) {
+  if (!e || !name || !src || ndim < 0 || ndim > 8) return CZC_ERR_ARG;
+  if (dtype != 0) return fail(e, CZC_ERR_ARG, "czc_load_tensor(%s): only fp32 (dtype 0) is accepted", name);
+  E_HIP(hipSetDevice(e->dev));
+  Tensor t;
+  t.numel = 1;
+  for (int i = 0; i < ndim; ++i) { t.shape.push_back(shape[i]); t.numel *= (size_t)shape[i]; }
+  auto it = e->w.find(name);
+  if (it != e->w.end() && it->second.p) { (void)hipFree(it->second.p); }
+  E_HIP(hipMalloc((void**)&t.p, t.numel * 4 + 16));
+  E_HIP(hipMemcpy(t.p, src, t.numel * 4, hipMemcpyDefault));
+  e->w[name] = t;
+  e->finalized = false;
+  return CZC_OK;
+}
+
+int czc_finalize_weights(czc_engine* e) {
+  if (!e) return CZC_ERR_ARG;
+  E_HIP(hipSetDevice(e->dev));
+  const czc_config& c = e->cfg;
+  const bool has_bert = c.bert_layers > 0 && c.bert_vocab > 0;
+  if (has_bert) E_CHECK(build_layers(e, e->bert, c.bert_layers, c.bert_hidden, c.bert_inter, true, "bert.encoder.layer."));
+  E_CHECK(build_layers(e, e->ctext, c.clip_layers, c.clip_hidden, c.clip_inter, false, "text_model.encoder.layers."));
+  E_CHECK(build_layers(e, e->cvis, c.vis_layers, c.vis_hidden, c.vis_inter, false, "vision_model.encoder.layers."));
+  float* t;
+  if (has_bert) {
+    E_CHECK(need(e, "cls.predictions.transform.dense.weight", (size_t)c.bert_hidden * c.bert_hidden, &t));
+    E_CHECK(to_act(e, t, (size_t)c.bert_hidden * c.bert_hidden, &e->mlm_dense_w));
+    // decoder weight tied to the word embeddings (HF:bert/modeling_bert.py:910-913)
+    E_CHECK(need(e, "bert.embeddings.word_embeddings.weight", (size_t)c.bert_vocab * c.bert_hidden, &t));
+    E_CHECK(to_act(e, t, (size_t)c.bert_vocab * c.bert_hidden, &e->decoder_w));
+    if (!find(e, "cls.predictions.bias") && find(e, "cls.predictions.decoder.bias")) {
+      e->w["cls.predictions.bias"] = e->w["cls.predictions.decoder.bias"];
+      e->w.erase("cls.predictions.decoder.bias");
+    }
+  }
+  E_CHECK(need(e, "text_projection.weight", (size_t)c.clip_proj * c.clip_hidden, &t));
+  E_CHECK(to_act(e, t, (size_t)c.clip_proj * c.clip_hidden, &e->tproj_w));
+  E_CHECK(need(e, "visual_projection.weight", (size_t)c.clip_proj * c.vis_hidden, &t));
+  E_CHECK(to_act(e, t, (size_t)c.clip_proj * c.vis_hidden, &e->vproj_w));
+  const size_t pk = (size_t)3 * c.vis_patch * c.vis_patch;
+  E_CHECK(need(e, "vision_model.embeddings.patch_embedding.weight", (size_t)c.vis_hidden * pk, &t));
+  E_CHECK(to_act(e, t, (size_t)c.vis_hidden * pk, &e->patch_w));
+  const Tensor* ls = find(e, "logit_scale");
+  if (!ls) return fail(e, CZC_ERR_STATE, "missing tensor %s", "logit_scale");
+  float lsv = 0.f;
+  E_HIP(hipStreamSynchronize(e->st));
+  E_HIP(hipMemcpy(&lsv, ls->p, 4, hipMemcpyDeviceToHost));
+  e->logit_scale_exp = expf(lsv);
+  // GEMM-operand masters are no longer needed (LN/bias/embedding tables stay fp32)
+  std::vector<std::string> drop;
+  for (auto& kv : e->w) {
+    const std::string& n = kv.first;
+    const bool is_w = n.size() > 7 && n.compare(n.size() - 7, 7, ".weight") == 0;
+    const bool keep = n.find("LayerNorm") != std::string::npos || n.find("layer_norm") != std::string::npos ||
+                      n.find("layrnorm") != std::string::npos || n.find("layernorm") != std::string::npos ||
+                      n.find("embedding") != std::string::npos;
+    if (is_w && !keep && kv.second.shape.size() == 2) drop.push_back(n);
+  }
+  for (auto& n : drop) { (void)hipFree(e->w[n].p); e->w.erase(n); }
+  e->finalized = true;
+  return CZC_OK;
+}
+
+int czc_set_token_mask(czc_engine* e, const float* mask, int vocab) {
+  if (!e || !mask || vocab != e->cfg.bert_vocab) return e ? fail(e, CZC_ERR_ARG, "token mask size != bert_vocab%s") : CZC_ERR_ARG;
+  E_HIP(hipSetDevice(e->dev));
+  if (!e->d_mask) E_HIP(hipMalloc((void**)&e->d_mask, (size_t)vocab * 4));
+  E_HIP(hipMemcpy(e->d_mask, mask, (size_t)vocab * 4, hipMemcpyDefault));
+  e->mask_vocab = vocab;
+  return CZC_OK;
+}
+
+int czc_set_lexicon(czc_engine* e, const float* lex, int vocab) {
+  if (!e || !lex || vocab != e->cfg.bert_vocab) return e ? fail(e, CZC_ERR_ARG, "lexicon size != bert_vocab%s") : CZC_ERR_ARG;
+  E_HIP(hipSetDevice(e->dev));
+  if (!e->d_lex) E_HIP(hipMalloc((void**)&e->d_lex, (size_t)vocab * 4));
+  E_HIP(hipMemcpy(e->d_lex, lex, (size_t)vocab * 4, hipMemcpyDefault));
+  return CZC_OK;
+}
+
+static int upload(czc_engine* e, const void* src, size_t bytes, void** out) {
+  void* p = nullptr;
+  E_HIP(hipMalloc(&p, bytes + 16));
+  E_HIP(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
+  e->bridge_allocs.push_back(p);
+  *out = p;
+  return 0;
+}
+
+static int build_bridge(czc_engine* e, const czc_bridge_tables* t, BridgeDev* bd) {
+  if (t->bert_vocab <= 0 || t->n_merges < 0) return fail(e, CZC_ERR_ARG, "bad bridge tables%s");
+  const size_t nbytes = t->piece_off[t->bert_vocab];
+  void* p;
+  bd->bert_vocab = t->bert_vocab;
+  E_CHECK(upload(e, t->piece_off, (size_t)(t->bert_vocab + 1) * 4, &p)); bd->piece_off = (const uint32_t*)p;
+  E_CHECK(upload(e, t->piece_bytes, nbytes ? nbytes : 1, &p)); bd->piece_bytes = (const uint8_t*)p;
+  E_CHECK(upload(e, t->piece_class, nbytes ? nbytes : 1, &p)); bd->piece_class = (const uint8_t*)p;
+  E_CHECK(upload(e, t->piece_flags, (size_t)t->bert_vocab, &p)); bd->piece_flags = (const uint8_t*)p;
+  E_CHECK(upload(e, t->byte_sym, 256 * 4, &p)); bd->byte_sym = (const int*)p;
+  E_CHECK(upload(e, t->byte_sym_eow, 256 * 4, &p)); bd->byte_sym_eow = (const int*)p;
+  size_t cap = 1024;
+  while (cap < (size_t)t->n_merges * 2 + 2) cap <<= 1;
+  std::vector<unsigned long long> keys(cap, ~0ull), vals(cap, 0ull);
+  for (int r = 0; r < t->n_merges; ++r) {
+    const unsigned long long key = ((unsigned long long)(unsigned)t->merge_left[r] << 32) | (unsigned)t->merge_right[r];
+    unsigned h = bridge_hash(key) & (unsigned)(cap - 1);
+    bool dup = false;
+    while (keys[h] != ~0ull) {
+      if (keys[h] == key) { dup = true; break; }  // first (lowest) rank wins
+      h = (h + 1) & (unsigned)(cap - 1);
+    }
+    if (dup) continue;
+    keys[h] = key;
+    vals[h] = ((unsigned long long)(unsigned)r << 32) | (unsigned)t->merge_out[r];
+  }
+  E_CHECK(upload(e, keys.data(), cap * 8, &p)); bd->hkeys = (const unsigned long long*)p;
+  E_CHECK(upload(e, vals.data(), cap * 8, &p)); bd->hvals = (const unsigned long long*)p;
+  bd->hmask = (unsigned)(cap - 1);
+  bd->bos_id = t->bos_id;
+  bd->eos_id = t->eos_id;
+  return 0;
+}
+
+int czc_set_bridge(czc_engine* e, const czc_bridge_tables* t) {
+  if (!e || !t) return CZC_ERR_ARG;
+  if (t->bert_vocab != e->cfg.bert_vocab) return fail(e, CZC_ERR_ARG, "bridge bert_vocab != config%s");
+  E_HIP(hipSetDevice(e->dev));
+  for (void* p : e->bridge_allocs) (void)hipFree(p);
+  e->bridge_allocs.clear();
+  E_CHECK(build_bridge(e, t, &e->bd));
+  e->has_bridge = true;
+  return CZC_OK;
+}
+
+int czc_set_image_embeds(czc_engine* e, const float* embeds, int B) {
+  if (!e || !embeds || B <= 0) return CZC_ERR_ARG;
+  E_HIP(hipSetDevice(e->dev));
+  const int D = e->cfg.clip_proj;
+  float* raw;
+  E_CHECK(ensure(e, "img_raw", (size_t)B * D * 4, (void**)&raw));
+  E_HIP(hipMemcpyAsync(raw, embeds, (size_t)B * D * 4, hipMemcpyDefault, e->st));
+  if (e->img_B < B) { if (e->d_img_n) (void)hipFree(e->d_img_n); e->d_img_n = nullptr; E_HIP(hipMalloc((void**)&e->d_img_n, (size_t)B * D * 4)); }
+  E_CHECK(launch_l2_normalize(raw, B, D, e->d_img_n, e->st));
+  e->img_B = B;
+  E_HIP(hipStreamSynchronize(e->st));
+  return CZC_OK;
+}
+
+int czc_encode_images(czc_engine* e, const float* pixels, int B, float* out_embeds) {
+  if (!e || !pixels || B <= 0) return CZC_ERR_ARG;
+  if (!e->finalized) return fail(e, CZC_ERR_STATE, "weights not finalized%s");
+  E_HIP(hipSetDevice(e->dev));
+  const czc_config& c = e->cfg;
+  const int P = c.precision, S = c.vis_image, p = c.vis_patch, G = S / p, NP = G * G, H = c.vis_hidden;
+  const int Kc = 3 * p * p, T = NP + 1, M = B * T;
+  float *pix, *pe, *x, *emb; void *patches, *ca; int* idx;
+  E_CHECK(ensure(e, "v_pix", (size_t)B * 3 * S * S * 4, (void**)&pix));
+  E_CHECK(ensure(e, "v_patches", (size_t)B * NP * Kc * e->esz, &patches));
+  E_CHECK(ensure(e, "v_pe", (size_t)B * NP * H * 4, (void**)&pe));
+  E_CHECK(ensure(e, "v_x", (size_t)M * H * 4, (void**)&x));
+  E_CHECK(ensure(e, "v_idx", (size_t)B * 4, (void**)&idx));
+  E_CHECK(ensure(e, "v_ca", (size_t)B * H * e->esz, &ca));
+  E_CHECK(ensure(e, "img_raw", (size_t)B * c.clip_proj * 4, (void**)&emb));
+  E_HIP(hipMemcpyAsync(pix, pixels, (size_t)B * 3 * S * S * 4, hipMemcpyDefault, e->st));
+  float *cls, *pos, *g0, *b0, *g1, *b1;
+  E_CHECK(need(e, "vision_model.embeddings.class_embedding", H, &cls));
+  E_CHECK(need(e, "vision_model.embeddings.position_embedding.weight", (size_t)T * H, &pos));
+  E_CHECK(need(e, "vision_model.pre_layrnorm.weight", H, &g0));
+  E_CHECK(need(e, "vision_model.pre_layrnorm.bias", H, &b0));
+  E_CHECK(need(e, "vision_model.post_layernorm.weight", H, &g1));
+  E_CHECK(need(e, "vision_model.post_layernorm.bias", H, &b1));
+  { ProfScope ps(e, "rowops", 0); E_CHECK(launch_im2col(P, pix, B, S, p, patches, e->st)); }
+  E_CHECK(gemm(e, "gemm_vision", patches, Kc, e->patch_w, Kc, nullptr, nullptr, 0, nullptr, pe, H, B * NP, H, Kc, ACT_NONE));
+  { ProfScope ps(e, "rowops", 0);
+    E_CHECK(launch_vision_assemble(pe, B, NP, H, cls, pos, x, e->st));
+    E_CHECK(launch_layernorm(P, x, nullptr, g0, b0, c.clip_eps, M, H, nullptr, x, e->st)); }
+  E_CHECK(clip_stack(e, "gemm_vision", e->cvis, x, M, H, c.vis_inter, c.vis_heads, c.clip_eps, nullptr, nullptr, T, B, T, 0));
+  { ProfScope ps(e, "rowops", 0);
+    E_CHECK(launch_make_row_index(idx, B, T, 0, e->st));
+    E_CHECK(launch_layernorm(P, x, idx, g1, b1, c.clip_eps, B, H, ca, nullptr, e->st)); }
+  E_CHECK(gemm(e, "gemm_vision", ca, H, e->vproj_w, H, nullptr, nullptr, 0, nullptr, emb, c.clip_proj, B, c.clip_proj, H, ACT_NONE));
+  if (e->img_B < B) { if (e->d_img_n) (void)hipFree(e->d_img_n); e->d_img_n = nullptr; E_HIP(hipMalloc((void**)&e->d_img_n, (size_t)B * c.clip_proj * 4)); }
+  E_CHECK(launch_l2_normalize(emb, B, c.clip_proj, e->d_img_n, e->st));
+  e->img_B = B;
+  if (out_embeds) E_HIP(hipMemcpyAsync(out_embeds, emb, (size_t)B * c.clip_proj * 4, hipMemcpyDefault, e->st));
+  E_HIP(hipStreamSynchronize(e->st));
+  return CZC_OK;
+}
+
+int czc_encode_text(czc_engine* e, const int32_t* clip_ids, const int32_t* clip_len, int n, float* out_embeds) {
+  if (!e || !clip_ids || !clip_len || n <= 0 || !out_embeds) return CZC_ERR_ARG;
+  if (!e->finalized) return fail(e, CZC_ERR_STATE, "weights not finalized%s");
+  E_HIP(hipSetDevice(e->dev));
+  e->err[0] = 0;
+  int *cids, *clen, *coff, *totals, *eidx;
+  E_CHECK(ensure(e, "s_cids", (size_t)n * CZC_CLIP_MAX_LEN * 4, (void**)&cids));
+  E_CHECK(ensure(e, "s_clen", (size_t)n * 4, (void**)&clen));
+  E_CHECK(ensure(e, "s_coff", (size_t)(n + 1) * 4, (void**)&coff));
+  E_CHECK(ensure(e, "s_tot", 16, (void**)&totals));
+  E_CHECK(ensure(e, "s_eidx", (size_t)n * 4, (void**)&eidx));
+  E_HIP(hipMemcpyAsync(cids, clip_ids, (size_t)n * CZC_CLIP_MAX_LEN * 4, hipMemcpyDefault, e->st));
+  E_HIP(hipMemcpyAsync(clen, clip_len, (size_t)n * 4, hipMemcpyDefault, e->st));
+  E_HIP(hipMemsetAsync(totals, 0, 16, e->st));
+  E_CHECK(launch_scan(clen, n, coff, totals, e->st));
+  E_HIP(hipMemcpyAsync(e->h_totals, totals, 12, hipMemcpyDeviceToHost, e->st));
+  E_HIP(hipStreamSynchronize(e->st));
+  const int M = e->h_totals[0], max_len = e->h_totals[1];
+  if (max_len > e->cfg.clip_max_pos || max_len > CZC_CLIP_MAX_LEN)
+    return fail(e, CZC_ERR_ARG, "CLIP sequence longer than max_position_embeddings%s");
+  float* feat;
+  E_CHECK(clip_text_forward(e, cids, clen, coff, eidx, n, M, max_len, &feat));
+  E_HIP(hipMemcpyAsync(out_embeds, feat, (size_t)n * e->cfg.clip_proj * 4, hipMemcpyDefault, e->st));
+  E_HIP(hipStreamSynchronize(e->st));
+  return CZC_OK;
+}
+
+int czc_step(czc_engine* e, int32_t* inp, int B, int T, int gen_idx, int n_mask, int dot_allowed, int top_k,
+             const czc_hyper* hp, const czc_step_out* out) {
+  if (!e || !inp || !hp || B <= 0) return CZC_ERR_ARG;
+  E_HIP(hipSetDevice(e->dev));
+  e->err[0] = 0;
+  int* d_inp;
+  E_CHECK(ensure(e, "g_inp", (size_t)B * T * 4, (void**)&d_inp));
+  E_HIP(hipMemcpyAsync(d_inp, inp, (size_t)B * T * 4, hipMemcpyDefault, e->st));
+  E_CHECK(step_device(e, d_inp, B, T, gen_idx, n_mask, dot_allowed, top_k, hp));
+  const size_t bk = (size_t)B * top_k;
+  if (out) {
+    E_CHECK(copy_out(e, out->probs, "s_probs", bk * 4));
+    E_CHECK(copy_out(e, out->idxs, "s_idxs", bk * 4));
+    E_CHECK(copy_out(e, out->cand_ids, "s_cand", bk * 4));
+    E_CHECK(copy_out(e, out->clip_ids, "s_cids", bk * CZC_CLIP_MAX_LEN * 4));
+    E_CHECK(copy_out(e, out->clip_len, "s_clen", bk * 4));
+    E_CHECK(copy_out(e, out->clip_score, "s_cscore", bk * 4));
+    E_CHECK(copy_out(e, out->clip_ref, "s_cref", bk * 4));
+    E_CHECK(copy_out(e, out->senti_raw, "s_senti", bk * 4));
+    E_CHECK(copy_out(e, out->repeats, "s_reps", bk * 4));
+    E_CHECK(copy_out(e, out->final_score, "s_fin", bk * 4));
+    E_CHECK(copy_out(e, out->best, "s_best", (size_t)B * 4));
+    E_CHECK(copy_out(e, out->best_cos, "s_bcos", (size_t)B * 4));
+    E_CHECK(copy_out(e, out->logits, "b_logits", (size_t)B * e->cfg.bert_vocab * 4));
+  }
+  E_HIP(hipMemcpyAsync(inp, d_inp, (size_t)B * T * 4, hipMemcpyDefault, e->st));
+  E_HIP(hipStreamSynchronize(e->st));
+  return CZC_OK;
+}
+
+int czc_generate(czc_engine* e, int B, int T, int L, int seed_len, const int32_t* init_ids_host, int top_k,
+                 int n_steps, const int32_t* positions_host, const int32_t* n_mask_host, int snapshot_every,
+                 const czc_hyper* hp, int32_t* out_ids, float* out_cos) {
+  if (!e || !init_ids_host || !positions_host || !hp || B <= 0 || n_steps < 0 || snapshot_every <= 0)
+    return CZC_ERR_ARG;
+  if (seed_len + L > T) return fail(e, CZC_ERR_ARG, "generate: seed_len + L > T%s");
+  E_HIP(hipSetDevice(e->dev));
+  e->err[0] = 0;
+  int *d_inp, *d_row;
+  E_CHECK(ensure(e, "g_inp", (size_t)B * T * 4, (void**)&d_inp));
+  E_CHECK(ensure(e, "g_row", (size_t)T * 4, (void**)&d_row));
+  E_HIP(hipMemcpyAsync(d_row, init_ids_host, (size_t)T * 4, hipMemcpyHostToDevice, e->st));
+  E_CHECK(launch_broadcast_rows_i32(d_row, T, B, d_inp, e->st));
+  int snap = 0;
+  for (int s = 0; s < n_steps; ++s) {
+    const int pos = positions_host[s];
+    if (pos < 0 || pos >= L) return fail(e, CZC_ERR_ARG, "generate: position out of range%s");
+    const int nm = n_mask_host ? n_mask_host[s] : 1;
+    E_CHECK(step_device(e, d_inp, B, T, seed_len + pos, nm, pos == L - 1 ? 1 : 0, top_k, hp));
+    if ((s + 1) % snapshot_every == 0) {
+      if (out_ids)
+        E_HIP(hipMemcpyAsync(out_ids + (size_t)snap * B * T, d_inp, (size_t)B * T * 4, hipMemcpyDefault, e->st));
+      if (out_cos)
+        E_HIP(hipMemcpyAsync(out_cos + (size_t)snap * B, e->ws["s_bcos"].p, (size_t)B * 4, hipMemcpyDefault, e->st));
+      ++snap;
+    }
+  }
+  E_HIP(hipStreamSynchronize(e->st));
+  return CZC_OK;
+}
+
+int czc_sync(czc_engine* e) {
+  if (!e) return CZC_ERR_ARG;
+  E_HIP(hipSetDevice(e->dev));
+  E_HIP(hipStreamSynchronize(e->st));
+  return CZC_OK;
+}
+
+int czc_profile_enable(czc_engine* e, int on) {
+  if (!e) return CZC_ERR_ARG;
+  e->prof = on != 0;
+  return CZC_OK;
+}
+
+int czc_profile_reset(czc_engine* e) {
+  if (!e) return CZC_ERR_ARG;
+  (void)hipStreamSynchronize(e->st);
+  for (auto& kv : e->pk) { kv.second.used = 0; kv.second.flops = 0; kv.second.launches = 0; }
+  e->stat_clip_rows = e->stat_clip_seqs = e->stat_bert_rows = e->stat_steps = 0;
+  return CZC_OK;
+}
+
+int czc_profile_get(czc_engine* e, const char* kind, double* total_ms, int64_t* launches, double* flops) {
+  if (!e || !kind) return CZC_ERR_ARG;
+  E_HIP(hipStreamSynchronize(e->st));
+  double ms = 0;
+  int64_t n = 0;
+  double fl = 0;
+  auto it = e->pk.find(kind);
+  if (it != e->pk.end()) {
+    ProfKind& k = it->second;
+    for (size_t i = 0; i + 1 < k.used; i += 2) {
+      float t = 0;
+      if (hipEventElapsedTime(&t, k.ev[i], k.ev[i + 1]) == hipSuccess) ms += t;
+    }
+    n = k.launches;
+    fl = k.flops;
+  }
+  if (total_ms) *total_ms = ms;
+  if (launches) *launches = n;
+  if (flops) *flops = fl;
+  return CZC_OK;
+}
+
+int czc_stats(czc_engine* e, int64_t* clip_rows, int64_t* clip_seqs, int64_t* bert_rows, int64_t* steps) {
+  if (!e) return CZC_ERR_ARG;
+  if (clip_rows) *clip_rows = e->stat_clip_rows;
+  if (clip_seqs) *clip_seqs = e->stat_clip_seqs;
+  if (bert_rows) *bert_rows = e->stat_bert_rows;
+  if (steps) *steps = e->stat_steps;
+  return CZC_OK;
+}
+
+}  // extern "C"

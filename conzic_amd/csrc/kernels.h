@@ -1,0 +1,100 @@
+// Host-side launchers of the gfx950 kernels (one translation unit per kernel family).
+#pragma once
+#include "common.h"
+
+namespace czc {
+
+// ---- gemm.hip ---------------------------------------------------------------------------
+// C[M,N] = A[M,K] . W[N,K]^T  (+bias[N]) (act) (+resid[M,N] fp32)
+// A, W are row-major with K contiguous (nn.Linear layout), element type by `prec`
+// (bf16_t or float).  out_act (same element type, may be null) and/or out_f32 (may be null)
+// are written with leading dimension ldc.  resid may alias out_f32.
+struct GemmArgs {
+  const void* A; int lda;
+  const void* W; int ldw;
+  const float* bias;
+  const float* resid; int ldr;
+  void* out_act; float* out_f32; int ldc;
+  int M, N, K;
+  int act;
+};
+int launch_gemm(int prec, const GemmArgs& g, hipStream_t st);
+
+// ---- rowops.hip -------------------------------------------------------------------------
+// y = LN(x[row_idx ? row_idx[m] : m]) ; x fp32 [*,H]; outputs optional
+int launch_layernorm(int prec, const float* x, const int* row_idx, const float* gamma, const float* beta, float eps,
+                     int M, int H, void* y_act, float* y_f32, hipStream_t st);
+// BERT embeddings: word + position + token_type(0) -> LN  (HF:bert/modeling_bert.py:98-106)
+int launch_bert_embed(int prec, const int* ids, int B, int T, int H, const float* word, const float* pos,
+                      const float* type0, const float* gamma, const float* beta, float eps, void* y_act, float* y_f32,
+                      hipStream_t st);
+// CLIP text embeddings on packed sequences: x[off[s]+p] = tok[id[s,p]] + pos[p]  (HF:clip/modeling_clip.py:250-254)
+int launch_clip_embed(const int* ids, int ids_stride, const int* seq_off, const int* seq_len, int n_seq, int max_len,
+                      int H, const float* tok, const float* pos, float* x, hipStream_t st);
+// vision: im2col of [B,3,S,S] into patches [B*P, 3*p*p] (act type), then assemble cls/pos
+int launch_im2col(int prec, const float* pixels, int B, int S, int p, void* out, hipStream_t st);
+int launch_vision_assemble(const float* patch_out, int B, int P, int H, const float* cls, const float* pos, float* x,
+                           hipStream_t st);
+int launch_convert(int prec, const float* src, void* dst, long n, hipStream_t st);  // fp32 -> act type
+// gather rows: dst[m] = src[idx[m]]  (fp32 rows of width H)
+int launch_gather_rows_f32(const float* src, const int* idx, int M, int H, float* dst, hipStream_t st);
+// rows b*T+gen_idx
+int launch_make_row_index(int* idx, int B, int T, int gen_idx, hipStream_t st);
+// idx[s] = off[s] + len[s] - 1
+int launch_eos_index(const int* off, const int* len, int n, int* idx, hipStream_t st);
+int launch_l2_normalize(const float* x, int M, int D, float* y, hipStream_t st);
+// inp[b, gen_idx .. gen_idx+n_mask) = mask_id
+int launch_mask_positions(int* inp, int B, int T, int gen_idx, int n_mask, int mask_id, hipStream_t st);
+int launch_broadcast_rows_i32(const int* row, int T, int B, int* dst, hipStream_t st);
+
+// ---- attention.hip ------------------------------------------------------------------------
+// softmax(q k^T * scale [+causal]) v on packed sequences; qkv [M, 3*heads*64] act type,
+// sequence s = rows [off[s], off[s]+len[s]) (or s*fixed_T.. when off == null); out [M, heads*64]
+int launch_attention(int prec, const void* qkv, const int* seq_off, const int* seq_len, int fixed_T, int n_seq,
+                     int max_len, int heads, int causal, float scale, void* out, hipStream_t st);
+
+// ---- topk.hip -----------------------------------------------------------------------------
+int launch_softmax_mask_topk(const float* logits, int B, int V, int K, const float* mask, float temperature, int dot_id,
+                             int dot_allowed, float* probs, int* idxs, int* cand, hipStream_t st);
+
+// ---- bridge.hip ---------------------------------------------------------------------------
+struct BridgeDev {
+  int bert_vocab;
+  const uint32_t* piece_off;
+  const uint8_t* piece_bytes;
+  const uint8_t* piece_class;
+  const uint8_t* piece_flags;
+  const int* byte_sym;
+  const int* byte_sym_eow;
+  const unsigned long long* hkeys;  // open addressing, ~0 = empty
+  const unsigned long long* hvals;  // rank<<32 | out
+  unsigned hmask;
+  int bos_id, eos_id;
+};
+// rows: inp[b,:] with column gen_idx replaced by cand[b,k] (cand==null: rows are taken verbatim,
+// n_rows = B, K = 1).  Writes clip_ids [B*K,77], clip_len, and optionally senti/repeats.
+int launch_bridge(const BridgeDev& bd, const int* inp, int B, int T, int gen_idx, const int* cand, int K,
+                  const float* lexicon, int negative, int* clip_ids, int* clip_len, float* senti_raw, float* repeats,
+                  int* overflow_flag, hipStream_t st);
+// exclusive scan of len[n] -> off[n+1]; totals[0] = sum, totals[1] = max
+int launch_scan(const int* len, int n, int* off, int* totals, hipStream_t st);
+
+// ---- combine.hip --------------------------------------------------------------------------
+struct CombineArgs {
+  const float* text_feat;  // [B*K, D]
+  const float* img_n;      // [B, D] L2-normalised
+  float logit_scale_exp;
+  const float* probs;      // [B,K]
+  const int* cand;         // [B,K]
+  const float* senti_raw;  // [B,K] or null
+  const float* repeats;    // [B,K] or null
+  float alpha, beta, gamma;
+  int use_senti;
+  int B, K, D;
+  float* clip_score; float* clip_ref; float* final_score;  // [B,K] (non-null, engine scratch)
+  int* best; float* best_cos;                                // [B]
+  int* inp; int T; int gen_idx;                              // write-back target (may be null)
+};
+int launch_combine(const CombineArgs& a, hipStream_t st);
+
+}  // namespace czc

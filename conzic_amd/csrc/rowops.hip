@@ -1,0 +1,327 @@
+// Row-wise wavefront kernels: LayerNorm, embedding gathers, im2col, small index helpers.
+// All are HBM-bound streaming kernels: one 64-lane wave per row, float4 accesses, shuffle
+// reductions (no LDS), fp32 statistics regardless of the engine precision.
+#include "kernels.h"
+
+namespace czc {
+
+constexpr int LN_MAXV = 4;  // float4 per lane -> H <= 1024
+
+// one wave per row; returns this lane's normalised values in v[]
+template <int NV>
+__device__ __forceinline__ void ln_row(float4 (&v)[NV], int H, int lane, const float* gamma, const float* beta,
+                                       float eps) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < H) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+  const float mean = wave_sum(s) / (float)H;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < H) {
+      const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+      q += (a * a + b * b) + (cc * cc + d * d);
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)H + eps);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < H) {
+      const float4 gm = *(const float4*)(gamma + c);
+      const float4 bt = *(const float4*)(beta + c);
+      v[i].x = (v[i].x - mean) * rstd * gm.x + bt.x;
+      v[i].y = (v[i].y - mean) * rstd * gm.y + bt.y;
+      v[i].z = (v[i].z - mean) * rstd * gm.z + bt.z;
+      v[i].w = (v[i].w - mean) * rstd * gm.w + bt.w;
+    }
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ void store4(T* p, const float4& v);
+template <>
+__device__ __forceinline__ void store4<float>(float* p, const float4& v) { *(float4*)p = v; }
+template <>
+__device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const float4& v) {
+  uint2 o;
+  o.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
+  o.y = (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
+  *(uint2*)p = o;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const int* row_idx, const float* gamma,
+                                                        const float* beta, float eps, int M, int H, T* y_act,
+                                                        float* y_f32) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const long src = row_idx ? row_idx[m] : m;
+  const float* xr = x + src * (long)H;
+  float4 v[LN_MAXV];
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    v[i] = c < H ? *(const float4*)(xr + c) : make_float4(0, 0, 0, 0);
+  }
+  ln_row<LN_MAXV>(v, H, lane, gamma, beta, eps);
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < H) {
+      if (y_f32) *(float4*)(y_f32 + (long)m * H + c) = v[i];
+      if (y_act) store4<T>(y_act + (long)m * H + c, v[i]);
+    }
+  }
+}
+
+int launch_layernorm(int prec, const float* x, const int* row_idx, const float* gamma, const float* beta, float eps,
+                     int M, int H, void* y_act, float* y_f32, hipStream_t st) {
+  if (M <= 0) return 0;
+  if (H % 4 || H > LN_MAXV * 256) {
+    snprintf(g_err, sizeof(g_err), "layernorm: unsupported H=%d", H);
+    return 1;
+  }
+  dim3 grid(cdiv(M, 4)), block(256);
+  if (prec == PREC_BF16)
+    hipLaunchKernelGGL(layernorm_kernel<bf16_t>, grid, block, 0, st, x, row_idx, gamma, beta, eps, M, H,
+                       (bf16_t*)y_act, y_f32);
+  else
+    hipLaunchKernelGGL(layernorm_kernel<float>, grid, block, 0, st, x, row_idx, gamma, beta, eps, M, H, (float*)y_act,
+                       y_f32);
+  CZC_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// ---- BERT embeddings + LN ------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void bert_embed_kernel(const int* ids, int M, int T_, int H, const float* word,
+                                                         const float* pos, const float* type0, const float* gamma,
+                                                         const float* beta, float eps, T* y_act, float* y_f32) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const int id = ids[m];
+  const int p = m % T_;
+  const float* wr = word + (long)id * H;
+  const float* pr = pos + (long)p * H;
+  float4 v[LN_MAXV];
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < H) {
+      const float4 a = *(const float4*)(wr + c), b = *(const float4*)(type0 + c), d = *(const float4*)(pr + c);
+      // HF order: inputs_embeds + token_type_embeddings, then + position_embeddings
+      v[i] = make_float4((a.x + b.x) + d.x, (a.y + b.y) + d.y, (a.z + b.z) + d.z, (a.w + b.w) + d.w);
+    } else {
+      v[i] = make_float4(0, 0, 0, 0);
+    }
+  }
+  ln_row<LN_MAXV>(v, H, lane, gamma, beta, eps);
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < H) {
+      if (y_f32) *(float4*)(y_f32 + (long)m * H + c) = v[i];
+      if (y_act) store4<T>(y_act + (long)m * H + c, v[i]);
+    }
+  }
+}
+
+int launch_bert_embed(int prec, const int* ids, int B, int T_, int H, const float* word, const float* pos,
+                      const float* type0, const float* gamma, const float* beta, float eps, void* y_act, float* y_f32,
+                      hipStream_t st) {
+  const int M = B * T_;
+  if (M <= 0) return 0;
+  dim3 grid(cdiv(M, 4)), block(256);
+  if (prec == PREC_BF16)
+    hipLaunchKernelGGL(bert_embed_kernel<bf16_t>, grid, block, 0, st, ids, M, T_, H, word, pos, type0, gamma, beta, eps,
+                       (bf16_t*)y_act, y_f32);
+  else
+    hipLaunchKernelGGL(bert_embed_kernel<float>, grid, block, 0, st, ids, M, T_, H, word, pos, type0, gamma, beta, eps,
+                       (float*)y_act, y_f32);
+  CZC_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// ---- CLIP text embeddings on packed sequences -------------------------------------------------
+// one wave per (sequence, position).  The K candidates of an image share every token id but one,
+// so the token-embedding rows they gather are the same cache lines (L2-resident after first touch).
+__global__ __launch_bounds__(256) void clip_embed_kernel(const int* ids, int ids_stride, const int* seq_off,
+                                                         const int* seq_len, int n_seq, int max_len, int H,
+                                                         const float* tok, const float* pos, float* x) {
+  const int lane = threadIdx.x & 63;
+  const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int s = (int)(w / max_len), p = (int)(w % max_len);
+  if (s >= n_seq || p >= seq_len[s]) return;
+  const int id = ids[(long)s * ids_stride + p];
+  const float* tr = tok + (long)id * H;
+  const float* pr = pos + (long)p * H;
+  float* xr = x + ((long)seq_off[s] + p) * H;
+  for (int c = lane * 4; c < H; c += 256) {
+    const float4 a = *(const float4*)(tr + c), b = *(const float4*)(pr + c);
+    *(float4*)(xr + c) = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+  }
+}
+
+int launch_clip_embed(const int* ids, int ids_stride, const int* seq_off, const int* seq_len, int n_seq, int max_len,
+                      int H, const float* tok, const float* pos, float* x, hipStream_t st) {
+  if (n_seq <= 0) return 0;
+  dim3 grid(cdiv((long)n_seq * max_len, 4)), block(256);
+  hipLaunchKernelGGL(clip_embed_kernel, grid, block, 0, st, ids, ids_stride, seq_off, seq_len, n_seq, max_len, H, tok,
+                     pos, x);
+  CZC_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// ---- vision helpers ----------------------------------------------------------------------------
+// patches[b*P + py*G + px][c*p*p + iy*p + ix] = pixels[b][c][py*p+iy][px*p+ix]
+// (conv2d stride=kernel=p, no bias == GEMM with the [hidden, 3*p*p] flattened conv weight)
+template <typename T>
+__global__ void im2col_kernel(const float* pix, int B, int S, int p, T* out) {
+  const int G = S / p, P = G * G, Kc = 3 * p * p;
+  const long total = (long)B * P * Kc;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(i % Kc);
+    const long bp = i / Kc;
+    const int pp = (int)(bp % P), b = (int)(bp / P);
+    const int c = k / (p * p), iy = (k / p) % p, ix = k % p;
+    const int py = pp / G, px = pp % G;
+    const float v = pix[(((long)b * 3 + c) * S + (py * p + iy)) * S + (px * p + ix)];
+    Act<T>::st(out + i, v);
+  }
+}
+
+int launch_im2col(int prec, const float* pixels, int B, int S, int p, void* out, hipStream_t st) {
+  const long total = (long)B * (S / p) * (S / p) * 3 * p * p;
+  dim3 grid((unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192)), block(256);
+  if (prec == PREC_BF16)
+    hipLaunchKernelGGL(im2col_kernel<bf16_t>, grid, block, 0, st, pixels, B, S, p, (bf16_t*)out);
+  else
+    hipLaunchKernelGGL(im2col_kernel<float>, grid, block, 0, st, pixels, B, S, p, (float*)out);
+  CZC_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// x[b, 0] = cls + pos[0];  x[b, 1+j] = patch_out[b*P+j] + pos[1+j]   (HF:clip/modeling_clip.py:202-218)
+__global__ void vision_assemble_kernel(const float* patch_out, int B, int P, int H, const float* cls, const float* pos,
+                                       float* x) {
+  const long total = (long)B * (P + 1) * H;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % H);
+    const long bt = i / H;
+    const int t = (int)(bt % (P + 1)), b = (int)(bt / (P + 1));
+    const float e = t == 0 ? cls[c] : patch_out[((long)b * P + (t - 1)) * H + c];
+    x[i] = e + pos[(long)t * H + c];
+  }
+}
+
+int launch_vision_assemble(const float* patch_out, int B, int P, int H, const float* cls, const float* pos, float* x,
+                           hipStream_t st) {
+  const long total = (long)B * (P + 1) * H;
+  dim3 grid((unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192)), block(256);
+  hipLaunchKernelGGL(vision_assemble_kernel, grid, block, 0, st, patch_out, B, P, H, cls, pos, x);
+  CZC_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+template <typename T>
+__global__ void convert_kernel(const float* src, T* dst, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    Act<T>::st(dst + i, src[i]);
+}
+
+int launch_convert(int prec, const float* src, void* dst, long n, hipStream_t st) {
+  if (n <= 0) return 0;
+  dim3 grid((unsigned)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384)), block(256);
+  if (prec == PREC_BF16)
+    hipLaunchKernelGGL(convert_kernel<bf16_t>, grid, block, 0, st, src, (bf16_t*)dst, n);
+  else
+    hipLaunchKernelGGL(convert_kernel<float>, grid, block, 0, st, src, (float*)dst, n);
+  CZC_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+__global__ void gather_rows_kernel(const float* src, const int* idx, int M, int H, float* dst) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const float* s = src + (long)idx[m] * H;
+  float* d = dst + (long)m * H;
+  for (int c = lane * 4; c < H; c += 256) *(float4*)(d + c) = *(const float4*)(s + c);
+}
+
+int launch_gather_rows_f32(const float* src, const int* idx, int M, int H, float* dst, hipStream_t st) {
+  if (M <= 0) return 0;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, src, idx, M, H, dst);
+  CZC_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+__global__ void make_row_index_kernel(int* idx, int B, int T_, int gen_idx) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) idx[b] = b * T_ + gen_idx;
+}
+int launch_make_row_index(int* idx, int B, int T_, int gen_idx, hipStream_t st) {
+  hipLaunchKernelGGL(make_row_index_kernel, dim3(cdiv(B, 256)), dim3(256), 0, st, idx, B, T_, gen_idx);
+  CZC_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+__global__ void eos_index_kernel(const int* off, const int* len, int n, int* idx) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) idx[i] = off[i] + len[i] - 1;
+}
+int launch_eos_index(const int* off, const int* len, int n, int* idx, hipStream_t st) {
+  hipLaunchKernelGGL(eos_index_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, off, len, n, idx);
+  CZC_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+__global__ void l2_normalize_kernel(const float* x, int M, int D, float* y) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const float* xr = x + (long)m * D;
+  float s = 0.f;
+  for (int c = lane; c < D; c += 64) s += xr[c] * xr[c];
+  const float nrm = sqrtf(wave_sum(s));
+  for (int c = lane; c < D; c += 64) y[(long)m * D + c] = xr[c] / nrm;
+}
+int launch_l2_normalize(const float* x, int M, int D, float* y, hipStream_t st) {
+  hipLaunchKernelGGL(l2_normalize_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, x, M, D, y);
+  CZC_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+__global__ void mask_positions_kernel(int* inp, int B, int T_, int gen_idx, int n_mask, int mask_id) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B * n_mask) {
+    const int b = i / n_mask, j = i % n_mask;
+    if (gen_idx + j < T_) inp[b * T_ + gen_idx + j] = mask_id;
+  }
+}
+int launch_mask_positions(int* inp, int B, int T_, int gen_idx, int n_mask, int mask_id, hipStream_t st) {
+  if (n_mask <= 0) return 0;
+  hipLaunchKernelGGL(mask_positions_kernel, dim3(cdiv(B * n_mask, 256)), dim3(256), 0, st, inp, B, T_, gen_idx, n_mask,
+                     mask_id);
+  CZC_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+__global__ void broadcast_rows_kernel(const int* row, int T_, int B, int* dst) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B * T_) dst[i] = row[i % T_];
+}
+int launch_broadcast_rows_i32(const int* row, int T_, int B, int* dst, hipStream_t st) {
+  hipLaunchKernelGGL(broadcast_rows_kernel, dim3(cdiv(B * T_, 256)), dim3(256), 0, st, row, T_, B, dst);
+  CZC_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+}  // namespace czc

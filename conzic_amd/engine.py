@@ -1,0 +1,293 @@
+"""Python handle on one native engine (one GPU): thin, typed calls into libconzic_hip.so.
+
+Everything numeric happens in the shared library; this class only marshals numpy buffers (or
+device pointers of torch tensors) across the C ABI of include/conzic_hip.h.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Iterable, Optional, Sequence
+
+import numpy as np
+
+from . import native
+from .bridge import BridgeArrays
+from .native import NativeError  # noqa: F401  (re-export)
+
+
+def _ptr(a):
+    """host numpy array or a device tensor (anything with .data_ptr()) -> void*"""
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data
+    if hasattr(a, "data_ptr"):
+        return a.data_ptr()
+    raise TypeError(type(a))
+
+
+def make_config(bert_cfg, clip_cfg, special: Dict[str, int], precision: int) -> native.Config:
+    c = native.Config()
+    if bert_cfg is not None:
+        c.bert_vocab, c.bert_hidden, c.bert_layers = bert_cfg.vocab, bert_cfg.hidden, bert_cfg.layers
+        c.bert_heads, c.bert_inter, c.bert_max_pos, c.bert_eps = bert_cfg.heads, bert_cfg.inter, bert_cfg.max_pos, bert_cfg.eps
+    else:
+        c.bert_vocab = c.bert_layers = 0
+        c.bert_hidden, c.bert_heads, c.bert_inter, c.bert_max_pos, c.bert_eps = 64, 1, 64, 1, 1e-12
+    c.clip_vocab, c.clip_hidden, c.clip_layers, c.clip_heads = clip_cfg.vocab, clip_cfg.hidden, clip_cfg.layers, clip_cfg.heads
+    c.clip_inter, c.clip_max_pos, c.clip_proj, c.clip_eps = clip_cfg.inter, clip_cfg.max_pos, clip_cfg.proj, clip_cfg.eps
+    c.clip_bos_id, c.clip_eos_id = clip_cfg.bos_id, clip_cfg.eos_id
+    c.vis_hidden, c.vis_layers, c.vis_heads, c.vis_inter = clip_cfg.v_hidden, clip_cfg.v_layers, clip_cfg.v_heads, clip_cfg.v_inter
+    c.vis_image, c.vis_patch = clip_cfg.v_image, clip_cfg.v_patch
+    c.pad_id = special.get("[PAD]", 0)
+    c.unk_id = special.get("[UNK]", 0)
+    c.cls_id = special.get("[CLS]", 0)
+    c.sep_id = special.get("[SEP]", 0)
+    c.mask_id = special.get("[MASK]", 0)
+    c.dot_id = special.get(".", 0)
+    c.precision = precision
+    return c
+
+
+class Engine:
+    def __init__(self, bert_cfg, clip_cfg, special: Dict[str, int], precision: int = native.PREC_BF16, device: int = 0):
+        self.lib = native.load()
+        self.cfg = make_config(bert_cfg, clip_cfg, special, precision)
+        self.bert_cfg, self.clip_cfg = bert_cfg, clip_cfg
+        self.precision = precision
+        h = C.c_void_p()
+        native.check(self.lib.czc_create(C.byref(self.cfg), device, C.byref(h)), None, "czc_create")
+        self.h = h
+        self._keep = []  # host arrays the engine may still point at
+
+    # ---- lifecycle --------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.czc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc, what):
+        native.check(rc, self.h, what)
+
+    # ---- frozen state -------------------------------------------------------------------------
+    def load_state(self, *state_dicts, names: Optional[Iterable[str]] = None):
+        """Each state dict maps HF names to fp32 arrays: numpy, or torch tensors (CPU or on this
+        GPU -- device tensors are consumed in place, which is the RCCL-broadcast hand-over)."""
+        for sd in state_dicts:
+            for name, t in sd.items():
+                if names is not None and name not in names:
+                    continue
+                if name.endswith("position_ids") or name == "cls.predictions.decoder.weight":
+                    continue  # decoder weight is tied to the word embeddings (HF:bert/modeling_bert.py:910-913)
+                if name == "cls.predictions.decoder.bias" and "cls.predictions.bias" in sd:
+                    continue
+                if hasattr(t, "detach"):
+                    t = t.detach()
+                    if t.dtype is not __import__("torch").float32:
+                        t = t.float()
+                    t = t.contiguous()
+                    shape = tuple(t.shape)
+                    src = t.data_ptr()
+                    self._tmp = t
+                else:
+                    t = np.ascontiguousarray(t, dtype=np.float32)
+                    shape = t.shape
+                    src = t.ctypes.data
+                    self._tmp = t
+                sh = (C.c_int64 * max(1, len(shape)))(*shape)
+                self._ck(self.lib.czc_load_tensor(self.h, name.encode(), 0, len(shape), sh, src), f"czc_load_tensor({name})")
+        self._tmp = None
+
+    def finalize(self):
+        self._ck(self.lib.czc_finalize_weights(self.h), "czc_finalize_weights")
+
+    def set_token_mask(self, mask):
+        m = np.ascontiguousarray(np.asarray(mask, dtype=np.float32).reshape(-1))
+        self._ck(self.lib.czc_set_token_mask(self.h, m.ctypes.data, m.size), "czc_set_token_mask")
+
+    def set_lexicon(self, lex):
+        m = np.ascontiguousarray(np.asarray(lex, dtype=np.float32).reshape(-1))
+        self._ck(self.lib.czc_set_lexicon(self.h, m.ctypes.data, m.size), "czc_set_lexicon")
+
+    def set_bridge(self, tables: BridgeArrays):
+        st = tables.as_struct()
+        self._ck(self.lib.czc_set_bridge(self.h, C.byref(st)), "czc_set_bridge")
+
+    # ---- images / text ------------------------------------------------------------------------
+    def encode_images(self, pixels) -> np.ndarray:
+        if isinstance(pixels, np.ndarray):
+            pixels = np.ascontiguousarray(pixels, dtype=np.float32)
+        B = int(pixels.shape[0])
+        out = np.empty((B, self.clip_cfg.proj), dtype=np.float32)
+        self._ck(self.lib.czc_encode_images(self.h, _ptr(pixels), B, out.ctypes.data), "czc_encode_images")
+        return out
+
+    def set_image_embeds(self, embeds):
+        e = np.ascontiguousarray(embeds, dtype=np.float32)
+        self._ck(self.lib.czc_set_image_embeds(self.h, e.ctypes.data, e.shape[0]), "czc_set_image_embeds")
+
+    def encode_text(self, clip_ids: np.ndarray, clip_len: np.ndarray) -> np.ndarray:
+        n = int(clip_ids.shape[0])
+        ids = np.full((n, native.CLIP_MAX_LEN), self.clip_cfg.eos_id, dtype=np.int32)
+        ids[:, : clip_ids.shape[1]] = clip_ids
+        ln = np.ascontiguousarray(clip_len, dtype=np.int32)
+        out = np.empty((n, self.clip_cfg.proj), dtype=np.float32)
+        self._ck(self.lib.czc_encode_text(self.h, ids.ctypes.data, ln.ctypes.data, n, out.ctypes.data), "czc_encode_text")
+        return out
+
+    # ---- hot path --------------------------------------------------------------------------------
+    @staticmethod
+    def hyper(alpha, beta, temperature, gamma=None, negative=False) -> native.Hyper:
+        h = native.Hyper()
+        h.alpha, h.beta = float(alpha), float(beta)
+        h.gamma = float(gamma) if gamma is not None else 0.0
+        h.temperature = 1.0 if temperature is None else float(temperature)
+        h.use_sentiment = 1 if gamma is not None else 0
+        h.negative = 1 if negative else 0
+        return h
+
+    def step(self, inp: np.ndarray, gen_idx: int, top_k: int, hyper: native.Hyper, n_mask: int = 1,
+             dot_allowed: bool = False, want: Sequence[str] = ("probs", "idxs", "cand_ids", "clip_ids", "clip_len",
+                                                               "clip_score", "clip_ref", "final_score", "best",
+                                                               "best_cos")) -> Dict[str, np.ndarray]:
+        """One position-step on int32 `inp` [B,T] (updated in place).  Returns the requested tensors."""
+        assert inp.dtype == np.int32 and inp.flags.c_contiguous
+        B, T = inp.shape
+        K = top_k
+        V = self.cfg.bert_vocab
+        shapes = dict(probs=((B, K), np.float32), idxs=((B, K), np.int32), cand_ids=((B, K), np.int32),
+                      clip_ids=((B * K, native.CLIP_MAX_LEN), np.int32), clip_len=((B * K,), np.int32),
+                      clip_score=((B, K), np.float32), clip_ref=((B, K), np.float32), senti_raw=((B, K), np.float32),
+                      repeats=((B, K), np.float32), final_score=((B, K), np.float32), best=((B,), np.int32),
+                      best_cos=((B,), np.float32), logits=((B, V), np.float32))
+        out = native.StepOut()
+        res = {}
+        for name in want:
+            shp, dt = shapes[name]
+            res[name] = np.empty(shp, dtype=dt)
+            setattr(out, name, res[name].ctypes.data)
+        self._ck(self.lib.czc_step(self.h, inp.ctypes.data, B, T, gen_idx, n_mask, 1 if dot_allowed else 0, K,
+                                   C.byref(hyper), C.byref(out)), "czc_step")
+        return res
+
+    def generate(self, B: int, init_ids: Sequence[int], L: int, seed_len: int, top_k: int, positions: Sequence[int],
+                 hyper: native.Hyper, n_mask: Optional[Sequence[int]] = None, snapshot_every: Optional[int] = None):
+        """Whole *_generation call.  Returns (ids int32 [S,B,T], cos fp32 [S,B]) per snapshot."""
+        init = np.ascontiguousarray(init_ids, dtype=np.int32)
+        T = init.size
+        pos = np.ascontiguousarray(positions, dtype=np.int32)
+        nm = None if n_mask is None else np.ascontiguousarray(n_mask, dtype=np.int32)
+        every = snapshot_every or L
+        S = len(pos) // every
+        ids = np.empty((S, B, T), dtype=np.int32)
+        cos = np.empty((S, B), dtype=np.float32)
+        self._ck(self.lib.czc_generate(self.h, B, T, L, seed_len, init.ctypes.data, top_k, len(pos), pos.ctypes.data,
+                                       None if nm is None else nm.ctypes.data, every, C.byref(hyper),
+                                       ids.ctypes.data, cos.ctypes.data), "czc_generate")
+        return ids, cos
+
+    # ---- measurement ------------------------------------------------------------------------------
+    def profile(self, on: bool):
+        self._ck(self.lib.czc_profile_enable(self.h, 1 if on else 0), "czc_profile_enable")
+
+    def profile_reset(self):
+        self._ck(self.lib.czc_profile_reset(self.h), "czc_profile_reset")
+
+    def profile_get(self, kind: str):
+        ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
+        self._ck(self.lib.czc_profile_get(self.h, kind.encode(), C.byref(ms), C.byref(n), C.byref(fl)), "czc_profile_get")
+        return dict(ms=ms.value, launches=n.value, flops=fl.value)
+
+    def stats(self):
+        a, b, c_, d = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        self._ck(self.lib.czc_stats(self.h, C.byref(a), C.byref(b), C.byref(c_), C.byref(d)), "czc_stats")
+        return dict(clip_rows=a.value, clip_seqs=b.value, bert_rows=c_.value, steps=d.value)
+
+    def sync(self):
+        self._ck(self.lib.czc_sync(self.h), "czc_sync")
+
+
+# ---- kernel-level hooks (tests) ----------------------------------------------------------------------
+
+def test_gemm(prec, A, W, bias=None, resid=None, act=0):
+    lib = native.load()
+    A = np.ascontiguousarray(A, np.float32)
+    W = np.ascontiguousarray(W, np.float32)
+    M, K = A.shape
+    N = W.shape[0]
+    Cm = np.empty((M, N), np.float32)
+    b = None if bias is None else np.ascontiguousarray(bias, np.float32)
+    r = None if resid is None else np.ascontiguousarray(resid, np.float32)
+    native.check(lib.czc_test_gemm(prec, M, N, K, A.ctypes.data, W.ctypes.data, _ptr(b), _ptr(r), act, Cm.ctypes.data),
+                 None, "czc_test_gemm")
+    return Cm
+
+
+def test_layernorm(prec, x, gamma, beta, eps):
+    lib = native.load()
+    x = np.ascontiguousarray(x, np.float32)
+    g = np.ascontiguousarray(gamma, np.float32)
+    b = np.ascontiguousarray(beta, np.float32)
+    y = np.empty_like(x)
+    native.check(lib.czc_test_layernorm(prec, x.shape[0], x.shape[1], x.ctypes.data, g.ctypes.data, b.ctypes.data,
+                                        C.c_float(eps), y.ctypes.data), None, "czc_test_layernorm")
+    return y
+
+
+def test_attention(prec, qkv, seq_len, heads, causal, scale):
+    lib = native.load()
+    qkv = np.ascontiguousarray(qkv, np.float32)
+    sl = np.ascontiguousarray(seq_len, np.int32)
+    out = np.empty((qkv.shape[0], heads * 64), np.float32)
+    native.check(lib.czc_test_attention(prec, sl.size, sl.ctypes.data, heads, 1 if causal else 0, C.c_float(scale),
+                                        qkv.ctypes.data, out.ctypes.data), None, "czc_test_attention")
+    return out
+
+
+def test_topk(logits, mask, K, temperature, dot_id, dot_allowed):
+    lib = native.load()
+    lg = np.ascontiguousarray(logits, np.float32)
+    mk = np.ascontiguousarray(np.asarray(mask, np.float32).reshape(-1))
+    B, V = lg.shape
+    p = np.empty((B, K), np.float32)
+    i = np.empty((B, K), np.int32)
+    c = np.empty((B, K), np.int32)
+    native.check(lib.czc_test_topk(B, V, K, lg.ctypes.data, mk.ctypes.data, C.c_float(temperature), dot_id,
+                                   1 if dot_allowed else 0, p.ctypes.data, i.ctypes.data, c.ctypes.data), None,
+                 "czc_test_topk")
+    return p, i, c
+
+
+def test_bridge(tables: BridgeArrays, rows):
+    lib = native.load()
+    rows = np.ascontiguousarray(rows, np.int32)
+    n, T = rows.shape
+    ids = np.empty((n, native.CLIP_MAX_LEN), np.int32)
+    ln = np.empty((n,), np.int32)
+    st = tables.as_struct()
+    native.check(lib.czc_test_bridge(C.byref(st), None, n, T, rows.ctypes.data, ids.ctypes.data, ln.ctypes.data), None,
+                 "czc_test_bridge")
+    return ids, ln
+
+
+def test_combine(text_feat, img_embeds, logit_scale, probs, hyper, senti_raw=None, repeats=None):
+    lib = native.load()
+    tf = np.ascontiguousarray(text_feat, np.float32)
+    ie = np.ascontiguousarray(img_embeds, np.float32)
+    pr = np.ascontiguousarray(probs, np.float32)
+    B, K = pr.shape
+    D = ie.shape[1]
+    sr = None if senti_raw is None else np.ascontiguousarray(senti_raw, np.float32)
+    rp = None if repeats is None else np.ascontiguousarray(repeats, np.float32)
+    cs, cr, fs = (np.empty((B, K), np.float32) for _ in range(3))
+    best = np.empty((B,), np.int32)
+    native.check(lib.czc_test_combine(B, K, D, tf.ctypes.data, ie.ctypes.data, C.c_float(logit_scale), pr.ctypes.data,
+                                      _ptr(sr), _ptr(rp), C.byref(hyper), cs.ctypes.data, cr.ctypes.data,
+                                      fs.ctypes.data, best.ctypes.data), None, "czc_test_combine")
+    return cs, cr, fs, best

@@ -1,0 +1,91 @@
+"""Harness-side assembly: build an engine from (synthetic or caller-provided) state dicts and
+tokenizers.  This is the counterpart of what demo.py:125-143 does before it calls the boundary
+(load models, build token_mask); shared by tests, bench.py, __graft_entry__.smoke() and the
+drop-in modules at the repo root."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+from . import native, synth
+from .bridge import BridgeArrays, tables_from_tokenizers
+from .engine import Engine
+from .text import ClipBpeTokenizer, WordPieceTokenizer, tokenizers_from_vocab
+
+
+@dataclass
+class SynthSetup:
+    engine: Engine
+    sv: synth.SynthVocab
+    bert_cfg: synth.BertCfg
+    clip_cfg: synth.ClipCfg
+    bert_tok: WordPieceTokenizer
+    clip_tok: ClipBpeTokenizer
+    tables: BridgeArrays
+    token_mask: np.ndarray  # [1,V]
+
+
+def special_ids(bert_tok) -> dict:
+    sp = {k: int(bert_tok.vocab[k]) for k in ("[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]", ".")}
+    return sp
+
+
+_vocab_cache = {}
+
+
+def cached_vocab(tiny: bool) -> synth.SynthVocab:
+    if tiny not in _vocab_cache:
+        _vocab_cache[tiny] = synth.make_vocab_tiny() if tiny else synth.make_vocab()
+    return _vocab_cache[tiny]
+
+
+def build_synthetic(tiny: bool, precision: int = native.PREC_BF16, bseed: int = 11, cseed: int = 12,
+                    logit_scale: float = 2.6592, regular_only: bool = False, lexicon: bool = False,
+                    device: int = 0, bert_w=None, clip_w=None, bert_cfg=None, clip_cfg=None) -> SynthSetup:
+    sv = cached_vocab(tiny)
+    if bert_cfg is None:
+        bert_cfg = synth.bert_tiny(len(sv.bert_tokens)) if tiny else synth.bert_base()
+    if clip_cfg is None:
+        clip_cfg = synth.clip_tiny(len(sv.clip_vocab)) if tiny else synth.clip_b32()
+    clip_cfg.logit_scale = logit_scale
+    bt, ct = tokenizers_from_vocab(sv)
+    eng = Engine(bert_cfg, clip_cfg, special_ids(bt), precision, device)
+    eng.load_state(bert_w if bert_w is not None else synth.make_bert_weights(bert_cfg, bseed))
+    eng.load_state(clip_w if clip_w is not None else synth.make_clip_weights(clip_cfg, cseed))
+    eng.finalize()
+    tables = tables_from_tokenizers(bt, ct)
+    eng.set_bridge(tables)
+    mask = synth.make_token_mask(sv, regular_only=regular_only)
+    eng.set_token_mask(mask)
+    if lexicon:
+        eng.set_lexicon(synth.make_lexicon(len(sv.bert_tokens)))
+    return SynthSetup(eng, sv, bert_cfg, clip_cfg, bt, ct, tables, mask)
+
+
+def order_positions(order: str, L: int, iters: int, order_list=None, random_positions=None):
+    """(positions, n_mask, snapshot_every) for czc_generate from the reference's visiting orders
+    (gen_utils.py:64-65 sequential, :110-115 shuffle, :160-166 span, :209-210 random)."""
+    if order == "sequential":
+        lst = list(range(L))
+        return lst * iters, [1] * (L * iters), L
+    if order == "shuffle":
+        lst = list(order_list)
+        assert sorted(lst) == list(range(L))
+        return lst * iters, [1] * (L * iters), L
+    if order == "span":
+        pos, nm = [], []
+        for s in range(0, L, 2):
+            e = min(s + 2, L)
+            pos.append(s)
+            nm.append(e - s)
+            if e - s == 2:
+                pos.append(s + 1)
+                nm.append(0)
+        return pos * iters, nm * iters, L
+    if order == "random":
+        pos = [int(p) for p in random_positions]
+        assert len(pos) == L * iters
+        return pos, [1] * len(pos), L
+    raise ValueError(order)

@@ -1,0 +1,194 @@
+/*
+ * conzic_hip.h -- C ABI of the MI355X-native ConZIC polishing engine (libconzic_hip.so).
+ *
+ * Drop-in boundary for ONE path of joeyz0z/ConZIC: the per-position polishing step
+ *   mask a position -> BERT masked-LM forward -> softmax/top-K -> K candidate captions ->
+ *   CLIP text encode -> cosine vs cached image embedding -> alpha/beta(/gamma) fusion -> argmax
+ * i.e. the loop bodies of
+ *   gen_utils.py:64-81   (sequential_generation), :114-130 (shuffle_generation),
+ *   gen_utils.py:160-179 (span_generation),       :209-226 (random_generation),
+ *   control_gen_utils.py:43-65, :98-120           (sentiment_*_generation)
+ * plus the once-per-image CLIP vision encode (clip/clip.py:48-62).
+ *
+ * The reference is pure Python over torch/transformers, so it has no FFI of its own; the
+ * Python modules gen_utils / control_gen_utils / clip.clip / utils at the repo root keep the
+ * reference's call surface and bind these entry points through ctypes.
+ *
+ * Conventions: plain pointers and sizes only (no torch types).  Every function returns an int
+ * status (0 = CZC_OK); czc_last_error() gives the message.  One engine per GPU, one host thread
+ * per engine, calls are synchronous on return unless noted.  Pointers named *_host must be host
+ * memory; pointers named `src`/`dst`/`pixels` may be host OR device memory (hipMemcpyDefault).
+ * The engine owns all device memory it allocates; caller buffers stay caller-owned.
+ */
+#ifndef CONZIC_HIP_H
+#define CONZIC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CZC_OK 0
+#define CZC_ERR_ARG 1
+#define CZC_ERR_HIP 2
+#define CZC_ERR_STATE 3
+#define CZC_ERR_OVERFLOW 4 /* text bridge scratch overflow (row text > CZC_BRIDGE_MAX_BYTES) */
+
+#define CZC_PREC_BF16 0 /* bf16 MFMA operands, fp32 accumulate/residual/LN/softmax (throughput mode) */
+#define CZC_PREC_F32 1  /* f32-input MFMA everywhere (verification mode, ~1e-6 of the CPU reference) */
+
+#define CZC_BRIDGE_MAX_BYTES 512 /* decoded caption text per candidate row */
+#define CZC_CLIP_MAX_LEN 77       /* clip/clip.py:71-72 (max_length = 77, truncation) */
+#define CZC_MAX_TOPK 1024
+#define CZC_MAX_BERT_LEN 64
+
+typedef struct czc_engine czc_engine;
+
+/* Shapes of the three frozen towers the reference loads at demo.py:125-132 / clip/clip.py:11-16. */
+typedef struct czc_config {
+  /* BertForMaskedLM (HF:bert/modeling_bert.py) */
+  int32_t bert_vocab, bert_hidden, bert_layers, bert_heads, bert_inter, bert_max_pos;
+  float bert_eps;
+  /* CLIP text tower + projection (HF:clip/modeling_clip.py:494-586, :675) */
+  int32_t clip_vocab, clip_hidden, clip_layers, clip_heads, clip_inter, clip_max_pos, clip_proj;
+  float clip_eps;
+  int32_t clip_bos_id, clip_eos_id;
+  /* CLIP vision tower + projection (HF:clip/modeling_clip.py:594-656, :674) */
+  int32_t vis_hidden, vis_layers, vis_heads, vis_inter, vis_image, vis_patch;
+  /* BERT special ids (tokenizer.mask_token_id gen_utils.py:67; vocab['.'] utils.py:55-58; skip set gen_utils.py:75) */
+  int32_t pad_id, unk_id, cls_id, sep_id, mask_id, dot_id;
+  int32_t precision; /* CZC_PREC_* */
+} czc_config;
+
+/* Tables that replace the host string round trip of gen_utils.py:75 (batch_decode) ->
+ * clip/clip.py:71-74 (CLIPTokenizer) with an on-device BERT-id -> CLIP-id bridge.
+ * Built once on the host from the two tokenizers (conzic_amd/bridge.py). */
+typedef struct czc_bridge_tables {
+  int32_t bert_vocab;
+  const uint32_t* piece_off;  /* [bert_vocab+1] offsets into piece_bytes/piece_class            */
+  const uint8_t* piece_bytes; /* UTF-8 of each piece, '##' stripped, NFC + lowercased            */
+  const uint8_t* piece_class; /* per byte: bits0-1 class of its char (0 L,1 N,2 other,3 space),  */
+                              /*           bit2 = first byte of a char                           */
+  const uint8_t* piece_flags; /* [bert_vocab] bit0 special (skipped), bit1 '##' continuation,    */
+                              /*              bit2 clean-up removes the space before it          */
+  int32_t clip_vocab;
+  const int32_t* byte_sym;     /* [256] CLIP id of a byte inside a word                          */
+  const int32_t* byte_sym_eow; /* [256] CLIP id of a byte that ends a word ('</w>' suffix)       */
+  int32_t n_merges;
+  const int32_t* merge_left;  /* [n_merges] BPE merges in rank order: (left,right) -> out        */
+  const int32_t* merge_right;
+  const int32_t* merge_out;
+  int32_t bos_id, eos_id;
+} czc_bridge_tables;
+
+/* Hyper-parameters of one generate call: demo.py:55-60 / gen_utils.py:289-292 keyword arguments. */
+typedef struct czc_hyper {
+  float alpha;       /* weight of BERT fluency probs          (gen_utils.py:77)              */
+  float beta;        /* weight of CLIP softmax_K score        (gen_utils.py:77)              */
+  float gamma;       /* weight of sentiment softmax_K         (control_gen_utils.py:59)      */
+  float temperature; /* lm_temperature                         (gen_utils.py:43-44)           */
+  int32_t use_sentiment; /* 0 caption path, 1 sentiment path (adds gamma term + repeat penalty) */
+  int32_t negative;      /* sentiment_ctl == "negative" (sentiments_classifer.py:31-32)         */
+} czc_hyper;
+
+/* Outputs of one position-step at parity granularity (every pointer optional / may be NULL).
+ * Shapes use B images, K = top_k.  Host or device memory. */
+typedef struct czc_step_out {
+  float* probs;      /* [B,K] masked softmax probs, descending   (gen_utils.py:45-47) */
+  int32_t* idxs;     /* [B,K] their vocab ids                     (gen_utils.py:47)    */
+  int32_t* cand_ids; /* [B,K] idxs * token_mask[idxs]             (gen_utils.py:72)    */
+  int32_t* clip_ids; /* [B*K, CZC_CLIP_MAX_LEN] bridged CLIP ids  (clip/clip.py:71-74) */
+  int32_t* clip_len; /* [B*K] tokens incl. BOS/EOS                                     */
+  float* clip_score; /* [B,K] softmax_K(cos * exp(logit_scale))   (clip/clip.py:97)    */
+  float* clip_ref;   /* [B,K] cosine                              (clip/clip.py:98)    */
+  float* senti_raw;  /* [B,K] sentence sentiment score            (sentiments_classifer.py:46) */
+  float* repeats;    /* [B,K] repeat count - 1                    (control_gen_utils.py:53)    */
+  float* final_score;/* [B,K] fused score                         (gen_utils.py:77 / control_gen_utils.py:59) */
+  int32_t* best;     /* [B]   argmax_K (first max)                (gen_utils.py:78)    */
+  float* best_cos;   /* [B]   cosine of the winner                (gen_utils.py:80)    */
+  float* logits;     /* [B,V] BERT logits of the masked row       (gen_utils.py:42)    */
+} czc_step_out;
+
+/* ---- lifecycle ---------------------------------------------------------------------- */
+int czc_create(const czc_config* cfg, int device_id, czc_engine** out_engine);
+int czc_destroy(czc_engine* e);
+const char* czc_last_error(const czc_engine* e); /* e may be NULL: last create error */
+int czc_version(void);
+
+/* ---- frozen state (replaces from_pretrained at demo.py:125-126, clip/clip.py:12-16) ---- */
+/* One call per state-dict entry (names and shapes: SURVEY.md §8b).  dtype must be 0 (fp32).
+ * `src` may be a device pointer, which is how ranks > 0 hand over weights they received
+ * through the RCCL broadcast (bench.py / conzic_amd/dist.py). */
+int czc_load_tensor(czc_engine* e, const char* name, int dtype, int ndim, const int64_t* shape, const void* src);
+/* After the last czc_load_tensor: checks completeness, fuses q/k/v, ties the MLM decoder to the
+ * word embeddings (HF:bert/modeling_bert.py:910-913), converts GEMM operands to the engine precision. */
+int czc_finalize_weights(czc_engine* e);
+/* token_mask of demo.py:135-143: fp32 [V]; the '.' entry is overridden per step (utils.py:53-59). */
+int czc_set_token_mask(czc_engine* e, const float* mask, int vocab);
+int czc_set_bridge(czc_engine* e, const czc_bridge_tables* t);
+/* Per-BERT-token sentiment score (stand-in for sentiments_classifer.py:9-33). */
+int czc_set_lexicon(czc_engine* e, const float* lexicon, int vocab);
+
+/* ---- once per image: clip/clip.py:48-62 after the image processor ------------------------ */
+/* pixels fp32 [B,3,S,S] -> un-normalised image_embeds [B,proj] (out may be NULL).  The engine
+ * keeps the L2-normalised embeds resident for the following step/generate calls (the north
+ * star's "encode once per image and cache"). */
+int czc_encode_images(czc_engine* e, const float* pixels, int B, float* out_embeds);
+/* Alternative: hand over image_embeds computed elsewhere (fp32 [B,proj], un-normalised). */
+int czc_set_image_embeds(czc_engine* e, const float* embeds, int B);
+
+/* clip/clip.py:64-84 after tokenisation: CLIP ids int32 [n, CZC_CLIP_MAX_LEN] (right-padded) and
+ * lengths (tokens incl. BOS/EOS) -> un-normalised text_embeds fp32 [n, proj]. */
+int czc_encode_text(czc_engine* e, const int32_t* clip_ids, const int32_t* clip_len, int n, float* out_embeds);
+
+/* ---- the hot path ------------------------------------------------------------------------ */
+/* Parity granularity: one position-step (gen_utils.py:66-81) on `inp` int32 [B,T] (in/out, host
+ * or device).  gen_idx = seed_len + position; n_mask = how many consecutive positions starting
+ * at gen_idx are overwritten with [MASK] before the BERT forward (1 normally, 2 for the first
+ * step of a span, 0 = re-use the previous forward, gen_utils.py:164-166); dot_allowed = the
+ * update_token_mask rule (utils.py:53-59). */
+int czc_step(czc_engine* e, int32_t* inp, int B, int T, int gen_idx, int n_mask, int dot_allowed, int top_k,
+             const czc_hyper* hp, const czc_step_out* out);
+
+/* Throughput granularity: a whole *_generation call with no host round trips except one 8-byte
+ * size read per step.  init_ids int32 [T] = `[CLS] prompt [MASK]xL [SEP]` (utils.py:46-51),
+ * seed_len = len(prompt.split())+1 (gen_utils.py:56), positions[n_steps] / n_mask[n_steps] as in
+ * czc_step, snapshot_every = steps per bookkeeping snapshot (gen_utils.py:82-92).
+ * out_ids int32 [n_steps/snapshot_every, B, T], out_cos fp32 [n_steps/snapshot_every, B]
+ * (the winner cosine of the snapshot's last step, gen_utils.py:80-81,92). */
+int czc_generate(czc_engine* e, int B, int T, int L, int seed_len, const int32_t* init_ids_host, int top_k,
+                 int n_steps, const int32_t* positions_host, const int32_t* n_mask_host, int snapshot_every,
+                 const czc_hyper* hp, int32_t* out_ids, float* out_cos);
+
+/* ---- measurement ------------------------------------------------------------------------- */
+/* HIP-event timing of kernel classes on the engine's own stream (bench.py roofline leg).
+ * kind: "gemm_clip_text" | "gemm_bert" | "gemm_vision" | "attention" | "rowops" | "topk" | "bridge" | "combine" */
+int czc_profile_enable(czc_engine* e, int on);
+int czc_profile_reset(czc_engine* e);
+int czc_profile_get(czc_engine* e, const char* kind, double* total_ms, int64_t* launches, double* flops);
+int czc_sync(czc_engine* e);
+/* counters of the last generate/step: rows pushed through the CLIP text tower etc. */
+int czc_stats(czc_engine* e, int64_t* clip_rows, int64_t* clip_seqs, int64_t* bert_rows, int64_t* steps);
+
+/* ---- kernel-level parity hooks (tests only; host pointers, synchronous) -------------------- */
+/* C[M,N] = A[M,K] * W[N,K]^T (+bias) (+activation: 0 none, 1 quick_gelu, 2 gelu_erf) (+resid[M,N]) */
+int czc_test_gemm(int precision, int M, int N, int K, const float* A, const float* W, const float* bias,
+                  const float* resid, int act, float* C);
+int czc_test_layernorm(int precision, int M, int H, const float* x, const float* gamma, const float* beta, float eps,
+                       float* y);
+/* qkv [sum(len), 3*heads*64] packed sequences; causal 0/1; scale; out [sum(len), heads*64] */
+int czc_test_attention(int precision, int n_seq, const int32_t* seq_len, int heads, int causal, float scale,
+                       const float* qkv, float* out);
+int czc_test_topk(int B, int V, int K, const float* logits, const float* mask, float temperature, int dot_id,
+                  int dot_allowed, float* probs, int32_t* idxs, int32_t* cand);
+int czc_test_bridge(const czc_bridge_tables* t, const czc_config* cfg, int n_rows, int T, const int32_t* rows,
+                    int32_t* clip_ids, int32_t* clip_len);
+int czc_test_combine(int B, int K, int D, const float* text_feat, const float* img_embeds, float logit_scale,
+                     const float* probs, const float* senti_raw, const float* repeats, const czc_hyper* hp,
+                     float* clip_score, float* clip_ref, float* final_score, int32_t* best);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CONZIC_HIP_H */

@@ -1,0 +1,110 @@
+"""CPU tests of the host side: C-ABI symbol export, product tokenizers, bridge tables."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conzic_amd import native, synth
+from conzic_amd.bridge import tables_from_tokenizers
+from conzic_amd.text import tokenizers_from_vocab
+from conzic_amd import harness
+from goldutil import GOLD
+from bridge_emulator import emulate_row
+
+
+def test_library_exports_every_declared_symbol():
+    """include/conzic_hip.h is the contract: every `int czc_*(` / `const char* czc_*(` must be
+    exported by the shared library and typed in native.SIGNATURES (no compute calls here)."""
+    hdr = open(native.HEADER_PATH).read()
+    declared = set(re.findall(r"\b(czc_[a-z_0-9]+)\s*\(", hdr))
+    declared -= {"czc_engine"}
+    assert declared, "no declarations parsed"
+    lib = native.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+        assert name in native.SIGNATURES, f"{name} has no ctypes signature"
+    assert set(native.SIGNATURES) <= declared
+    assert lib.czc_version() >= 100
+
+
+def test_struct_sizes_match_header_layout():
+    assert native.ctypes_sizeof_ok() if hasattr(native, "ctypes_sizeof_ok") else True
+    import ctypes as C
+    assert C.sizeof(native.Config) == 30 * 4
+    assert C.sizeof(native.Hyper) == 6 * 4
+    assert C.sizeof(native.StepOut) == 13 * C.sizeof(C.c_void_p)
+
+
+def test_create_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(native.NativeError, match="no HIP device|no CPU fallback|failed"):
+        harness.build_synthetic(tiny=True)
+
+
+@pytest.fixture(scope="module")
+def bridge_gold():
+    return json.load(open(os.path.join(GOLD, "text_bridge.json")))
+
+
+@pytest.mark.parametrize("label", ["tiny", "full"])
+def test_product_tokenizers_match_hf_golden(bridge_gold, label):
+    sv = harness.cached_vocab(label == "tiny")
+    bt, ct = tokenizers_from_vocab(sv)
+    g = bridge_gold[label]
+    assert bt.encode("Image of a" + bt.mask_token * 5) == g["init_ids"]
+    for ids, s, c in zip(g["rows"], g["strings"], g["clip_ids"]):
+        assert bt.decode(ids, skip_special_tokens=True) == s
+        assert ct([s])["input_ids"][0] == c
+    for ids, s in zip(g["rows"], g["full_decode"]):
+        assert bt.decode(ids) == s
+
+
+@pytest.mark.parametrize("label", ["tiny", "full"])
+def test_bridge_tables_and_device_algorithm_emulated(bridge_gold, label):
+    """The device bridge's algorithm, executed in Python on the real tables, reproduces the HF
+    decode -> CLIP tokenise round trip id-for-id (incl. '##' gluing, punctuation clean-up,
+    contractions, non-ASCII, [unusedN], truncation to 77)."""
+    sv = harness.cached_vocab(label == "tiny")
+    bt, ct = tokenizers_from_vocab(sv)
+    t = tables_from_tokenizers(bt, ct)
+    g = bridge_gold[label]
+    n_over = 0
+    for ids, c in zip(g["rows"], g["clip_ids"]):
+        try:
+            assert emulate_row(t, ids) == c
+        except OverflowError:
+            n_over += 1
+    assert n_over <= len(g["rows"]) // 8  # only the deliberately over-long rows may overflow
+
+
+def test_token_mask_composition():
+    sv = harness.cached_vocab(True)
+    m = synth.make_token_mask(sv)
+    bv = sv.bert_vocab
+    assert m.shape == (1, len(sv.bert_tokens))
+    assert m[0, bv["[UNK]"]] == 0 and m[0, bv["[unused1]"]] == 0 and m[0, bv["!"]] == 0
+    assert m[0, bv["image"]] == 1 and m[0, bv["[MASK]"]] == 1  # specials are NOT stop words (demo.py:135-143)
+    mr = synth.make_token_mask(sv, regular_only=True)
+    assert mr[0, sv.regular_lo:sv.regular_hi].all() and mr.sum() == sv.regular_hi - sv.regular_lo
+
+
+def test_order_positions():
+    pos, nm, every = harness.order_positions("span", 5, 2)
+    assert pos == [0, 1, 2, 3, 4] * 2 and nm == [2, 0, 2, 0, 1] * 2 and every == 5
+    pos, nm, every = harness.order_positions("shuffle", 4, 2, order_list=[2, 1, 3, 0])
+    assert pos == [2, 1, 3, 0, 2, 1, 3, 0]
+
+
+def test_weight_generator_is_order_independent_and_tied():
+    cfg = synth.bert_tiny(640)
+    a = synth.make_bert_weights(cfg, 11)
+    b = synth.make_bert_weights(cfg, 11)
+    for k in a:
+        assert np.array_equal(a[k], b[k])
+    assert a["cls.predictions.decoder.weight"] is a["bert.embeddings.word_embeddings.weight"]
+    c = synth.make_bert_weights(cfg, 12)
+    assert not np.array_equal(a["cls.predictions.bias"], c["cls.predictions.bias"])

@@ -1,0 +1,96 @@
+"""Pins the CPU oracle (oracle/) against goldens captured from the real reference
+(/root/reference driven by HF transformers; tests/golden/make_goldens.py).  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conzic_amd import synth
+from goldutil import GOLD, load_case, make_oracle
+from oracle import models as M
+from oracle import step as S
+from oracle import text as T
+
+TINY_CASES = ["tiny_seq", "tiny_shuffle", "tiny_span", "tiny_random", "tiny_senti_seq", "tiny_senti_shuffle",
+              "tiny_scale100"]
+
+
+def _run_oracle(meta, arr):
+    o, sv, mask = make_oracle(meta)
+    pix = synth.pixels_from_u8(synth.make_images_u8(meta["B"], o.clip_cfg.v_image))
+    trace = []
+    kw = {}
+    if meta["order"] == "shuffle":
+        kw["order_list"] = meta["order_list"]
+    if meta["order"] == "random":
+        kw["random_positions"] = meta["positions"]
+    texts, scores, ids = S.generate(o, pix, mask, meta["prompt"], meta["L"], meta["K"], meta["temperature"],
+                                    meta["alpha"], meta["beta"], meta["I"], order=meta["order"], gamma=meta["gamma"],
+                                    ctl_signal=meta["style"], trace=trace, **kw)
+    return o, texts, scores, ids, trace
+
+
+@pytest.mark.parametrize("name", TINY_CASES)
+def test_oracle_reproduces_reference_trajectory(name):
+    meta, arr = load_case(name)
+    o, texts, scores, ids, trace = _run_oracle(meta, arr)
+    assert texts == meta["texts"]
+    np.testing.assert_allclose(np.array(scores, dtype=np.float64), np.array(meta["scores"]), atol=2e-6)
+    assert [t["pos"] for t in trace] == meta["positions"]
+    for i, t in enumerate(trace):
+        np.testing.assert_array_equal(t["idxs"].numpy(), arr["idxs"][i])
+        np.testing.assert_allclose(t["probs"].numpy(), arr["probs"][i], rtol=2e-4, atol=1e-7)
+        np.testing.assert_allclose(t["clip_score"].numpy(), arr["clip_score"][i], atol=2e-6, rtol=5e-5)
+        np.testing.assert_allclose(t["clip_ref"].numpy(), arr["clip_ref"][i], atol=2e-6)
+        ln = arr["clip_lens"][i]
+        np.testing.assert_array_equal(t["clip_lens"].numpy(), ln)
+        for r in range(len(ln)):
+            np.testing.assert_array_equal(t["clip_ids"][r, :ln[r]].numpy(), arr["clip_ids"][i][r, :ln[r]])
+    # sweep snapshots (ids after every sweep, as the reference's batch_decode(inp) saw them)
+    for s, snap in enumerate(ids):
+        np.testing.assert_array_equal(snap.numpy(), arr["snaps"][s])
+
+
+def test_shuffle_order_matches_cpython_stream():
+    meta, _ = load_case("tiny_shuffle")
+    assert S.shuffle_order(meta["L"], seed=meta["seed"]) == meta["order_list"]
+    # L=10 -> [7,3,2,8,5,6,9,4,0,1] for random.seed(42)
+    assert S.shuffle_order(10, seed=42) == [7, 3, 2, 8, 5, 6, 9, 4, 0, 1]
+
+
+@pytest.mark.parametrize("label", ["tiny", "full"])
+def test_oracle_text_bridge_matches_hf(label):
+    g = json.load(open(os.path.join(GOLD, "text_bridge.json")))[label]
+    sv = synth.make_vocab_tiny() if label == "tiny" else synth.make_vocab()
+    bpe = T.ClipBpe(sv.clip_vocab, sv.clip_merges)
+    assert T.bert_encode("Image of a" + "[MASK]" * 5, sv.bert_vocab) == g["init_ids"]
+    for ids, s, c in zip(g["rows"], g["strings"], g["clip_ids"]):
+        assert T.bert_decode(ids, sv.bert_tokens) == s
+        assert bpe.encode(s) == c
+
+
+def test_oracle_vision_tower_tiny():
+    z = np.load(os.path.join(GOLD, "vision_tiny.npz"))
+    sv = synth.make_vocab_tiny()
+    ccfg = synth.clip_tiny(len(sv.clip_vocab))
+    w = M.to_torch(synth.make_clip_weights(ccfg, 12))
+    pix = synth.pixels_from_u8(synth.make_images_u8(3, ccfg.v_image))
+    emb = M.clip_image_embeds(w, ccfg, torch.from_numpy(pix)).numpy()
+    np.testing.assert_allclose(emb, z["image_embeds"], atol=3e-6)
+
+
+def test_oracle_full_size_first_step_cfg1():
+    """BASELINE config 1 (bert-base / CLIP ViT-B/32 shapes, K=200): first position-step."""
+    meta, arr = load_case("full_cfg1")
+    o, sv, mask = make_oracle(meta)
+    inp = torch.from_numpy(arr["inp_before"][0].astype(np.int64))
+    emb = torch.from_numpy(arr["image_embeds"])
+    o.update_token_mask(mask, meta["L"], 0)
+    r = S.polish_step(o, inp, emb, mask, 4, meta["K"], meta["temperature"], meta["alpha"], meta["beta"])
+    np.testing.assert_allclose(r["logits_row"].numpy(), arr["logits_row0"], atol=3e-5)
+    np.testing.assert_array_equal(r["idxs"].numpy(), arr["idxs"][0])
+    np.testing.assert_allclose(r["clip_ref"].numpy(), arr["clip_ref"][0], atol=3e-6)
+    np.testing.assert_allclose(r["clip_score"].numpy(), arr["clip_score"][0], atol=1e-6)
+    np.testing.assert_array_equal(r["inp_after"].numpy()[:, 4], arr["inp_before"][1][:, 4])
