@@ -56,7 +56,9 @@ struct czc_engine {
   hipStream_t st = nullptr;
   char err[512] = {0};
   bool finalized = false;
-  size_t esz = 2;  // bytes per activation element
+  size_t esz = 2;  // bytes per CLIP activation element
+  int pb = PREC_F32, pc = PREC_BF16;  // BERT / CLIP tower precisions
+  size_t eb = 4;   // bytes per BERT activation element
 
   std::map<std::string, Tensor> w;
   std::vector<LayerW> bert, ctext, cvis;
@@ -158,16 +160,18 @@ int need(czc_engine* e, const std::string& n, size_t numel, float** out) {
 }
 
 // GEMM operand in engine precision (new allocation); frees nothing
-int to_act(czc_engine* e, const float* src, size_t numel, void** out) {
+int to_act(czc_engine* e, int prec, const float* src, size_t numel, void** out) {
   void* p = nullptr;
-  E_HIP(hipMalloc(&p, numel * e->esz));
-  E_CHECK(launch_convert(e->cfg.precision, src, p, (long)numel, e->st));
+  E_HIP(hipMalloc(&p, numel * (prec == PREC_BF16 ? 2 : 4)));
+  E_CHECK(launch_convert(prec, src, p, (long)numel, e->st));
   *out = p;
   return 0;
 }
 
 int build_layers(czc_engine* e, std::vector<LayerW>& L, int n_layers, int H, int I, bool bert_style,
                  const std::string& prefix) {
+  const int prec = bert_style ? e->pb : e->pc;
+  const size_t es = prec == PREC_BF16 ? 2 : 4;
   L.resize(n_layers);
   for (int n = 0; n < n_layers; ++n) {
     LayerW& l = L[n];
@@ -189,34 +193,34 @@ int build_layers(czc_engine* e, std::vector<LayerW>& L, int n_layers, int H, int
     E_CHECK(need(e, q + ".bias", H, &qb));
     E_CHECK(need(e, k + ".bias", H, &kb));
     E_CHECK(need(e, v + ".bias", H, &vb));
-    E_HIP(hipMalloc(&l.qkv_w, (size_t)3 * H * H * e->esz));
+    E_HIP(hipMalloc(&l.qkv_w, (size_t)3 * H * H * es));
     char* base = (char*)l.qkv_w;
-    E_CHECK(launch_convert(e->cfg.precision, qw, base, (long)H * H, e->st));
-    E_CHECK(launch_convert(e->cfg.precision, kw, base + (size_t)H * H * e->esz, (long)H * H, e->st));
-    E_CHECK(launch_convert(e->cfg.precision, vw, base + (size_t)2 * H * H * e->esz, (long)H * H, e->st));
+    E_CHECK(launch_convert(prec, qw, base, (long)H * H, e->st));
+    E_CHECK(launch_convert(prec, kw, base + (size_t)H * H * es, (long)H * H, e->st));
+    E_CHECK(launch_convert(prec, vw, base + (size_t)2 * H * H * es, (long)H * H, e->st));
     E_HIP(hipMalloc((void**)&l.qkv_b, (size_t)3 * H * 4));
     E_HIP(hipMemcpyAsync(l.qkv_b, qb, (size_t)H * 4, hipMemcpyDeviceToDevice, e->st));
     E_HIP(hipMemcpyAsync(l.qkv_b + H, kb, (size_t)H * 4, hipMemcpyDeviceToDevice, e->st));
     E_HIP(hipMemcpyAsync(l.qkv_b + 2 * H, vb, (size_t)H * 4, hipMemcpyDeviceToDevice, e->st));
-    E_CHECK(need(e, o + ".weight", (size_t)H * H, &t)); E_CHECK(to_act(e, t, (size_t)H * H, &l.o_w));
+    E_CHECK(need(e, o + ".weight", (size_t)H * H, &t)); E_CHECK(to_act(e, prec, t, (size_t)H * H, &l.o_w));
     E_CHECK(need(e, o + ".bias", H, &l.o_b));
     E_CHECK(need(e, ln1 + ".weight", H, &l.ln1_g)); E_CHECK(need(e, ln1 + ".bias", H, &l.ln1_b));
-    E_CHECK(need(e, fc1 + ".weight", (size_t)I * H, &t)); E_CHECK(to_act(e, t, (size_t)I * H, &l.fc1_w));
+    E_CHECK(need(e, fc1 + ".weight", (size_t)I * H, &t)); E_CHECK(to_act(e, prec, t, (size_t)I * H, &l.fc1_w));
     E_CHECK(need(e, fc1 + ".bias", I, &l.fc1_b));
-    E_CHECK(need(e, fc2 + ".weight", (size_t)H * I, &t)); E_CHECK(to_act(e, t, (size_t)H * I, &l.fc2_w));
+    E_CHECK(need(e, fc2 + ".weight", (size_t)H * I, &t)); E_CHECK(to_act(e, prec, t, (size_t)H * I, &l.fc2_w));
     E_CHECK(need(e, fc2 + ".bias", H, &l.fc2_b));
     E_CHECK(need(e, ln2 + ".weight", H, &l.ln2_g)); E_CHECK(need(e, ln2 + ".bias", H, &l.ln2_b));
   }
   return 0;
 }
 
-int gemm(czc_engine* e, const char* kind, const void* A, int lda, const void* W, int ldw, const float* bias,
+int gemm(czc_engine* e, int prec, const char* kind, const void* A, int lda, const void* W, int ldw, const float* bias,
          const float* resid, int ldr, void* out_act, float* out_f32, int ldc, int M, int N, int K, int act) {
   GemmArgs g;
   g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.resid = resid; g.ldr = ldr;
   g.out_act = out_act; g.out_f32 = out_f32; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.act = act;
   ProfScope ps(e, kind, 2.0 * M * (double)N * K);
-  E_CHECK(launch_gemm(e->cfg.precision, g, e->st));
+  E_CHECK(launch_gemm(prec, g, e->st));
   return 0;
 }
 
@@ -224,7 +228,7 @@ int gemm(czc_engine* e, const char* kind, const void* A, int lda, const void* W,
 // x_f32 [M,H] residual stream (updated in place); packed sequences described by off/len or fixed_T
 int clip_stack(czc_engine* e, const char* gk, std::vector<LayerW>& L, float* x, int M, int H, int I, int heads,
                float eps, const int* off, const int* len, int fixed_T, int n_seq, int max_len, int causal) {
-  const int P = e->cfg.precision;
+  const int P = e->pc;
   void *y, *qkv, *ctx, *hbuf;
   E_CHECK(ensure(e, "cs_y", (size_t)M * H * e->esz, &y));
   E_CHECK(ensure(e, "cs_qkv", (size_t)M * 3 * H * e->esz, &qkv));
@@ -234,13 +238,13 @@ int clip_stack(czc_engine* e, const char* gk, std::vector<LayerW>& L, float* x, 
   for (size_t n = 0; n < L.size(); ++n) {
     LayerW& l = L[n];
     { ProfScope ps(e, "rowops", 0); E_CHECK(launch_layernorm(P, x, nullptr, l.ln1_g, l.ln1_b, eps, M, H, y, nullptr, e->st)); }
-    E_CHECK(gemm(e, gk, y, H, l.qkv_w, H, l.qkv_b, nullptr, 0, qkv, nullptr, 3 * H, M, 3 * H, H, ACT_NONE));
+    E_CHECK(gemm(e, P, gk, y, H, l.qkv_w, H, l.qkv_b, nullptr, 0, qkv, nullptr, 3 * H, M, 3 * H, H, ACT_NONE));
     { ProfScope ps(e, "attention", 0);
       E_CHECK(launch_attention(P, qkv, off, len, fixed_T, n_seq, max_len, heads, causal, scale, ctx, e->st)); }
-    E_CHECK(gemm(e, gk, ctx, H, l.o_w, H, l.o_b, x, H, nullptr, x, H, M, H, H, ACT_NONE));
+    E_CHECK(gemm(e, P, gk, ctx, H, l.o_w, H, l.o_b, x, H, nullptr, x, H, M, H, H, ACT_NONE));
     { ProfScope ps(e, "rowops", 0); E_CHECK(launch_layernorm(P, x, nullptr, l.ln2_g, l.ln2_b, eps, M, H, y, nullptr, e->st)); }
-    E_CHECK(gemm(e, gk, y, H, l.fc1_w, H, l.fc1_b, nullptr, 0, hbuf, nullptr, I, M, I, H, ACT_QUICK_GELU));
-    E_CHECK(gemm(e, gk, hbuf, I, l.fc2_w, I, l.fc2_b, x, H, nullptr, x, H, M, H, I, ACT_NONE));
+    E_CHECK(gemm(e, P, gk, y, H, l.fc1_w, H, l.fc1_b, nullptr, 0, hbuf, nullptr, I, M, I, H, ACT_QUICK_GELU));
+    E_CHECK(gemm(e, P, gk, hbuf, I, l.fc2_w, I, l.fc2_b, x, H, nullptr, x, H, M, H, I, ACT_NONE));
   }
   return 0;
 }
@@ -248,14 +252,14 @@ int clip_stack(czc_engine* e, const char* gk, std::vector<LayerW>& L, float* x, 
 // ---- BERT encoder (post-LN) on [B*T] rows: leaves the final hidden state in ws "b_x" ----------
 int bert_forward(czc_engine* e, const int* d_inp, int B, int T) {
   const czc_config& c = e->cfg;
-  const int P = c.precision, M = B * T, H = c.bert_hidden, I = c.bert_inter;
+  const int P = e->pb, M = B * T, H = c.bert_hidden, I = c.bert_inter;
   void *xa, *qkv, *ctx, *hbuf; float *x, *tmp;
   E_CHECK(ensure(e, "b_x", (size_t)M * H * 4, (void**)&x));
   E_CHECK(ensure(e, "b_tmp", (size_t)M * H * 4, (void**)&tmp));
-  E_CHECK(ensure(e, "b_xa", (size_t)M * H * e->esz, &xa));
-  E_CHECK(ensure(e, "b_qkv", (size_t)M * 3 * H * e->esz, &qkv));
-  E_CHECK(ensure(e, "b_ctx", (size_t)M * H * e->esz, &ctx));
-  E_CHECK(ensure(e, "b_h", (size_t)M * I * e->esz, &hbuf));
+  E_CHECK(ensure(e, "b_xa", (size_t)M * H * e->eb, &xa));
+  E_CHECK(ensure(e, "b_qkv", (size_t)M * 3 * H * e->eb, &qkv));
+  E_CHECK(ensure(e, "b_ctx", (size_t)M * H * e->eb, &ctx));
+  E_CHECK(ensure(e, "b_h", (size_t)M * I * e->eb, &hbuf));
   float *word, *pos, *typ, *g, *b;
   E_CHECK(need(e, "bert.embeddings.word_embeddings.weight", (size_t)c.bert_vocab * H, &word));
   E_CHECK(need(e, "bert.embeddings.position_embeddings.weight", (size_t)c.bert_max_pos * H, &pos));
@@ -267,13 +271,13 @@ int bert_forward(czc_engine* e, const int* d_inp, int B, int T) {
   const float scale = 1.0f / sqrtf(64.0f);
   for (int n = 0; n < c.bert_layers; ++n) {
     LayerW& l = e->bert[n];
-    E_CHECK(gemm(e, "gemm_bert", xa, H, l.qkv_w, H, l.qkv_b, nullptr, 0, qkv, nullptr, 3 * H, M, 3 * H, H, ACT_NONE));
+    E_CHECK(gemm(e, P, "gemm_bert", xa, H, l.qkv_w, H, l.qkv_b, nullptr, 0, qkv, nullptr, 3 * H, M, 3 * H, H, ACT_NONE));
     { ProfScope ps(e, "attention", 0);
       E_CHECK(launch_attention(P, qkv, nullptr, nullptr, T, B, T, c.bert_heads, 0, scale, ctx, e->st)); }
-    E_CHECK(gemm(e, "gemm_bert", ctx, H, l.o_w, H, l.o_b, x, H, nullptr, tmp, H, M, H, H, ACT_NONE));
+    E_CHECK(gemm(e, P, "gemm_bert", ctx, H, l.o_w, H, l.o_b, x, H, nullptr, tmp, H, M, H, H, ACT_NONE));
     { ProfScope ps(e, "rowops", 0); E_CHECK(launch_layernorm(P, tmp, nullptr, l.ln1_g, l.ln1_b, c.bert_eps, M, H, xa, x, e->st)); }
-    E_CHECK(gemm(e, "gemm_bert", xa, H, l.fc1_w, H, l.fc1_b, nullptr, 0, hbuf, nullptr, I, M, I, H, ACT_GELU_ERF));
-    E_CHECK(gemm(e, "gemm_bert", hbuf, I, l.fc2_w, I, l.fc2_b, x, H, nullptr, tmp, H, M, H, I, ACT_NONE));
+    E_CHECK(gemm(e, P, "gemm_bert", xa, H, l.fc1_w, H, l.fc1_b, nullptr, 0, hbuf, nullptr, I, M, I, H, ACT_GELU_ERF));
+    E_CHECK(gemm(e, P, "gemm_bert", hbuf, I, l.fc2_w, I, l.fc2_b, x, H, nullptr, tmp, H, M, H, I, ACT_NONE));
     { ProfScope ps(e, "rowops", 0); E_CHECK(launch_layernorm(P, tmp, nullptr, l.ln2_g, l.ln2_b, c.bert_eps, M, H, xa, x, e->st)); }
   }
   e->stat_bert_rows += M;
@@ -284,14 +288,14 @@ int bert_forward(czc_engine* e, const int* d_inp, int B, int T) {
 // MLM head on row gen_idx of every sequence -> logits fp32 [B,V] in ws "b_logits"
 int mlm_head(czc_engine* e, int B, int T, int gen_idx, float** logits_out) {
   const czc_config& c = e->cfg;
-  const int P = c.precision, H = c.bert_hidden, V = c.bert_vocab;
+  const int P = e->pb, H = c.bert_hidden, V = c.bert_vocab;
   float* x = (float*)e->ws["b_x"].p;
   int* idx; float *gx, *t32, *logits; void *ga, *ta;
   E_CHECK(ensure(e, "h_idx", (size_t)B * 4, (void**)&idx));
   E_CHECK(ensure(e, "h_gx", (size_t)B * H * 4, (void**)&gx));
-  E_CHECK(ensure(e, "h_ga", (size_t)B * H * e->esz, &ga));
+  E_CHECK(ensure(e, "h_ga", (size_t)B * H * e->eb, &ga));
   E_CHECK(ensure(e, "h_t32", (size_t)B * H * 4, (void**)&t32));
-  E_CHECK(ensure(e, "h_ta", (size_t)B * H * e->esz, &ta));
+  E_CHECK(ensure(e, "h_ta", (size_t)B * H * e->eb, &ta));
   E_CHECK(ensure(e, "b_logits", (size_t)B * V * 4, (void**)&logits));
   float *db, *g, *b, *bias;
   E_CHECK(need(e, "cls.predictions.transform.dense.bias", H, &db));
@@ -302,9 +306,9 @@ int mlm_head(czc_engine* e, int B, int T, int gen_idx, float** logits_out) {
     E_CHECK(launch_make_row_index(idx, B, T, gen_idx, e->st));
     E_CHECK(launch_gather_rows_f32(x, idx, B, H, gx, e->st));
     E_CHECK(launch_convert(P, gx, ga, (long)B * H, e->st)); }
-  E_CHECK(gemm(e, "gemm_bert", ga, H, e->mlm_dense_w, H, db, nullptr, 0, nullptr, t32, H, B, H, H, ACT_GELU_ERF));
+  E_CHECK(gemm(e, P, "gemm_bert", ga, H, e->mlm_dense_w, H, db, nullptr, 0, nullptr, t32, H, B, H, H, ACT_GELU_ERF));
   { ProfScope ps(e, "rowops", 0); E_CHECK(launch_layernorm(P, t32, nullptr, g, b, c.bert_eps, B, H, ta, nullptr, e->st)); }
-  E_CHECK(gemm(e, "gemm_bert", ta, H, e->decoder_w, H, bias, nullptr, 0, nullptr, logits, V, B, V, H, ACT_NONE));
+  E_CHECK(gemm(e, P, "gemm_bert", ta, H, e->decoder_w, H, bias, nullptr, 0, nullptr, logits, V, B, V, H, ACT_NONE));
   *logits_out = logits;
   return 0;
 }
@@ -313,7 +317,7 @@ int mlm_head(czc_engine* e, int B, int T, int gen_idx, float** logits_out) {
 int clip_text_forward(czc_engine* e, const int* cids, const int* clen, const int* coff, int* eidx, int n_seq, int M,
                       int max_len, float** feat_out) {
   const czc_config& c = e->cfg;
-  const int P = c.precision;
+  const int P = e->pc;
   const int H = c.clip_hidden;
   float *x, *feat, *tok, *pos, *fg, *fb; void* pa;
   E_CHECK(ensure(e, "c_x", (size_t)M * H * 4, (void**)&x));
@@ -330,7 +334,7 @@ int clip_text_forward(czc_engine* e, const int* cids, const int* clen, const int
   { ProfScope ps(e, "rowops", 0);
     E_CHECK(launch_eos_index(coff, clen, n_seq, eidx, e->st));
     E_CHECK(launch_layernorm(P, x, eidx, fg, fb, c.clip_eps, n_seq, H, pa, nullptr, e->st)); }
-  E_CHECK(gemm(e, "gemm_clip_text", pa, H, e->tproj_w, H, nullptr, nullptr, 0, nullptr, feat, c.clip_proj, n_seq,
+  E_CHECK(gemm(e, P, "gemm_clip_text", pa, H, e->tproj_w, H, nullptr, nullptr, 0, nullptr, feat, c.clip_proj, n_seq,
                c.clip_proj, H, ACT_NONE));
 
   *feat_out = feat;
@@ -349,7 +353,6 @@ int step_device(czc_engine* e, int* d_inp, int B, int T, int gen_idx, int n_mask
   if (T > CZC_MAX_BERT_LEN || gen_idx < 0 || gen_idx >= T || K > CZC_MAX_TOPK)
     return fail(e, CZC_ERR_ARG, "step: bad T/gen_idx/K%s");
   if (hp->use_sentiment && !e->d_lex) return fail(e, CZC_ERR_STATE, "sentiment path needs a lexicon%s");
-  const int P = c.precision;
   const int n_seq = B * K;
 
   if (n_mask > 0) {
@@ -429,7 +432,7 @@ int czc_create(const czc_config* cfg, int device_id, czc_engine** out) {
     snprintf(czc::g_err, sizeof(czc::g_err), "czc_create: head_dim must be 64 for all towers");
     return CZC_ERR_ARG;
   }
-  if (cfg->precision != CZC_PREC_BF16 && cfg->precision != CZC_PREC_F32) {
+  if (cfg->precision != CZC_PREC_BF16 && cfg->precision != CZC_PREC_F32 && cfg->precision != CZC_PREC_ALL_BF16) {
     snprintf(czc::g_err, sizeof(czc::g_err), "czc_create: unknown precision");
     return CZC_ERR_ARG;
   }
@@ -445,7 +448,12 @@ int czc_create(const czc_config* cfg, int device_id, czc_engine** out) {
   czc_engine* e = new czc_engine();
   e->cfg = *cfg;
   e->dev = device_id;
-  e->esz = cfg->precision == CZC_PREC_BF16 ? 2 : 4;
+  // precision 0: CLIP towers on bf16 MFMA, BERT on f32 MFMA (the tau=0.1 softmax amplifies logit
+  // error tenfold and BERT is 1.4% of the FLOPs); 1: everything f32; 2: everything bf16 (experiments)
+  e->pc = cfg->precision == CZC_PREC_F32 ? PREC_F32 : PREC_BF16;
+  e->pb = cfg->precision == CZC_PREC_ALL_BF16 ? PREC_BF16 : PREC_F32;
+  e->esz = e->pc == PREC_BF16 ? 2 : 4;
+  e->eb = e->pb == PREC_BF16 ? 2 : 4;
   if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&e->st) != hipSuccess ||
       hipHostMalloc((void**)&e->h_totals, 64) != hipSuccess) {
     snprintf(czc::g_err, sizeof(czc::g_err), "czc_create: stream/host allocation failed");
@@ -505,22 +513,22 @@ int czc_finalize_weights(czc_engine* e) {
   float* t;
   if (has_bert) {
     E_CHECK(need(e, "cls.predictions.transform.dense.weight", (size_t)c.bert_hidden * c.bert_hidden, &t));
-    E_CHECK(to_act(e, t, (size_t)c.bert_hidden * c.bert_hidden, &e->mlm_dense_w));
+    E_CHECK(to_act(e, e->pb, t, (size_t)c.bert_hidden * c.bert_hidden, &e->mlm_dense_w));
     // decoder weight tied to the word embeddings (HF:bert/modeling_bert.py:910-913)
     E_CHECK(need(e, "bert.embeddings.word_embeddings.weight", (size_t)c.bert_vocab * c.bert_hidden, &t));
-    E_CHECK(to_act(e, t, (size_t)c.bert_vocab * c.bert_hidden, &e->decoder_w));
+    E_CHECK(to_act(e, e->pb, t, (size_t)c.bert_vocab * c.bert_hidden, &e->decoder_w));
     if (!find(e, "cls.predictions.bias") && find(e, "cls.predictions.decoder.bias")) {
       e->w["cls.predictions.bias"] = e->w["cls.predictions.decoder.bias"];
       e->w.erase("cls.predictions.decoder.bias");
     }
   }
   E_CHECK(need(e, "text_projection.weight", (size_t)c.clip_proj * c.clip_hidden, &t));
-  E_CHECK(to_act(e, t, (size_t)c.clip_proj * c.clip_hidden, &e->tproj_w));
+  E_CHECK(to_act(e, e->pc, t, (size_t)c.clip_proj * c.clip_hidden, &e->tproj_w));
   E_CHECK(need(e, "visual_projection.weight", (size_t)c.clip_proj * c.vis_hidden, &t));
-  E_CHECK(to_act(e, t, (size_t)c.clip_proj * c.vis_hidden, &e->vproj_w));
+  E_CHECK(to_act(e, e->pc, t, (size_t)c.clip_proj * c.vis_hidden, &e->vproj_w));
   const size_t pk = (size_t)3 * c.vis_patch * c.vis_patch;
   E_CHECK(need(e, "vision_model.embeddings.patch_embedding.weight", (size_t)c.vis_hidden * pk, &t));
-  E_CHECK(to_act(e, t, (size_t)c.vis_hidden * pk, &e->patch_w));
+  E_CHECK(to_act(e, e->pc, t, (size_t)c.vis_hidden * pk, &e->patch_w));
   const Tensor* ls = find(e, "logit_scale");
   if (!ls) return fail(e, CZC_ERR_STATE, "missing tensor %s", "logit_scale");
   float lsv = 0.f;
@@ -632,7 +640,7 @@ int czc_encode_images(czc_engine* e, const float* pixels, int B, float* out_embe
   if (!e->finalized) return fail(e, CZC_ERR_STATE, "weights not finalized%s");
   E_HIP(hipSetDevice(e->dev));
   const czc_config& c = e->cfg;
-  const int P = c.precision, S = c.vis_image, p = c.vis_patch, G = S / p, NP = G * G, H = c.vis_hidden;
+  const int P = e->pc, S = c.vis_image, p = c.vis_patch, G = S / p, NP = G * G, H = c.vis_hidden;
   const int Kc = 3 * p * p, T = NP + 1, M = B * T;
   float *pix, *pe, *x, *emb; void *patches, *ca; int* idx;
   E_CHECK(ensure(e, "v_pix", (size_t)B * 3 * S * S * 4, (void**)&pix));
@@ -651,7 +659,7 @@ int czc_encode_images(czc_engine* e, const float* pixels, int B, float* out_embe
   E_CHECK(need(e, "vision_model.post_layernorm.weight", H, &g1));
   E_CHECK(need(e, "vision_model.post_layernorm.bias", H, &b1));
   { ProfScope ps(e, "rowops", 0); E_CHECK(launch_im2col(P, pix, B, S, p, patches, e->st)); }
-  E_CHECK(gemm(e, "gemm_vision", patches, Kc, e->patch_w, Kc, nullptr, nullptr, 0, nullptr, pe, H, B * NP, H, Kc, ACT_NONE));
+  E_CHECK(gemm(e, P, "gemm_vision", patches, Kc, e->patch_w, Kc, nullptr, nullptr, 0, nullptr, pe, H, B * NP, H, Kc, ACT_NONE));
   { ProfScope ps(e, "rowops", 0);
     E_CHECK(launch_vision_assemble(pe, B, NP, H, cls, pos, x, e->st));
     E_CHECK(launch_layernorm(P, x, nullptr, g0, b0, c.clip_eps, M, H, nullptr, x, e->st)); }
@@ -659,7 +667,7 @@ int czc_encode_images(czc_engine* e, const float* pixels, int B, float* out_embe
   { ProfScope ps(e, "rowops", 0);
     E_CHECK(launch_make_row_index(idx, B, T, 0, e->st));
     E_CHECK(launch_layernorm(P, x, idx, g1, b1, c.clip_eps, B, H, ca, nullptr, e->st)); }
-  E_CHECK(gemm(e, "gemm_vision", ca, H, e->vproj_w, H, nullptr, nullptr, 0, nullptr, emb, c.clip_proj, B, c.clip_proj, H, ACT_NONE));
+  E_CHECK(gemm(e, P, "gemm_vision", ca, H, e->vproj_w, H, nullptr, nullptr, 0, nullptr, emb, c.clip_proj, B, c.clip_proj, H, ACT_NONE));
   if (e->img_B < B) { if (e->d_img_n) (void)hipFree(e->d_img_n); e->d_img_n = nullptr; E_HIP(hipMalloc((void**)&e->d_img_n, (size_t)B * c.clip_proj * 4)); }
   E_CHECK(launch_l2_normalize(emb, B, c.clip_proj, e->d_img_n, e->st));
   e->img_B = B;

@@ -1,0 +1,233 @@
+"""-m gpu: every HIP kernel, called through the C ABI (czc_test_*), against the CPU oracle /
+a plain torch fp32 statement of the same op."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conzic_amd import engine as E
+from conzic_amd import harness, native, synth
+from conzic_amd.bridge import tables_from_tokenizers
+from conzic_amd.text import tokenizers_from_vocab
+from goldutil import GOLD
+
+pytestmark = pytest.mark.gpu
+
+BF16, F32 = native.PREC_BF16, native.PREC_F32
+
+
+def _bf16_round(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(torch.bfloat16).to(torch.float32).numpy()
+
+
+def _act(v, act):
+    t = torch.from_numpy(v)
+    if act == 1:
+        return (t * torch.sigmoid(1.702 * t)).numpy()
+    if act == 2:
+        return torch.nn.functional.gelu(t).numpy()
+    return v
+
+
+@pytest.mark.parametrize("prec", [F32, BF16])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 256, 512), (15, 768, 768), (300, 200, 192), (1, 30522, 128),
+                                   (3000, 512, 2048), (129, 1536, 512), (77, 64, 3072)])
+def test_gemm_asymmetric(prec, M, N, K):
+    """Asymmetric random operands (catches operand/row-col transposes), ragged M/N edges."""
+    rng = np.random.default_rng(M * 7 + N * 3 + K)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
+    W[:, : K // 2] *= 3.0  # asymmetric along K too
+    C = E.test_gemm(prec, A, W)
+    if prec == BF16:
+        ref = _bf16_round(A).astype(np.float64) @ _bf16_round(W).astype(np.float64).T
+        tol = 2e-3 * np.sqrt(K / 64)
+    else:
+        ref = A.astype(np.float64) @ W.astype(np.float64).T
+        tol = 2e-5 * np.sqrt(K / 64)
+    err = np.abs(C - ref).max()
+    assert err < tol, f"max err {err} (tol {tol})"
+
+
+@pytest.mark.parametrize("prec", [F32, BF16])
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_gemm_epilogues(prec, act):
+    rng = np.random.default_rng(act + 10)
+    M, N, K = 200, 320, 256
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) * 0.1).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    resid = rng.standard_normal((M, N)).astype(np.float32)
+    C = E.test_gemm(prec, A, W, bias=bias, resid=resid, act=act)
+    a, w = (A, W) if prec == F32 else (_bf16_round(A), _bf16_round(W))
+    pre = (a.astype(np.float64) @ w.astype(np.float64).T + bias).astype(np.float32)
+    ref = _act(pre, act) + resid
+    assert np.abs(C - ref).max() < (3e-5 if prec == F32 else 2e-3)
+
+
+@pytest.mark.parametrize("prec", [F32, BF16])
+@pytest.mark.parametrize("H", [128, 512, 768])
+def test_layernorm(prec, H):
+    rng = np.random.default_rng(H)
+    x = (rng.standard_normal((37, H)) * 3 + 0.5).astype(np.float32)
+    g = (1 + 0.1 * rng.standard_normal(H)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(H)).astype(np.float32)
+    for eps in (1e-5, 1e-12):
+        y = E.test_layernorm(prec, x, g, b, eps)
+        ref = torch.nn.functional.layer_norm(torch.from_numpy(x), (H,), torch.from_numpy(g), torch.from_numpy(b), eps).numpy()
+        tol = 3e-6 * 10 if prec == F32 else 2e-2
+        assert np.abs(y - ref).max() < tol
+
+
+def _attn_ref(qkv, lens, heads, causal, scale):
+    Hd = heads * 64
+    out = np.zeros((qkv.shape[0], Hd), np.float32)
+    o = 0
+    for L in lens:
+        blk = torch.from_numpy(qkv[o:o + L])
+        q, k, v = blk[:, :Hd], blk[:, Hd:2 * Hd], blk[:, 2 * Hd:]
+        q = q.view(L, heads, 64).transpose(0, 1)
+        k = k.view(L, heads, 64).transpose(0, 1)
+        v = v.view(L, heads, 64).transpose(0, 1)
+        s = q @ k.transpose(-1, -2) * scale
+        if causal:
+            s = s + torch.full((L, L), float("-inf")).triu(1)
+        out[o:o + L] = (torch.softmax(s, -1) @ v).transpose(0, 1).reshape(L, Hd).numpy()
+        o += L
+    return out
+
+
+@pytest.mark.parametrize("prec", [F32, BF16])
+@pytest.mark.parametrize("causal", [True, False])
+def test_attention_packed_sequences(prec, causal):
+    rng = np.random.default_rng(3)
+    heads = 8
+    lens = [15, 1, 7, 16, 20, 77, 50, 64, 65, 2]
+    M = sum(lens)
+    qkv = rng.standard_normal((M, 3 * heads * 64)).astype(np.float32)
+    if prec == BF16:
+        qkv = _bf16_round(qkv)
+    out = E.test_attention(prec, qkv, lens, heads, causal, 0.125)
+    ref = _attn_ref(qkv, lens, heads, causal, 0.125)
+    assert np.abs(out - ref).max() < (2e-5 if prec == F32 else 1.5e-2)
+
+
+@pytest.mark.parametrize("heads", [2, 12])
+def test_attention_other_head_counts(heads):
+    rng = np.random.default_rng(4)
+    lens = [17, 17, 50]
+    qkv = rng.standard_normal((sum(lens), 3 * heads * 64)).astype(np.float32)
+    out = E.test_attention(F32, qkv, lens, heads, False, 0.125)
+    assert np.abs(out - _attn_ref(qkv, lens, heads, False, 0.125)).max() < 2e-5
+
+
+@pytest.mark.parametrize("V,K", [(640, 12), (30522, 200), (30522, 512), (5000, 1024)])
+def test_softmax_mask_topk(V, K):
+    rng = np.random.default_rng(V + K)
+    B = 5
+    logits = (rng.standard_normal((B, V)) * 0.6).astype(np.float32)
+    mask = (rng.random(V) > 0.1).astype(np.float32)
+    dot_id = 17
+    for dot_allowed in (False, True):
+        p, i, c = E.test_topk(logits, mask, K, 0.1, dot_id, dot_allowed)
+        m = torch.from_numpy(mask.copy())
+        m[dot_id] = 1.0 if dot_allowed else 0.0
+        probs = torch.softmax(torch.from_numpy(logits) / 0.1, -1) * m
+        rp, ri = probs.topk(K, dim=-1)
+        np.testing.assert_allclose(p, rp.numpy(), rtol=2e-5, atol=1e-30)
+        # ids must agree except where two neighbours are tied to within exp() rounding
+        bad = np.argwhere(i != ri.numpy())
+        for b_, k_ in bad:
+            assert np.isclose(probs[b_, int(i[b_, k_])].item(), rp[b_, k_].item(), rtol=1e-5), (b_, k_)
+        assert len(bad) <= 4
+        mi = torch.from_numpy(i.astype(np.int64))
+        np.testing.assert_array_equal(c, (mi * m[mi]).long().numpy())
+        assert (np.diff(p, axis=1) <= 0).all()
+
+
+def test_topk_ties_and_all_masked():
+    """Fewer than K non-zero probabilities: zeros are taken in ascending id, cand -> 0 ([PAD])."""
+    V, K = 1000, 16
+    logits = np.zeros((2, V), np.float32)
+    logits[0, [5, 900, 33]] = [3.0, 2.0, 1.0]
+    logits[1, :] = np.linspace(0, 1, V)
+    mask = np.zeros(V, np.float32)
+    mask[[5, 33, 900]] = 1
+    p, i, c = E.test_topk(logits, mask, K, 1.0, 0, False)
+    assert i[0, :3].tolist() == [5, 900, 33]
+    assert i[0, 3:].tolist() == [j for j in range(V) if j not in (5, 33, 900)][: K - 3]
+    assert (p[0, 3:] == 0).all() and (c[0, 3:] == 0).all()
+    assert i[1, :3].tolist() == [900, 33, 5]
+
+
+@pytest.mark.parametrize("label", ["tiny", "full"])
+def test_device_bridge_matches_hf_golden(label):
+    g = json.load(open(os.path.join(GOLD, "text_bridge.json")))[label]
+    sv = harness.cached_vocab(label == "tiny")
+    bt, ct = tokenizers_from_vocab(sv)
+    t = tables_from_tokenizers(bt, ct)
+    by_len = {}
+    for ids, c in zip(g["rows"], g["clip_ids"]):
+        if len(ids) <= 64:
+            by_len.setdefault(len(ids), []).append((ids, c))
+    n = 0
+    for T, items in by_len.items():
+        rows = np.array([it[0] for it in items], np.int32)
+        ids, ln = E.test_bridge(t, rows)
+        for r, (_, c) in enumerate(items):
+            assert ln[r] == len(c)
+            assert ids[r, : ln[r]].tolist() == c
+            assert (ids[r, ln[r]:] == t.eos_id).all()
+            n += 1
+    assert n > 200
+
+
+def test_device_bridge_overflow_fails_loudly():
+    sv = harness.cached_vocab(True)
+    bt, ct = tokenizers_from_vocab(sv)
+    t = tables_from_tokenizers(bt, ct)
+    longest = max(range(len(sv.bert_tokens)), key=lambda i: len(sv.bert_tokens[i].encode()))
+    rows = np.full((1, 64), longest, np.int32)
+    if 64 * (len(sv.bert_tokens[longest].encode()) + 1) > 512:
+        with pytest.raises(native.NativeError, match="overflow"):
+            E.test_bridge(t, rows)
+
+
+@pytest.mark.parametrize("senti", [False, True])
+def test_fused_score_combine(senti):
+    rng = np.random.default_rng(11)
+    B, K, D = 3, 200, 512
+    tf = rng.standard_normal((B * K, D)).astype(np.float32)
+    ie = rng.standard_normal((B, D)).astype(np.float32)
+    probs = np.sort(rng.random((B, K)).astype(np.float32), axis=1)[:, ::-1].copy()
+    sraw = rng.standard_normal((B, K)).astype(np.float32)
+    reps = rng.integers(0, 3, (B, K)).astype(np.float32)
+    for ls in (2.6592, 4.6052):
+        hp = E.Engine.hyper(0.02, 2.0, 0.1, gamma=5.0 if senti else None)
+        cs, cr, fs, best = E.test_combine(tf, ie, ls, probs, hp, sraw if senti else None, reps if senti else None)
+        t = torch.from_numpy(tf).view(B, K, D)
+        i = torch.from_numpy(ie)
+        t = t / t.norm(dim=-1, keepdim=True)
+        i = i / i.norm(dim=-1, keepdim=True)
+        scale = torch.tensor(ls).exp()
+        lg = torch.matmul(t, i.unsqueeze(-1)).squeeze(-1) * scale
+        rcs, rcr = lg.softmax(1), lg / scale
+        fin = 0.02 * torch.from_numpy(probs) + 2.0 * rcs
+        if senti:
+            fin = fin + 5.0 * torch.softmax(torch.from_numpy(sraw), 1) + 0.1 * (1 - torch.exp(torch.from_numpy(reps)))
+        np.testing.assert_allclose(cr, rcr.numpy(), atol=2e-6)
+        np.testing.assert_allclose(cs, rcs.numpy(), atol=2e-6, rtol=2e-4)
+        np.testing.assert_allclose(fs, fin.numpy(), atol=1e-5, rtol=2e-4)
+        np.testing.assert_array_equal(best, fin.argmax(1).numpy())
+
+
+def test_combine_first_argmax_on_ties():
+    B, K, D = 1, 8, 64
+    tf = np.tile(np.arange(1, D + 1, dtype=np.float32), (K, 1))  # identical candidates
+    ie = np.ones((B, D), np.float32)
+    probs = np.zeros((B, K), np.float32)
+    hp = E.Engine.hyper(0.02, 2.0, 0.1)
+    _, _, fs, best = E.test_combine(tf, ie, 2.0, probs, hp)
+    assert best[0] == 0 and np.allclose(fs, fs[0, 0])

@@ -1,0 +1,242 @@
+"""-m gpu: the polishing step and whole trajectories through the C ABI (czc_step / czc_generate /
+czc_encode_images / czc_encode_text) against goldens captured from the real reference."""
+import numpy as np
+import pytest
+import torch
+
+from conzic_amd import harness, native, synth
+from conzic_amd.engine import Engine
+from goldutil import load_case
+
+pytestmark = pytest.mark.gpu
+
+BF16, F32 = native.PREC_BF16, native.PREC_F32
+SEED_LEN = 4
+
+# fused-score tolerance of the north star ("within 1e-3 on the fused logits") at the BASELINE
+# shapes (K=200).  The tiny fixtures use K<=16, where one candidate carries ~1/K of the CLIP
+# softmax mass, so the same bf16 cosine error (<=4e-3) moves the fused score ~K_full/K_tiny more.
+def tol_final(prec, tiny):
+    if prec == F32:
+        return 2e-5
+    return 2.5e-2 if tiny else 1e-3
+
+_setups = {}
+
+
+def setup_for(meta, prec):
+    key = (meta["tiny"], prec, meta["bseed"], meta["cseed"], round(meta["logit_scale"], 4), meta["regular_only"],
+           meta["gamma"] is not None)
+    if key not in _setups:
+        if len(_setups) >= 3:  # bound device memory: drop the oldest engines
+            k0 = next(iter(_setups))
+            _setups.pop(k0).engine.close()
+        _setups[key] = harness.build_synthetic(meta["tiny"], prec, meta["bseed"], meta["cseed"], meta["logit_scale"],
+                                               meta["regular_only"], lexicon=meta["gamma"] is not None)
+    return _setups[key]
+
+
+def gold_final(meta, arr, i, su):
+    """final_score exactly as the reference forms it from the captured tensors
+    (gen_utils.py:77, control_gen_utils.py:53-59)."""
+    probs = torch.from_numpy(arr["probs"][i])
+    cs = torch.from_numpy(arr["clip_score"][i])
+    fin = meta["alpha"] * probs + meta["beta"] * cs
+    if meta["gamma"] is not None:
+        B, K = probs.shape
+        gen_idx = SEED_LEN + meta["positions"][i]
+        inp = torch.from_numpy(arr["inp_before"][i].astype(np.int64))
+        mask = torch.from_numpy(su.token_mask.copy())
+        mask[0, su.bert_tok.vocab["."]] = 1.0 if meta["positions"][i] == meta["L"] - 1 else 0.0
+        idxs = torch.from_numpy(arr["idxs"][i].astype(np.int64))
+        idxs_ = (idxs * mask[0][idxs]).long()
+        rows = inp.unsqueeze(1).repeat(1, K, 1)
+        rows[:, :, gen_idx] = idxs_
+        reps = (idxs_[:, :, None] == rows).float().sum(2) - 1
+        lex = torch.from_numpy(synth.make_lexicon(len(su.sv.bert_tokens)))
+        keep = torch.ones_like(rows, dtype=torch.bool)
+        for s in su.bert_tok.all_special_ids:
+            keep &= rows != s
+        sraw = (lex[rows] * keep).sum(2)
+        if meta["style"] == "negative":
+            sraw = -sraw
+        fin = fin + meta["gamma"] * torch.softmax(sraw, 1) + 0.1 * (1 - torch.exp(reps))
+    return fin.numpy()
+
+
+def check_step(meta, arr, i, res, su, prec, next_inp):
+    """Compare one engine step with golden step i; returns number of soft mismatches."""
+    B, K = arr["probs"][i].shape
+    tol = tol_final(prec, meta["tiny"])
+    gfin = gold_final(meta, arr, i, su)
+    gen_idx = SEED_LEN + meta["positions"][i]
+    soft = 0
+    for b in range(B):
+        gi, ei = arr["idxs"][i][b], res["idxs"][b]
+        gmap = {int(t): k for k, t in enumerate(gi)}
+        common = [(k, gmap[int(t)]) for k, t in enumerate(ei) if int(t) in gmap]
+        need = K - 1  # BERT runs on f32 MFMA in both engine precisions
+        assert len(common) >= need, f"step {i} img {b}: only {len(common)}/{K} candidates shared"
+        ek = np.array([c[0] for c in common])
+        gk = np.array([c[1] for c in common])
+        # fluency probs (tau=0.1 amplifies logit error tenfold)
+        np.testing.assert_allclose(res["probs"][b][ek], arr["probs"][i][b][gk], rtol=3e-3, atol=1e-12)
+        assert (ek == gk).mean() > 0.97, "top-K order differs beyond near-ties"
+        # bridged CLIP ids are integer work: exact
+        for e_, g_ in zip(ek, gk):
+            ln = arr["clip_lens"][i][b * K + g_]
+            assert res["clip_len"][b * K + e_] == ln
+            np.testing.assert_array_equal(res["clip_ids"][b * K + e_, :ln], arr["clip_ids"][i][b * K + g_, :ln])
+        np.testing.assert_allclose(res["clip_ref"][b][ek], arr["clip_ref"][i][b][gk], atol=5e-6 if prec == F32 else 4e-3)
+        if len(common) == K:
+            np.testing.assert_allclose(res["clip_score"][b][ek], arr["clip_score"][i][b][gk],
+                                       atol=2e-6 if prec == F32 else tol / 2,
+                                       rtol=1e-4 if prec == F32 else (5e-2 if meta["logit_scale"] < 4.0 else 0.5))
+            if not (prec == BF16 and meta["logit_scale"] > 4.0):
+                # scale = 100 (published-checkpoint emulation) multiplies the bf16 cosine error by 100 before
+                # the softmax: out of budget by construction (SURVEY.md §7 hard part 2); the cosine bound
+                # above still holds, and the f32 engine passes this case at 2e-5.
+                np.testing.assert_allclose(res["final_score"][b][ek], gfin[b][gk], atol=tol, rtol=0)
+        # winner: identical token wherever the reference's own top-2 margin exceeds the error bound
+        srt = np.sort(gfin[b])[::-1]
+        margin = srt[0] - srt[1]
+        gbest_tok = int(next_inp[b, gen_idx]) if next_inp is not None else None
+        ebest_tok = int(res["cand_ids"][b][res["best"][b]])
+        if gbest_tok is not None:
+            if margin > 2 * tol:
+                assert ebest_tok == gbest_tok, f"step {i} img {b}: winner {ebest_tok} != {gbest_tok} (margin {margin})"
+            elif ebest_tok != gbest_tok:
+                soft += 1
+    return soft
+
+
+def teacher_forced(meta, arr, prec, n_steps=None):
+    su = setup_for(meta, prec)
+    eng = su.engine
+    eng.set_image_embeds(arr["image_embeds"])
+    hp = Engine.hyper(meta["alpha"], meta["beta"], meta["temperature"], meta["gamma"], meta["style"] == "negative")
+    n = arr["probs"].shape[0] if n_steps is None else min(n_steps, arr["probs"].shape[0])
+    soft = 0
+    prev_inp = None
+    for i in range(n):
+        pos = meta["positions"][i]
+        reuse = meta["reuse"][i]
+        if reuse:
+            inp = prev_inp  # second position of a span: state after the first, same forward
+            n_mask = 0
+        else:
+            inp = np.ascontiguousarray(arr["inp_before"][i], dtype=np.int32)
+            n_mask = 1
+            if i + 1 < len(meta["reuse"]) and meta["reuse"][i + 1]:
+                n_mask = 2
+        res = eng.step(inp, SEED_LEN + pos, meta["K"], hp, n_mask=n_mask, dot_allowed=(pos == meta["L"] - 1),
+                       want=("probs", "idxs", "cand_ids", "clip_ids", "clip_len", "clip_score", "clip_ref",
+                             "final_score", "best", "best_cos"))
+        nxt = None
+        if i + 1 < arr["inp_before"].shape[0] and not (i + 1 < len(meta["reuse"]) and meta["reuse"][i + 1]):
+            nxt = arr["inp_before"][i + 1]
+            if meta["positions"][i + 1] == pos:
+                nxt = None  # the next step re-masks the same slot: winner not observable
+        soft += check_step(meta, arr, i, res, su, prec, nxt)
+        prev_inp = inp
+    return soft, n
+
+
+TINY = ["tiny_seq", "tiny_shuffle", "tiny_span", "tiny_random", "tiny_senti_seq", "tiny_senti_shuffle", "tiny_scale100"]
+
+
+@pytest.mark.parametrize("name", TINY)
+def test_step_parity_tiny_f32(name):
+    meta, arr = load_case(name)
+    soft, n = teacher_forced(meta, arr, F32)
+    assert soft <= max(1, n // 10)
+
+
+@pytest.mark.parametrize("name", TINY)
+def test_step_parity_tiny_bf16(name):
+    meta, arr = load_case(name)
+    soft, n = teacher_forced(meta, arr, BF16)
+    assert soft <= n  # near-tie winners may flip in bf16; hard asserts are inside check_step
+
+
+@pytest.mark.parametrize("name", ["full_cfg1", "full_synth_b2", "full_regular"])
+def test_step_parity_full_size_f32(name):
+    """BASELINE configs 1/2 shapes (bert-base + CLIP ViT-B/32, K=200) in the verification precision."""
+    meta, arr = load_case(name)
+    soft, n = teacher_forced(meta, arr, F32, n_steps=6)
+    assert soft <= 1
+
+
+@pytest.mark.parametrize("name", ["full_cfg1", "full_synth_b2", "full_regular"])
+def test_step_parity_full_size_bf16(name):
+    """BASELINE config 2: bf16 MFMA engine vs the CPU reference: fused score within 1e-3."""
+    meta, arr = load_case(name)
+    teacher_forced(meta, arr, BF16, n_steps=10)
+
+
+@pytest.mark.parametrize("name", TINY)
+def test_generate_free_running_tiny_f32(name):
+    """czc_generate (no host round trips) reproduces the reference trajectory id-for-id."""
+    meta, arr = load_case(name)
+    su = setup_for(meta, F32)
+    eng = su.engine
+    eng.set_image_embeds(arr["image_embeds"])
+    hp = Engine.hyper(meta["alpha"], meta["beta"], meta["temperature"], meta["gamma"], meta["style"] == "negative")
+    init = su.bert_tok.encode(meta["prompt"] + su.bert_tok.mask_token * meta["L"])
+    pos, nm, every = harness.order_positions(meta["order"], meta["L"], meta["I"], order_list=meta["order_list"],
+                                             random_positions=meta["positions"])
+    assert pos == meta["positions"]
+    ids, cos = eng.generate(meta["B"], init, meta["L"], SEED_LEN, meta["K"], pos, hp, n_mask=nm, snapshot_every=every)
+    np.testing.assert_array_equal(ids, arr["snaps"])
+    np.testing.assert_allclose(cos, np.array(meta["scores"][:-1], dtype=np.float32), atol=1e-5)
+    texts = [su.bert_tok.batch_decode(s, skip_special_tokens=True) for s in ids]
+    assert texts == meta["texts"][:-1]
+
+
+@pytest.mark.parametrize("prec", [F32, BF16])
+@pytest.mark.parametrize("label", ["tiny", "full"])
+def test_vision_tower(prec, label):
+    z = np.load(f"{harness.__file__.rsplit('/', 2)[0]}/tests/golden/vision_{label}.npz")
+    meta = dict(tiny=label == "tiny", bseed=11, cseed=12, logit_scale=2.6592, regular_only=False, gamma=None)
+    su = setup_for(meta, prec)
+    pix = synth.pixels_from_u8(synth.make_images_u8(3, su.clip_cfg.v_image))
+    emb = su.engine.encode_images(pix)
+    ref = z["image_embeds"]
+    err = np.abs(emb - ref).max()
+    scale = np.abs(ref).max()
+    assert err < (3e-5 if prec == F32 else 3e-2) * max(1.0, scale), (err, scale)
+    cosv = (emb * ref).sum(1) / np.linalg.norm(emb, axis=1) / np.linalg.norm(ref, axis=1)
+    assert (cosv > (0.999999 if prec == F32 else 0.9995)).all()
+
+
+@pytest.mark.parametrize("prec", [F32, BF16])
+def test_encode_text_ragged_lengths(prec):
+    """CLIP text tower on packed ragged sequences (empty caption = BOS,EOS; longest = 77)."""
+    from oracle import models as M
+    meta = dict(tiny=True, bseed=11, cseed=12, logit_scale=2.6592, regular_only=False, gamma=None)
+    su = setup_for(meta, prec)
+    ccfg = su.clip_cfg
+    rng = np.random.default_rng(0)
+    lens = np.array([2, 3, 77, 16, 15, 40, 2, 64], np.int32)
+    ids = np.full((len(lens), 77), ccfg.eos_id, np.int32)
+    for r, L in enumerate(lens):
+        ids[r, 0] = ccfg.bos_id
+        ids[r, 1:L - 1] = rng.integers(0, ccfg.vocab - 2, size=L - 2)
+    out = su.engine.encode_text(ids, lens)
+    w = M.to_torch(synth.make_clip_weights(ccfg, 12))
+    ref = M.clip_text_embeds(w, ccfg, torch.from_numpy(ids.astype(np.int64)), torch.from_numpy(lens)).numpy()
+    assert np.abs(out - ref).max() < (3e-5 if prec == F32 else 5e-2)
+
+
+def test_step_rejects_bad_arguments():
+    meta = dict(tiny=True, bseed=11, cseed=12, logit_scale=2.6592, regular_only=False, gamma=None)
+    su = setup_for(meta, F32)
+    su.engine.set_image_embeds(np.ones((2, su.clip_cfg.proj), np.float32))
+    inp = np.array([su.bert_tok.encode("Image of a" + "[MASK]" * 3)] * 2, np.int32)
+    hp = Engine.hyper(0.02, 2.0, 0.1)
+    with pytest.raises(native.NativeError):
+        su.engine.step(inp, 99, 8, hp)
+    with pytest.raises(native.NativeError, match="lexicon"):
+        e2 = harness.build_synthetic(True, F32)
+        e2.engine.set_image_embeds(np.ones((2, su.clip_cfg.proj), np.float32))
+        e2.engine.step(inp.copy(), 4, 8, Engine.hyper(0.02, 2.0, 0.1, gamma=5.0))
