@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Throughput benchmark of the polishing engine (contract: see the task prompt / DESIGN.md §5).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One *step* = one full `generate_caption` pass over one batch of synthetic images on every rank:
+BASELINE.json configs[2] -- 256 random-pixel 224x224 images per GPU, sequential order, L=10,
+K=200, I=10 sweeps, alpha=0.02, beta=2.0, tau=0.1, prompt "Image of a" -- including the CLIP
+vision encode of the batch (once per image).  value = captions/s of the whole job
+(N * 256 * K / max-over-ranks time).  Weak scaling: per-GPU work is fixed.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def f_step(K, T, Tc):
+    """Algorithmic FLOPs of one image-position-step as the reference executes it."""
+    return K * (Tc * 75.87e6 + 0.52e6) + T * 218.5e6
+
+
+def caption_flops(L, K, I, P=3):
+    T = L + P + 2
+    tot = 0.0
+    for it in range(I):
+        for j in range(L):
+            Tc = (P + 2 + j + 1) if it == 0 else T  # first sweep: unfilled [MASK]s are dropped
+            tot += f_step(K, T, Tc)
+    return tot + 8.7e9
+
+
+def cpu_baseline(L, K, threads=None):
+    """The oracle (CPU restatement of the reference, oracle/) timed on this host: B=1, config-1
+    shape.  Bounded sample: sweeps 1 and 2 of 10 (2*L position-steps); sweeps 3..10 cost the same
+    as sweep 2 (all positions filled, Tc = T), so caption time = t_sweep1 + 9 * t_sweep2."""
+    import torch
+    from conzic_amd import synth
+    from oracle import models as M, step as S, text as T
+    if threads:
+        torch.set_num_threads(threads)
+    sv = synth.make_vocab()
+    bcfg, ccfg = synth.bert_base(), synth.clip_b32()
+    o = S.Oracle(M.to_torch(synth.make_bert_weights(bcfg, 11)), bcfg, M.to_torch(synth.make_clip_weights(ccfg, 12)),
+                 ccfg, sv.bert_tokens, T.ClipBpe(sv.clip_vocab, sv.clip_merges))
+    mask = torch.from_numpy(synth.make_token_mask(sv, regular_only=True))
+    pix = synth.pixels_from_u8(synth.make_images_u8(1))
+    with torch.no_grad():
+        t0 = time.time()
+        emb = o.image_embeds(pix)
+        t_img = time.time() - t0
+        inp = torch.tensor(o.init_text("Image of a", L, 1))
+        ts = []
+        for sweep in range(2):
+            t0 = time.time()
+            for ii in range(L):
+                o.update_token_mask(mask, L, ii)
+                inp[:, 4 + ii] = o.mask_id
+                S.polish_step(o, inp, emb, mask, 4 + ii, K, 0.1, 0.02, 2.0)
+            ts.append(time.time() - t0)
+    t_caption = t_img + ts[0] + 9 * ts[1]
+    return dict(value=1.0 / t_caption, unit="captions/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"oracle (plain torch fp32) B=1 L={L} K={K}: sweeps 1-2 of 10 timed "
+                       f"({ts[0]:.2f}s + {ts[1]:.2f}s, image encode {t_img:.2f}s); caption = t1 + 9*t2 = {t_caption:.1f}s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--images", type=int, default=256, help="images per GPU per step (configs[2]: 256)")
+    ap.add_argument("--len", type=int, default=10, dest="L")
+    ap.add_argument("--topk", type=int, default=200)
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--order", default="sequential", choices=["sequential", "shuffle"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event kernel timing (roofline)")
+    a = ap.parse_args()
+
+    import torch
+    from conzic_amd import dist as czd
+    from conzic_amd import harness, native, synth
+    from conzic_amd.engine import Engine
+
+    rank, world, local = czd.env_rank_world()
+    assert world == a.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {a.gpus}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the engine has no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    prec = native.PREC_BF16 if a.precision == "bf16" else native.PREC_F32
+    bcfg, ccfg = synth.bert_base(), synth.clip_b32()
+    # frozen weights: generated on rank 0, broadcast once over RCCL (xGMI), consumed in place
+    t0 = time.time()
+    if world > 1:
+        bw = czd.broadcast_state(synth.make_bert_weights(bcfg, 11) if rank == 0 else None, dev)
+        cw = czd.broadcast_state(synth.make_clip_weights(ccfg, 12) if rank == 0 else None, dev)
+        torch.cuda.synchronize()
+    else:
+        bw, cw = synth.make_bert_weights(bcfg, 11), synth.make_clip_weights(ccfg, 12)
+    su = harness.build_synthetic(False, prec, regular_only=True, device=local, bert_w=bw, clip_w=cw,
+                                 bert_cfg=bcfg, clip_cfg=ccfg)
+    del bw, cw
+    eng = su.engine
+    t_setup = time.time() - t0
+
+    B, L, K, I = a.images, a.L, a.topk, a.iters
+    lo = rank * B  # weak scaling: rank r polishes images [r*B, (r+1)*B)
+    u8 = synth.make_images_u8(B, first=lo)
+    pixels = torch.from_numpy(synth.pixels_from_u8(u8)).to(dev)  # resident in HBM before the clock starts
+    init = su.bert_tok.encode("Image of a" + su.bert_tok.mask_token * L)
+    seed_len = 4
+    order_list = None
+    if a.order == "shuffle":
+        import random
+        order_list = list(range(L))
+        random.Random(42).shuffle(order_list)
+    pos, nm, every = harness.order_positions(a.order, L, I, order_list=order_list)
+    hp = Engine.hyper(0.02, 2.0, 0.1)
+
+    def step():
+        eng.encode_images(pixels)
+        return eng.generate(B, init, L, seed_len, K, pos, hp, n_mask=nm, snapshot_every=every)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    eng.profile_reset()
+    eng.profile(not a.no_profile)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        ids, cos = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    eng.profile(False)
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        captions = world * B * a.steps
+        value = captions / dt
+        kinds = ["gemm_clip_text", "gemm_bert", "gemm_vision", "attention", "rowops", "topk", "bridge", "combine"]
+        prof = {k: eng.profile_get(k) for k in kinds} if not a.no_profile else {}
+        st = eng.stats()
+        roof = None
+        if prof and prof["gemm_clip_text"]["launches"]:
+            g = prof["gemm_clip_text"]
+            ach = g["flops"] / (g["ms"] * 1e-3) / 1e12
+            roof = dict(bound="mfma", kernel="czc::gemm_kernel<bf16> (CLIP-text linear layers)",
+                        achieved=round(ach, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_BF16_TFLOPS, 4),
+                        traffic=None, launches=g["launches"], avg_launch_ms=round(g["ms"] / g["launches"], 4),
+                        flops_per_launch=g["flops"] / g["launches"])
+        f_cap = caption_flops(L, K, I)
+        out = dict(metric="captions/sec (L=10, K=200, seq order)", value=round(value, 4), unit="captions/s",
+                   n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(dt / a.steps * 1e3, 2),
+                   higher_is_better=True, scaling="weak", vs_baseline=None, dtype="bf16" if prec == 0 else "f32",
+                   data="synthetic",
+                   config=dict(workload=f"BASELINE configs[2]: {B} random-pixel 224x224 images per GPU, {a.order}, "
+                                        f"L={L}, K={K}, I={I}, alpha=0.02 beta=2.0 tau=0.1, bert-base + CLIP ViT-B/32 shapes, "
+                                        "random-init weights, synthetic vocab (1 CLIP token per word)",
+                               images_per_gpu=B, sentence_len=L, candidate_k=K, num_iterations=I, order=a.order,
+                               parallelism=f"image-sharded x{world} (no per-step collective)"),
+                   image_position_steps_per_s=round(value * L * I, 2),
+                   algorithmic_tflop_per_caption=round(f_cap / 1e12, 3),
+                   mfma_util_vs_reference_flops=round(value / world * f_cap / (PEAK_BF16_TFLOPS * 1e12), 4),
+                   roofline=roof,
+                   kernel_ms={k: round(v["ms"], 1) for k, v in prof.items()},
+                   clip_rows_per_step=st["clip_rows"] // max(1, a.steps), setup_s=round(t_setup, 1))
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(L, K)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

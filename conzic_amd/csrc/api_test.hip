@@ -2,6 +2,7 @@
 // Used only by tests/ (-m gpu) to compare each HIP kernel with the CPU oracle.
 #include <vector>
 #include <cstring>
+#include <algorithm>
 
 #include "../../include/conzic_hip.h"
 #include "kernels.h"
@@ -85,6 +86,55 @@ int czc_test_gemm(int precision, int M, int N, int K, const float* A, const floa
   T_HIP(hipDeviceSynchronize());
   T_HIP(hipMemcpy(C, dC, (size_t)M * N * 4, hipMemcpyDeviceToHost));
   return 0;
+}
+
+// Microbenchmark of the GEMM kernels on device-resident random data (tools/bench_gemm.py).
+// out_mode 0: bf16/act output (+bias, act); 1: fp32 output with in-place fp32 residual (+bias).
+int czc_bench_gemm(int precision, int M, int N, int K, int act, int out_mode, int iters, int use256, double* ms_out) {
+  DevPool pool;
+  const size_t es = precision == PREC_BF16 ? 2 : 4;
+  std::vector<float> ha((size_t)1 << 20), hw((size_t)N * K), hb(N);
+  unsigned s = 12345u;
+  auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 32768.0f - 1.0f; };
+  for (auto& v : ha) v = rnd();
+  for (auto& v : hw) v = rnd() * 0.05f;
+  for (auto& v : hb) v = rnd();
+  void* dA = pool.alloc((size_t)M * K * es); T_PTR(dA);
+  float* tmp = (float*)pool.up(ha.data(), ha.size() * 4); T_PTR(tmp);
+  for (size_t off = 0; off < (size_t)M * K; off += ha.size()) {
+    const size_t n = std::min(ha.size(), (size_t)M * K - off);
+    T_CHECK(launch_convert(precision, tmp, (char*)dA + off * es, (long)n, nullptr));
+  }
+  void* dW = up_act(pool, precision, hw.data(), hw.size()); T_PTR(dW);
+  float* dB = (float*)pool.up(hb.data(), hb.size() * 4); T_PTR(dB);
+  void* dOa = nullptr; float* dOf = nullptr;
+  if (out_mode == 0) { dOa = pool.alloc((size_t)M * N * es); T_PTR(dOa); }
+  else { dOf = (float*)pool.alloc((size_t)M * N * 4); T_PTR(dOf); T_HIP(hipMemset(dOf, 0, (size_t)M * N * 4)); }
+  GemmArgs g;
+  g.A = dA; g.lda = K; g.W = dW; g.ldw = K; g.bias = dB; g.resid = dOf; g.ldr = N; g.out_act = dOa; g.out_f32 = dOf;
+  g.ldc = N; g.M = M; g.N = N; g.K = K; g.act = act;
+  const int saved = g_use_gemm256;
+  g_use_gemm256 = use256;
+  hipEvent_t e0, e1;
+  T_HIP(hipEventCreate(&e0)); T_HIP(hipEventCreate(&e1));
+  for (int i = 0; i < 2; ++i) T_CHECK(launch_gemm(precision, g, nullptr));
+  T_HIP(hipDeviceSynchronize());
+  T_HIP(hipEventRecord(e0, nullptr));
+  for (int i = 0; i < iters; ++i) T_CHECK(launch_gemm(precision, g, nullptr));
+  T_HIP(hipEventRecord(e1, nullptr));
+  T_HIP(hipEventSynchronize(e1));
+  float ms = 0;
+  T_HIP(hipEventElapsedTime(&ms, e0, e1));
+  g_use_gemm256 = saved;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  *ms_out = ms / iters;
+  return 0;
+}
+
+int czc_test_set_option(const char* name, int value) {
+  if (!strcmp(name, "gemm256")) { g_use_gemm256 = value; return 0; }
+  snprintf(czc::g_err, sizeof(czc::g_err), "unknown option %s", name);
+  return CZC_ERR_ARG;
 }
 
 int czc_test_layernorm(int precision, int M, int H, const float* x, const float* gamma, const float* beta, float eps,

@@ -44,7 +44,87 @@ template <> struct Mma<float> {
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
+// ---- epilogue -----------------------------------------------------------------------------------
+// The MFMA is issued with the WEIGHT fragment as its A operand and the ACTIVATION fragment as its
+// B operand, so D[row][col] = C^T: col (lane&31) is the output ROW m and the accumulator
+// registers walk the output COLUMNS n = (r&3) + 8*(r>>2) + 4*(lane>>5).  Every group of four
+// registers is therefore four consecutive columns of one row: bias / residual / stores are
+// 8-byte (bf16) or 16-byte (fp32) vector accesses, 4x fewer instructions than the natural layout.
+template <typename T, int ACT>
+__device__ __forceinline__ float apply_act(float v) {
+  if (ACT == ACT_QUICK_GELU) {
+    if (sizeof(T) == 2) return v * __frcp_rn(1.0f + __expf(-1.702f * v));  // bf16 engine: fast path
+    return v / (1.0f + expf(-1.702f * v));
+  }
+  if (ACT == ACT_GELU_ERF) return gelu_erf(v);
+  return v;
+}
+
 template <typename T>
+__device__ __forceinline__ void store_act4(T* p, float a, float b, float c, float d);
+template <>
+__device__ __forceinline__ void store_act4<float>(float* p, float a, float b, float c, float d) {
+  *(float4*)p = make_float4(a, b, c, d);
+}
+template <>
+__device__ __forceinline__ void store_act4<bf16_t>(bf16_t* p, float a, float b, float c, float d) {
+  uint2 o;
+  o.x = (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16);
+  o.y = (uint32_t)f2bf(c) | ((uint32_t)f2bf(d) << 16);
+  *(uint2*)p = o;
+}
+
+// VEC: N % 4 == 0 and ldc/ldr % 4 == 0 (every call of the polishing step except the 30522-wide
+// MLM decoder, which takes the scalar form).
+template <typename T, int ACT, bool VEC>
+__device__ __forceinline__ void epilogue(const GemmArgs& g, f32x16_t (&acc)[2][2], int m0, int n0, int wm, int wn,
+                                         int lane) {
+  const int half = lane >> 5;
+  T* oa = (T*)g.out_act;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = m0 + wm * 64 + i * 32 + (lane & 31);
+    if (row >= g.M) continue;
+    const long ro = (long)row * g.ldc;
+    const long rr = (long)row * g.ldr;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int col = n0 + wn * 64 + j * 32 + 8 * q + 4 * half;
+        if (VEC) {
+          if (col >= g.N) continue;
+          float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+          if (g.bias) {
+            const float4 b = *(const float4*)(g.bias + col);
+            v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+          }
+          v.x = apply_act<T, ACT>(v.x); v.y = apply_act<T, ACT>(v.y);
+          v.z = apply_act<T, ACT>(v.z); v.w = apply_act<T, ACT>(v.w);
+          if (g.resid) {
+            const float4 r4 = *(const float4*)(g.resid + rr + col);
+            v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+          }
+          if (g.out_f32) *(float4*)(g.out_f32 + ro + col) = v;
+          if (oa) store_act4<T>(oa + ro + col, v.x, v.y, v.z, v.w);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int c = col + e;
+            if (c >= g.N) continue;
+            float v = acc[i][j][4 * q + e] + (g.bias ? g.bias[c] : 0.f);
+            v = apply_act<T, ACT>(v);
+            if (g.resid) v += g.resid[rr + c];
+            if (g.out_f32) g.out_f32[ro + c] = v;
+            if (oa) Act<T>::st(oa + ro + c, v);
+          }
+        }
+      }
+    }
+  }
+}
+
+template <typename T, int ACT, bool VEC>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, int tiles_m, int tiles_n) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE_BYTES];
   const int tid = threadIdx.x;
@@ -63,24 +143,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, int tiles_m, int 
   const int tm = lin / tiles_n, tn = lin - tm * tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
 
-  const unsigned char* Ab = (const unsigned char*)g.A;
-  const unsigned char* Wb = (const unsigned char*)g.W;
-  const long lda_b = (long)g.lda * sizeof(T), ldw_b = (long)g.ldw * sizeof(T);
-
+  // Rebased buffer descriptors: rows past M / N read as zero (hardware bounds check), offsets are
+  // 32-bit and linear in the staging index (no per-row pointer arrays -> no scratch).
+  const int lda_b = g.lda * (int)sizeof(T), ldw_b = g.ldw * (int)sizeof(T);
+  const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)((const unsigned char*)g.A + (long)m0 * lda_b), (short)0,
+                                                     min(BM, g.M - m0) * lda_b, 0x00020000);
+  const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)((const unsigned char*)g.W + (long)n0 * ldw_b), (short)0,
+                                                     min(BN, g.N - n0) * ldw_b, 0x00020000);
   // staging map: thread t moves chunk (t&7) of rows (t>>3) + 32*i, i = 0..3, of both tiles
   const int sc = tid & 7, sr = tid >> 3;
-  const unsigned char* ap[4];
-  const unsigned char* wp[4];
-  int soff[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = sr + 32 * i;
-    int ra = m0 + r; ra = ra < g.M ? ra : g.M - 1;
-    int rw = n0 + r; rw = rw < g.N ? rw : g.N - 1;
-    ap[i] = Ab + (long)ra * lda_b + sc * 16;
-    wp[i] = Wb + (long)rw * ldw_b + sc * 16;
-    soff[i] = swz(r, sc);
-  }
+  const int voA = sr * lda_b + sc * 16, voW = sr * ldw_b + sc * 16;
+  const int soff = swz(sr, sc);  // rows +32: same swizzle phase, +4096 bytes
 
   f32x16_t acc[2][2];
 #pragma unroll
@@ -91,17 +164,27 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, int tiles_m, int 
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nk = g.K / Mma<T>::KPT;
-  uint4 ra[4], rw[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    ra[i] = *(const uint4*)(ap[i]);
-    rw[i] = *(const uint4*)(wp[i]);
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    *(uint4*)(smem + soff[i]) = ra[i];
-    *(uint4*)(smem + TILE_BYTES + soff[i]) = rw[i];
-  }
+  u32x4_t ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3;
+#define CZC_LOAD_TILE(KT)                                                                     \
+  ra0 = __builtin_amdgcn_raw_buffer_load_b128(rsA, voA, (KT) * ROWB, 0);                       \
+  ra1 = __builtin_amdgcn_raw_buffer_load_b128(rsA, voA + 32 * lda_b, (KT) * ROWB, 0);          \
+  ra2 = __builtin_amdgcn_raw_buffer_load_b128(rsA, voA + 64 * lda_b, (KT) * ROWB, 0);          \
+  ra3 = __builtin_amdgcn_raw_buffer_load_b128(rsA, voA + 96 * lda_b, (KT) * ROWB, 0);          \
+  rw0 = __builtin_amdgcn_raw_buffer_load_b128(rsW, voW, (KT) * ROWB, 0);                       \
+  rw1 = __builtin_amdgcn_raw_buffer_load_b128(rsW, voW + 32 * ldw_b, (KT) * ROWB, 0);          \
+  rw2 = __builtin_amdgcn_raw_buffer_load_b128(rsW, voW + 64 * ldw_b, (KT) * ROWB, 0);          \
+  rw3 = __builtin_amdgcn_raw_buffer_load_b128(rsW, voW + 96 * ldw_b, (KT) * ROWB, 0);
+#define CZC_STORE_TILE(dst)                                   \
+  *(u32x4_t*)((dst) + soff) = ra0;                            \
+  *(u32x4_t*)((dst) + soff + 4096) = ra1;                     \
+  *(u32x4_t*)((dst) + soff + 8192) = ra2;                     \
+  *(u32x4_t*)((dst) + soff + 12288) = ra3;                    \
+  *(u32x4_t*)((dst) + TILE_BYTES + soff) = rw0;               \
+  *(u32x4_t*)((dst) + TILE_BYTES + soff + 4096) = rw1;        \
+  *(u32x4_t*)((dst) + TILE_BYTES + soff + 8192) = rw2;        \
+  *(u32x4_t*)((dst) + TILE_BYTES + soff + 12288) = rw3;
+  CZC_LOAD_TILE(0)
+  CZC_STORE_TILE(smem)
   __syncthreads();
 
   const int arow = wm * 64 + (lane & 31);
@@ -111,14 +194,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, int tiles_m, int 
   for (int kt = 0; kt < nk; ++kt) {
     const unsigned char* sA = smem + (kt & 1) * STAGE_BYTES;
     const unsigned char* sB = sA + TILE_BYTES;
-    if (kt + 1 < nk) {
-      const long ko = (long)(kt + 1) * ROWB;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        ra[i] = *(const uint4*)(ap[i] + ko);
-        rw[i] = *(const uint4*)(wp[i] + ko);
-      }
-    }
+    if (kt + 1 < nk) { CZC_LOAD_TILE(kt + 1) }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int ch = 2 * ks + half;
@@ -131,42 +207,36 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, int tiles_m, int 
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) Mma<T>::run(a[i], b[j], acc[i][j]);
+        for (int j = 0; j < 2; ++j) Mma<T>::run(b[j], a[i], acc[i][j]);  // weight = A operand: D = C^T
     }
     if (kt + 1 < nk) {
       unsigned char* dA = smem + ((kt + 1) & 1) * STAGE_BYTES;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        *(uint4*)(dA + soff[i]) = ra[i];
-        *(uint4*)(dA + TILE_BYTES + soff[i]) = rw[i];
-      }
+      CZC_STORE_TILE(dA)
     }
     __syncthreads();
   }
-
-  // epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  T* oa = (T*)g.out_act;
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int col = n0 + wn * 64 + j * 32 + (lane & 31);
-    if (col >= g.N) continue;
-    const float bv = g.bias ? g.bias[col] : 0.f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (row >= g.M) continue;
-        float v = acc[i][j][r] + bv;
-        if (g.act == ACT_QUICK_GELU) v = v / (1.0f + expf(-1.702f * v));
-        else if (g.act == ACT_GELU_ERF) v = gelu_erf(v);
-        if (g.resid) v += g.resid[(long)row * g.ldr + col];
-        if (g.out_f32) g.out_f32[(long)row * g.ldc + col] = v;
-        if (oa) Act<T>::st(oa + (long)row * g.ldc + col, v);
-      }
-    }
-  }
+#undef CZC_LOAD_TILE
+#undef CZC_STORE_TILE
+  epilogue<T, ACT, VEC>(g, acc, m0, n0, wm, wn, lane);
 }
+
+template <typename T>
+static void launch_t(const GemmArgs& g, int tiles_m, int tiles_n, bool vec, hipStream_t st) {
+  dim3 grid(tiles_m * tiles_n), block(256);
+#define CZC_GEMM_LAUNCH(ACT_, VEC_) hipLaunchKernelGGL((gemm_kernel<T, ACT_, VEC_>), grid, block, 0, st, g, tiles_m, tiles_n)
+  if (vec) {
+    if (g.act == ACT_QUICK_GELU) CZC_GEMM_LAUNCH(ACT_QUICK_GELU, true);
+    else if (g.act == ACT_GELU_ERF) CZC_GEMM_LAUNCH(ACT_GELU_ERF, true);
+    else CZC_GEMM_LAUNCH(ACT_NONE, true);
+  } else {
+    if (g.act == ACT_QUICK_GELU) CZC_GEMM_LAUNCH(ACT_QUICK_GELU, false);
+    else if (g.act == ACT_GELU_ERF) CZC_GEMM_LAUNCH(ACT_GELU_ERF, false);
+    else CZC_GEMM_LAUNCH(ACT_NONE, false);
+  }
+#undef CZC_GEMM_LAUNCH
+}
+
+int g_use_gemm256 = 1;  // A/B switch (czc_test_set_option)
 
 int launch_gemm(int prec, const GemmArgs& g, hipStream_t st) {
   if (g.M <= 0) return 0;
@@ -175,12 +245,11 @@ int launch_gemm(int prec, const GemmArgs& g, hipStream_t st) {
     snprintf(g_err, sizeof(g_err), "gemm: K=%d must be a multiple of %d", g.K, kpt);
     return 1;
   }
+  if (prec == PREC_BF16 && g_use_gemm256 && gemm256_eligible(g)) return launch_gemm256(g, st);
   const int tiles_m = cdiv(g.M, BM), tiles_n = cdiv(g.N, BN);
-  dim3 grid(tiles_m * tiles_n), block(256);
-  if (prec == PREC_BF16)
-    hipLaunchKernelGGL(gemm_kernel<bf16_t>, grid, block, 0, st, g, tiles_m, tiles_n);
-  else
-    hipLaunchKernelGGL(gemm_kernel<float>, grid, block, 0, st, g, tiles_m, tiles_n);
+  const bool vec = (g.N % 4 == 0) && (g.ldc % 4 == 0) && (!g.resid || g.ldr % 4 == 0);
+  if (prec == PREC_BF16) launch_t<bf16_t>(g, tiles_m, tiles_n, vec, st);
+  else launch_t<float>(g, tiles_m, tiles_n, vec, st);
   CZC_HIP_CHECK(hipGetLastError());
   return 0;
 }

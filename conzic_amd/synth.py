@@ -177,11 +177,12 @@ CLIP_MEAN = np.array([0.48145466, 0.4578275, 0.40821073], dtype=np.float32)
 CLIP_STD = np.array([0.26862954, 0.26130258, 0.27577711], dtype=np.float32)
 
 
-def make_images_u8(n: int, size: int = 224, seed: int = 1234) -> np.ndarray:
-    """[n, size, size, 3] uint8; image j is independent of n (per-image stream)."""
+def make_images_u8(n: int, size: int = 224, seed: int = 1234, first: int = 0) -> np.ndarray:
+    """[n, size, size, 3] uint8: images first..first+n-1 of the synthetic stream (image j has its
+    own generator, so any shard of the stream can be produced independently)."""
     out = np.empty((n, size, size, 3), dtype=np.uint8)
     for j in range(n):
-        out[j] = np.random.default_rng([seed, j]).integers(0, 256, size=(size, size, 3), dtype=np.uint8)
+        out[j] = np.random.default_rng([seed, first + j]).integers(0, 256, size=(size, size, 3), dtype=np.uint8)
     return out
 
 

@@ -178,6 +178,11 @@ int czc_stats(czc_engine* e, int64_t* clip_rows, int64_t* clip_seqs, int64_t* be
 /* C[M,N] = A[M,K] * W[N,K]^T (+bias) (+activation: 0 none, 1 quick_gelu, 2 gelu_erf) (+resid[M,N]) */
 int czc_test_gemm(int precision, int M, int N, int K, const float* A, const float* W, const float* bias,
                   const float* resid, int act, float* C);
+/* GEMM microbenchmark on device-resident data: ms per launch (tools/bench_gemm.py); use256 selects the
+ * 256x256 LDS-DMA kernel where eligible.  czc_test_set_option("gemm256", 0|1) is the same A/B switch
+ * for whole-engine runs. */
+int czc_bench_gemm(int precision, int M, int N, int K, int act, int out_mode, int iters, int use256, double* ms_out);
+int czc_test_set_option(const char* name, int value);
 int czc_test_layernorm(int precision, int M, int H, const float* x, const float* gamma, const float* beta, float eps,
                        float* y);
 /* qkv [sum(len), 3*heads*64] packed sequences; causal 0/1; scale; out [sum(len), heads*64] */
