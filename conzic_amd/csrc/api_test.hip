@@ -133,6 +133,7 @@ int czc_bench_gemm(int precision, int M, int N, int K, int act, int out_mode, in
 
 int czc_test_set_option(const char* name, int value) {
   if (!strcmp(name, "gemm256")) { g_use_gemm256 = value; return 0; }
+  if (!strcmp(name, "mfma_attention")) { g_use_mfma_attention = value; return 0; }
   snprintf(czc::g_err, sizeof(czc::g_err), "unknown option %s", name);
   return CZC_ERR_ARG;
 }
@@ -162,7 +163,8 @@ int czc_test_attention(int precision, int n_seq, const int32_t* seq_len, int hea
   int* doff = (int*)pool.up(off.data(), (n_seq + 1) * 4); T_PTR(doff);
   int* dlen = (int*)pool.up(seq_len, n_seq * 4); T_PTR(dlen);
   void* dout = pool.alloc(M * Hd * 4); T_PTR(dout);
-  T_CHECK(launch_attention(precision, dq, doff, dlen, 0, n_seq, mx, heads, causal, scale, dout, nullptr));
+  SegTable tab{nullptr, nullptr, doff, dlen, n_seq, 0};
+  T_CHECK(launch_attention(precision, dq, tab, mx, heads, causal, scale, dout, nullptr));
   T_HIP(hipDeviceSynchronize());
   T_CHECK(down_act(pool, precision, dout, M * Hd, out));
   return 0;

@@ -1,20 +1,201 @@
-// Attention over many tiny sequences (BERT T<=64 bidirectional, CLIP text Tc<=77 causal,
-// CLIP vision T=50): softmax(q k^T * scale [+causal mask]) v, head_dim 64
+// Attention over many tiny segments (BERT T<=64 bidirectional, CLIP text Tc<=77 causal, CLIP
+// vision T=50): softmax(q k^T * scale [+causal mask]) v, head_dim 64
 // (HF:bert/modeling_bert.py:111-136, HF:clip/modeling_clip.py:259-277,:309-333).
 //
-// v1: exact-fp32 wavefront kernel, one wave per (sequence, head).  Whole K^T/V/Q of the head sit
-// in LDS as fp32 (K transposed with an odd pitch, so both the transposing store and the
-// lane-per-key reads are bank-conflict free); lane j owns key j (and j+64), lanes reduce with
-// shuffles; lane d owns output dim d.  FLOPs here are <0.5% of the step; the cost is HBM
-// streaming of qkv.  (An MFMA 16x16x32 variant for the bf16 engine replaces it in mfma_attention.)
+// A *segment* is a run of `own` rows (queries + keys/values) preceded by an optional run of
+// `pre` rows that contribute keys/values only.  That is how the K candidate captions of one image
+// share their causal prefix (all hidden states before the first differing CLIP
+// token are bit-identical across candidates): the prefix ("trunk") is a segment of its own,
+// computed once per image, and each candidate ("branch") attends to trunk rows + its own rows.
+//
+// Two kernels, same contract:
+//  * attention_mfma_kernel (bf16 engine): one wave per (segment, head).  S^T = K.Q^T with
+//    v_mfma_f32_32x32x16_bf16 (K rows are the A operand, Q rows the B operand, both fetched as
+//    16-byte fragments straight from the packed qkv rows -- no LDS).  In that layout a lane owns
+//    one query column and 16 of every 32 keys, so the softmax is in-lane plus one cross-half
+//    shuffle, and the probabilities already sit in the B-operand layout of O^T = V^T.P^T; only V
+//    goes through LDS (transposed on the way in).  8 MFMAs per (segment, head) at Tc<=32.
+//  * attention_valu_kernel (f32 engine): exact-fp32 wavefront version, K^T/V/Q in LDS.
 #include "kernels.h"
 
 namespace czc {
 
+// ------------------------------------------------------------------------------------------------
+// common segment decoding
+// ------------------------------------------------------------------------------------------------
+struct Seg {
+  int pre_off, pre_len, own_off, own_len;
+};
+
+__device__ __forceinline__ Seg load_seg(const SegTable& t, int s) {
+  Seg g;
+  if (t.own_len) {
+    g.pre_off = t.pre_off ? t.pre_off[s] : 0;
+    g.pre_len = t.pre_len ? t.pre_len[s] : 0;
+    g.own_off = t.own_off[s];
+    g.own_len = t.own_len[s];
+  } else {
+    g.pre_off = 0;
+    g.pre_len = 0;
+    g.own_off = s * t.fixed_T;
+    g.own_len = t.fixed_T;
+  }
+  return g;
+}
+
+__device__ __forceinline__ long key_row(const Seg& g, int k) {
+  return k < g.pre_len ? (long)g.pre_off + k : (long)g.own_off + (k - g.pre_len);
+}
+
+// ------------------------------------------------------------------------------------------------
+// bf16 MFMA kernel
+// ------------------------------------------------------------------------------------------------
+constexpr int AT_MAXKT = 3;  // key tiles of 32 -> up to 96 keys
+
+__global__ __launch_bounds__(256) void attention_mfma_kernel(const bf16_t* qkv, SegTable tab, int heads, int causal,
+                                                             float scale, int KP, bf16_t* out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char at_lds[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int wpb = blockDim.x >> 6;
+  const int s = blockIdx.x;
+  int h = blockIdx.y * wpb + wave;
+  const bool live = h < heads;
+  if (!live) h = heads - 1;
+  const Seg g = load_seg(tab, s);
+  const int nk = g.pre_len + g.own_len, nq = g.own_len;
+  if (nq <= 0) return;  // uniform per block
+  const int Hd = heads * 64;
+  const long pitch = 3L * Hd;  // elements per qkv row
+  bf16_t* Vt = (bf16_t*)at_lds + (size_t)wave * 64 * KP;  // [64 d][KP keys]
+
+  // ---- V^T -> LDS: 8 keys per pass, lane = (key, 16-byte chunk of the head row) ----
+  for (int k0 = 0; k0 < nk; k0 += 8) {
+    const int k = k0 + (lane >> 3);
+    if (k < nk) {
+      const int d0 = (lane & 7) * 8;
+      const uint4 v = *(const uint4*)(qkv + key_row(g, k) * pitch + 2 * Hd + h * 64 + d0);
+      const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) Vt[(d0 + e) * KP + k] = (bf16_t)((w[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+    }
+  }
+  // zero the padding keys this wave will read (nk..32*ceil(nk/32))
+  const int nkt_all = (nk + 31) >> 5;
+  for (int i = lane; i < 64 * (nkt_all * 32 - nk); i += 64) {
+    const int d = i / (nkt_all * 32 - nk), k = nk + i % (nkt_all * 32 - nk);
+    Vt[d * KP + k] = 0;
+  }
+  __syncthreads();
+
+  const int half = lane >> 5, l31 = lane & 31;
+  for (int q0 = 0; q0 < nq; q0 += 32) {
+    const int q = min(q0 + l31, nq - 1);  // padded query lanes recompute the last real query
+    const bf16_t* qp = qkv + ((long)g.own_off + q) * pitch + h * 64 + 8 * half;
+    uint4 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const uint4*)(qp + 16 * ks);
+    const int kmax = causal ? min(nk, g.pre_len + min(q0 + 32, nq)) : nk;  // keys any lane of this tile may see
+    const int nkt = (kmax + 31) >> 5;
+    const int vis = causal ? g.pre_len + q : nk - 1;  // last visible key of this lane's query
+
+    f32x16_t st[AT_MAXKT];
+#pragma unroll
+    for (int kt = 0; kt < AT_MAXKT; ++kt) {
+      if (kt < nkt) {
+        const int kk = min(kt * 32 + l31, nk - 1);
+        const bf16_t* kp = qkv + key_row(g, kk) * pitch + Hd + h * 64 + 8 * half;
+        f32x16_t acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const uint4 kf = *(const uint4*)(kp + 16 * ks);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, kf),
+                                                        __builtin_bit_cast(bf16x8_t, qf[ks]), acc, 0, 0, 0);
+        }
+        st[kt] = acc;
+      }
+    }
+    // softmax over keys: lane holds keys kt*32 + (r&3) + 8*(r>>2) + 4*half of query column l31
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < AT_MAXKT; ++kt) {
+      if (kt < nkt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          const float v = key <= vis && key < nk ? st[kt][r] * scale : -INFINITY;
+          st[kt][r] = v;
+          mx = fmaxf(mx, v);
+        }
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+    uint4 pf[AT_MAXKT][2];
+#pragma unroll
+    for (int kt = 0; kt < AT_MAXKT; ++kt) {
+      if (kt < nkt) {
+        float e[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          e[r] = expf(st[kt][r] - mx);  // exp(-inf) = 0 for masked keys
+          sum += e[r];
+        }
+#pragma unroll
+        for (int sstep = 0; sstep < 2; ++sstep) {
+          pf[kt][sstep].x = (uint32_t)f2bf(e[8 * sstep + 0]) | ((uint32_t)f2bf(e[8 * sstep + 1]) << 16);
+          pf[kt][sstep].y = (uint32_t)f2bf(e[8 * sstep + 2]) | ((uint32_t)f2bf(e[8 * sstep + 3]) << 16);
+          pf[kt][sstep].z = (uint32_t)f2bf(e[8 * sstep + 4]) | ((uint32_t)f2bf(e[8 * sstep + 5]) << 16);
+          pf[kt][sstep].w = (uint32_t)f2bf(e[8 * sstep + 6]) | ((uint32_t)f2bf(e[8 * sstep + 7]) << 16);
+        }
+      }
+    }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+
+    // O^T[d][query] = sum_key V^T[d][key] P^T[key][query]; k-slot j of step s, half h <-> key
+    // 16s + 4h + (j&3) + 8*(j>>2): exactly the accumulator order the probabilities were produced in.
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      f32x16_t o;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[r] = 0.f;
+      const bf16_t* vrow = Vt + (dt * 32 + l31) * KP;
+#pragma unroll
+      for (int kt = 0; kt < AT_MAXKT; ++kt) {
+        if (kt < nkt) {
+#pragma unroll
+          for (int sstep = 0; sstep < 2; ++sstep) {
+            const uint2 lo = *(const uint2*)(vrow + kt * 32 + 16 * sstep + 4 * half);
+            const uint2 hi = *(const uint2*)(vrow + kt * 32 + 16 * sstep + 8 + 4 * half);
+            const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vf),
+                                                        __builtin_bit_cast(bf16x8_t, pf[kt][sstep]), o, 0, 0, 0);
+          }
+        }
+      }
+      if (live && q0 + l31 < nq) {
+        bf16_t* op = out + ((long)g.own_off + q0 + l31) * Hd + h * 64 + dt * 32 + 4 * half;
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          uint2 w;
+          w.x = (uint32_t)f2bf(o[4 * qd] * inv) | ((uint32_t)f2bf(o[4 * qd + 1] * inv) << 16);
+          w.y = (uint32_t)f2bf(o[4 * qd + 2] * inv) | ((uint32_t)f2bf(o[4 * qd + 3] * inv) << 16);
+          *(uint2*)(op + 8 * qd) = w;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// exact-fp32 wavefront kernel (f32 engine; also the reference the MFMA kernel is tested against)
+// ------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void attention_kernel(const T* qkv, const int* seq_off, const int* seq_len,
-                                                        int fixed_T, int heads, int causal, float scale, int Tcap,
-                                                        T* out) {
+__global__ __launch_bounds__(256) void attention_valu_kernel(const T* qkv, SegTable tab, int heads, int causal,
+                                                             float scale, int Tcap, T* out) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -23,8 +204,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* qkv, const int*
   int h = blockIdx.y * wpb + wave;
   const bool live = h < heads;
   if (!live) h = heads - 1;
-  const int len = seq_len ? seq_len[s] : fixed_T;
-  const long row0 = seq_off ? seq_off[s] : (long)s * fixed_T;
+  const Seg g = load_seg(tab, s);
+  const int nk = g.pre_len + g.own_len, nq = g.own_len;
   const int Hd = heads * 64;
   const int Tp = Tcap | 1;
   float* Kt = lds + (size_t)wave * (64 * Tp + 2 * 64 * Tcap + 128);
@@ -32,19 +213,20 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* qkv, const int*
   float* Qs = Vs + 64 * Tcap;
   float* Ps = Qs + 64 * Tcap;  // 128 floats
 
-  for (int t = 0; t < len; ++t) {
-    const T* r = qkv + (row0 + t) * (long)(3 * Hd) + h * 64 + lane;
-    Qs[t * 64 + lane] = Act<T>::ld(r);
+  for (int t = 0; t < nk; ++t) {
+    const T* r = qkv + key_row(g, t) * (long)(3 * Hd) + h * 64 + lane;
     Kt[lane * Tp + t] = Act<T>::ld(r + Hd);
     Vs[t * 64 + lane] = Act<T>::ld(r + 2 * Hd);
   }
+  for (int t = 0; t < nq; ++t)
+    Qs[t * 64 + lane] = Act<T>::ld(qkv + ((long)g.own_off + t) * (long)(3 * Hd) + h * 64 + lane);
   __syncthreads();
 
-  for (int i = 0; i < len; ++i) {
-    const int nk = causal ? i + 1 : len;
+  for (int i = 0; i < nq; ++i) {
+    const int vis = causal ? g.pre_len + i + 1 : nk;  // number of visible keys
     float s0 = 0.f, s1 = 0.f;
     const int j0 = lane, j1 = lane + 64;
-    const int j0c = j0 < len ? j0 : 0, j1c = j1 < len ? j1 : 0;
+    const int j0c = j0 < nk ? j0 : 0, j1c = j1 < nk ? j1 : 0;
     const float* qi = Qs + i * 64;
 #pragma unroll 4
     for (int d = 0; d < 64; d += 4) {
@@ -53,55 +235,67 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* qkv, const int*
       s0 += q.y * Kt[(d + 1) * Tp + j0c];
       s0 += q.z * Kt[(d + 2) * Tp + j0c];
       s0 += q.w * Kt[(d + 3) * Tp + j0c];
-      if (len > 64) {
+      if (nk > 64) {
         s1 += q.x * Kt[(d + 0) * Tp + j1c];
         s1 += q.y * Kt[(d + 1) * Tp + j1c];
         s1 += q.z * Kt[(d + 2) * Tp + j1c];
         s1 += q.w * Kt[(d + 3) * Tp + j1c];
       }
     }
-    s0 = j0 < nk ? s0 * scale : -INFINITY;
-    s1 = j1 < nk ? s1 * scale : -INFINITY;
+    s0 = j0 < vis ? s0 * scale : -INFINITY;
+    s1 = j1 < vis ? s1 * scale : -INFINITY;
     const float m = wave_max(fmaxf(s0, s1));
-    const float e0 = j0 < nk ? expf(s0 - m) : 0.f;
-    const float e1 = j1 < nk ? expf(s1 - m) : 0.f;
+    const float e0 = j0 < vis ? expf(s0 - m) : 0.f;
+    const float e1 = j1 < vis ? expf(s1 - m) : 0.f;
     const float sum = wave_sum(e0 + e1);
     Ps[j0] = e0 / sum;
     Ps[j1] = e1 / sum;
     __syncthreads();
     float o = 0.f;
-    for (int j = 0; j < nk; ++j) o += Ps[j] * Vs[j * 64 + lane];
-    if (live) Act<T>::st(out + (row0 + i) * (long)Hd + h * 64 + lane, o);
+    for (int j = 0; j < vis; ++j) o += Ps[j] * Vs[j * 64 + lane];
+    if (live) Act<T>::st(out + ((long)g.own_off + i) * (long)Hd + h * 64 + lane, o);
     __syncthreads();
   }
 }
 
-int launch_attention(int prec, const void* qkv, const int* seq_off, const int* seq_len, int fixed_T, int n_seq,
-                     int max_len, int heads, int causal, float scale, void* out, hipStream_t st) {
-  if (n_seq <= 0) return 0;
-  if (max_len > 128 || max_len <= 0) {
-    snprintf(g_err, sizeof(g_err), "attention: max_len=%d unsupported (1..128)", max_len);
+int g_use_mfma_attention = 1;
+
+int launch_attention(int prec, const void* qkv, const SegTable& tab, int max_keys, int heads, int causal, float scale,
+                     void* out, hipStream_t st) {
+  if (tab.n_seg <= 0) return 0;
+  if (max_keys > 96 || max_keys <= 0) {
+    snprintf(g_err, sizeof(g_err), "attention: %d keys per segment unsupported (1..96)", max_keys);
     return 1;
   }
-  const int Tcap = (max_len + 3) & ~3;
+  if (prec == PREC_BF16 && g_use_mfma_attention) {
+    const int KP = ((max_keys + 31) & ~31) + 4;
+    int wpb = heads >= 4 ? 4 : (heads >= 2 ? 2 : 1);
+    const size_t shmem = (size_t)wpb * 64 * KP * 2;
+    dim3 grid(tab.n_seg, cdiv(heads, wpb)), block(64 * wpb);
+    hipLaunchKernelGGL(attention_mfma_kernel, grid, block, shmem, st, (const bf16_t*)qkv, tab, heads, causal, scale, KP,
+                       (bf16_t*)out);
+    CZC_HIP_CHECK(hipGetLastError());
+    return 0;
+  }
+  const int Tcap = (max_keys + 3) & ~3;
   const size_t per_wave = (size_t)(64 * (Tcap | 1) + 2 * 64 * Tcap + 128) * sizeof(float);
   int wpb = 4;
   while (wpb > 1 && per_wave * wpb > 60 * 1024) wpb >>= 1;
   if (wpb > heads) wpb = heads >= 2 ? 2 : 1;
   const size_t shmem = per_wave * wpb;
-  dim3 grid(n_seq, cdiv(heads, wpb)), block(64 * wpb);
+  dim3 grid(tab.n_seg, cdiv(heads, wpb)), block(64 * wpb);
   if (prec == PREC_BF16) {
     if (shmem > 64 * 1024)
-      CZC_HIP_CHECK(hipFuncSetAttribute((const void*)attention_kernel<bf16_t>,
+      CZC_HIP_CHECK(hipFuncSetAttribute((const void*)attention_valu_kernel<bf16_t>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    hipLaunchKernelGGL(attention_kernel<bf16_t>, grid, block, shmem, st, (const bf16_t*)qkv, seq_off, seq_len, fixed_T,
-                       heads, causal, scale, Tcap, (bf16_t*)out);
+    hipLaunchKernelGGL(attention_valu_kernel<bf16_t>, grid, block, shmem, st, (const bf16_t*)qkv, tab, heads, causal,
+                       scale, Tcap, (bf16_t*)out);
   } else {
     if (shmem > 64 * 1024)
-      CZC_HIP_CHECK(hipFuncSetAttribute((const void*)attention_kernel<float>,
+      CZC_HIP_CHECK(hipFuncSetAttribute((const void*)attention_valu_kernel<float>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    hipLaunchKernelGGL(attention_kernel<float>, grid, block, shmem, st, (const float*)qkv, seq_off, seq_len, fixed_T,
-                       heads, causal, scale, Tcap, (float*)out);
+    hipLaunchKernelGGL(attention_valu_kernel<float>, grid, block, shmem, st, (const float*)qkv, tab, heads, causal, scale,
+                       Tcap, (float*)out);
   }
   CZC_HIP_CHECK(hipGetLastError());
   return 0;

@@ -179,4 +179,69 @@ int launch_scan(const int* len, int n, int* off, int* totals, hipStream_t st) {
   return 0;
 }
 
+// ---- shared-prefix plan ---------------------------------------------------------------------------
+// Causal attention + EOS pooling make every hidden state in front of the first differing CLIP token
+// identical across the K candidates of an image, so that prefix is encoded once.
+__global__ __launch_bounds__(256) void prefix_plan_kernel(const int* cids, const int* clen, int B, int K, int share,
+                                                          int* own_len, int* pre_len, int* seg_src, int* seg_pos0,
+                                                          int* max_len_out) {
+  __shared__ int s_p, s_max;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (tid == 0) { s_p = 1 << 30; s_max = 0; }
+  __syncthreads();
+  const int* r0 = cids + (long)b * K * BR_LEN;
+  const int l0 = clen[b * K];
+  int p = 1 << 30, mx = 0;
+  for (int k = tid; k < K; k += blockDim.x) {
+    const int* rk = r0 + (long)k * BR_LEN;
+    const int lk = clen[b * K + k];
+    const int lim = min(lk, l0);
+    int c = 0;
+    while (c < lim && rk[c] == r0[c]) ++c;
+    p = min(p, min(c, lk - 1));
+    mx = max(mx, lk);
+  }
+  atomicMin(&s_p, p);
+  atomicMax(&s_max, mx);
+  __syncthreads();
+  const int pb = share ? s_p : 0;
+  if (tid == 0) {
+    own_len[b] = pb; pre_len[b] = 0; seg_src[b] = b * K; seg_pos0[b] = 0;
+    atomicMax(max_len_out, s_max);
+  }
+  for (int k = tid; k < K; k += blockDim.x) {
+    const int s = B + b * K + k;
+    own_len[s] = clen[b * K + k] - pb;
+    pre_len[s] = pb;
+    seg_src[s] = b * K + k;
+    seg_pos0[s] = pb;
+  }
+}
+
+int launch_prefix_plan(const int* clip_ids, const int* clip_len, int B, int K, int share, int* own_len, int* pre_len,
+                       int* seg_src, int* seg_pos0, int* max_len_out, hipStream_t st) {
+  hipLaunchKernelGGL(prefix_plan_kernel, dim3(B), dim3(256), 0, st, clip_ids, clip_len, B, K, share, own_len, pre_len,
+                     seg_src, seg_pos0, max_len_out);
+  CZC_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+__global__ void prefix_finish_kernel(const int* own_off, const int* own_len, int B, int K, int* pre_off, int* eos_idx) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B) pre_off[i] = 0;
+  if (i < B * K) {
+    const int s = B + i;
+    pre_off[s] = own_off[i / K];
+    eos_idx[i] = own_off[s] + own_len[s] - 1;
+  }
+}
+
+int launch_prefix_finish(const int* own_off, const int* own_len, int B, int K, int* pre_off, int* eos_idx,
+                         hipStream_t st) {
+  hipLaunchKernelGGL(prefix_finish_kernel, dim3(cdiv((long)B * K, 256)), dim3(256), 0, st, own_off, own_len, B, K,
+                     pre_off, eos_idx);
+  CZC_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
 }  // namespace czc

@@ -75,6 +75,7 @@ struct czc_engine {
   float logit_scale_exp = 1.f;
   int* h_totals = nullptr;  // pinned: [0]=rows [1]=max len [2]=overflow
   int last_BT = 0;
+  int share_prefix = 1;  // encode the candidates' common causal prefix once per image
 
   bool prof = false;
   std::map<std::string, ProfKind> pk;
@@ -227,7 +228,7 @@ int gemm(czc_engine* e, int prec, const char* kind, const void* A, int lda, cons
 // ---- pre-LN transformer stack shared by the CLIP text and vision towers -----------------------
 // x_f32 [M,H] residual stream (updated in place); packed sequences described by off/len or fixed_T
 int clip_stack(czc_engine* e, const char* gk, std::vector<LayerW>& L, float* x, int M, int H, int I, int heads,
-               float eps, const int* off, const int* len, int fixed_T, int n_seq, int max_len, int causal) {
+               float eps, const SegTable& tab, int max_keys, int causal) {
   const int P = e->pc;
   void *y, *qkv, *ctx, *hbuf;
   E_CHECK(ensure(e, "cs_y", (size_t)M * H * e->esz, &y));
@@ -240,7 +241,7 @@ int clip_stack(czc_engine* e, const char* gk, std::vector<LayerW>& L, float* x, 
     { ProfScope ps(e, "rowops", 0); E_CHECK(launch_layernorm(P, x, nullptr, l.ln1_g, l.ln1_b, eps, M, H, y, nullptr, e->st)); }
     E_CHECK(gemm(e, P, gk, y, H, l.qkv_w, H, l.qkv_b, nullptr, 0, qkv, nullptr, 3 * H, M, 3 * H, H, ACT_NONE));
     { ProfScope ps(e, "attention", 0);
-      E_CHECK(launch_attention(P, qkv, off, len, fixed_T, n_seq, max_len, heads, causal, scale, ctx, e->st)); }
+      E_CHECK(launch_attention(P, qkv, tab, max_keys, heads, causal, scale, ctx, e->st)); }
     E_CHECK(gemm(e, P, gk, ctx, H, l.o_w, H, l.o_b, x, H, nullptr, x, H, M, H, H, ACT_NONE));
     { ProfScope ps(e, "rowops", 0); E_CHECK(launch_layernorm(P, x, nullptr, l.ln2_g, l.ln2_b, eps, M, H, y, nullptr, e->st)); }
     E_CHECK(gemm(e, P, gk, y, H, l.fc1_w, H, l.fc1_b, nullptr, 0, hbuf, nullptr, I, M, I, H, ACT_QUICK_GELU));
@@ -273,7 +274,8 @@ int bert_forward(czc_engine* e, const int* d_inp, int B, int T) {
     LayerW& l = e->bert[n];
     E_CHECK(gemm(e, P, "gemm_bert", xa, H, l.qkv_w, H, l.qkv_b, nullptr, 0, qkv, nullptr, 3 * H, M, 3 * H, H, ACT_NONE));
     { ProfScope ps(e, "attention", 0);
-      E_CHECK(launch_attention(P, qkv, nullptr, nullptr, T, B, T, c.bert_heads, 0, scale, ctx, e->st)); }
+      SegTable tab{nullptr, nullptr, nullptr, nullptr, B, T};
+      E_CHECK(launch_attention(P, qkv, tab, T, c.bert_heads, 0, scale, ctx, e->st)); }
     E_CHECK(gemm(e, P, "gemm_bert", ctx, H, l.o_w, H, l.o_b, x, H, nullptr, tmp, H, M, H, H, ACT_NONE));
     { ProfScope ps(e, "rowops", 0); E_CHECK(launch_layernorm(P, tmp, nullptr, l.ln1_g, l.ln1_b, c.bert_eps, M, H, xa, x, e->st)); }
     E_CHECK(gemm(e, P, "gemm_bert", xa, H, l.fc1_w, H, l.fc1_b, nullptr, 0, hbuf, nullptr, I, M, I, H, ACT_GELU_ERF));
@@ -313,12 +315,35 @@ int mlm_head(czc_engine* e, int B, int T, int gen_idx, float** logits_out) {
   return 0;
 }
 
-// CLIP text tower on packed sequences (clip/clip.py:78-83): ids [n_seq,77] + len -> feat fp32 [n_seq, proj]
-int clip_text_forward(czc_engine* e, const int* cids, const int* clen, const int* coff, int* eidx, int n_seq, int M,
-                      int max_len, float** feat_out) {
+// CLIP text tower (clip/clip.py:78-83) on B x K candidate sequences: ids [B*K,77] + len -> feat fp32
+// [B*K, proj].  With `share` the causal prefix common to an image's K candidates is encoded once
+// (trunk segment) and every candidate only carries the rows from its first differing token on.
+// Contains the step's single host round trip: 16 bytes of totals (rows, longest sequence, overflow).
+int clip_text_forward(czc_engine* e, const int* cids, const int* clen, int B, int K, int share, int* totals,
+                      float** feat_out) {
   const czc_config& c = e->cfg;
   const int P = e->pc;
   const int H = c.clip_hidden;
+  const int n_seq = B * K, S = B + n_seq;
+  int *own_len, *pre_len, *src, *pos0, *own_off, *pre_off, *eidx;
+  E_CHECK(ensure(e, "p_own_len", (size_t)S * 4, (void**)&own_len));
+  E_CHECK(ensure(e, "p_pre_len", (size_t)S * 4, (void**)&pre_len));
+  E_CHECK(ensure(e, "p_src", (size_t)S * 4, (void**)&src));
+  E_CHECK(ensure(e, "p_pos0", (size_t)S * 4, (void**)&pos0));
+  E_CHECK(ensure(e, "p_own_off", (size_t)(S + 1) * 4, (void**)&own_off));
+  E_CHECK(ensure(e, "p_pre_off", (size_t)S * 4, (void**)&pre_off));
+  E_CHECK(ensure(e, "s_eidx", (size_t)n_seq * 4, (void**)&eidx));
+  { ProfScope ps(e, "bridge", 0);
+    E_CHECK(launch_prefix_plan(cids, clen, B, K, share, own_len, pre_len, src, pos0, totals + 3, e->st));
+    E_CHECK(launch_scan(own_len, S, own_off, totals, e->st));
+    E_CHECK(launch_prefix_finish(own_off, own_len, B, K, pre_off, eidx, e->st)); }
+  E_HIP(hipMemcpyAsync(e->h_totals, totals, 16, hipMemcpyDeviceToHost, e->st));
+  E_HIP(hipStreamSynchronize(e->st));  // the one host round trip per step (the reference has one too, gen_utils.py:81)
+  const int M = e->h_totals[0], max_len = e->h_totals[3];
+  if (e->h_totals[2]) return fail(e, CZC_ERR_OVERFLOW, "text bridge overflow (row text > CZC_BRIDGE_MAX_BYTES)%s");
+  if (max_len > c.clip_max_pos || max_len > CZC_CLIP_MAX_LEN)
+    return fail(e, CZC_ERR_ARG, "CLIP sequence longer than max_position_embeddings%s");
+
   float *x, *feat, *tok, *pos, *fg, *fb; void* pa;
   E_CHECK(ensure(e, "c_x", (size_t)M * H * 4, (void**)&x));
   E_CHECK(ensure(e, "c_pa", (size_t)n_seq * H * e->esz, &pa));
@@ -328,15 +353,15 @@ int clip_text_forward(czc_engine* e, const int* cids, const int* clen, const int
   E_CHECK(need(e, "text_model.final_layer_norm.weight", H, &fg));
   E_CHECK(need(e, "text_model.final_layer_norm.bias", H, &fb));
   { ProfScope ps(e, "rowops", 0);
-    E_CHECK(launch_clip_embed(cids, CZC_CLIP_MAX_LEN, coff, clen, n_seq, max_len, H, tok, pos, x, e->st)); }
-  E_CHECK(clip_stack(e, "gemm_clip_text", e->ctext, x, M, H, c.clip_inter, c.clip_heads, c.clip_eps, coff, clen, 0,
-                     n_seq, max_len, 1));
+    E_CHECK(launch_clip_embed(cids, CZC_CLIP_MAX_LEN, src, pos0, own_off, own_len, S, max_len, H, tok, pos, x, e->st)); }
+  SegTable tab{pre_off, pre_len, own_off, own_len, S, 0};
+  E_CHECK(clip_stack(e, "gemm_clip_text", e->ctext, x, M, H, c.clip_inter, c.clip_heads, c.clip_eps, tab, max_len, 1));
   { ProfScope ps(e, "rowops", 0);
-    E_CHECK(launch_eos_index(coff, clen, n_seq, eidx, e->st));
     E_CHECK(launch_layernorm(P, x, eidx, fg, fb, c.clip_eps, n_seq, H, pa, nullptr, e->st)); }
   E_CHECK(gemm(e, P, "gemm_clip_text", pa, H, e->tproj_w, H, nullptr, nullptr, 0, nullptr, feat, c.clip_proj, n_seq,
                c.clip_proj, H, ACT_NONE));
-
+  e->stat_clip_rows += M;
+  e->stat_clip_seqs += n_seq;
   *feat_out = feat;
   return 0;
 }
@@ -364,15 +389,13 @@ int step_device(czc_engine* e, int* d_inp, int B, int T, int gen_idx, int n_mask
   float* logits;
   E_CHECK(mlm_head(e, B, T, gen_idx, &logits));
 
-  float *probs, *senti, *reps; int *idxs, *cand, *cids, *clen, *coff, *totals, *eidx;
+  float *probs, *senti, *reps; int *idxs, *cand, *cids, *clen, *totals;
   E_CHECK(ensure(e, "s_probs", (size_t)n_seq * 4, (void**)&probs));
   E_CHECK(ensure(e, "s_idxs", (size_t)n_seq * 4, (void**)&idxs));
   E_CHECK(ensure(e, "s_cand", (size_t)n_seq * 4, (void**)&cand));
   E_CHECK(ensure(e, "s_cids", (size_t)n_seq * CZC_CLIP_MAX_LEN * 4, (void**)&cids));
   E_CHECK(ensure(e, "s_clen", (size_t)n_seq * 4, (void**)&clen));
-  E_CHECK(ensure(e, "s_coff", (size_t)(n_seq + 1) * 4, (void**)&coff));
   E_CHECK(ensure(e, "s_tot", 16, (void**)&totals));
-  E_CHECK(ensure(e, "s_eidx", (size_t)n_seq * 4, (void**)&eidx));
   E_CHECK(ensure(e, "s_senti", (size_t)n_seq * 4, (void**)&senti));
   E_CHECK(ensure(e, "s_reps", (size_t)n_seq * 4, (void**)&reps));
   { ProfScope ps(e, "topk", 0);
@@ -381,16 +404,9 @@ int step_device(czc_engine* e, int* d_inp, int B, int T, int gen_idx, int n_mask
   E_HIP(hipMemsetAsync(totals, 0, 16, e->st));
   { ProfScope ps(e, "bridge", 0);
     E_CHECK(launch_bridge(e->bd, d_inp, B, T, gen_idx, cand, K, hp->use_sentiment ? e->d_lex : nullptr, hp->negative,
-                          cids, clen, senti, reps, totals + 2, e->st));
-    E_CHECK(launch_scan(clen, n_seq, coff, totals, e->st)); }
-  E_HIP(hipMemcpyAsync(e->h_totals, totals, 12, hipMemcpyDeviceToHost, e->st));
-  E_HIP(hipStreamSynchronize(e->st));  // the one host round trip per step (the reference has one too, gen_utils.py:81)
-  const int M = e->h_totals[0], max_len = e->h_totals[1];
-  if (e->h_totals[2]) return fail(e, CZC_ERR_OVERFLOW, "text bridge overflow (row text > CZC_BRIDGE_MAX_BYTES)%s");
-  if (max_len > c.clip_max_pos) return fail(e, CZC_ERR_ARG, "CLIP sequence longer than max_position_embeddings%s");
-
+                          cids, clen, senti, reps, totals + 2, e->st)); }
   float* feat;
-  E_CHECK(clip_text_forward(e, cids, clen, coff, eidx, n_seq, M, max_len, &feat));
+  E_CHECK(clip_text_forward(e, cids, clen, B, K, e->share_prefix, totals, &feat));
 
   float *cscore, *cref, *fin, *bcos; int* best;
   E_CHECK(ensure(e, "s_cscore", (size_t)n_seq * 4, (void**)&cscore));
@@ -404,8 +420,6 @@ int step_device(czc_engine* e, int* d_inp, int B, int T, int gen_idx, int n_mask
   a.use_senti = hp->use_sentiment; a.B = B; a.K = K; a.D = c.clip_proj; a.clip_score = cscore; a.clip_ref = cref;
   a.final_score = fin; a.best = best; a.best_cos = bcos; a.inp = d_inp; a.T = T; a.gen_idx = gen_idx;
   { ProfScope ps(e, "combine", 0); E_CHECK(launch_combine(a, e->st)); }
-  e->stat_clip_rows += M;
-  e->stat_clip_seqs += n_seq;
   e->stat_steps += 1;
   return 0;
 }
@@ -663,7 +677,8 @@ int czc_encode_images(czc_engine* e, const float* pixels, int B, float* out_embe
   { ProfScope ps(e, "rowops", 0);
     E_CHECK(launch_vision_assemble(pe, B, NP, H, cls, pos, x, e->st));
     E_CHECK(launch_layernorm(P, x, nullptr, g0, b0, c.clip_eps, M, H, nullptr, x, e->st)); }
-  E_CHECK(clip_stack(e, "gemm_vision", e->cvis, x, M, H, c.vis_inter, c.vis_heads, c.clip_eps, nullptr, nullptr, T, B, T, 0));
+  SegTable vtab{nullptr, nullptr, nullptr, nullptr, B, T};
+  E_CHECK(clip_stack(e, "gemm_vision", e->cvis, x, M, H, c.vis_inter, c.vis_heads, c.clip_eps, vtab, T, 0));
   { ProfScope ps(e, "rowops", 0);
     E_CHECK(launch_make_row_index(idx, B, T, 0, e->st));
     E_CHECK(launch_layernorm(P, x, idx, g1, b1, c.clip_eps, B, H, ca, nullptr, e->st)); }
@@ -681,23 +696,15 @@ int czc_encode_text(czc_engine* e, const int32_t* clip_ids, const int32_t* clip_
   if (!e->finalized) return fail(e, CZC_ERR_STATE, "weights not finalized%s");
   E_HIP(hipSetDevice(e->dev));
   e->err[0] = 0;
-  int *cids, *clen, *coff, *totals, *eidx;
+  int *cids, *clen, *totals;
   E_CHECK(ensure(e, "s_cids", (size_t)n * CZC_CLIP_MAX_LEN * 4, (void**)&cids));
   E_CHECK(ensure(e, "s_clen", (size_t)n * 4, (void**)&clen));
-  E_CHECK(ensure(e, "s_coff", (size_t)(n + 1) * 4, (void**)&coff));
   E_CHECK(ensure(e, "s_tot", 16, (void**)&totals));
-  E_CHECK(ensure(e, "s_eidx", (size_t)n * 4, (void**)&eidx));
   E_HIP(hipMemcpyAsync(cids, clip_ids, (size_t)n * CZC_CLIP_MAX_LEN * 4, hipMemcpyDefault, e->st));
   E_HIP(hipMemcpyAsync(clen, clip_len, (size_t)n * 4, hipMemcpyDefault, e->st));
   E_HIP(hipMemsetAsync(totals, 0, 16, e->st));
-  E_CHECK(launch_scan(clen, n, coff, totals, e->st));
-  E_HIP(hipMemcpyAsync(e->h_totals, totals, 12, hipMemcpyDeviceToHost, e->st));
-  E_HIP(hipStreamSynchronize(e->st));
-  const int M = e->h_totals[0], max_len = e->h_totals[1];
-  if (max_len > e->cfg.clip_max_pos || max_len > CZC_CLIP_MAX_LEN)
-    return fail(e, CZC_ERR_ARG, "CLIP sequence longer than max_position_embeddings%s");
   float* feat;
-  E_CHECK(clip_text_forward(e, cids, clen, coff, eidx, n, M, max_len, &feat));
+  E_CHECK(clip_text_forward(e, cids, clen, n, 1, 0, totals, &feat));  // independent sequences: no sharing
   E_HIP(hipMemcpyAsync(out_embeds, feat, (size_t)n * e->cfg.clip_proj * 4, hipMemcpyDefault, e->st));
   E_HIP(hipStreamSynchronize(e->st));
   return CZC_OK;
@@ -762,6 +769,12 @@ int czc_generate(czc_engine* e, int B, int T, int L, int seed_len, const int32_t
   }
   E_HIP(hipStreamSynchronize(e->st));
   return CZC_OK;
+}
+
+int czc_set_option(czc_engine* e, const char* name, int value) {
+  if (!e || !name) return CZC_ERR_ARG;
+  if (!strcmp(name, "share_prefix")) { e->share_prefix = value ? 1 : 0; return CZC_OK; }
+  return fail(e, CZC_ERR_ARG, "unknown option %s", name);
 }
 
 int czc_sync(czc_engine* e) {

@@ -31,9 +31,11 @@ int launch_layernorm(int prec, const float* x, const int* row_idx, const float* 
 int launch_bert_embed(int prec, const int* ids, int B, int T, int H, const float* word, const float* pos,
                       const float* type0, const float* gamma, const float* beta, float eps, void* y_act, float* y_f32,
                       hipStream_t st);
-// CLIP text embeddings on packed sequences: x[off[s]+p] = tok[id[s,p]] + pos[p]  (HF:clip/modeling_clip.py:250-254)
-int launch_clip_embed(const int* ids, int ids_stride, const int* seq_off, const int* seq_len, int n_seq, int max_len,
-                      int H, const float* tok, const float* pos, float* x, hipStream_t st);
+// CLIP text embeddings on packed segments: x[own_off[s]+i] = tok[ids[src[s], pos0[s]+i]] + pos[pos0[s]+i]
+// (HF:clip/modeling_clip.py:250-254)
+int launch_clip_embed(const int* ids, int ids_stride, const int* seg_src, const int* seg_pos0, const int* own_off,
+                      const int* own_len, int n_seg, int max_len, int H, const float* tok, const float* pos, float* x,
+                      hipStream_t st);
 // vision: im2col of [B,3,S,S] into patches [B*P, 3*p*p] (act type), then assemble cls/pos
 int launch_im2col(int prec, const float* pixels, int B, int S, int p, void* out, hipStream_t st);
 int launch_vision_assemble(const float* patch_out, int B, int P, int H, const float* cls, const float* pos, float* x,
@@ -51,10 +53,17 @@ int launch_mask_positions(int* inp, int B, int T, int gen_idx, int n_mask, int m
 int launch_broadcast_rows_i32(const int* row, int T, int B, int* dst, hipStream_t st);
 
 // ---- attention.hip ------------------------------------------------------------------------
-// softmax(q k^T * scale [+causal]) v on packed sequences; qkv [M, 3*heads*64] act type,
-// sequence s = rows [off[s], off[s]+len[s]) (or s*fixed_T.. when off == null); out [M, heads*64]
-int launch_attention(int prec, const void* qkv, const int* seq_off, const int* seq_len, int fixed_T, int n_seq,
-                     int max_len, int heads, int causal, float scale, void* out, hipStream_t st);
+// Segment s = `own_len[s]` rows starting at own_off[s] (queries and keys/values) preceded by
+// `pre_len[s]` key/value-only rows starting at pre_off[s] (the shared causal prefix of an image's
+// candidates).  own_len == null: fixed-length segments s*fixed_T.. (BERT, vision).
+struct SegTable {
+  const int* pre_off; const int* pre_len; const int* own_off; const int* own_len;
+  int n_seg; int fixed_T;
+};
+// softmax(q k^T * scale [+causal]) v; qkv [M, 3*heads*64] act type; out [M, heads*64] (own rows only)
+int launch_attention(int prec, const void* qkv, const SegTable& tab, int max_keys, int heads, int causal, float scale,
+                     void* out, hipStream_t st);
+extern int g_use_mfma_attention;
 
 // ---- topk.hip -----------------------------------------------------------------------------
 int launch_softmax_mask_topk(const float* logits, int B, int V, int K, const float* mask, float temperature, int dot_id,
@@ -81,6 +90,16 @@ int launch_bridge(const BridgeDev& bd, const int* inp, int B, int T, int gen_idx
                   int* overflow_flag, hipStream_t st);
 // exclusive scan of len[n] -> off[n+1]; totals[0] = sum, totals[1] = max
 int launch_scan(const int* len, int n, int* off, int* totals, hipStream_t st);
+// Shared-prefix plan for B images x K candidates (segments: B trunks, then B*K branches):
+//   p_b = share ? min(min_k LCP(ids[b,k], ids[b,0]), min_k len[b,k] - 1) : 0
+//   trunk b: own_len p_b, src row b*K, pos0 0, pre_len 0;  branch (b,k): own_len len-p_b, src b*K+k, pos0 p_b, pre_len p_b
+// max_len_out (device int, pre-zeroed) receives max_k len via atomicMax.
+int launch_prefix_plan(const int* clip_ids, const int* clip_len, int B, int K, int share, int* own_len, int* pre_len,
+                       int* seg_src, int* seg_pos0, int* max_len_out, hipStream_t st);
+// after the scan of own_len: pre_off[trunk] = 0, pre_off[branch (b,k)] = own_off[b];
+// eos_idx[b*K+k] = own_off[B+b*K+k] + own_len[B+b*K+k] - 1
+int launch_prefix_finish(const int* own_off, const int* own_len, int B, int K, int* pre_off, int* eos_idx,
+                         hipStream_t st);
 
 // ---- combine.hip --------------------------------------------------------------------------
 struct CombineArgs {

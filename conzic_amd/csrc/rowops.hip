@@ -149,32 +149,35 @@ int launch_bert_embed(int prec, const int* ids, int B, int T_, int H, const floa
   return 0;
 }
 
-// ---- CLIP text embeddings on packed sequences -------------------------------------------------
-// one wave per (sequence, position).  The K candidates of an image share every token id but one,
+// ---- CLIP text embeddings on packed segments ----------------------------------------------------
+// one wave per (segment, own row).  The K candidates of an image share every token id but one,
 // so the token-embedding rows they gather are the same cache lines (L2-resident after first touch).
-__global__ __launch_bounds__(256) void clip_embed_kernel(const int* ids, int ids_stride, const int* seq_off,
-                                                         const int* seq_len, int n_seq, int max_len, int H,
-                                                         const float* tok, const float* pos, float* x) {
+__global__ __launch_bounds__(256) void clip_embed_kernel(const int* ids, int ids_stride, const int* seg_src,
+                                                         const int* seg_pos0, const int* own_off, const int* own_len,
+                                                         int n_seg, int max_len, int H, const float* tok,
+                                                         const float* pos, float* x) {
   const int lane = threadIdx.x & 63;
   const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int s = (int)(w / max_len), p = (int)(w % max_len);
-  if (s >= n_seq || p >= seq_len[s]) return;
-  const int id = ids[(long)s * ids_stride + p];
+  const int s = (int)(w / max_len), i = (int)(w % max_len);
+  if (s >= n_seg || i >= own_len[s]) return;
+  const int p = seg_pos0[s] + i;
+  const int id = ids[(long)seg_src[s] * ids_stride + p];
   const float* tr = tok + (long)id * H;
   const float* pr = pos + (long)p * H;
-  float* xr = x + ((long)seq_off[s] + p) * H;
+  float* xr = x + ((long)own_off[s] + i) * H;
   for (int c = lane * 4; c < H; c += 256) {
     const float4 a = *(const float4*)(tr + c), b = *(const float4*)(pr + c);
     *(float4*)(xr + c) = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
   }
 }
 
-int launch_clip_embed(const int* ids, int ids_stride, const int* seq_off, const int* seq_len, int n_seq, int max_len,
-                      int H, const float* tok, const float* pos, float* x, hipStream_t st) {
-  if (n_seq <= 0) return 0;
-  dim3 grid(cdiv((long)n_seq * max_len, 4)), block(256);
-  hipLaunchKernelGGL(clip_embed_kernel, grid, block, 0, st, ids, ids_stride, seq_off, seq_len, n_seq, max_len, H, tok,
-                     pos, x);
+int launch_clip_embed(const int* ids, int ids_stride, const int* seg_src, const int* seg_pos0, const int* own_off,
+                      const int* own_len, int n_seg, int max_len, int H, const float* tok, const float* pos, float* x,
+                      hipStream_t st) {
+  if (n_seg <= 0) return 0;
+  dim3 grid(cdiv((long)n_seg * max_len, 4)), block(256);
+  hipLaunchKernelGGL(clip_embed_kernel, grid, block, 0, st, ids, ids_stride, seg_src, seg_pos0, own_off, own_len, n_seg,
+                     max_len, H, tok, pos, x);
   CZC_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -192,6 +192,9 @@ class Engine:
                                        ids.ctypes.data, cos.ctypes.data), "czc_generate")
         return ids, cos
 
+    def set_option(self, name: str, value: int):
+        self._ck(self.lib.czc_set_option(self.h, name.encode(), int(value)), f"czc_set_option({name})")
+
     # ---- measurement ------------------------------------------------------------------------------
     def profile(self, on: bool):
         self._ck(self.lib.czc_profile_enable(self.h, 1 if on else 0), "czc_profile_enable")

@@ -81,6 +81,7 @@ SIGNATURES = {
     "czc_encode_text": (_I, [_P, _P, _P, _I, _P]),
     "czc_step": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, C.POINTER(Hyper), C.POINTER(StepOut)]),
     "czc_generate": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _P, _P, _I, C.POINTER(Hyper), _P, _P]),
+    "czc_set_option": (_I, [_P, C.c_char_p, _I]),
     "czc_profile_enable": (_I, [_P, _I]),
     "czc_profile_reset": (_I, [_P]),
     "czc_profile_get": (_I, [_P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),

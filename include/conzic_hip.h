@@ -164,6 +164,10 @@ int czc_generate(czc_engine* e, int B, int T, int L, int seed_len, const int32_t
                  int n_steps, const int32_t* positions_host, const int32_t* n_mask_host, int snapshot_every,
                  const czc_hyper* hp, int32_t* out_ids, float* out_cos);
 
+/* Engine options.  "share_prefix" (default 1): encode the causal prefix common to an image's K
+ * candidates once per step instead of K times (results are identical). */
+int czc_set_option(czc_engine* e, const char* name, int value);
+
 /* ---- measurement ------------------------------------------------------------------------- */
 /* HIP-event timing of kernel classes on the engine's own stream (bench.py roofline leg).
  * kind: "gemm_clip_text" | "gemm_bert" | "gemm_vision" | "attention" | "rowops" | "topk" | "bridge" | "combine" */

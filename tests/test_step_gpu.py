@@ -122,7 +122,16 @@ def teacher_forced(meta, arr, prec, n_steps=None):
         pos = meta["positions"][i]
         reuse = meta["reuse"][i]
         if reuse:
-            inp = prev_inp  # second position of a span: state after the first, same forward
+            # second position of a span: same forward, state after the first position.  Put the
+            # REFERENCE's winner of the previous step there (a near-tie flip of the engine's own
+            # winner must not leak into this step's comparison).
+            inp = prev_inp
+            j = next((t for t in range(i + 1, len(meta["reuse"])) if not meta["reuse"][t]), None)
+            prev_gen = SEED_LEN + meta["positions"][i - 1]
+            if j is not None and j < arr["inp_before"].shape[0] and \
+                    SEED_LEN + meta["positions"][j] != prev_gen and not (j + 1 < len(meta["reuse"]) and meta["reuse"][j + 1]
+                                                                         and SEED_LEN + meta["positions"][j] + 1 == prev_gen):
+                inp[:, prev_gen] = arr["inp_before"][j][:, prev_gen]
             n_mask = 0
         else:
             inp = np.ascontiguousarray(arr["inp_before"][i], dtype=np.int32)
@@ -240,3 +249,34 @@ def test_step_rejects_bad_arguments():
         e2 = harness.build_synthetic(True, F32)
         e2.engine.set_image_embeds(np.ones((2, su.clip_cfg.proj), np.float32))
         e2.engine.step(inp.copy(), 4, 8, Engine.hyper(0.02, 2.0, 0.1, gamma=5.0))
+
+
+@pytest.mark.parametrize("prec", [F32, BF16])
+@pytest.mark.parametrize("name", ["tiny_shuffle", "full_synth_b2"])
+def test_prefix_sharing_is_exact(prec, name):
+    """Encoding the candidates' common causal prefix once (trunk + branches) must not change the
+    result: same step with share_prefix on and off."""
+    meta, arr = load_case(name)
+    su = setup_for(meta, prec)
+    eng = su.engine
+    eng.set_image_embeds(arr["image_embeds"])
+    hp = Engine.hyper(meta["alpha"], meta["beta"], meta["temperature"])
+    outs = []
+    for share in (1, 0):
+        eng.set_option("share_prefix", share)
+        eng.profile_reset()
+        rows = []
+        for i in (0, 3, arr["probs"].shape[0] - 1):
+            inp = np.ascontiguousarray(arr["inp_before"][i], dtype=np.int32)
+            r = eng.step(inp, SEED_LEN + meta["positions"][i], meta["K"], hp,
+                         dot_allowed=(meta["positions"][i] == meta["L"] - 1))
+            rows.append((r, inp.copy()))
+        outs.append((rows, eng.stats()["clip_rows"]))
+    eng.set_option("share_prefix", 1)
+    (a, rows_a), (b, rows_b) = outs
+    assert rows_a < rows_b, "sharing must push fewer rows through the CLIP text tower"
+    for (ra, ia), (rb, ib) in zip(a, b):
+        np.testing.assert_array_equal(ra["clip_ids"], rb["clip_ids"])
+        np.testing.assert_allclose(ra["clip_ref"], rb["clip_ref"], atol=1e-6 if prec == F32 else 2e-5)
+        np.testing.assert_allclose(ra["final_score"], rb["final_score"], atol=1e-6 if prec == F32 else 2e-5)
+        np.testing.assert_array_equal(ia, ib)
