@@ -191,6 +191,178 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const bf16_t* qkv, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// bf16 MFMA kernel for the BRANCH segments of a shared-prefix plan.
+// The K candidates of an image own only a handful of rows each (the rows from the first differing
+// token on) and are laid out back to back, so one wave packs G consecutive candidates of one image
+// into a single 32-query MFMA tile: their trunk keys are shared (one S^T tile per 32 trunk keys for
+// all G candidates at once), their own keys form one block-diagonal 32x32 tile (a query sees the
+// own keys of its own candidate up to itself).  ~G times fewer waves and MFMAs than one wave per
+// candidate; requires G * max(own_len) <= 32.
+// ------------------------------------------------------------------------------------------------
+constexpr int AB_MAXT = 3;  // trunk key tiles (<= 96 trunk keys)
+
+__global__ __launch_bounds__(256) void attention_branch_kernel(const bf16_t* qkv, SegTable tab, int B, int K, int G,
+                                                               int heads, float scale, int KP, bf16_t* out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char at_lds[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int wpb = blockDim.x >> 6;
+  int h = blockIdx.y * wpb + wave;
+  const bool live = h < heads;
+  if (!live) h = heads - 1;
+  const int gpi = (K + G - 1) / G;  // groups per image
+  const int b = blockIdx.x / gpi, k0 = (blockIdx.x - b * gpi) * G;
+  const int Gc = min(G, K - k0);
+  const int s0 = B + b * K + k0;
+  const int pre_off = tab.pre_off[s0], pre_len = tab.pre_len[s0];
+  const int r0 = tab.own_off[s0];
+  const int n_own = tab.own_off[s0 + Gc - 1] + tab.own_len[s0 + Gc - 1] - r0;  // <= 32 by construction
+  const int nkt_t = (pre_len + 31) >> 5;
+  const int Hd = heads * 64;
+  const long pitch = 3L * Hd;
+  bf16_t* Vt = (bf16_t*)at_lds + (size_t)wave * 64 * KP;
+  const int own_slot0 = nkt_t * 32;
+
+  // ---- V^T -> LDS (trunk keys, then the packed own rows), padding slots zeroed ----
+  const int d0 = (lane & 7) * 8;
+  for (int k = lane >> 3; k < own_slot0 + 32; k += 8) {
+    long row = -1;
+    if (k < pre_len) row = (long)pre_off + k;
+    else if (k >= own_slot0 && k - own_slot0 < n_own) row = (long)r0 + (k - own_slot0);
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row >= 0) v = *(const uint4*)(qkv + row * pitch + 2 * Hd + h * 64 + d0);
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) Vt[(d0 + e) * KP + k] = (bf16_t)((w[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+  }
+  __syncthreads();
+
+  const int half = lane >> 5, l31 = lane & 31;
+  const int q = min(l31, n_own - 1);
+  // first slot of this query's own candidate
+  int ss = 0;
+  for (int j = 1; j < Gc; ++j) {
+    const int o = tab.own_off[s0 + j] - r0;
+    if (o <= q) ss = o;
+  }
+  const bf16_t* qp = qkv + ((long)r0 + q) * pitch + h * 64 + 8 * half;
+  uint4 qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const uint4*)(qp + 16 * ks);
+
+  f32x16_t st[AB_MAXT + 1];
+#pragma unroll
+  for (int t = 0; t <= AB_MAXT; ++t) {
+    if (t <= nkt_t) {  // tiles 0..nkt_t-1 trunk, tile nkt_t = own
+      long krow;
+      if (t < nkt_t) krow = (long)pre_off + min(t * 32 + l31, pre_len - 1);
+      else krow = (long)r0 + min(l31, n_own - 1);
+      const bf16_t* kp = qkv + krow * pitch + Hd + h * 64 + 8 * half;
+      f32x16_t acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const uint4 kf = *(const uint4*)(kp + 16 * ks);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, kf),
+                                                      __builtin_bit_cast(bf16x8_t, qf[ks]), acc, 0, 0, 0);
+      }
+      st[t] = acc;
+    }
+  }
+  float mx = -INFINITY;
+#pragma unroll
+  for (int t = 0; t <= AB_MAXT; ++t) {
+    if (t <= nkt_t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int idx = (r & 3) + 8 * (r >> 2) + 4 * half;
+        const bool ok = t < nkt_t ? (t * 32 + idx < pre_len) : (idx >= ss && idx <= q);
+        const float v = ok ? st[t][r] * scale : -INFINITY;
+        st[t][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    }
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  float sum = 0.f;
+  uint4 pf[AB_MAXT + 1][2];
+#pragma unroll
+  for (int t = 0; t <= AB_MAXT; ++t) {
+    if (t <= nkt_t) {
+      float e[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        e[r] = __expf(st[t][r] - mx);
+        sum += e[r];
+      }
+#pragma unroll
+      for (int sstep = 0; sstep < 2; ++sstep) {
+        pf[t][sstep].x = (uint32_t)f2bf(e[8 * sstep + 0]) | ((uint32_t)f2bf(e[8 * sstep + 1]) << 16);
+        pf[t][sstep].y = (uint32_t)f2bf(e[8 * sstep + 2]) | ((uint32_t)f2bf(e[8 * sstep + 3]) << 16);
+        pf[t][sstep].z = (uint32_t)f2bf(e[8 * sstep + 4]) | ((uint32_t)f2bf(e[8 * sstep + 5]) << 16);
+        pf[t][sstep].w = (uint32_t)f2bf(e[8 * sstep + 6]) | ((uint32_t)f2bf(e[8 * sstep + 7]) << 16);
+      }
+    }
+  }
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = 1.0f / sum;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt) {
+    f32x16_t o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+    const bf16_t* vrow = Vt + (dt * 32 + l31) * KP;
+#pragma unroll
+    for (int t = 0; t <= AB_MAXT; ++t) {
+      if (t <= nkt_t) {
+#pragma unroll
+        for (int sstep = 0; sstep < 2; ++sstep) {
+          const uint2 lo = *(const uint2*)(vrow + t * 32 + 16 * sstep + 4 * half);
+          const uint2 hi = *(const uint2*)(vrow + t * 32 + 16 * sstep + 8 + 4 * half);
+          const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
+          o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vf),
+                                                      __builtin_bit_cast(bf16x8_t, pf[t][sstep]), o, 0, 0, 0);
+        }
+      }
+    }
+    if (live && l31 < n_own) {
+      bf16_t* op = out + ((long)r0 + l31) * Hd + h * 64 + dt * 32 + 4 * half;
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        uint2 w;
+        w.x = (uint32_t)f2bf(o[4 * qd] * inv) | ((uint32_t)f2bf(o[4 * qd + 1] * inv) << 16);
+        w.y = (uint32_t)f2bf(o[4 * qd + 2] * inv) | ((uint32_t)f2bf(o[4 * qd + 3] * inv) << 16);
+        *(uint2*)(op + 8 * qd) = w;
+      }
+    }
+  }
+}
+
+// trunks through the generic kernel (n_seg = B), branches packed G per wave
+int launch_attention_shared(const void* qkv, const SegTable& tab, int B, int K, int max_own, int max_keys, int heads,
+                            float scale, void* out, hipStream_t st) {
+  if (max_keys > 96 || max_own > 32 || max_own <= 0) return -1;  // caller falls back to the generic path
+  const int G = 32 / max_own;
+  const int KPt = ((max_keys + 31) & ~31) + 4;
+  const int wpb = heads >= 4 ? 4 : (heads >= 2 ? 2 : 1);
+  {
+    SegTable trunks = tab;
+    trunks.n_seg = B;
+    dim3 grid(B, cdiv(heads, wpb)), block(64 * wpb);
+    hipLaunchKernelGGL(attention_mfma_kernel, grid, block, (size_t)wpb * 64 * KPt * 2, st, (const bf16_t*)qkv, trunks,
+                       heads, 1, scale, KPt, (bf16_t*)out);
+  }
+  const int KP = ((max_keys + 31) & ~31) + 32 + 4;  // trunk tiles + the own tile
+  const int gpi = cdiv(K, G);
+  dim3 grid(B * gpi, cdiv(heads, wpb)), block(64 * wpb);
+  hipLaunchKernelGGL(attention_branch_kernel, grid, block, (size_t)wpb * 64 * KP * 2, st, (const bf16_t*)qkv, tab, B, K,
+                     G, heads, scale, KP, (bf16_t*)out);
+  CZC_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // exact-fp32 wavefront kernel (f32 engine; also the reference the MFMA kernel is tested against)
 // ------------------------------------------------------------------------------------------------
 template <typename T>

@@ -208,6 +208,7 @@ __global__ __launch_bounds__(256) void prefix_plan_kernel(const int* cids, const
   if (tid == 0) {
     own_len[b] = pb; pre_len[b] = 0; seg_src[b] = b * K; seg_pos0[b] = 0;
     atomicMax(max_len_out, s_max);
+    atomicMax(max_len_out + 1, s_max - pb);  // longest branch (own rows of one candidate)
   }
   for (int k = tid; k < K; k += blockDim.x) {
     const int s = B + b * K + k;

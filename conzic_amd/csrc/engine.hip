@@ -76,6 +76,7 @@ struct czc_engine {
   int* h_totals = nullptr;  // pinned: [0]=rows [1]=max len [2]=overflow
   int last_BT = 0;
   int share_prefix = 1;  // encode the candidates' common causal prefix once per image
+  int pack_branches = 1; // pack several candidates' rows into one attention MFMA tile
 
   bool prof = false;
   std::map<std::string, ProfKind> pk;
@@ -228,7 +229,8 @@ int gemm(czc_engine* e, int prec, const char* kind, const void* A, int lda, cons
 // ---- pre-LN transformer stack shared by the CLIP text and vision towers -----------------------
 // x_f32 [M,H] residual stream (updated in place); packed sequences described by off/len or fixed_T
 int clip_stack(czc_engine* e, const char* gk, std::vector<LayerW>& L, float* x, int M, int H, int I, int heads,
-               float eps, const SegTable& tab, int max_keys, int causal) {
+               float eps, const SegTable& tab, int max_keys, int causal, int plan_B = 0, int plan_K = 0,
+               int plan_max_own = 0) {
   const int P = e->pc;
   void *y, *qkv, *ctx, *hbuf;
   E_CHECK(ensure(e, "cs_y", (size_t)M * H * e->esz, &y));
@@ -241,7 +243,11 @@ int clip_stack(czc_engine* e, const char* gk, std::vector<LayerW>& L, float* x, 
     { ProfScope ps(e, "rowops", 0); E_CHECK(launch_layernorm(P, x, nullptr, l.ln1_g, l.ln1_b, eps, M, H, y, nullptr, e->st)); }
     E_CHECK(gemm(e, P, gk, y, H, l.qkv_w, H, l.qkv_b, nullptr, 0, qkv, nullptr, 3 * H, M, 3 * H, H, ACT_NONE));
     { ProfScope ps(e, "attention", 0);
-      E_CHECK(launch_attention(P, qkv, tab, max_keys, heads, causal, scale, ctx, e->st)); }
+      int rc = -1;
+      if (plan_B > 0 && P == PREC_BF16 && g_use_mfma_attention && e->pack_branches)
+        rc = launch_attention_shared(qkv, tab, plan_B, plan_K, plan_max_own, max_keys, heads, scale, ctx, e->st);
+      if (rc > 0) E_CHECK(rc);
+      if (rc < 0) E_CHECK(launch_attention(P, qkv, tab, max_keys, heads, causal, scale, ctx, e->st)); }
     E_CHECK(gemm(e, P, gk, ctx, H, l.o_w, H, l.o_b, x, H, nullptr, x, H, M, H, H, ACT_NONE));
     { ProfScope ps(e, "rowops", 0); E_CHECK(launch_layernorm(P, x, nullptr, l.ln2_g, l.ln2_b, eps, M, H, y, nullptr, e->st)); }
     E_CHECK(gemm(e, P, gk, y, H, l.fc1_w, H, l.fc1_b, nullptr, 0, hbuf, nullptr, I, M, I, H, ACT_QUICK_GELU));
@@ -337,9 +343,9 @@ int clip_text_forward(czc_engine* e, const int* cids, const int* clen, int B, in
     E_CHECK(launch_prefix_plan(cids, clen, B, K, share, own_len, pre_len, src, pos0, totals + 3, e->st));
     E_CHECK(launch_scan(own_len, S, own_off, totals, e->st));
     E_CHECK(launch_prefix_finish(own_off, own_len, B, K, pre_off, eidx, e->st)); }
-  E_HIP(hipMemcpyAsync(e->h_totals, totals, 16, hipMemcpyDeviceToHost, e->st));
+  E_HIP(hipMemcpyAsync(e->h_totals, totals, 32, hipMemcpyDeviceToHost, e->st));
   E_HIP(hipStreamSynchronize(e->st));  // the one host round trip per step (the reference has one too, gen_utils.py:81)
-  const int M = e->h_totals[0], max_len = e->h_totals[3];
+  const int M = e->h_totals[0], max_len = e->h_totals[3], max_branch = e->h_totals[4];
   if (e->h_totals[2]) return fail(e, CZC_ERR_OVERFLOW, "text bridge overflow (row text > CZC_BRIDGE_MAX_BYTES)%s");
   if (max_len > c.clip_max_pos || max_len > CZC_CLIP_MAX_LEN)
     return fail(e, CZC_ERR_ARG, "CLIP sequence longer than max_position_embeddings%s");
@@ -355,7 +361,8 @@ int clip_text_forward(czc_engine* e, const int* cids, const int* clen, int B, in
   { ProfScope ps(e, "rowops", 0);
     E_CHECK(launch_clip_embed(cids, CZC_CLIP_MAX_LEN, src, pos0, own_off, own_len, S, max_len, H, tok, pos, x, e->st)); }
   SegTable tab{pre_off, pre_len, own_off, own_len, S, 0};
-  E_CHECK(clip_stack(e, "gemm_clip_text", e->ctext, x, M, H, c.clip_inter, c.clip_heads, c.clip_eps, tab, max_len, 1));
+  E_CHECK(clip_stack(e, "gemm_clip_text", e->ctext, x, M, H, c.clip_inter, c.clip_heads, c.clip_eps, tab, max_len, 1, B,
+                     K, max_branch));
   { ProfScope ps(e, "rowops", 0);
     E_CHECK(launch_layernorm(P, x, eidx, fg, fb, c.clip_eps, n_seq, H, pa, nullptr, e->st)); }
   E_CHECK(gemm(e, P, "gemm_clip_text", pa, H, e->tproj_w, H, nullptr, nullptr, 0, nullptr, feat, c.clip_proj, n_seq,
@@ -395,13 +402,13 @@ int step_device(czc_engine* e, int* d_inp, int B, int T, int gen_idx, int n_mask
   E_CHECK(ensure(e, "s_cand", (size_t)n_seq * 4, (void**)&cand));
   E_CHECK(ensure(e, "s_cids", (size_t)n_seq * CZC_CLIP_MAX_LEN * 4, (void**)&cids));
   E_CHECK(ensure(e, "s_clen", (size_t)n_seq * 4, (void**)&clen));
-  E_CHECK(ensure(e, "s_tot", 16, (void**)&totals));
+  E_CHECK(ensure(e, "s_tot", 32, (void**)&totals));
   E_CHECK(ensure(e, "s_senti", (size_t)n_seq * 4, (void**)&senti));
   E_CHECK(ensure(e, "s_reps", (size_t)n_seq * 4, (void**)&reps));
   { ProfScope ps(e, "topk", 0);
     E_CHECK(launch_softmax_mask_topk(logits, B, c.bert_vocab, K, e->d_mask, hp->temperature, c.dot_id, dot_allowed,
                                      probs, idxs, cand, e->st)); }
-  E_HIP(hipMemsetAsync(totals, 0, 16, e->st));
+  E_HIP(hipMemsetAsync(totals, 0, 32, e->st));
   { ProfScope ps(e, "bridge", 0);
     E_CHECK(launch_bridge(e->bd, d_inp, B, T, gen_idx, cand, K, hp->use_sentiment ? e->d_lex : nullptr, hp->negative,
                           cids, clen, senti, reps, totals + 2, e->st)); }
@@ -699,10 +706,10 @@ int czc_encode_text(czc_engine* e, const int32_t* clip_ids, const int32_t* clip_
   int *cids, *clen, *totals;
   E_CHECK(ensure(e, "s_cids", (size_t)n * CZC_CLIP_MAX_LEN * 4, (void**)&cids));
   E_CHECK(ensure(e, "s_clen", (size_t)n * 4, (void**)&clen));
-  E_CHECK(ensure(e, "s_tot", 16, (void**)&totals));
+  E_CHECK(ensure(e, "s_tot", 32, (void**)&totals));
   E_HIP(hipMemcpyAsync(cids, clip_ids, (size_t)n * CZC_CLIP_MAX_LEN * 4, hipMemcpyDefault, e->st));
   E_HIP(hipMemcpyAsync(clen, clip_len, (size_t)n * 4, hipMemcpyDefault, e->st));
-  E_HIP(hipMemsetAsync(totals, 0, 16, e->st));
+  E_HIP(hipMemsetAsync(totals, 0, 32, e->st));
   float* feat;
   E_CHECK(clip_text_forward(e, cids, clen, n, 1, 0, totals, &feat));  // independent sequences: no sharing
   E_HIP(hipMemcpyAsync(out_embeds, feat, (size_t)n * e->cfg.clip_proj * 4, hipMemcpyDefault, e->st));
@@ -774,6 +781,7 @@ int czc_generate(czc_engine* e, int B, int T, int L, int seed_len, const int32_t
 int czc_set_option(czc_engine* e, const char* name, int value) {
   if (!e || !name) return CZC_ERR_ARG;
   if (!strcmp(name, "share_prefix")) { e->share_prefix = value ? 1 : 0; return CZC_OK; }
+  if (!strcmp(name, "pack_branches")) { e->pack_branches = value ? 1 : 0; return CZC_OK; }
   return fail(e, CZC_ERR_ARG, "unknown option %s", name);
 }
 

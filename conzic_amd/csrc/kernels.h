@@ -64,6 +64,10 @@ struct SegTable {
 int launch_attention(int prec, const void* qkv, const SegTable& tab, int max_keys, int heads, int causal, float scale,
                      void* out, hipStream_t st);
 extern int g_use_mfma_attention;
+// bf16 engine, shared-prefix plan (B trunk segments then B*K branch segments): returns -1 when the
+// shapes do not fit the packed-branch kernel (caller then uses launch_attention)
+int launch_attention_shared(const void* qkv, const SegTable& tab, int B, int K, int max_own, int max_keys, int heads,
+                            float scale, void* out, hipStream_t st);
 
 // ---- topk.hip -----------------------------------------------------------------------------
 int launch_softmax_mask_topk(const float* logits, int B, int V, int K, const float* mask, float temperature, int dot_id,
@@ -93,7 +97,7 @@ int launch_scan(const int* len, int n, int* off, int* totals, hipStream_t st);
 // Shared-prefix plan for B images x K candidates (segments: B trunks, then B*K branches):
 //   p_b = share ? min(min_k LCP(ids[b,k], ids[b,0]), min_k len[b,k] - 1) : 0
 //   trunk b: own_len p_b, src row b*K, pos0 0, pre_len 0;  branch (b,k): own_len len-p_b, src b*K+k, pos0 p_b, pre_len p_b
-// max_len_out (device int, pre-zeroed) receives max_k len via atomicMax.
+// max_len_out (two device ints, pre-zeroed) receive max len and max branch own_len via atomicMax.
 int launch_prefix_plan(const int* clip_ids, const int* clip_len, int B, int K, int share, int* own_len, int* pre_len,
                        int* seg_src, int* seg_pos0, int* max_len_out, hipStream_t st);
 // after the scan of own_len: pre_off[trunk] = 0, pre_off[branch (b,k)] = own_off[b];
