@@ -1,0 +1,109 @@
+"""Drop-in for the reference's clip/clip.py `CLIP` wrapper (clip/clip.py:6-102): same method
+names and return conventions, executed by the native engine.
+
+    clip = CLIP("openai/clip-vit-base-patch32")          # needs `transformers` + a local checkpoint
+    clip = CLIP.from_state(cfg, state_dict, tokenizer)   # synthetic / already-loaded weights
+
+Returned tensors are torch CPU tensors when torch is importable (the reference returns torch
+tensors), numpy arrays otherwise.  Index-building helpers of the reference (clip/clip.py:105-144)
+belong to its retrieval baseline and are out of scope.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from conzic_amd import native, synth
+from conzic_amd.imageproc import preprocess
+
+
+def _wrap(a: np.ndarray):
+    try:
+        import torch
+        return torch.from_numpy(np.ascontiguousarray(a))
+    except ImportError:
+        return a
+
+
+class CLIP:
+    def __init__(self, model_name=None):
+        self.model = None
+        self.processor = None
+        self.tokenizer = None
+        self.czc_cfg = None
+        self._state = None
+        self._engine = None
+        self.lexicon = None  # fp32 [bert_vocab] sentiment table for control_gen_utils
+        self.cuda_has_been_checked = False
+        if model_name is not None:
+            print('Initializing CLIP model...')
+            from transformers import CLIPModel, CLIPProcessor, CLIPTokenizer
+            self.model = CLIPModel.from_pretrained(model_name)
+            self.model.eval()
+            self.processor = CLIPProcessor.from_pretrained(model_name)
+            self.tokenizer = CLIPTokenizer.from_pretrained(model_name)
+            print('CLIP model initialized.')
+
+    @classmethod
+    def from_state(cls, cfg: synth.ClipCfg, state_dict, tokenizer):
+        self = cls(None)
+        self.czc_cfg = cfg
+        self._state = state_dict
+        self.tokenizer = tokenizer
+        return self
+
+    # nn.Module-ish no-ops the reference's callers use (demo.py:128-132)
+    def eval(self):
+        return self
+
+    def to(self, device):
+        return self
+
+    def clip_state_dict(self):
+        return self._state if self._state is not None else self.model.state_dict()
+
+    def _eng(self):
+        if self._engine is None:
+            from conzic_amd.runtime import clip_only_engine
+            self._engine = clip_only_engine(self)
+        return self._engine
+
+    def _image_size(self):
+        if self.czc_cfg is not None:
+            return self.czc_cfg.v_image
+        return self.model.config.vision_config.image_size
+
+    # ---- clip/clip.py:48-62 ------------------------------------------------------------------
+    def compute_image_representation_from_image_instance(self, image):
+        if self.processor is not None:
+            pixels = self.processor(images=image, return_tensors="np")['pixel_values'].astype(np.float32)
+        else:
+            pixels = preprocess(image, self._image_size())
+        return _wrap(self._eng().encode_images(pixels))
+
+    def compute_image_representation_from_image_path(self, image_path):
+        from PIL import Image
+        return self.compute_image_representation_from_image_instance(Image.open(image_path))
+
+    # ---- clip/clip.py:64-84 ------------------------------------------------------------------
+    def compute_text_representation(self, text_list):
+        enc = self.tokenizer(text_list, padding=True, max_length=self.tokenizer.max_len_single_sentence + 2,
+                             truncation=True)
+        ids = np.asarray(enc['input_ids'], dtype=np.int32)
+        lens = np.asarray(enc['attention_mask'], dtype=np.int32).sum(1).astype(np.int32)
+        return _wrap(self._eng().encode_text(ids, lens))
+
+    # ---- clip/clip.py:86-98 ------------------------------------------------------------------
+    def compute_image_text_similarity_via_embeddings(self, image_embeds, text_embeds):
+        """-> (softmax over the text list of cos*exp(logit_scale), cos), both [batch, len(text_list)]"""
+        from conzic_amd.engine import Engine, test_combine
+        ie = np.asarray(image_embeds, dtype=np.float32)
+        te = np.asarray(text_embeds, dtype=np.float32).reshape(ie.shape[0], -1, ie.shape[1])
+        B, K, D = te.shape
+        ls = float(np.asarray(self.clip_state_dict()["logit_scale"], dtype=np.float32))
+        cs, cr, _, _ = test_combine(te.reshape(B * K, D), ie, ls, np.zeros((B, K), np.float32),
+                                    Engine.hyper(0.0, 1.0, 1.0))
+        return _wrap(cs), _wrap(cr)
+
+    def compute_image_text_similarity_via_raw_text(self, image_embeds, text_list):
+        text_embeds = self.compute_text_representation(text_list)
+        return self.compute_image_text_similarity_via_embeddings(image_embeds, text_embeds)

@@ -1,0 +1,32 @@
+"""CLIP image pre-processing on the host (clip/clip.py:55-56 -> CLIPProcessor): RGB, resize the
+shorter side to S with bicubic resampling, centre crop SxS, /255, normalise, CHW.
+Once per image; the result feeds czc_encode_images."""
+from __future__ import annotations
+
+import numpy as np
+
+from .synth import CLIP_MEAN, CLIP_STD
+
+
+def preprocess(images, size: int = 224) -> np.ndarray:
+    from PIL import Image
+    if not isinstance(images, (list, tuple)):
+        images = [images]
+    out = np.empty((len(images), 3, size, size), dtype=np.float32)
+    for i, im in enumerate(images):
+        if isinstance(im, np.ndarray):
+            im = Image.fromarray(im)
+        im = im.convert("RGB")
+        w, h = im.size
+        if (w, h) != (size, size):
+            if w <= h:
+                nw, nh = size, int(size * h / w)
+            else:
+                nw, nh = int(size * w / h), size
+            im = im.resize((nw, nh), resample=Image.BICUBIC)
+            left, top = (nw - size) // 2, (nh - size) // 2
+            im = im.crop((left, top, left + size, top + size))
+        x = np.asarray(im, dtype=np.float32) * np.float32(1.0 / 255.0)
+        x = (x - CLIP_MEAN) / CLIP_STD
+        out[i] = np.moveaxis(x, -1, 0)
+    return out

@@ -1,0 +1,162 @@
+"""Glue between the reference-shaped call surface (gen_utils / control_gen_utils / clip.clip at
+the repo root) and the native engine: builds ONE engine per (masked-LM, CLIP, tokenizer) triple,
+pulls weights from `state_dict()`, builds the device text-bridge tables from the two tokenizers,
+and turns the reference's visiting orders into czc_generate step lists.
+
+`model` may be a HF `BertForMaskedLM` (demo.py:125) or `conzic_amd.models.SyntheticLM`;
+`clip` is `clip.clip.CLIP` (this repo's drop-in); `tokenizer` a HF `BertTokenizer` or
+`conzic_amd.text.WordPieceTokenizer`.  There is no CPU fallback: without the HIP library or a GPU
+`Engine(...)` raises `NativeError`.
+"""
+from __future__ import annotations
+
+import os
+import random
+import time
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import native, synth
+from .bridge import tables_from_tokenizers
+from .engine import Engine
+from .harness import order_positions
+
+_ENGINES: Dict[tuple, Engine] = {}
+
+
+def _precision() -> int:
+    p = os.environ.get("CZC_PRECISION", "bf16").lower()
+    return {"bf16": native.PREC_BF16, "f32": native.PREC_F32, "fp32": native.PREC_F32}[p]
+
+
+def _to_numpy_state(sd) -> Dict[str, np.ndarray]:
+    out = {}
+    for k, v in sd.items():
+        if hasattr(v, "detach"):
+            v = v.detach().float().cpu().numpy()
+        out[k] = np.asarray(v, dtype=np.float32)
+    return out
+
+
+def bert_cfg_of(model) -> synth.BertCfg:
+    c = getattr(model, "czc_cfg", None)
+    if c is not None:
+        return c
+    h = model.config  # HF BertConfig
+    return synth.BertCfg(vocab=h.vocab_size, hidden=h.hidden_size, layers=h.num_hidden_layers,
+                         heads=h.num_attention_heads, inter=h.intermediate_size, max_pos=h.max_position_embeddings,
+                         eps=h.layer_norm_eps)
+
+
+def clip_cfg_of(clip) -> synth.ClipCfg:
+    c = getattr(clip, "czc_cfg", None)
+    if c is not None:
+        return c
+    h = clip.model.config  # HF CLIPConfig
+    t, v = h.text_config, h.vision_config
+    return synth.ClipCfg(vocab=t.vocab_size, hidden=t.hidden_size, layers=t.num_hidden_layers,
+                         heads=t.num_attention_heads, inter=t.intermediate_size, max_pos=t.max_position_embeddings,
+                         eps=t.layer_norm_eps, proj=h.projection_dim, bos_id=clip.tokenizer.bos_token_id,
+                         eos_id=clip.tokenizer.eos_token_id, v_hidden=v.hidden_size, v_layers=v.num_hidden_layers,
+                         v_heads=v.num_attention_heads, v_inter=v.intermediate_size, v_image=v.image_size,
+                         v_patch=v.patch_size)
+
+
+def special_ids_of(tokenizer) -> Dict[str, int]:
+    vocab = tokenizer.vocab if hasattr(tokenizer, "vocab") else tokenizer.get_vocab()
+    return {k: int(vocab[k]) for k in ("[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]", ".")}
+
+
+def get_engine(model, clip, tokenizer, device: int = 0) -> Engine:
+    """One engine per (model, clip, tokenizer) object triple, created on first use."""
+    key = (id(model), id(clip), id(tokenizer), _precision(), device)
+    eng = _ENGINES.get(key)
+    if eng is None:
+        bcfg, ccfg = bert_cfg_of(model), clip_cfg_of(clip)
+        eng = Engine(bcfg, ccfg, special_ids_of(tokenizer), _precision(), device)
+        eng.load_state(model.state_dict())
+        eng.load_state(clip.clip_state_dict())
+        eng.finalize()
+        eng.set_bridge(tables_from_tokenizers(tokenizer, clip.tokenizer))
+        _ENGINES[key] = eng
+    clip._engine = eng
+    return eng
+
+
+def clip_only_engine(clip, device: int = 0) -> Engine:
+    """Engine without the BERT tower, for `CLIP.compute_*` calls made outside a generate call."""
+    key = (id(clip), "clip-only", _precision(), device)
+    eng = _ENGINES.get(key)
+    if eng is None:
+        eng = Engine(None, clip_cfg_of(clip), {}, _precision(), device)
+        eng.load_state(clip.clip_state_dict())
+        eng.finalize()
+        _ENGINES[key] = eng
+    return eng
+
+
+def _mask_to_numpy(token_mask) -> np.ndarray:
+    if hasattr(token_mask, "detach"):
+        return token_mask.detach().float().cpu().numpy()
+    return np.asarray(token_mask, dtype=np.float32)
+
+
+def run_generation(order: str, img_name, model, clip, tokenizer, image_instance, token_mask, prompt, logger, max_len,
+                   top_k, temperature, alpha, beta, max_iters, batch_size, verbose=True, gamma=None,
+                   ctl_signal="positive", print_every: Optional[int] = None):
+    """Body shared by every *_generation function (gen_utils.py:51-242, control_gen_utils.py:30-134):
+    returns (gen_texts_list, clip_score_sequence) with the reference's list structure."""
+    import utils as ref_utils  # the repo-root drop-in (same functions as the reference's utils.py)
+    eng = get_engine(model, clip, tokenizer)
+    seed_len = len(prompt.split()) + 1                                   # gen_utils.py:56
+    batch = ref_utils.get_init_text(tokenizer, prompt, max_len, batch_size)  # gen_utils.py:57
+    clip.compute_image_representation_from_image_instance(image_instance)    # gen_utils.py:58 (cached in the engine)
+    eng.set_token_mask(_mask_to_numpy(token_mask))
+    if gamma is not None:
+        if getattr(clip, "lexicon", None) is None:
+            raise RuntimeError("the sentiment path needs a per-token lexicon: set clip.lexicon (see DESIGN.md)")
+        eng.set_lexicon(clip.lexicon)
+    order_list = random_positions = None
+    if order == "shuffle":
+        order_list = list(range(max_len))
+        random.shuffle(order_list)                                       # gen_utils.py:110-111 (process-global stream)
+        logger.info(f"Order_list:{order_list}")
+    elif order == "random":
+        random_positions = [int(np.random.randint(0, max_len)) for _ in range(max_iters)]  # gen_utils.py:210
+    iters = max_iters if order != "random" else max_iters // max_len
+    if order == "random":
+        positions, n_mask, every = [int(p) for p in random_positions], [1] * len(random_positions), 1
+    else:
+        positions, n_mask, every = order_positions(order, max_len, iters, order_list=order_list)
+    hp = Engine.hyper(alpha, beta, temperature, gamma, ctl_signal == "negative")
+    ids, cos = eng.generate(batch_size, batch[0], max_len, seed_len, top_k, positions, hp, n_mask=n_mask,
+                            snapshot_every=every)
+    # utils.update_token_mask mutates the caller's mask in place (utils.py:53-59): leave it as the
+    # reference would after the last visited position
+    if positions:
+        ref_utils.update_token_mask(tokenizer, token_mask, max_len, positions[-1])
+    # bookkeeping (gen_utils.py:82-96)
+    best_score = [0] * batch_size
+    best_cap = ['None'] * batch_size
+    texts_out, scores_out = [], []
+    pe = print_every or 1
+    for s in range(ids.shape[0]):
+        cur = [float(x) for x in cos[s]]
+        cur_text = tokenizer.batch_decode(ids[s].tolist(), skip_special_tokens=True)
+        for jj in range(batch_size):
+            if best_score[jj] < cur[jj]:
+                best_score[jj] = cur[jj]
+                best_cap[jj] = cur_text[jj]
+        if order == "random" and (s + 1) % pe != 0:
+            continue
+        if verbose:
+            for_print = tokenizer.batch_decode(ids[s].tolist())
+            for jj in range(batch_size):
+                logger.info(f"iter {s + 1}, The {jj + 1}-th image: {img_name[jj]},"
+                            f"clip score {cur[jj]:.3f}: " + for_print[jj])
+        texts_out.append(cur_text)
+        scores_out.append(cur)
+    texts_out.append(best_cap)
+    scores_out.append(best_score)
+    return texts_out, scores_out

@@ -1,0 +1,84 @@
+"""-m gpu: the reference-shaped call surface (gen_utils / control_gen_utils / clip.clip / utils at
+the repo root) driven like demo.py drives the reference, compared with reference goldens."""
+import logging
+import os
+
+import numpy as np
+import pytest
+
+from conzic_amd import synth
+from goldutil import load_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _f32_engine(monkeypatch):
+    monkeypatch.setenv("CZC_PRECISION", "f32")  # id-for-id trajectories need the verification precision
+
+
+def _objects(meta):
+    from clip.clip import CLIP
+    from conzic_amd.models import SyntheticLM
+    from conzic_amd.text import tokenizers_from_vocab
+    sv = synth.make_vocab_tiny()
+    bcfg = synth.BertCfg(**meta["bert_cfg"])
+    ccfg = synth.ClipCfg(**meta["clip_cfg"])
+    bt, ct = tokenizers_from_vocab(sv)
+    lm = SyntheticLM(bcfg, meta["bseed"])
+    clip = CLIP.from_state(ccfg, synth.make_clip_weights(ccfg, meta["cseed"]), ct)
+    if meta["gamma"] is not None:
+        clip.lexicon = synth.make_lexicon(len(sv.bert_tokens))
+    from PIL import Image
+    imgs = [Image.fromarray(u) for u in synth.make_images_u8(meta["B"], ccfg.v_image)]
+    mask = synth.make_token_mask(sv)
+    return lm, clip, bt, imgs, mask
+
+
+@pytest.mark.parametrize("name", ["tiny_seq", "tiny_shuffle", "tiny_span", "tiny_random", "tiny_senti_seq",
+                                  "tiny_senti_shuffle"])
+def test_generate_caption_dropin_matches_reference(name):
+    import utils
+    from control_gen_utils import control_generate_caption
+    from gen_utils import generate_caption
+    meta, arr = load_case(name)
+    lm, clip, tok, imgs, mask = _objects(meta)
+    utils.set_seed(meta["seed"])  # once per process, as demo.py:107 does
+    logger = logging.getLogger("dropin-test")
+    names = [f"img{j}" for j in range(meta["B"])]
+    kw = dict(prompt=meta["prompt"], batch_size=meta["B"], max_len=meta["L"], top_k=meta["K"],
+              temperature=meta["temperature"], max_iter=meta["I"], alpha=meta["alpha"], beta=meta["beta"],
+              generate_order=meta["order"])
+    if meta["gamma"] is None:
+        texts, scores = generate_caption(names, lm, clip, tok, imgs, mask, logger, **kw)
+    else:
+        texts, scores = control_generate_caption(names, lm, clip, tok, imgs, mask, logger, gamma=meta["gamma"],
+                                                 ctl_type="sentiment", style_type=meta["style"], **kw)
+    assert texts == meta["texts"]
+    np.testing.assert_allclose(np.array(scores, dtype=np.float64), np.array(meta["scores"]), atol=2e-5)
+    # in-place mask mutation contract (utils.py:53-59): '.' reflects the last visited position
+    last = meta["positions"][-1]
+    assert mask[0, tok.vocab["."]] == (1.0 if last == meta["L"] - 1 else 0.0)
+
+
+def test_clip_wrapper_methods():
+    from oracle import models as M
+    import torch
+    meta, arr = load_case("tiny_seq")
+    lm, clip, tok, imgs, mask = _objects(meta)
+    emb = clip.compute_image_representation_from_image_instance(imgs)
+    np.testing.assert_allclose(np.asarray(emb), arr["image_embeds"], atol=3e-5)
+    texts = ["image of a " + " ".join(w for w in synth.make_vocab_tiny().bert_tokens[300:303]), "image of a", "the . of"]
+    te = clip.compute_text_representation(texts)
+    score, ref = clip.compute_image_text_similarity_via_raw_text(emb[:1], texts)
+    ccfg = synth.ClipCfg(**meta["clip_cfg"])
+    w = M.to_torch(synth.make_clip_weights(ccfg, meta["cseed"]))
+    enc = clip.tokenizer(texts)
+    ids = torch.tensor(enc["input_ids"])
+    lens = torch.tensor(enc["attention_mask"]).sum(1)
+    rte = M.clip_text_embeds(w, ccfg, ids, lens)
+    np.testing.assert_allclose(np.asarray(te), rte.numpy(), atol=3e-5)
+    rs, rr = M.clip_similarity(w, torch.from_numpy(arr["image_embeds"][:1]), rte)
+    np.testing.assert_allclose(np.asarray(ref), rr.numpy(), atol=5e-6)
+    np.testing.assert_allclose(np.asarray(score), rs.numpy(), atol=5e-6)
+    assert abs(float(np.asarray(score).sum()) - 1.0) < 1e-5
