@@ -133,6 +133,7 @@ int czc_bench_gemm(int precision, int M, int N, int K, int act, int out_mode, in
 
 int czc_test_set_option(const char* name, int value) {
   if (!strcmp(name, "gemm256")) { g_use_gemm256 = value; return 0; }
+  if (!strcmp(name, "gemm_krot")) { g_gemm_krot = value; return 0; }
   if (!strcmp(name, "mfma_attention")) { g_use_mfma_attention = value; return 0; }
   snprintf(czc::g_err, sizeof(czc::g_err), "unknown option %s", name);
   return CZC_ERR_ARG;

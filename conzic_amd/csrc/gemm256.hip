@@ -35,7 +35,8 @@ __device__ __forceinline__ int swz(int row, int chunk) { return row * ROWB + ((c
 
 template <int ACT>
 __device__ __forceinline__ float act_fn(float v) {
-  if (ACT == ACT_QUICK_GELU) return v * __frcp_rn(1.0f + __expf(-1.702f * v));
+  // x*sigmoid(1.702x) with the raw v_exp_f32 (2^x) and v_rcp_f32: ~1 ulp each, output is bf16 anyway
+  if (ACT == ACT_QUICK_GELU) return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930156f * v));
   return v;
 }
 
@@ -180,7 +181,253 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g, int tiles_m, i
   }
 }
 
+// ================================================================================================
+// gemm256p: persistent, wave-specialised variant.
+//   * 12 waves per work-group: waves 0-7 are MFMA waves (never issue a global load), waves 8-11 are
+//     LOADER waves that only issue the LDS-DMA of the next K step (16 x 1 KiB each) -- PMC on the
+//     plain kernel showed the 8 DMA issues per K step costing the MFMA waves about as many cycles as
+//     their 32 MFMAs, and 53 % of wave cycles parked in s_waitcnt/s_barrier.
+//   * one work-group per CU walks tiles wg, wg+grid, ...; the K-step sequence is continuous across
+//     tiles (stage = step & 1), so while the MFMA waves run a tile's epilogue the loaders already
+//     fetch the next tile's first K step: the pipeline prologue disappears behind the epilogue.
+//   * hand-off per K step: loader `s_waitcnt vmcnt(0)` -> one s_barrier shared by all 12 waves ->
+//     loaders issue step+1 into the stage the MFMA waves just left, MFMA waves compute step.
+// ================================================================================================
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+
+__device__ __forceinline__ void tile_of(int t, int tiles_m, int tiles_n, int& tm, int& tn) {
+  // XCD-aware: work-group b runs on XCD b%8 and (persistent, grid = #CUs) handles virtual tiles
+  // t = b, b+grid, ...; map t so that one XCD sweeps all N tiles of an M tile back to back.
+  const int nt = tiles_m * tiles_n;
+  const int xcd = t & 7, q = nt >> 3, r = nt & 7;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  const int lin = base + (t >> 3);
+  tm = lin / tiles_n;
+  tn = lin - tm * tiles_n;
+}
+
+template <int ACT, bool OUT_F32>
+__global__ __launch_bounds__(768) void gemm256p_kernel(GemmArgs g, int tiles_m, int tiles_n, int g_krot_enable) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nk = g.K >> 6;
+  const int ntiles = tiles_m * tiles_n;
+  const int lda_b = g.lda * 2, ldw_b = g.ldw * 2;
+
+  if (wave >= 8) {
+    // ------------------------------- loader waves -------------------------------------------
+    const int lw = wave - 8;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(
+        (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem);
+    // instruction ii (0..7) lands tile rows lw*64 + ii*8 + (lane>>3); swizzle phase depends on ii&1
+    const int rbase = lw * 64 + (lane >> 3);
+    const int ce = ((lane & 7) ^ ((lane >> 4) & 7)) << 4;        // ii even: (row>>1)&7 = lane>>4
+    const int co = ((lane & 7) ^ (((lane >> 4) + 4) & 7)) << 4;  // ii odd : +4
+    const int a_e = rbase * lda_b + ce, a_o = (rbase + 8) * lda_b + co;
+    const int w_e = rbase * ldw_b + ce, w_o = (rbase + 8) * ldw_b + co;
+    const int a16 = 16 * lda_b, w16 = 16 * ldw_b;
+    unsigned step = 0;
+    bool first = true;
+    const int krot = (g_krot_enable & 1) ? (int)((blockIdx.x >> 3) % (unsigned)nk) : 0;
+    const bool dbg_no_dma = g_krot_enable & 4;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+      int tm, tn;
+      tile_of(t, tiles_m, tiles_n, tm, tn);
+      const int m0 = tm * TM, n0 = tn * TN;
+      const unsigned long long pa = (unsigned long long)g.A + (unsigned long long)m0 * lda_b;
+      const unsigned long long pw = (unsigned long long)g.W + (unsigned long long)n0 * ldw_b;
+      u32x4_t rsA, rsW;
+      rsA.x = (unsigned)pa; rsA.y = (unsigned)(pa >> 32) & 0xffffu;
+      rsA.z = (unsigned)(min(TM, g.M - m0) * lda_b); rsA.w = 0x00020000u;
+      rsW.x = (unsigned)pw; rsW.y = (unsigned)(pw >> 32) & 0xffffu;
+      rsW.z = (unsigned)(min(TN, g.N - n0) * ldw_b); rsW.w = 0x00020000u;
+      for (int kt = 0; kt < nk; ++kt, ++step) {
+        if (!first) {
+          // previous step's DMA has landed -> publish it; the same barrier proves the stage this
+          // step is written to has been left by every MFMA wave
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+        }
+        first = false;
+        const unsigned dstA = lds0 + (step & 1) * STAGE + lw * (64 * ROWB);
+        const unsigned dstW = dstA + A_BYTES;
+        // K steps are visited in a per-work-group rotated order (a sum is order-free): work-groups
+        // that share a W tile would otherwise all request the same lines of it at the same moment
+        int kr = kt + krot;
+        if (kr >= nk) kr -= nk;
+        const unsigned so = kr * ROWB;
+        unsigned keep;
+        if (!dbg_no_dma) asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %11, %13 offen lds\n\t"
+            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %11, %13 offen lds\n\t"
+            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %5, %11, %13 offen lds\n\t"
+            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %6, %11, %13 offen lds\n\t"
+            "s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %7, %12, %13 offen lds\n\t"
+            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %8, %12, %13 offen lds\n\t"
+            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %9, %12, %13 offen lds\n\t"
+            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %10, %12, %13 offen lds\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "s"(dstA), "s"(dstW), "v"(a_e), "v"(a_o), "v"(a_e + a16), "v"(a_o + a16), "v"(w_e), "v"(w_o),
+              "v"(w_e + w16), "v"(w_o + w16), "s"(rsA), "s"(rsW), "s"(so)
+            : "memory", "scc");
+        if (!dbg_no_dma) asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %11, %13 offen lds\n\t"
+            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %11, %13 offen lds\n\t"
+            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %5, %11, %13 offen lds\n\t"
+            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %6, %11, %13 offen lds\n\t"
+            "s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %7, %12, %13 offen lds\n\t"
+            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %8, %12, %13 offen lds\n\t"
+            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %9, %12, %13 offen lds\n\t"
+            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %10, %12, %13 offen lds\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "s"(dstA + 32 * ROWB), "s"(dstW + 32 * ROWB), "v"(a_e + 2 * a16), "v"(a_o + 2 * a16), "v"(a_e + 3 * a16),
+              "v"(a_o + 3 * a16), "v"(w_e + 2 * w16), "v"(w_o + 2 * w16), "v"(w_e + 3 * w16), "v"(w_o + 3 * w16),
+              "s"(rsA), "s"(rsW), "s"(so)
+            : "memory", "scc");
+      }
+    }
+    if (!first) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // publishes the very last step
+    }
+    return;
+  }
+
+  // --------------------------------- MFMA waves ---------------------------------------------
+  const int wm = wave >> 2, wn = wave & 3;
+  const int half = lane >> 5;
+  const int arow = wm * 128 + (lane & 31);
+  const int brow = wn * 64 + (lane & 31);
+  bf16_t* oa = (bf16_t*)g.out_act;
+  unsigned step = 0;
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    int tm, tn;
+    tile_of(t, tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * TM, n0 = tn * TN;
+    f32x16_t acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int kt = 0; kt < nk; ++kt, ++step) {
+      __builtin_amdgcn_s_barrier();  // step's tile is in LDS (loaders waited for it before arriving)
+      asm volatile("" ::: "memory");
+      const unsigned char* sA = smem + (step & 1) * STAGE;
+      const unsigned char* sB = sA + A_BYTES;
+      if (g_krot_enable & 2) continue;  // debug: fill-rate measurement without MFMA work
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int ch = 2 * ks + half;
+        uint4 a[4], b[2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = *(const uint4*)(sA + swz(arow + 32 * i, ch));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[j] = *(const uint4*)(sB + swz(brow + 32 * j, ch));
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, b[j]),
+                                                                __builtin_bit_cast(bf16x8_t, a[i]), acc[i][j], 0, 0, 0);
+      }
+    }
+    // epilogue (no barrier inside: the loaders are already fetching the next tile's first K step).
+    // Accumulators leave through a wave-private 4 KiB LDS patch (the 32 KiB above the two stages)
+    // that turns the MFMA layout (lane = one row, 4 columns per quad -> 8-byte pieces scattered over
+    // 32 rows) into row-major 16-byte pieces: 8 lanes cover one 128-byte line, so every global
+    // store / residual load is a full cache line instead of 64 partial ones.
+    unsigned char* patch = smem + 2 * STAGE + wave * 4096;
+    const int l31 = lane & 31;
+    const int rrow = lane >> 3, rslot = lane & 7;  // read side: 8 rows x 8 sixteen-byte slots per pass
+    if (!OUT_F32) {
+      // bf16 output: 32 rows x 64 columns per pass (128-byte rows), 8-byte slots XOR (row & 15)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int cl = j * 32 + 8 * q + 4 * half;  // column inside the wave's 64
+            float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+            if (g.bias) {
+              const int col = min(n0 + wn * 64 + cl, g.N - 4);
+              const float4 b4 = *(const float4*)(g.bias + col);
+              v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+            }
+            v.x = act_fn<ACT>(v.x); v.y = act_fn<ACT>(v.y); v.z = act_fn<ACT>(v.z); v.w = act_fn<ACT>(v.w);
+            const int slot = (cl >> 2) ^ (l31 & 15);
+            *(uint2*)(patch + l31 * 128 + slot * 8) = make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w));
+          }
+        }
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+          const int r = pass * 8 + rrow;
+          const int x = r & 15;
+          // logical 8-byte slots 2*rslot, 2*rslot+1 live in the physical pair ((2*rslot)^x)>>1, swapped if x&1
+          uint4 d = *(const uint4*)(patch + r * 128 + ((((2 * rslot) ^ x) >> 1) << 4));
+          if (x & 1) d = make_uint4(d.z, d.w, d.x, d.y);
+          const int row = m0 + wm * 128 + i * 32 + r;
+          const int col = n0 + wn * 64 + rslot * 8;
+          if (row < g.M && col < g.N) *(uint4*)(oa + (long)row * g.ldc + col) = d;
+        }
+      }
+    } else {
+      // fp32 output (+bias, +fp32 residual, optional bf16 copy): 32 rows x 32 columns per pass
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int col = n0 + wn * 64 + j * 32 + rslot * 4;
+          float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (g.bias && col < g.N) b4 = *(const float4*)(g.bias + col);
+          // residual rows first: four independent 16-byte loads in flight across the LDS round trip
+          float4 r4[4];
+#pragma unroll
+          for (int pass = 0; pass < 4; ++pass) {
+            const int row = m0 + wm * 128 + i * 32 + pass * 8 + rrow;
+            r4[pass] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (g.resid && row < g.M && col < g.N) r4[pass] = *(const float4*)(g.resid + (long)row * g.ldr + col);
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int slot = (2 * q + half) ^ (l31 & 7);
+            *(float4*)(patch + l31 * 128 + slot * 16) =
+                make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+          }
+#pragma unroll
+          for (int pass = 0; pass < 4; ++pass) {
+            const int r = pass * 8 + rrow;
+            float4 v = *(const float4*)(patch + r * 128 + ((rslot ^ (r & 7)) << 4));
+            const int row = m0 + wm * 128 + i * 32 + r;
+            if (row < g.M && col < g.N) {
+              v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+              v.x = act_fn<ACT>(v.x); v.y = act_fn<ACT>(v.y); v.z = act_fn<ACT>(v.z); v.w = act_fn<ACT>(v.w);
+              v.x += r4[pass].x; v.y += r4[pass].y; v.z += r4[pass].z; v.w += r4[pass].w;
+              if (g.out_f32) *(float4*)(g.out_f32 + (long)row * g.ldc + col) = v;
+              if (oa) *(uint2*)(oa + (long)row * g.ldc + col) = make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w));
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
 }  // namespace
+
+int g_gemm_krot = 0;  // bit0: rotate K order per work-group (no gain measured); bits1-2: debug (skip MFMA / skip DMA)
 
 bool gemm256_eligible(const GemmArgs& g) {
   return g.M >= 2048 && g.N % 4 == 0 && g.K % 64 == 0 && g.ldc % 4 == 0 && (!g.resid || g.ldr % 4 == 0) &&
@@ -190,7 +437,34 @@ bool gemm256_eligible(const GemmArgs& g) {
 
 int launch_gemm256(const GemmArgs& g, hipStream_t st) {
   static bool attr_set = false;
+  static int n_cu = 0;
   const int shmem = 2 * STAGE;
+  if (g_use_gemm256 == 2 && g.N % 8 == 0 && g.ldc % 8 == 0) {
+    const int shp = shmem + 8 * 4096;  // + one 4 KiB epilogue patch per MFMA wave = the full 160 KiB
+    if (!n_cu) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      CZC_HIP_CHECK(hipGetDevice(&dev));
+      CZC_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+      n_cu = prop.multiProcessorCount;
+#define CZC_ATTR(K_) CZC_HIP_CHECK(hipFuncSetAttribute((const void*)K_, hipFuncAttributeMaxDynamicSharedMemorySize, shp))
+      CZC_ATTR((gemm256p_kernel<ACT_NONE, false>));
+      CZC_ATTR((gemm256p_kernel<ACT_NONE, true>));
+      CZC_ATTR((gemm256p_kernel<ACT_QUICK_GELU, false>));
+      CZC_ATTR((gemm256p_kernel<ACT_QUICK_GELU, true>));
+#undef CZC_ATTR
+    }
+    const int tiles_m = cdiv(g.M, TM), tiles_n = cdiv(g.N, TN);
+    const int nt = tiles_m * tiles_n;
+    dim3 grid(nt < n_cu ? nt : n_cu), block(768);
+    const bool f32 = g.out_f32 != nullptr || g.resid != nullptr;
+#define CZC_GO(A_, F_) hipLaunchKernelGGL((gemm256p_kernel<A_, F_>), grid, block, shp, st, g, tiles_m, tiles_n, g_gemm_krot)
+    if (g.act == ACT_QUICK_GELU) { if (f32) CZC_GO(ACT_QUICK_GELU, true); else CZC_GO(ACT_QUICK_GELU, false); }
+    else { if (f32) CZC_GO(ACT_NONE, true); else CZC_GO(ACT_NONE, false); }
+#undef CZC_GO
+    CZC_HIP_CHECK(hipGetLastError());
+    return 0;
+  }
   if (!attr_set) {
     CZC_HIP_CHECK(hipFuncSetAttribute((const void*)gemm256_kernel<ACT_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       shmem));

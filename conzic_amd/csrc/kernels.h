@@ -22,6 +22,7 @@ int launch_gemm(int prec, const GemmArgs& g, hipStream_t st);
 bool gemm256_eligible(const GemmArgs& g);
 int launch_gemm256(const GemmArgs& g, hipStream_t st);  // gemm256.hip: 256x256 LDS-DMA bf16 kernel
 extern int g_use_gemm256;
+extern int g_gemm_krot;
 
 // ---- rowops.hip -------------------------------------------------------------------------
 // y = LN(x[row_idx ? row_idx[m] : m]) ; x fp32 [*,H]; outputs optional

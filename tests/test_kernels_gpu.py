@@ -231,3 +231,27 @@ def test_combine_first_argmax_on_ties():
     hp = E.Engine.hyper(0.02, 2.0, 0.1)
     _, _, fs, best = E.test_combine(tf, ie, 2.0, probs, hp)
     assert best[0] == 0 and np.allclose(fs, fs[0, 0])
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("M,N,K,act,resid", [(2048, 512, 512, 0, True), (3000, 1536, 512, 0, False),
+                                             (5000, 2048, 512, 1, False), (2500, 512, 2048, 0, True),
+                                             (2304, 320, 192, 1, True), (70000, 512, 512, 0, True)])
+def test_gemm256_variants(variant, M, N, K, act, resid):
+    """The 256x256 LDS-DMA kernels (plain and persistent/wave-specialised): ragged M and N edges,
+    many tiles per work-group, all epilogues."""
+    lib = native.load()
+    rng = np.random.default_rng(M + N + K + act)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    R = rng.standard_normal((M, N)).astype(np.float32) if resid else None
+    try:
+        assert lib.czc_test_set_option(b"gemm256", variant) == 0
+        C = E.test_gemm(BF16, A, W, bias=bias, resid=R, act=act)
+    finally:
+        lib.czc_test_set_option(b"gemm256", 2)
+    pre = (_bf16_round(A).astype(np.float64) @ _bf16_round(W).astype(np.float64).T + bias).astype(np.float32)
+    ref = _act(pre, act) + (R if resid else 0)
+    err = np.abs(C - ref).max()
+    assert err < 3e-3 * np.sqrt(K / 64), err
