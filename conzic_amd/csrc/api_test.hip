@@ -45,22 +45,18 @@ void* up_act(DevPool& pool, int prec, const float* src, size_t n) {
   float* f = (float*)pool.up(src, n * 4);
   if (!f) return nullptr;
   if (prec == PREC_F32) return f;
-  void* a = pool.alloc(n * 2);
+  void* a = pool.alloc(n * prec_bytes(prec));
   if (!a) return nullptr;
   if (launch_convert(prec, f, a, (long)n, nullptr)) return nullptr;
   return a;
 }
 
-__global__ void act_to_f32_kernel(const bf16_t* src, float* dst, long n) {
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] = bf2f(src[i]);
-}
-
 int down_act(DevPool& pool, int prec, const void* src, size_t n, float* host) {
   const float* f = (const float*)src;
-  if (prec == PREC_BF16) {
+  if (prec != PREC_F32) {
     float* t = (float*)pool.alloc(n * 4);
     T_PTR(t);
-    hipLaunchKernelGGL(act_to_f32_kernel, dim3(1024), dim3(256), 0, nullptr, (const bf16_t*)src, t, (long)n);
+    T_CHECK(launch_act_to_f32(prec, src, t, (long)n, nullptr));
     f = t;
   }
   T_HIP(hipMemcpy(host, f, n * 4, hipMemcpyDeviceToHost));
@@ -92,7 +88,7 @@ int czc_test_gemm(int precision, int M, int N, int K, const float* A, const floa
 // out_mode 0: bf16/act output (+bias, act); 1: fp32 output with in-place fp32 residual (+bias).
 int czc_bench_gemm(int precision, int M, int N, int K, int act, int out_mode, int iters, int use256, double* ms_out) {
   DevPool pool;
-  const size_t es = precision == PREC_BF16 ? 2 : 4;
+  const size_t es = prec_bytes(precision);
   std::vector<float> ha((size_t)1 << 20), hw((size_t)N * K), hb(N);
   unsigned s = 12345u;
   auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 32768.0f - 1.0f; };

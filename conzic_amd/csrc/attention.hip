@@ -386,12 +386,12 @@ __global__ __launch_bounds__(256) void attention_valu_kernel(const T* qkv, SegTa
   float* Ps = Qs + 64 * Tcap;  // 128 floats
 
   for (int t = 0; t < nk; ++t) {
-    const T* r = qkv + key_row(g, t) * (long)(3 * Hd) + h * 64 + lane;
-    Kt[lane * Tp + t] = Act<T>::ld(r + Hd);
-    Vs[t * 64 + lane] = Act<T>::ld(r + 2 * Hd);
+    const long r = key_row(g, t) * (long)(3 * Hd) + h * 64 + lane;
+    Kt[lane * Tp + t] = Act<T>::ld(qkv, r + Hd);
+    Vs[t * 64 + lane] = Act<T>::ld(qkv, r + 2 * Hd);
   }
   for (int t = 0; t < nq; ++t)
-    Qs[t * 64 + lane] = Act<T>::ld(qkv + ((long)g.own_off + t) * (long)(3 * Hd) + h * 64 + lane);
+    Qs[t * 64 + lane] = Act<T>::ld(qkv, ((long)g.own_off + t) * (long)(3 * Hd) + h * 64 + lane);
   __syncthreads();
 
   for (int i = 0; i < nq; ++i) {
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(256) void attention_valu_kernel(const T* qkv, SegTa
     __syncthreads();
     float o = 0.f;
     for (int j = 0; j < vis; ++j) o += Ps[j] * Vs[j * 64 + lane];
-    if (live) Act<T>::st(out + ((long)g.own_off + i) * (long)Hd + h * 64 + lane, o);
+    if (live) Act<T>::st(out, ((long)g.own_off + i) * (long)Hd + h * 64 + lane, o);
     __syncthreads();
   }
 }
@@ -456,7 +456,13 @@ int launch_attention(int prec, const void* qkv, const SegTable& tab, int max_key
   if (wpb > heads) wpb = heads >= 2 ? 2 : 1;
   const size_t shmem = per_wave * wpb;
   dim3 grid(tab.n_seg, cdiv(heads, wpb)), block(64 * wpb);
-  if (prec == PREC_BF16) {
+  if (prec == PREC_F16X3) {
+    if (shmem > 64 * 1024)
+      CZC_HIP_CHECK(hipFuncSetAttribute((const void*)attention_valu_kernel<split_t>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    hipLaunchKernelGGL(attention_valu_kernel<split_t>, grid, block, shmem, st, (const split_t*)qkv, tab, heads, causal,
+                       scale, Tcap, (split_t*)out);
+  } else if (prec == PREC_BF16) {
     if (shmem > 64 * 1024)
       CZC_HIP_CHECK(hipFuncSetAttribute((const void*)attention_valu_kernel<bf16_t>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));

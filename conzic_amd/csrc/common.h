@@ -27,15 +27,53 @@ __host__ __device__ __forceinline__ bf16_t f2bf(float f) {
   return (bf16_t)(u >> 16);
 }
 
-// activation storage type per engine precision
+// activation storage type per engine precision.  All accessors take (base pointer, ELEMENT index):
+// for the linear types that is base[idx]; split_t stores an fp32-sized element as two fp16 planes
+// in groups of 8 elements -- 16 bytes of hi parts, then 16 bytes of lo parts (v ~ hi + lo, 22
+// mantissa bits) -- so that an MFMA fragment (8 consecutive k) is one 16-byte load per plane.
+// Row lengths must be multiples of 8 elements.
+struct split_t { unsigned int raw; };
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+
 template <typename T> struct Act;
 template <> struct Act<bf16_t> {
-  __device__ static __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
-  __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+  __device__ static __forceinline__ float ld(const bf16_t* b, long i) { return bf2f(b[i]); }
+  __device__ static __forceinline__ void st(bf16_t* b, long i, float v) { b[i] = f2bf(v); }
+  __device__ static __forceinline__ void st4(bf16_t* b, long i, float x, float y, float z, float w) {
+    uint2 o;
+    o.x = (uint32_t)f2bf(x) | ((uint32_t)f2bf(y) << 16);
+    o.y = (uint32_t)f2bf(z) | ((uint32_t)f2bf(w) << 16);
+    *(uint2*)(b + i) = o;
+  }
 };
 template <> struct Act<float> {
-  __device__ static __forceinline__ float ld(const float* p) { return *p; }
-  __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+  __device__ static __forceinline__ float ld(const float* b, long i) { return b[i]; }
+  __device__ static __forceinline__ void st(float* b, long i, float v) { b[i] = v; }
+  __device__ static __forceinline__ void st4(float* b, long i, float x, float y, float z, float w) {
+    *(float4*)(b + i) = make_float4(x, y, z, w);
+  }
+};
+template <> struct Act<split_t> {
+  __device__ static __forceinline__ long off(long i) { return (i >> 3) * 32 + (i & 7) * 2; }
+  __device__ static __forceinline__ float ld(const split_t* b, long i) {
+    const unsigned char* p = (const unsigned char*)b + off(i);
+    return (float)*(const _Float16*)p + (float)*(const _Float16*)(p + 16);
+  }
+  __device__ static __forceinline__ void st(split_t* b, long i, float v) {
+    unsigned char* p = (unsigned char*)b + off(i);
+    const _Float16 hi = (_Float16)v;
+    *(_Float16*)p = hi;
+    *(_Float16*)(p + 16) = (_Float16)(v - (float)hi);
+  }
+  __device__ static __forceinline__ void st4(split_t* b, long i, float x, float y, float z, float w) {  // i % 4 == 0
+    unsigned char* p = (unsigned char*)b + off(i);
+    typedef __attribute__((ext_vector_type(4))) _Float16 h4;
+    h4 hi = {(_Float16)x, (_Float16)y, (_Float16)z, (_Float16)w};
+    h4 lo = {(_Float16)(x - (float)hi[0]), (_Float16)(y - (float)hi[1]), (_Float16)(z - (float)hi[2]),
+             (_Float16)(w - (float)hi[3])};
+    *(h4*)p = hi;
+    *(h4*)(p + 16) = lo;
+  }
 };
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -53,7 +91,8 @@ __device__ __forceinline__ float quick_gelu(float x) { return x / (1.0f + __expf
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 enum { ACT_NONE = 0, ACT_QUICK_GELU = 1, ACT_GELU_ERF = 2 };
-enum { PREC_BF16 = 0, PREC_F32 = 1 };
+enum { PREC_BF16 = 0, PREC_F32 = 1, PREC_F16X3 = 3 };  // 3: split_t storage, three fp16 MFMA passes (~fp32 accuracy)
+__host__ __device__ inline size_t prec_bytes(int p) { return p == PREC_BF16 ? 2 : 4; }
 
 #define CZC_HIP_CHECK(expr)                                                                      \
   do {                                                                                           \

@@ -469,10 +469,11 @@ int czc_create(const czc_config* cfg, int device_id, czc_engine** out) {
   czc_engine* e = new czc_engine();
   e->cfg = *cfg;
   e->dev = device_id;
-  // precision 0: CLIP towers on bf16 MFMA, BERT on f32 MFMA (the tau=0.1 softmax amplifies logit
-  // error tenfold and BERT is 1.4% of the FLOPs); 1: everything f32; 2: everything bf16 (experiments)
+  // precision 0: CLIP towers on bf16 MFMA; BERT on split-fp16 MFMA (hi+lo planes, three fp16 passes,
+  // ~22 mantissa bits: the tau=0.1 softmax amplifies logit error tenfold, and BERT is 1.4% of the
+  // FLOPs); 1: everything on f32 MFMA; 2: everything bf16 (experiments)
   e->pc = cfg->precision == CZC_PREC_F32 ? PREC_F32 : PREC_BF16;
-  e->pb = cfg->precision == CZC_PREC_ALL_BF16 ? PREC_BF16 : PREC_F32;
+  e->pb = cfg->precision == CZC_PREC_ALL_BF16 ? PREC_BF16 : (cfg->precision == CZC_PREC_BF16 ? PREC_F16X3 : PREC_F32);
   e->esz = e->pc == PREC_BF16 ? 2 : 4;
   e->eb = e->pb == PREC_BF16 ? 2 : 4;
   if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&e->st) != hipSuccess ||

@@ -31,6 +31,12 @@ template <> struct Mma<bf16_t> {
                                                 0, 0);
   }
 };
+template <> struct Mma<split_t> {
+  static constexpr int KPT = ROWB / 4;  // 32 elements per 128-byte tile row (4 groups of 8 hi + 8 lo)
+  __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x16_t& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+  }
+};
 template <> struct Mma<float> {
   static constexpr int KPT = ROWB / 4;
   __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x16_t& c) {
@@ -58,20 +64,6 @@ __device__ __forceinline__ float apply_act(float v) {
   }
   if (ACT == ACT_GELU_ERF) return gelu_erf(v);
   return v;
-}
-
-template <typename T>
-__device__ __forceinline__ void store_act4(T* p, float a, float b, float c, float d);
-template <>
-__device__ __forceinline__ void store_act4<float>(float* p, float a, float b, float c, float d) {
-  *(float4*)p = make_float4(a, b, c, d);
-}
-template <>
-__device__ __forceinline__ void store_act4<bf16_t>(bf16_t* p, float a, float b, float c, float d) {
-  uint2 o;
-  o.x = (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16);
-  o.y = (uint32_t)f2bf(c) | ((uint32_t)f2bf(d) << 16);
-  *(uint2*)p = o;
 }
 
 // VEC: N % 4 == 0 and ldc/ldr % 4 == 0 (every call of the polishing step except the 30522-wide
@@ -106,7 +98,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs& g, f32x16_t (&acc)[2][2
             v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
           }
           if (g.out_f32) *(float4*)(g.out_f32 + ro + col) = v;
-          if (oa) store_act4<T>(oa + ro + col, v.x, v.y, v.z, v.w);
+          if (oa) Act<T>::st4(oa, ro + col, v.x, v.y, v.z, v.w);
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -116,7 +108,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs& g, f32x16_t (&acc)[2][2
             v = apply_act<T, ACT>(v);
             if (g.resid) v += g.resid[rr + c];
             if (g.out_f32) g.out_f32[ro + c] = v;
-            if (oa) Act<T>::st(oa + ro + c, v);
+            if (oa) Act<T>::st(oa, ro + c, v);
           }
         }
       }
@@ -195,6 +187,30 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, int tiles_m, int 
     const unsigned char* sA = smem + (kt & 1) * STAGE_BYTES;
     const unsigned char* sB = sA + TILE_BYTES;
     if (kt + 1 < nk) { CZC_LOAD_TILE(kt + 1) }
+    if constexpr (sizeof(T) == 4 && !__is_same(T, float)) {
+      // split_t: chunk 2g = hi plane, 2g+1 = lo plane of k-group g; MFMA step s takes group 2s+half.
+      // (a_hi + a_lo)(w_hi + w_lo) ~ a_hi w_hi + a_lo w_hi + a_hi w_lo   (lo*lo ~ 2^-22, dropped)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int ch = 2 * (2 * s2 + half);
+        uint4 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          ah[i] = *(const uint4*)(sA + swz(arow + 32 * i, ch));
+          al[i] = *(const uint4*)(sA + swz(arow + 32 * i, ch + 1));
+          bh[i] = *(const uint4*)(sB + swz(brow + 32 * i, ch));
+          bl[i] = *(const uint4*)(sB + swz(brow + 32 * i, ch + 1));
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            Mma<T>::run(bl[j], ah[i], acc[i][j]);
+            Mma<T>::run(bh[j], al[i], acc[i][j]);
+            Mma<T>::run(bh[j], ah[i], acc[i][j]);
+          }
+      }
+    } else {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int ch = 2 * ks + half;
@@ -208,6 +224,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, int tiles_m, int 
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) Mma<T>::run(b[j], a[i], acc[i][j]);  // weight = A operand: D = C^T
+    }
     }
     if (kt + 1 < nk) {
       unsigned char* dA = smem + ((kt + 1) & 1) * STAGE_BYTES;
@@ -240,7 +257,7 @@ int g_use_gemm256 = 2;  // 0: 128x128 only, 1: gemm256, 2: persistent wave-speci
 
 int launch_gemm(int prec, const GemmArgs& g, hipStream_t st) {
   if (g.M <= 0) return 0;
-  const int kpt = prec == PREC_BF16 ? Mma<bf16_t>::KPT : Mma<float>::KPT;
+  const int kpt = prec == PREC_BF16 ? Mma<bf16_t>::KPT : Mma<float>::KPT;  // split_t: 32 like float
   if (g.K % kpt != 0 || g.N <= 0) {
     snprintf(g_err, sizeof(g_err), "gemm: K=%d must be a multiple of %d", g.K, kpt);
     return 1;
@@ -249,6 +266,7 @@ int launch_gemm(int prec, const GemmArgs& g, hipStream_t st) {
   const int tiles_m = cdiv(g.M, BM), tiles_n = cdiv(g.N, BN);
   const bool vec = (g.N % 4 == 0) && (g.ldc % 4 == 0) && (!g.resid || g.ldr % 4 == 0);
   if (prec == PREC_BF16) launch_t<bf16_t>(g, tiles_m, tiles_n, vec, st);
+  else if (prec == PREC_F16X3) launch_t<split_t>(g, tiles_m, tiles_n, vec, st);
   else launch_t<float>(g, tiles_m, tiles_n, vec, st);
   CZC_HIP_CHECK(hipGetLastError());
   return 0;

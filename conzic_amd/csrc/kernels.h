@@ -42,6 +42,7 @@ int launch_im2col(int prec, const float* pixels, int B, int S, int p, void* out,
 int launch_vision_assemble(const float* patch_out, int B, int P, int H, const float* cls, const float* pos, float* x,
                            hipStream_t st);
 int launch_convert(int prec, const float* src, void* dst, long n, hipStream_t st);  // fp32 -> act type
+int launch_act_to_f32(int prec, const void* src, float* dst, long n, hipStream_t st);  // act type -> fp32
 // gather rows: dst[m] = src[idx[m]]  (fp32 rows of width H)
 int launch_gather_rows_f32(const float* src, const int* idx, int M, int H, float* dst, hipStream_t st);
 // rows b*T+gen_idx

@@ -43,18 +43,6 @@ __device__ __forceinline__ void ln_row(float4 (&v)[NV], int H, int lane, const f
 }
 
 template <typename T>
-__device__ __forceinline__ void store4(T* p, const float4& v);
-template <>
-__device__ __forceinline__ void store4<float>(float* p, const float4& v) { *(float4*)p = v; }
-template <>
-__device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const float4& v) {
-  uint2 o;
-  o.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
-  o.y = (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
-  *(uint2*)p = o;
-}
-
-template <typename T>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const int* row_idx, const float* gamma,
                                                         const float* beta, float eps, int M, int H, T* y_act,
                                                         float* y_f32) {
@@ -75,7 +63,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const in
     const int c = (i * 64 + lane) * 4;
     if (c < H) {
       if (y_f32) *(float4*)(y_f32 + (long)m * H + c) = v[i];
-      if (y_act) store4<T>(y_act + (long)m * H + c, v[i]);
+      if (y_act) Act<T>::st4(y_act, (long)m * H + c, v[i].x, v[i].y, v[i].z, v[i].w);
     }
   }
 }
@@ -91,6 +79,9 @@ int launch_layernorm(int prec, const float* x, const int* row_idx, const float* 
   if (prec == PREC_BF16)
     hipLaunchKernelGGL(layernorm_kernel<bf16_t>, grid, block, 0, st, x, row_idx, gamma, beta, eps, M, H,
                        (bf16_t*)y_act, y_f32);
+  else if (prec == PREC_F16X3)
+    hipLaunchKernelGGL(layernorm_kernel<split_t>, grid, block, 0, st, x, row_idx, gamma, beta, eps, M, H,
+                       (split_t*)y_act, y_f32);
   else
     hipLaunchKernelGGL(layernorm_kernel<float>, grid, block, 0, st, x, row_idx, gamma, beta, eps, M, H, (float*)y_act,
                        y_f32);
@@ -128,7 +119,7 @@ __global__ __launch_bounds__(256) void bert_embed_kernel(const int* ids, int M, 
     const int c = (i * 64 + lane) * 4;
     if (c < H) {
       if (y_f32) *(float4*)(y_f32 + (long)m * H + c) = v[i];
-      if (y_act) store4<T>(y_act + (long)m * H + c, v[i]);
+      if (y_act) Act<T>::st4(y_act, (long)m * H + c, v[i].x, v[i].y, v[i].z, v[i].w);
     }
   }
 }
@@ -142,6 +133,9 @@ int launch_bert_embed(int prec, const int* ids, int B, int T_, int H, const floa
   if (prec == PREC_BF16)
     hipLaunchKernelGGL(bert_embed_kernel<bf16_t>, grid, block, 0, st, ids, M, T_, H, word, pos, type0, gamma, beta, eps,
                        (bf16_t*)y_act, y_f32);
+  else if (prec == PREC_F16X3)
+    hipLaunchKernelGGL(bert_embed_kernel<split_t>, grid, block, 0, st, ids, M, T_, H, word, pos, type0, gamma, beta, eps,
+                       (split_t*)y_act, y_f32);
   else
     hipLaunchKernelGGL(bert_embed_kernel<float>, grid, block, 0, st, ids, M, T_, H, word, pos, type0, gamma, beta, eps,
                        (float*)y_act, y_f32);
@@ -196,7 +190,7 @@ __global__ void im2col_kernel(const float* pix, int B, int S, int p, T* out) {
     const int c = k / (p * p), iy = (k / p) % p, ix = k % p;
     const int py = pp / G, px = pp % G;
     const float v = pix[(((long)b * 3 + c) * S + (py * p + iy)) * S + (px * p + ix)];
-    Act<T>::st(out + i, v);
+    Act<T>::st(out, i, v);
   }
 }
 
@@ -236,7 +230,7 @@ int launch_vision_assemble(const float* patch_out, int B, int P, int H, const fl
 template <typename T>
 __global__ void convert_kernel(const float* src, T* dst, long n) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-    Act<T>::st(dst + i, src[i]);
+    Act<T>::st(dst, i, src[i]);
 }
 
 int launch_convert(int prec, const float* src, void* dst, long n, hipStream_t st) {
@@ -244,8 +238,26 @@ int launch_convert(int prec, const float* src, void* dst, long n, hipStream_t st
   dim3 grid((unsigned)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384)), block(256);
   if (prec == PREC_BF16)
     hipLaunchKernelGGL(convert_kernel<bf16_t>, grid, block, 0, st, src, (bf16_t*)dst, n);
+  else if (prec == PREC_F16X3)
+    hipLaunchKernelGGL(convert_kernel<split_t>, grid, block, 0, st, src, (split_t*)dst, n);
   else
     hipLaunchKernelGGL(convert_kernel<float>, grid, block, 0, st, src, (float*)dst, n);
+  CZC_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+template <typename T>
+__global__ void act_to_f32_kernel(const T* src, float* dst, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    dst[i] = Act<T>::ld(src, i);
+}
+
+int launch_act_to_f32(int prec, const void* src, float* dst, long n, hipStream_t st) {
+  if (n <= 0) return 0;
+  dim3 grid((unsigned)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384)), block(256);
+  if (prec == PREC_BF16) hipLaunchKernelGGL(act_to_f32_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)src, dst, n);
+  else if (prec == PREC_F16X3) hipLaunchKernelGGL(act_to_f32_kernel<split_t>, grid, block, 0, st, (const split_t*)src, dst, n);
+  else hipLaunchKernelGGL(act_to_f32_kernel<float>, grid, block, 0, st, (const float*)src, dst, n);
   CZC_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -36,8 +36,9 @@ extern "C" {
 #define CZC_ERR_OVERFLOW 4 /* text bridge scratch overflow (row text > CZC_BRIDGE_MAX_BYTES) */
 
 #define CZC_PREC_BF16 0 /* throughput mode: CLIP towers on bf16 MFMA operands (fp32 accumulate, residual, LN, */
-                        /* softmax); the BERT tower stays on f32 MFMA because softmax(logits/0.1) amplifies */
-                        /* logit error tenfold and BERT is only 1.4% of the step's FLOPs */
+                        /* softmax); the BERT tower runs on split-fp16 MFMA (hi+lo planes, 3 passes, ~22  */
+                        /* mantissa bits) because softmax(logits/0.1) amplifies logit error tenfold and   */
+                        /* BERT is only 1.4% of the step's FLOPs                                          */
 #define CZC_PREC_F32 1  /* f32-input MFMA everywhere (verification mode, ~1e-6 of the CPU reference) */
 #define CZC_PREC_ALL_BF16 2 /* bf16 MFMA in every tower (experiments only) */
 

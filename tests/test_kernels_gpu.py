@@ -255,3 +255,33 @@ def test_gemm256_variants(variant, M, N, K, act, resid):
     ref = _act(pre, act) + (R if resid else 0)
     err = np.abs(C - ref).max()
     assert err < 3e-3 * np.sqrt(K / 64), err
+
+
+F16X3 = 3  # internal precision code: split-fp16 storage, three fp16 MFMA passes (BERT tower of the bf16 engine)
+
+
+@pytest.mark.parametrize("M,N,K,act", [(15, 768, 768, 0), (300, 2304, 768, 0), (256, 3072, 768, 2), (129, 768, 3072, 0),
+                                       (7, 30522, 768, 0)])
+def test_split_fp16_gemm_is_fp32_class(M, N, K, act):
+    rng = np.random.default_rng(M + N)
+    A = (rng.standard_normal((M, K)) * 2).astype(np.float32)
+    W = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    C = E.test_gemm(F16X3, A, W, bias=bias, act=act)
+    ref = _act((A.astype(np.float64) @ W.astype(np.float64).T + bias).astype(np.float32), act)
+    err = np.abs(C - ref).max()
+    assert err < 1e-5 * np.sqrt(K / 64) * 4, err
+
+
+def test_split_fp16_layernorm_and_attention():
+    rng = np.random.default_rng(5)
+    x = (rng.standard_normal((33, 768)) * 2).astype(np.float32)
+    g = (1 + 0.1 * rng.standard_normal(768)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(768)).astype(np.float32)
+    y = E.test_layernorm(F16X3, x, g, b, 1e-12)
+    ref = torch.nn.functional.layer_norm(torch.from_numpy(x), (768,), torch.from_numpy(g), torch.from_numpy(b), 1e-12).numpy()
+    assert np.abs(y - ref).max() < 2e-5
+    lens = [15, 17, 64]
+    qkv = rng.standard_normal((sum(lens), 3 * 12 * 64)).astype(np.float32)
+    out = E.test_attention(F16X3, qkv, lens, 12, False, 0.125)
+    assert np.abs(out - _attn_ref(qkv, lens, 12, False, 0.125)).max() < 3e-5
