@@ -77,6 +77,7 @@ struct czc_engine {
   int last_BT = 0;
   int share_prefix = 1;  // encode the candidates' common causal prefix once per image
   int pack_branches = 1; // pack several candidates' rows into one attention MFMA tile
+  int pool_last_layer = 1; // last CLIP-text layer: out-proj + MLP on the EOS rows only
 
   bool prof = false;
   std::map<std::string, ProfKind> pk;
@@ -228,9 +229,12 @@ int gemm(czc_engine* e, int prec, const char* kind, const void* A, int lda, cons
 
 // ---- pre-LN transformer stack shared by the CLIP text and vision towers -----------------------
 // x_f32 [M,H] residual stream (updated in place); packed sequences described by off/len or fixed_T
+// `pool_idx` (optional): only these n_pool rows are needed after the stack (EOS rows of the CLIP text
+// tower).  The last layer then runs its out-projection and MLP on those rows only (K/V of every row
+// are still produced); the pooled residual rows are returned in *pooled (fp32 [n_pool, H]).
 int clip_stack(czc_engine* e, const char* gk, std::vector<LayerW>& L, float* x, int M, int H, int I, int heads,
                float eps, const SegTable& tab, int max_keys, int causal, int plan_B = 0, int plan_K = 0,
-               int plan_max_own = 0) {
+               int plan_max_own = 0, const int* pool_idx = nullptr, int n_pool = 0, float** pooled = nullptr) {
   const int P = e->pc;
   void *y, *qkv, *ctx, *hbuf;
   E_CHECK(ensure(e, "cs_y", (size_t)M * H * e->esz, &y));
@@ -248,6 +252,23 @@ int clip_stack(czc_engine* e, const char* gk, std::vector<LayerW>& L, float* x, 
         rc = launch_attention_shared(qkv, tab, plan_B, plan_K, plan_max_own, max_keys, heads, scale, ctx, e->st);
       if (rc > 0) E_CHECK(rc);
       if (rc < 0) E_CHECK(launch_attention(P, qkv, tab, max_keys, heads, causal, scale, ctx, e->st)); }
+    if (pool_idx && n + 1 == L.size() && e->pool_last_layer) {
+      void *ctx_e, *y_e, *h_e; float* x_e;
+      E_CHECK(ensure(e, "cs_ctx_e", (size_t)n_pool * H * e->esz, &ctx_e));
+      E_CHECK(ensure(e, "cs_y_e", (size_t)n_pool * H * e->esz, &y_e));
+      E_CHECK(ensure(e, "cs_h_e", (size_t)n_pool * I * e->esz, &h_e));
+      E_CHECK(ensure(e, "cs_x_e", (size_t)n_pool * H * 4, (void**)&x_e));
+      { ProfScope ps(e, "rowops", 0);
+        E_CHECK(launch_gather_rows_bytes(ctx, pool_idx, n_pool, H * (int)e->esz, ctx_e, e->st));
+        E_CHECK(launch_gather_rows_f32(x, pool_idx, n_pool, H, x_e, e->st)); }
+      E_CHECK(gemm(e, P, gk, ctx_e, H, l.o_w, H, l.o_b, x_e, H, nullptr, x_e, H, n_pool, H, H, ACT_NONE));
+      { ProfScope ps(e, "rowops", 0);
+        E_CHECK(launch_layernorm(P, x_e, nullptr, l.ln2_g, l.ln2_b, eps, n_pool, H, y_e, nullptr, e->st)); }
+      E_CHECK(gemm(e, P, gk, y_e, H, l.fc1_w, H, l.fc1_b, nullptr, 0, h_e, nullptr, I, n_pool, I, H, ACT_QUICK_GELU));
+      E_CHECK(gemm(e, P, gk, h_e, I, l.fc2_w, I, l.fc2_b, x_e, H, nullptr, x_e, H, n_pool, H, I, ACT_NONE));
+      *pooled = x_e;
+      return 0;
+    }
     E_CHECK(gemm(e, P, gk, ctx, H, l.o_w, H, l.o_b, x, H, nullptr, x, H, M, H, H, ACT_NONE));
     { ProfScope ps(e, "rowops", 0); E_CHECK(launch_layernorm(P, x, nullptr, l.ln2_g, l.ln2_b, eps, M, H, y, nullptr, e->st)); }
     E_CHECK(gemm(e, P, gk, y, H, l.fc1_w, H, l.fc1_b, nullptr, 0, hbuf, nullptr, I, M, I, H, ACT_QUICK_GELU));
@@ -361,10 +382,12 @@ int clip_text_forward(czc_engine* e, const int* cids, const int* clen, int B, in
   { ProfScope ps(e, "rowops", 0);
     E_CHECK(launch_clip_embed(cids, CZC_CLIP_MAX_LEN, src, pos0, own_off, own_len, S, max_len, H, tok, pos, x, e->st)); }
   SegTable tab{pre_off, pre_len, own_off, own_len, S, 0};
+  float* pooled = nullptr;
   E_CHECK(clip_stack(e, "gemm_clip_text", e->ctext, x, M, H, c.clip_inter, c.clip_heads, c.clip_eps, tab, max_len, 1, B,
-                     K, max_branch));
+                     K, max_branch, eidx, n_seq, &pooled));
   { ProfScope ps(e, "rowops", 0);
-    E_CHECK(launch_layernorm(P, x, eidx, fg, fb, c.clip_eps, n_seq, H, pa, nullptr, e->st)); }
+    if (pooled) E_CHECK(launch_layernorm(P, pooled, nullptr, fg, fb, c.clip_eps, n_seq, H, pa, nullptr, e->st));
+    else E_CHECK(launch_layernorm(P, x, eidx, fg, fb, c.clip_eps, n_seq, H, pa, nullptr, e->st)); }
   E_CHECK(gemm(e, P, "gemm_clip_text", pa, H, e->tproj_w, H, nullptr, nullptr, 0, nullptr, feat, c.clip_proj, n_seq,
                c.clip_proj, H, ACT_NONE));
   e->stat_clip_rows += M;
@@ -783,6 +806,7 @@ int czc_set_option(czc_engine* e, const char* name, int value) {
   if (!e || !name) return CZC_ERR_ARG;
   if (!strcmp(name, "share_prefix")) { e->share_prefix = value ? 1 : 0; return CZC_OK; }
   if (!strcmp(name, "pack_branches")) { e->pack_branches = value ? 1 : 0; return CZC_OK; }
+  if (!strcmp(name, "pool_last_layer")) { e->pool_last_layer = value ? 1 : 0; return CZC_OK; }
   return fail(e, CZC_ERR_ARG, "unknown option %s", name);
 }
 

@@ -45,6 +45,7 @@ int launch_convert(int prec, const float* src, void* dst, long n, hipStream_t st
 int launch_act_to_f32(int prec, const void* src, float* dst, long n, hipStream_t st);  // act type -> fp32
 // gather rows: dst[m] = src[idx[m]]  (fp32 rows of width H)
 int launch_gather_rows_f32(const float* src, const int* idx, int M, int H, float* dst, hipStream_t st);
+int launch_gather_rows_bytes(const void* src, const int* idx, int M, int row_bytes, void* dst, hipStream_t st);
 // rows b*T+gen_idx
 int launch_make_row_index(int* idx, int B, int T, int gen_idx, hipStream_t st);
 // idx[s] = off[s] + len[s] - 1

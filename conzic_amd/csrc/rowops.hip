@@ -271,6 +271,25 @@ __global__ void gather_rows_kernel(const float* src, const int* idx, int M, int 
   for (int c = lane * 4; c < H; c += 256) *(float4*)(d + c) = *(const float4*)(s + c);
 }
 
+// generic row gather on raw bytes (row_bytes % 16 == 0): dst[m] = src[idx[m]]
+__global__ void gather_rows_bytes_kernel(const unsigned char* src, const int* idx, int M, int row_bytes,
+                                         unsigned char* dst) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const unsigned char* s = src + (long)idx[m] * row_bytes;
+  unsigned char* d = dst + (long)m * row_bytes;
+  for (int c = lane * 16; c < row_bytes; c += 1024) *(uint4*)(d + c) = *(const uint4*)(s + c);
+}
+
+int launch_gather_rows_bytes(const void* src, const int* idx, int M, int row_bytes, void* dst, hipStream_t st) {
+  if (M <= 0) return 0;
+  hipLaunchKernelGGL(gather_rows_bytes_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, (const unsigned char*)src, idx, M,
+                     row_bytes, (unsigned char*)dst);
+  CZC_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
 int launch_gather_rows_f32(const float* src, const int* idx, int M, int H, float* dst, hipStream_t st) {
   if (M <= 0) return 0;
   hipLaunchKernelGGL(gather_rows_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, src, idx, M, H, dst);

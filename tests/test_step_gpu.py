@@ -306,3 +306,21 @@ def test_packed_branch_attention_matches_per_segment(name):
     for ra, rb in zip(*outs):
         np.testing.assert_allclose(ra["clip_ref"], rb["clip_ref"], atol=1e-3)
         np.testing.assert_allclose(ra["final_score"], rb["final_score"], atol=2e-4)
+
+
+@pytest.mark.parametrize("prec", [F32, BF16])
+def test_last_layer_pooling_is_exact(prec):
+    """Running the last CLIP-text layer's out-projection/MLP on the EOS rows only is the same math."""
+    meta, arr = load_case("full_synth_b2")
+    su = setup_for(meta, prec)
+    eng = su.engine
+    eng.set_image_embeds(arr["image_embeds"])
+    hp = Engine.hyper(meta["alpha"], meta["beta"], meta["temperature"])
+    outs = []
+    for pool in (1, 0):
+        eng.set_option("pool_last_layer", pool)
+        inp = np.ascontiguousarray(arr["inp_before"][4], dtype=np.int32)
+        outs.append(eng.step(inp, SEED_LEN + meta["positions"][4], meta["K"], hp))
+    eng.set_option("pool_last_layer", 1)
+    np.testing.assert_allclose(outs[0]["clip_ref"], outs[1]["clip_ref"], atol=1e-6 if prec == F32 else 1e-5)
+    np.testing.assert_allclose(outs[0]["final_score"], outs[1]["final_score"], atol=1e-6 if prec == F32 else 1e-5)
