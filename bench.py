@@ -84,6 +84,8 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--order", default="sequential", choices=["sequential", "shuffle"])
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--gamma", type=float, default=None, help="sentiment control weight (BASELINE configs[4]: 5.0)")
+    ap.add_argument("--sentiment", default="positive", choices=["positive", "negative"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event kernel timing (roofline)")
     a = ap.parse_args()
@@ -96,11 +98,16 @@ def main():
     rank, world, local = czd.env_rank_world()
     assert world == a.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {a.gpus}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (the engine has no CPU fallback)"
+    local = local % torch.cuda.device_count()  # (single-GPU smoke runs of the N>1 path share device 0)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    backend = os.environ.get("CZC_DIST_BACKEND", "nccl")  # "nccl" == RCCL on ROCm
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     prec = native.PREC_BF16 if a.precision == "bf16" else native.PREC_F32
     bcfg, ccfg = synth.bert_base(), synth.clip_b32()
@@ -113,7 +120,7 @@ def main():
     else:
         bw, cw = synth.make_bert_weights(bcfg, 11), synth.make_clip_weights(ccfg, 12)
     su = harness.build_synthetic(False, prec, regular_only=True, device=local, bert_w=bw, clip_w=cw,
-                                 bert_cfg=bcfg, clip_cfg=ccfg)
+                                 bert_cfg=bcfg, clip_cfg=ccfg, lexicon=a.gamma is not None)
     del bw, cw
     eng = su.engine
     t_setup = time.time() - t0
@@ -130,7 +137,7 @@ def main():
         order_list = list(range(L))
         random.Random(42).shuffle(order_list)
     pos, nm, every = harness.order_positions(a.order, L, I, order_list=order_list)
-    hp = Engine.hyper(0.02, 2.0, 0.1)
+    hp = Engine.hyper(0.02, 2.0, 0.1, a.gamma, a.sentiment == "negative")
 
     def step():
         eng.encode_images(pixels)
@@ -155,7 +162,7 @@ def main():
     eng.profile(False)
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -169,9 +176,15 @@ def main():
         if prof and prof["gemm_clip_text"]["launches"]:
             g = prof["gemm_clip_text"]
             ach = g["flops"] / (g["ms"] * 1e-3) / 1e12
-            roof = dict(bound="mfma", kernel="czc::gemm_kernel<bf16> (CLIP-text linear layers)",
+            # HBM bytes per launch come from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this
+            # same command (profiles/r01_bench_gemm_traffic.json); only quoted for the workload they were taken on
+            traffic = None
+            tp = os.path.join(ROOT, "profiles", "r01_bench_gemm_traffic.json")
+            if os.path.exists(tp) and (B, L, K, I, a.order, a.gamma) == (256, 10, 200, 10, "sequential", None):
+                traffic = json.load(open(tp))["hbm_bytes_per_launch"]
+            roof = dict(bound="mfma", kernel="czc::gemm256p_kernel<bf16> (CLIP-text linear layers)",
                         achieved=round(ach, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_BF16_TFLOPS, 4),
-                        traffic=None, launches=g["launches"], avg_launch_ms=round(g["ms"] / g["launches"], 4),
+                        traffic=traffic, launches=g["launches"], avg_launch_ms=round(g["ms"] / g["launches"], 4),
                         flops_per_launch=g["flops"] / g["launches"])
         f_cap = caption_flops(L, K, I)
         out = dict(metric="captions/sec (L=10, K=200, seq order)", value=round(value, 4), unit="captions/s",
@@ -182,6 +195,7 @@ def main():
                                         f"L={L}, K={K}, I={I}, alpha=0.02 beta=2.0 tau=0.1, bert-base + CLIP ViT-B/32 shapes, "
                                         "random-init weights, synthetic vocab (1 CLIP token per word)",
                                images_per_gpu=B, sentence_len=L, candidate_k=K, num_iterations=I, order=a.order,
+                               gamma=a.gamma, sentiment=a.sentiment if a.gamma is not None else None,
                                parallelism=f"image-sharded x{world} (no per-step collective)"),
                    image_position_steps_per_s=round(value * L * I, 2),
                    algorithmic_tflop_per_caption=round(f_cap / 1e12, 3),

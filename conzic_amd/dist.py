@@ -42,7 +42,9 @@ def broadcast_state(state: Optional[Dict[str, np.ndarray]], device, src: int = 0
     dist.broadcast_object_list(manifest, src=src)
     items = manifest[0]
     total = sum(int(np.prod(s)) if len(s) else 1 for _, s, alias in items if alias is None)
-    flat = torch.empty(total, dtype=torch.float32, device=device)
+    # RCCL ("nccl") moves device memory directly over xGMI; gloo (CPU tests) stages through the host
+    bdev = device if dist.get_backend() == "nccl" else torch.device("cpu")
+    flat = torch.empty(total, dtype=torch.float32, device=bdev)
     if rank == src:
         host = torch.empty(total, dtype=torch.float32)
         o = 0
@@ -53,6 +55,8 @@ def broadcast_state(state: Optional[Dict[str, np.ndarray]], device, src: int = 0
                 o += n
         flat.copy_(host)
     dist.broadcast(flat, src=src)
+    if flat.device != torch.device(device):
+        flat = flat.to(device)
     out = {}
     o = 0
     for k, s, alias in items:
