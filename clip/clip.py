@@ -33,6 +33,7 @@ class CLIP:
         self._state = None
         self._engine = None
         self.lexicon = None  # fp32 [bert_vocab] sentiment table for control_gen_utils
+        self.pos_tags = None  # uint8 [bert_vocab] universal-tag ids for POS control
         self.cuda_has_been_checked = False
         if model_name is not None:
             print('Initializing CLIP model...')

@@ -5,8 +5,10 @@ The reference scores every candidate sentence through nltk + SentiWordNet on the
 (sentiments_classifer.py:9-48).  Here the sentence score is the sum of a per-BERT-token lexicon
 (`clip.lexicon`, fp32 [vocab]) over the sentence's non-special tokens, evaluated inside the text
 bridge kernel, and softmax_K / gamma / repeat penalty are fused into the score-combine kernel
-(control_gen_utils.py:53-59).  POS control (control_gen_utils.py:136-195) is not built yet
-(SURVEY.md §8f rank 1)."""
+(control_gen_utils.py:53-59).  POS control (control_gen_utils.py:136-195) works the same way: the
+tagger is a per-BERT-token universal-tag table (`clip.pos_tags`, uint8 [vocab]); the template match
+fraction of POS_classifier.py:17-29 is evaluated in the bridge kernel and softmax_K(acc/0.1) in the
+combine kernel."""
 import time
 
 from conzic_amd.runtime import run_generation
@@ -30,18 +32,32 @@ def sentiment_shuffle_generation(img_name, model, clip, tokenizer, image_instanc
                           ctl_signal=ctl_signal)
 
 
+def POS_sequential_generation(img_name, model, clip, tokenizer, image_instance, token_mask, prompt, logger,
+                              max_len=15, top_k=0, temperature=None, alpha=0.7, beta=1, gamma=0.1,
+                              max_iters=20, batch_size=1, ctl_signal=["DET"], verbose=True):
+    """control_gen_utils.py:136-195"""
+    logger.info(ctl_signal)
+    return run_generation("sequential", img_name, model, clip, tokenizer, image_instance, token_mask, prompt, logger,
+                          max_len, top_k, temperature, alpha, beta, max_iters, batch_size, verbose, gamma=gamma,
+                          pos_template=ctl_signal)
+
+
 def control_generate_caption(img_name, model, clip, tokenizer, image_instance, token_mask, logger,
                              prompt="", batch_size=10, max_len=25,
                              top_k=100, temperature=1.0, max_iter=500, alpha=0.7, beta=1, gamma=5,
                              ctl_type="sentiment", style_type="positive", pos_type=None, generate_order="sequential"):
     """control_gen_utils.py:197-232"""
     start_time = time.time()
-    if ctl_type != "sentiment":
-        raise NotImplementedError("POS control (control_gen_utils.py:136-195) is not part of this build yet")
-    fn = sentiment_sequential_generation if generate_order == "sequential" else sentiment_shuffle_generation
-    generate_texts, clip_scores = fn(img_name, model, clip, tokenizer, image_instance, token_mask, prompt, logger,
-                                     batch_size=batch_size, max_len=max_len, top_k=top_k, alpha=alpha, beta=beta,
-                                     gamma=gamma, temperature=temperature, max_iters=max_iter, ctl_signal=style_type)
+    if ctl_type == "sentiment":
+        fn = sentiment_sequential_generation if generate_order == "sequential" else sentiment_shuffle_generation
+        generate_texts, clip_scores = fn(img_name, model, clip, tokenizer, image_instance, token_mask, prompt, logger,
+                                         batch_size=batch_size, max_len=max_len, top_k=top_k, alpha=alpha, beta=beta,
+                                         gamma=gamma, temperature=temperature, max_iters=max_iter, ctl_signal=style_type)
+    else:  # POS control (control_gen_utils.py:218-223)
+        generate_texts, clip_scores = POS_sequential_generation(
+            img_name, model, clip, tokenizer, image_instance, token_mask, prompt, logger, batch_size=batch_size,
+            max_len=max_len, top_k=top_k, alpha=alpha, beta=beta, gamma=gamma, temperature=temperature,
+            ctl_signal=pos_type, max_iters=max_iter)
     logger.info("Finished in %.3fs" % (time.time() - start_time))
     final_caption = generate_texts[-2]
     best_caption = generate_texts[-1]

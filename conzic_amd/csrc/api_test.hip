@@ -221,7 +221,8 @@ int czc_test_bridge(const czc_bridge_tables* t, const czc_config* cfg, int n_row
   int* dlen = (int*)pool.alloc((size_t)n_rows * 4); T_PTR(dlen);
   int* dovf = (int*)pool.alloc(4); T_PTR(dovf);
   T_HIP(hipMemset(dovf, 0, 4));
-  T_CHECK(launch_bridge(bd, drows, n_rows, T, -1, nullptr, 1, nullptr, 0, dids, dlen, nullptr, nullptr, dovf, nullptr));
+  PosDev nopos{nullptr, nullptr, 0};
+  T_CHECK(launch_bridge(bd, drows, n_rows, T, -1, nullptr, 1, nullptr, 0, nopos, dids, dlen, nullptr, nullptr, dovf, nullptr));
   T_HIP(hipDeviceSynchronize());
   int ovf = 0;
   T_HIP(hipMemcpy(&ovf, dovf, 4, hipMemcpyDeviceToHost));
@@ -251,7 +252,7 @@ int czc_test_combine(int B, int K, int D, const float* text_feat, const float* i
   CombineArgs a;
   a.text_feat = dt; a.img_n = din; a.logit_scale_exp = expf(logit_scale); a.probs = dp; a.cand = dcand;
   a.senti_raw = ds; a.repeats = dr; a.alpha = hp->alpha; a.beta = hp->beta; a.gamma = hp->gamma;
-  a.use_senti = hp->use_sentiment && ds && dr; a.B = B; a.K = K; a.D = D; a.clip_score = o1; a.clip_ref = o2;
+  a.use_senti = (ds && (dr || hp->control == 2)) ? hp->control : 0; a.B = B; a.K = K; a.D = D; a.clip_score = o1; a.clip_ref = o2;
   a.final_score = o3; a.best = ob; a.best_cos = oc; a.inp = nullptr; a.T = 0; a.gen_idx = 0;
   T_CHECK(launch_combine(a, nullptr));
   T_HIP(hipDeviceSynchronize());

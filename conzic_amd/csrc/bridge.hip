@@ -42,7 +42,7 @@ __device__ __forceinline__ bool merge_lookup(const BridgeDev& bd, int l, int r, 
 
 __global__ __launch_bounds__(BR_THREADS) void bridge_kernel(BridgeDev bd, const int* inp, int B, int T, int gen_idx,
                                                             const int* cand, int K, const float* lexicon, int negative,
-                                                            int* clip_ids, int* clip_len, float* senti_raw,
+                                                            PosDev pos, int* clip_ids, int* clip_len, float* senti_raw,
                                                             float* repeats, int* overflow) {
   extern __shared__ __attribute__((aligned(16))) unsigned char br_lds[];
   unsigned char* txt = br_lds + (size_t)threadIdx.x * BR_MAXB;
@@ -59,12 +59,20 @@ __global__ __launch_bounds__(BR_THREADS) void bridge_kernel(BridgeDev bd, const 
   bool first = true, ovf = false;
   float senti = 0.f;
   int rep = 0;
+  int n_words = 0, pos_ok = 0;  // POS control: words = non-special pieces that do not continue a word
   for (int t = 0; t < T; ++t) {
     const int id = (cand && t == gen_idx) ? cid : inp[b * T + t];
     if (cand && id == cid) ++rep;
     const unsigned fl = bd.piece_flags[id];
     if (fl & 1u) continue;  // special token: skipped
     if (lexicon) senti += lexicon[id];
+    if (pos.tag_of_token && (first || !(fl & 2u))) {
+      if (n_words < pos.n) {
+        const unsigned m = pos.masks[n_words];
+        if (m == 0xFFFFu || (m >> pos.tag_of_token[id]) & 1u) ++pos_ok;
+      }
+      ++n_words;
+    }
     const unsigned o0 = bd.piece_off[id], o1 = bd.piece_off[id + 1];
     int need = (int)(o1 - o0) + 2;
     if (n + need > BR_MAXB) { ovf = true; break; }
@@ -130,20 +138,26 @@ __global__ __launch_bounds__(BR_THREADS) void bridge_kernel(BridgeDev bd, const 
   outp[1 + nt] = bd.eos_id;
   for (int q = nt + 2; q < BR_LEN; ++q) outp[q] = bd.eos_id;
   clip_len[row] = nt + 2;
-  if (senti_raw) senti_raw[row] = negative ? -senti : senti;
+  if (pos.tag_of_token) {
+    // template positions past the last word only match the "" wildcard (POS_classifier.py:19-27)
+    for (int w = n_words; w < pos.n; ++w) pos_ok += pos.masks[w] == 0xFFFFu ? 1 : 0;
+    if (senti_raw) senti_raw[row] = (float)pos_ok / (float)pos.n;
+  } else if (senti_raw) {
+    senti_raw[row] = negative ? -senti : senti;
+  }
   if (repeats) repeats[row] = (float)(rep - 1);
   if (ovf) atomicAdd(overflow, 1);
 }
 
 int launch_bridge(const BridgeDev& bd, const int* inp, int B, int T, int gen_idx, const int* cand, int K,
-                  const float* lexicon, int negative, int* clip_ids, int* clip_len, float* senti_raw, float* repeats,
-                  int* overflow_flag, hipStream_t st) {
+                  const float* lexicon, int negative, const PosDev& pos, int* clip_ids, int* clip_len, float* senti_raw,
+                  float* repeats, int* overflow_flag, hipStream_t st) {
   const long rows = (long)B * K;
   if (rows <= 0) return 0;
   const size_t shmem = (size_t)BR_THREADS * (2 * BR_MAXB + BR_MAXSYM * 4);
   CZC_HIP_CHECK(hipFuncSetAttribute((const void*)bridge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
   hipLaunchKernelGGL(bridge_kernel, dim3(cdiv(rows, BR_THREADS)), dim3(BR_THREADS), shmem, st, bd, inp, B, T, gen_idx,
-                     cand, K, lexicon, negative, clip_ids, clip_len, senti_raw, repeats, overflow_flag);
+                     cand, K, lexicon, negative, pos, clip_ids, clip_len, senti_raw, repeats, overflow_flag);
   CZC_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -55,11 +55,12 @@ __global__ __launch_bounds__(CB_THREADS) void combine_kernel(CombineArgs a) {
   for (int k = tid; k < K; k += CB_THREADS) sm += expf(s_cos[k] * a.logit_scale_exp - mx);
   sm = blk_reduce(sm, red, 0);
   float smx = -INFINITY, ssm = 1.f;
+  const float ctemp = a.use_senti == 2 ? 0.1f : 1.0f;  // POS: softmax(acc/0.1); sentiment: softmax(score/1)
   if (a.use_senti) {
-    for (int k = tid; k < K; k += CB_THREADS) smx = fmaxf(smx, a.senti_raw[(long)b * K + k]);
+    for (int k = tid; k < K; k += CB_THREADS) smx = fmaxf(smx, a.senti_raw[(long)b * K + k] / ctemp);
     smx = blk_reduce(smx, red, 1);
     float s2 = 0.f;
-    for (int k = tid; k < K; k += CB_THREADS) s2 += expf(a.senti_raw[(long)b * K + k] - smx);
+    for (int k = tid; k < K; k += CB_THREADS) s2 += expf(a.senti_raw[(long)b * K + k] / ctemp - smx);
     ssm = blk_reduce(s2, red, 0);
   }
   for (int k = tid; k < K; k += CB_THREADS) {
@@ -69,8 +70,9 @@ __global__ __launch_bounds__(CB_THREADS) void combine_kernel(CombineArgs a) {
     const float ref = lg / a.logit_scale_exp;  // the reference divides the scaled logit back
     float f = a.alpha * a.probs[o] + a.beta * cs;
     if (a.use_senti) {
-      const float sp = expf(a.senti_raw[o] - smx) / ssm;
-      f = f + a.gamma * sp + 0.1f * (1.0f - expf(a.repeats[o]));
+      const float sp = expf(a.senti_raw[o] / ctemp - smx) / ssm;
+      f = f + a.gamma * sp;
+      if (a.use_senti == 1) f = f + 0.1f * (1.0f - expf(a.repeats[o]));
     }
     a.clip_score[o] = cs;
     a.clip_ref[o] = ref;
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(CB_THREADS) void combine_kernel(CombineArgs a) {
     if (s_fin[k] == bm) atomicMin(&s_best, k);
   __syncthreads();
   if (tid == 0) {
-    const int bi = s_best;
+    const int bi = s_best < K ? s_best : 0;  // all-NaN scores: keep candidate 0
     a.best[b] = bi;
     a.best_cos[b] = s_cos[bi];
     if (a.inp) a.inp[(long)b * a.T + a.gen_idx] = a.cand[(long)b * K + bi];

@@ -69,6 +69,7 @@ struct czc_engine {
   std::map<std::string, Buf> ws;
   float* d_mask = nullptr; int mask_vocab = 0;
   float* d_lex = nullptr;
+  uint8_t* d_pos_tags = nullptr; uint16_t* d_pos_masks = nullptr; int pos_n = 0;
   BridgeDev bd; bool has_bridge = false;
   std::vector<void*> bridge_allocs;
   float* d_img_n = nullptr; int img_B = 0;
@@ -407,7 +408,8 @@ int step_device(czc_engine* e, int* d_inp, int B, int T, int gen_idx, int n_mask
   if (!e->d_img_n || e->img_B != B) return fail(e, CZC_ERR_STATE, "image embeds not set for this batch size%s");
   if (T > CZC_MAX_BERT_LEN || gen_idx < 0 || gen_idx >= T || K > CZC_MAX_TOPK)
     return fail(e, CZC_ERR_ARG, "step: bad T/gen_idx/K%s");
-  if (hp->use_sentiment && !e->d_lex) return fail(e, CZC_ERR_STATE, "sentiment path needs a lexicon%s");
+  if (hp->control == 1 && !e->d_lex) return fail(e, CZC_ERR_STATE, "sentiment path needs a lexicon%s");
+  if (hp->control == 2 && !e->d_pos_tags) return fail(e, CZC_ERR_STATE, "POS path needs czc_set_pos%s");
   const int n_seq = B * K;
 
   if (n_mask > 0) {
@@ -433,8 +435,9 @@ int step_device(czc_engine* e, int* d_inp, int B, int T, int gen_idx, int n_mask
                                      probs, idxs, cand, e->st)); }
   E_HIP(hipMemsetAsync(totals, 0, 32, e->st));
   { ProfScope ps(e, "bridge", 0);
-    E_CHECK(launch_bridge(e->bd, d_inp, B, T, gen_idx, cand, K, hp->use_sentiment ? e->d_lex : nullptr, hp->negative,
-                          cids, clen, senti, reps, totals + 2, e->st)); }
+    PosDev pos{hp->control == 2 ? e->d_pos_tags : nullptr, e->d_pos_masks, e->pos_n};
+    E_CHECK(launch_bridge(e->bd, d_inp, B, T, gen_idx, cand, K, hp->control == 1 ? e->d_lex : nullptr, hp->negative,
+                          pos, cids, clen, senti, reps, totals + 2, e->st)); }
   float* feat;
   E_CHECK(clip_text_forward(e, cids, clen, B, K, e->share_prefix, totals, &feat));
 
@@ -447,7 +450,7 @@ int step_device(czc_engine* e, int* d_inp, int B, int T, int gen_idx, int n_mask
   CombineArgs a;
   a.text_feat = feat; a.img_n = e->d_img_n; a.logit_scale_exp = e->logit_scale_exp; a.probs = probs; a.cand = cand;
   a.senti_raw = senti; a.repeats = reps; a.alpha = hp->alpha; a.beta = hp->beta; a.gamma = hp->gamma;
-  a.use_senti = hp->use_sentiment; a.B = B; a.K = K; a.D = c.clip_proj; a.clip_score = cscore; a.clip_ref = cref;
+  a.use_senti = hp->control; a.B = B; a.K = K; a.D = c.clip_proj; a.clip_score = cscore; a.clip_ref = cref;
   a.final_score = fin; a.best = best; a.best_cos = bcos; a.inp = d_inp; a.T = T; a.gen_idx = gen_idx;
   { ProfScope ps(e, "combine", 0); E_CHECK(launch_combine(a, e->st)); }
   e->stat_steps += 1;
@@ -524,6 +527,7 @@ int czc_destroy(czc_engine* e) {
   for (auto& kv : e->ws) if (kv.second.p) (void)hipFree(kv.second.p);
   for (void* p : e->bridge_allocs) (void)hipFree(p);
   (void)hipFree(e->d_mask); (void)hipFree(e->d_lex); (void)hipFree(e->d_img_n);
+  (void)hipFree(e->d_pos_tags); (void)hipFree(e->d_pos_masks);
   for (auto& kv : e->pk) for (hipEvent_t ev : kv.second.ev) (void)hipEventDestroy(ev);
   if (e->h_totals) (void)hipHostFree(e->h_totals);
   (void)hipStreamDestroy(e->st);
@@ -609,6 +613,18 @@ int czc_set_lexicon(czc_engine* e, const float* lex, int vocab) {
   E_HIP(hipSetDevice(e->dev));
   if (!e->d_lex) E_HIP(hipMalloc((void**)&e->d_lex, (size_t)vocab * 4));
   E_HIP(hipMemcpy(e->d_lex, lex, (size_t)vocab * 4, hipMemcpyDefault));
+  return CZC_OK;
+}
+
+int czc_set_pos(czc_engine* e, const uint8_t* tag_of_token, int vocab, const uint16_t* template_masks, int n_template) {
+  if (!e || !tag_of_token || !template_masks) return CZC_ERR_ARG;
+  if (vocab != e->cfg.bert_vocab || n_template <= 0 || n_template > 32) return fail(e, CZC_ERR_ARG, "bad POS tables%s");
+  E_HIP(hipSetDevice(e->dev));
+  if (!e->d_pos_tags) E_HIP(hipMalloc((void**)&e->d_pos_tags, (size_t)vocab));
+  if (!e->d_pos_masks) E_HIP(hipMalloc((void**)&e->d_pos_masks, 64));
+  E_HIP(hipMemcpy(e->d_pos_tags, tag_of_token, (size_t)vocab, hipMemcpyDefault));
+  E_HIP(hipMemcpy(e->d_pos_masks, template_masks, (size_t)n_template * 2, hipMemcpyDefault));
+  e->pos_n = n_template;
   return CZC_OK;
 }
 

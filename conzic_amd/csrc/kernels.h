@@ -92,9 +92,15 @@ struct BridgeDev {
 };
 // rows: inp[b,:] with column gen_idx replaced by cand[b,k] (cand==null: rows are taken verbatim,
 // n_rows = B, K = 1).  Writes clip_ids [B*K,77], clip_len, and optionally senti/repeats.
+// POS template for the control score (null tags = no POS score)
+struct PosDev {
+  const uint8_t* tag_of_token;  // [V]
+  const uint16_t* masks;        // [n] accepted-tag bit masks, 0xFFFF = wildcard
+  int n;
+};
 int launch_bridge(const BridgeDev& bd, const int* inp, int B, int T, int gen_idx, const int* cand, int K,
-                  const float* lexicon, int negative, int* clip_ids, int* clip_len, float* senti_raw, float* repeats,
-                  int* overflow_flag, hipStream_t st);
+                  const float* lexicon, int negative, const PosDev& pos, int* clip_ids, int* clip_len, float* senti_raw,
+                  float* repeats, int* overflow_flag, hipStream_t st);
 // exclusive scan of len[n] -> off[n+1]; totals[0] = sum, totals[1] = max
 int launch_scan(const int* len, int n, int* off, int* totals, hipStream_t st);
 // Shared-prefix plan for B images x K candidates (segments: B trunks, then B*K branches):
@@ -118,7 +124,7 @@ struct CombineArgs {
   const float* senti_raw;  // [B,K] or null
   const float* repeats;    // [B,K] or null
   float alpha, beta, gamma;
-  int use_senti;
+  int use_senti;           // 0 none, 1 sentiment (softmax(raw/1) + repeat penalty), 2 POS (softmax(raw/0.1))
   int B, K, D;
   float* clip_score; float* clip_ref; float* final_score;  // [B,K] (non-null, engine scratch)
   int* best; float* best_cos;                                // [B]

@@ -115,6 +115,11 @@ class Engine:
         m = np.ascontiguousarray(np.asarray(lex, dtype=np.float32).reshape(-1))
         self._ck(self.lib.czc_set_lexicon(self.h, m.ctypes.data, m.size), "czc_set_lexicon")
 
+    def set_pos(self, tag_of_token, template_masks):
+        t = np.ascontiguousarray(np.asarray(tag_of_token, dtype=np.uint8).reshape(-1))
+        m = np.ascontiguousarray(np.asarray(template_masks, dtype=np.uint16).reshape(-1))
+        self._ck(self.lib.czc_set_pos(self.h, t.ctypes.data, t.size, m.ctypes.data, m.size), "czc_set_pos")
+
     def set_bridge(self, tables: BridgeArrays):
         st = tables.as_struct()
         self._ck(self.lib.czc_set_bridge(self.h, C.byref(st)), "czc_set_bridge")
@@ -143,12 +148,16 @@ class Engine:
 
     # ---- hot path --------------------------------------------------------------------------------
     @staticmethod
-    def hyper(alpha, beta, temperature, gamma=None, negative=False) -> native.Hyper:
+    def hyper(alpha, beta, temperature, gamma=None, negative=False, control=None) -> native.Hyper:
+        """control: None -> 'sentiment' when gamma is given (back-compat), else 'sentiment' | 'pos'."""
         h = native.Hyper()
         h.alpha, h.beta = float(alpha), float(beta)
         h.gamma = float(gamma) if gamma is not None else 0.0
         h.temperature = 1.0 if temperature is None else float(temperature)
-        h.use_sentiment = 1 if gamma is not None else 0
+        if gamma is None:
+            h.control = 0
+        else:
+            h.control = 2 if control == "pos" else 1
         h.negative = 1 if negative else 0
         return h
 

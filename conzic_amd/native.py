@@ -52,7 +52,7 @@ class BridgeTables(C.Structure):
 
 class Hyper(C.Structure):
     _fields_ = [("alpha", C.c_float), ("beta", C.c_float), ("gamma", C.c_float), ("temperature", C.c_float),
-                ("use_sentiment", C.c_int32), ("negative", C.c_int32)]
+                ("control", C.c_int32), ("negative", C.c_int32)]
 
 
 STEP_OUT_FIELDS = ["probs", "idxs", "cand_ids", "clip_ids", "clip_len", "clip_score", "clip_ref", "senti_raw",
@@ -76,6 +76,7 @@ SIGNATURES = {
     "czc_set_token_mask": (_I, [_P, _P, _I]),
     "czc_set_bridge": (_I, [_P, C.POINTER(BridgeTables)]),
     "czc_set_lexicon": (_I, [_P, _P, _I]),
+    "czc_set_pos": (_I, [_P, _P, _I, _P, _I]),
     "czc_encode_images": (_I, [_P, _P, _I, _P]),
     "czc_set_image_embeds": (_I, [_P, _P, _I]),
     "czc_encode_text": (_I, [_P, _P, _P, _I, _P]),

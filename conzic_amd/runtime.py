@@ -104,7 +104,7 @@ def _mask_to_numpy(token_mask) -> np.ndarray:
 
 def run_generation(order: str, img_name, model, clip, tokenizer, image_instance, token_mask, prompt, logger, max_len,
                    top_k, temperature, alpha, beta, max_iters, batch_size, verbose=True, gamma=None,
-                   ctl_signal="positive", print_every: Optional[int] = None):
+                   ctl_signal="positive", print_every: Optional[int] = None, pos_template=None):
     """Body shared by every *_generation function (gen_utils.py:51-242, control_gen_utils.py:30-134):
     returns (gen_texts_list, clip_score_sequence) with the reference's list structure."""
     import utils as ref_utils  # the repo-root drop-in (same functions as the reference's utils.py)
@@ -113,7 +113,11 @@ def run_generation(order: str, img_name, model, clip, tokenizer, image_instance,
     batch = ref_utils.get_init_text(tokenizer, prompt, max_len, batch_size)  # gen_utils.py:57
     clip.compute_image_representation_from_image_instance(image_instance)    # gen_utils.py:58 (cached in the engine)
     eng.set_token_mask(_mask_to_numpy(token_mask))
-    if gamma is not None:
+    if gamma is not None and pos_template is not None:
+        if getattr(clip, "pos_tags", None) is None:
+            raise RuntimeError("the POS path needs a per-token tag table: set clip.pos_tags (see DESIGN.md)")
+        eng.set_pos(clip.pos_tags, synth.pos_template_masks(pos_template))
+    elif gamma is not None:
         if getattr(clip, "lexicon", None) is None:
             raise RuntimeError("the sentiment path needs a per-token lexicon: set clip.lexicon (see DESIGN.md)")
         eng.set_lexicon(clip.lexicon)
@@ -129,7 +133,8 @@ def run_generation(order: str, img_name, model, clip, tokenizer, image_instance,
         positions, n_mask, every = [int(p) for p in random_positions], [1] * len(random_positions), 1
     else:
         positions, n_mask, every = order_positions(order, max_len, iters, order_list=order_list)
-    hp = Engine.hyper(alpha, beta, temperature, gamma, ctl_signal == "negative")
+    hp = Engine.hyper(alpha, beta, temperature, gamma, ctl_signal == "negative",
+                      control="pos" if pos_template is not None else None)
     ids, cos = eng.generate(batch_size, batch[0], max_len, seed_len, top_k, positions, hp, n_mask=n_mask,
                             snapshot_every=every)
     # utils.update_token_mask mutates the caller's mask in place (utils.py:53-59): leave it as the

@@ -388,5 +388,30 @@ def make_lexicon(V: int, seed: int = 99) -> np.ndarray:
     return np.random.default_rng(seed).uniform(-1.0, 1.0, size=V).astype(np.float32)
 
 
+UNIVERSAL_TAGS = ["ADJ", "ADP", "ADV", "CONJ", "DET", "NOUN", "NUM", "PRT", "PRON", "VERB", ".", "X"]
+
+
+def make_pos_tags(V: int, seed: int = 77) -> np.ndarray:
+    """Deterministic per-token universal-tagset id (stand-in for nltk.pos_tag(tagset='universal') of
+    POS_classifier.py:13-14; 'parity unpinned' for the values, like the sentiment lexicon)."""
+    return np.random.default_rng(seed).integers(0, len(UNIVERSAL_TAGS), size=V).astype(np.uint8)
+
+
+def pos_template_masks(template) -> np.ndarray:
+    """Template (list of lists of tag names, "" = wildcard, as demo.py:40-45) -> uint16 bit masks."""
+    out = []
+    for entry in template:
+        if entry == "" or entry == [""]:
+            out.append(0xFFFF)
+            continue
+        names = [entry] if isinstance(entry, str) else list(entry)
+        m = 0
+        for n in names:
+            if n in UNIVERSAL_TAGS:
+                m |= 1 << UNIVERSAL_TAGS.index(n)
+        out.append(m)
+    return np.array(out, dtype=np.uint16)
+
+
 def cfg_dict(cfg) -> dict:
     return asdict(cfg)

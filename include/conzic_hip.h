@@ -92,7 +92,8 @@ typedef struct czc_hyper {
   float beta;        /* weight of CLIP softmax_K score        (gen_utils.py:77)              */
   float gamma;       /* weight of sentiment softmax_K         (control_gen_utils.py:59)      */
   float temperature; /* lm_temperature                         (gen_utils.py:43-44)           */
-  int32_t use_sentiment; /* 0 caption path, 1 sentiment path (adds gamma term + repeat penalty) */
+  int32_t control;   /* 0 caption path (gen_utils.py:77); 1 sentiment: + gamma*softmax_K(senti) + 0.1*(1-e^repeats) */
+                     /* (control_gen_utils.py:59); 2 POS: + gamma*softmax_K(acc/0.1) (control_gen_utils.py:165-169)  */
   int32_t negative;      /* sentiment_ctl == "negative" (sentiments_classifer.py:31-32)         */
 } czc_hyper;
 
@@ -106,7 +107,8 @@ typedef struct czc_step_out {
   int32_t* clip_len; /* [B*K] tokens incl. BOS/EOS                                     */
   float* clip_score; /* [B,K] softmax_K(cos * exp(logit_scale))   (clip/clip.py:97)    */
   float* clip_ref;   /* [B,K] cosine                              (clip/clip.py:98)    */
-  float* senti_raw;  /* [B,K] sentence sentiment score            (sentiments_classifer.py:46) */
+  float* senti_raw;  /* [B,K] control score: sentence sentiment (sentiments_classifer.py:46) or POS-template */
+                     /*       match fraction (POS_classifier.py:17-29), by czc_hyper.control                  */
   float* repeats;    /* [B,K] repeat count - 1                    (control_gen_utils.py:53)    */
   float* final_score;/* [B,K] fused score                         (gen_utils.py:77 / control_gen_utils.py:59) */
   int32_t* best;     /* [B]   argmax_K (first max)                (gen_utils.py:78)    */
@@ -133,6 +135,11 @@ int czc_set_token_mask(czc_engine* e, const float* mask, int vocab);
 int czc_set_bridge(czc_engine* e, const czc_bridge_tables* t);
 /* Per-BERT-token sentiment score (stand-in for sentiments_classifer.py:9-33). */
 int czc_set_lexicon(czc_engine* e, const float* lexicon, int vocab);
+
+/* POS control (control_gen_utils.py:136-195 / POS_classifier.py:6-31): per-BERT-token universal-tagset id
+ * (stand-in for nltk.pos_tag) and the template as one bit mask of accepted tag ids per word
+ * position (0xFFFF = the reference's "" wildcard); n_template <= 32. */
+int czc_set_pos(czc_engine* e, const uint8_t* tag_of_token, int vocab, const uint16_t* template_masks, int n_template);
 
 /* ---- once per image: clip/clip.py:48-62 after the image processor ------------------------ */
 /* pixels fp32 [B,3,S,S] -> un-normalised image_embeds [B,proj] (out may be NULL).  The engine

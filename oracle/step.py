@@ -44,6 +44,7 @@ class Oracle:
     id2tok: List[str]
     bpe: T.ClipBpe
     lexicon: Optional[np.ndarray] = None
+    pos_tags: Optional[np.ndarray] = None
     vocab: Dict[str, int] = field(default_factory=dict)
 
     def __post_init__(self):
@@ -107,10 +108,37 @@ def senti_scores(o: Oracle, rows: torch.Tensor, ctl_signal: str) -> torch.Tensor
     return -sc if ctl_signal == "negative" else sc
 
 
+def pos_scores(o: Oracle, rows: torch.Tensor, template) -> torch.Tensor:
+    """Stand-in for POS_classifier.py:6-31: words = non-special pieces that do not continue a word
+    ('##'), tag of a word = table tag of its first piece; acc = matches / len(template) with the
+    reference's padding/wildcard rules (POS_classifier.py:17-29)."""
+    from conzic_amd.synth import UNIVERSAL_TAGS
+    out = torch.zeros(rows.shape[0])
+    for r, row in enumerate(rows.tolist()):
+        tags = []
+        first = True
+        for i in row:
+            if i in o.special:
+                continue
+            if first or not o.id2tok[i].startswith("##"):
+                tags.append(UNIVERSAL_TAGS[int(o.pos_tags[i])])
+            first = False
+        total = len(template)
+        cur = tags + [""] * (total - len(tags)) if len(tags) <= total else tags[:total]
+        correct = 0
+        for w in range(len(cur)):
+            if template[w] == "":
+                correct += 1
+            elif cur[w] in template[w]:
+                correct += 1
+        out[r] = correct / total
+    return out
+
+
 def polish_step(o: Oracle, inp: torch.Tensor, image_embeds: torch.Tensor, token_mask: torch.Tensor,
                 gen_idx: int, top_k: int, temperature, alpha: float, beta: float,
-                gamma: Optional[float] = None, ctl_signal: str = "positive",
-                logits_row: Optional[torch.Tensor] = None) -> dict:
+                gamma: Optional[float] = None, ctl_signal="positive",
+                logits_row: Optional[torch.Tensor] = None, pos_template=None) -> dict:
     """One position-step: gen_utils.py:68-81 (+ control_gen_utils.py:53-63 when gamma is given).
     `inp` (int64 [B,T]) must already carry [MASK] at gen_idx; it is updated in place.
     Returns every intermediate the parity tests compare."""
@@ -130,7 +158,13 @@ def polish_step(o: Oracle, inp: torch.Tensor, image_embeds: torch.Tensor, token_
     final = alpha * probs + beta * clip_score
     out = dict(logits_row=logits_row, probs=probs, idxs=idxs, idxs_=idxs_, texts=texts,
                clip_ids=clip_ids, clip_lens=clip_lens, clip_score=clip_score, clip_ref=clip_ref)
-    if gamma is not None:
+    if gamma is not None and pos_template is not None:
+        # control_gen_utils.py:163-169
+        praw = pos_scores(o, rows, pos_template).view(B, -1)
+        pprob = torch.softmax(praw / 0.1, dim=-1)
+        final = final + gamma * pprob
+        out.update(senti_raw=praw, senti_prob=pprob)
+    elif gamma is not None:
         repeats = (idxs_[:, :, None] == topk_inp).float().sum(2) - 1
         sraw = senti_scores(o, rows, ctl_signal).view(B, -1)
         sprob = torch.softmax(sraw / 1, dim=1)
@@ -156,7 +190,7 @@ def generate(o: Oracle, pixels: np.ndarray, token_mask: torch.Tensor, prompt: st
              order: str = "sequential", order_list: Optional[Sequence[int]] = None,
              gamma: Optional[float] = None, ctl_signal: str = "positive",
              random_positions: Optional[Sequence[int]] = None, trace: Optional[list] = None,
-             image_embeds: Optional[torch.Tensor] = None):
+             image_embeds: Optional[torch.Tensor] = None, pos_template=None):
     """The *_generation functions of gen_utils.py / control_gen_utils.py behind one signature.
     Returns (gen_texts_list, clip_score_sequence, ids_per_snapshot) with the reference's list
     structure (I snapshots + best)."""
@@ -180,7 +214,7 @@ def generate(o: Oracle, pixels: np.ndarray, token_mask: torch.Tensor, prompt: st
     def one(ii, logits_row=None):
         o.update_token_mask(token_mask, max_len, ii)
         r = polish_step(o, inp, image_embeds, token_mask, seed_len + ii, top_k, temperature,
-                        alpha, beta, gamma, ctl_signal, logits_row)
+                        alpha, beta, gamma, ctl_signal, logits_row, pos_template)
         if trace is not None:
             r["pos"] = ii
             trace.append(r)

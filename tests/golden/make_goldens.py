@@ -48,7 +48,12 @@ _nltk.corpus = _nltk_corpus
 sys.modules["nltk"] = _nltk
 sys.modules["nltk.tokenize"] = _nltk_tok
 sys.modules["nltk.corpus"] = _nltk_corpus
+# The repo root carries drop-in modules with the reference's names (utils, gen_utils, ...): make sure
+# the REAL reference is what gets imported below, and only `conzic_amd` comes from the repo.
+sys.path = [p_ for p_ in sys.path if os.path.abspath(p_ or ".") != REPO]
 sys.path.insert(0, REF)
+for _m in ("utils", "gen_utils", "control_gen_utils", "sentiments_classifer", "POS_classifier", "clip", "clip.clip"):
+    assert _m not in sys.modules, _m
 
 import transformers  # noqa: E402
 from transformers import (BertConfig, BertForMaskedLM, BertTokenizer, CLIPConfig, CLIPModel,  # noqa: E402
@@ -60,6 +65,8 @@ import gen_utils as ref_gen  # noqa: E402
 import control_gen_utils as ref_ctl  # noqa: E402
 import sentiments_classifer as ref_senti  # noqa: E402
 from clip.clip import CLIP as RefCLIP  # noqa: E402
+for _mod in (ref_utils, ref_gen, ref_ctl, ref_senti):
+    assert _mod.__file__.startswith(REF + "/"), _mod.__file__
 
 torch.set_grad_enabled(False)
 
@@ -102,7 +109,7 @@ def build_hf(bcfg: synth.BertCfg, ccfg: synth.ClipCfg, sv: synth.SynthVocab, bse
 class Tap:
     """Wraps the reference's call sites from outside and records what flows through them."""
 
-    def __init__(self, model, clip, tok, lexicon=None, sign=1.0):
+    def __init__(self, model, clip, tok, lexicon=None, sign=1.0, pos_tags=None):
         self.steps = []
         self.snaps = []
         self.cur = None
@@ -111,6 +118,9 @@ class Tap:
         self.sign = sign
         self.special = set(tok.all_special_ids)
         self._senti_queue = []
+        self.pos_tags = pos_tags
+        self._pos_queue = []
+        self.id2tok = tok.convert_ids_to_tokens(list(range(tok.vocab_size)))
 
         orig_fwd = model.forward
 
@@ -170,6 +180,19 @@ class Tap:
                     keep &= t != s
                 sc = (torch.from_numpy(self.lexicon)[t] * keep).sum(1) * self.sign
                 self._senti_queue = sc.tolist()
+            if skip and self.pos_tags is not None and t.ndim == 2:
+                # tag lists for the nltk-free POS stand-in, consumed in call order by word_tokenize
+                q = []
+                for row in t.tolist():
+                    tags, first = [], True
+                    for i in row:
+                        if i in self.special:
+                            continue
+                        if first or not self.id2tok[i].startswith("##"):
+                            tags.append(synth.UNIVERSAL_TAGS[int(self.pos_tags[i])])
+                        first = False
+                    q.append(tags)
+                self._pos_queue = q
             if not skip and t.ndim == 2:
                 self.snaps.append(t.clone().numpy().astype(np.int32))
             return res
@@ -179,9 +202,14 @@ class Tap:
             # stands in for sentiments_classifer.py:9-33 (nltk + SentiWordNet are absent)
             return self._senti_queue.pop(0), [], []
         ref_senti.text_POS_Sentiments_analysis = senti_stub
+        # POS_classifier.py:12-14 calls word_tokenize(text) then pos_tag(words, tagset="universal"):
+        # the stubs hand the per-row tag list through as the "words" (nltk + its tagger are absent)
+        import POS_classifier as ref_pos
+        ref_pos.word_tokenize = lambda text: self._pos_queue.pop(0)
+        ref_pos.pos_tag = lambda words, tagset=None: [(w, w) for w in words]
 
 
-def run_case(name, *, tiny, B, L, K, I, order, alpha=0.02, beta=2.0, temperature=0.1, gamma=None, style="positive",
+def run_case(name, *, tiny, B, L, K, I, order, alpha=0.02, beta=2.0, temperature=0.1, gamma=None, style="positive", pos=None,
              seed=42, bseed=11, cseed=12, logit_scale=2.6592, image="synthetic", regular_only=False, tmp=None,
              keep_step_tensors=None):
     t0 = time.time()
@@ -196,8 +224,9 @@ def run_case(name, *, tiny, B, L, K, I, order, alpha=0.02, beta=2.0, temperature
     ccfg.logit_scale = logit_scale
     model, tok, clip = build_hf(bcfg, ccfg, sv, bseed, cseed, tmp)
     V = len(sv.bert_tokens)
-    lexicon = synth.make_lexicon(V) if gamma is not None else None
-    tap = Tap(model, clip, tok, lexicon, -1.0 if style == "negative" else 1.0)
+    lexicon = synth.make_lexicon(V) if (gamma is not None and pos is None) else None
+    tap = Tap(model, clip, tok, lexicon, -1.0 if style == "negative" else 1.0,
+              pos_tags=synth.make_pos_tags(V) if pos is not None else None)
     token_mask = torch.from_numpy(synth.make_token_mask(sv, regular_only=regular_only))
     from PIL import Image
     if image == "synthetic":
@@ -221,6 +250,9 @@ def run_case(name, *, tiny, B, L, K, I, order, alpha=0.02, beta=2.0, temperature
               alpha=alpha, beta=beta, generate_order=order)
     if gamma is None:
         texts, scores = ref_gen.generate_caption(names, model, clip, tok, image_instance, token_mask, L_(), **kw)
+    elif pos is not None:
+        texts, scores = ref_ctl.control_generate_caption(names, model, clip, tok, image_instance, token_mask, L_(),
+                                                         gamma=gamma, ctl_type="pos", pos_type=pos, **kw)
     else:
         texts, scores = ref_ctl.control_generate_caption(names, model, clip, tok, image_instance, token_mask, L_(),
                                                          gamma=gamma, ctl_type="sentiment", style_type=style, **kw)
@@ -229,7 +261,7 @@ def run_case(name, *, tiny, B, L, K, I, order, alpha=0.02, beta=2.0, temperature
     steps = tap.steps
     seed_len = 4
     meta = dict(name=name, tiny=tiny, B=B, L=L, K=K, I=I, order=order, alpha=alpha, beta=beta,
-                temperature=temperature, gamma=gamma, style=style, seed=seed, bseed=bseed, cseed=cseed,
+                temperature=temperature, gamma=gamma, style=style, pos=pos, seed=seed, bseed=bseed, cseed=cseed,
                 logit_scale=logit_scale, image=image, regular_only=regular_only, prompt="Image of a",
                 order_list=orders_logged[0] if orders_logged else None,
                 positions=[int(s["gen_idx"]) - seed_len for s in steps],
@@ -315,6 +347,8 @@ CASES = dict(
     tiny_random=dict(tiny=True, B=2, L=4, K=8, I=2, order="random"),
     tiny_senti_seq=dict(tiny=True, B=2, L=5, K=12, I=2, order="sequential", gamma=5.0, style="positive"),
     tiny_senti_shuffle=dict(tiny=True, B=2, L=5, K=12, I=2, order="shuffle", gamma=5.0, style="negative"),
+    tiny_pos_seq=dict(tiny=True, B=2, L=5, K=12, I=2, order="sequential", gamma=5.0,
+                      pos=[["DET"], ["ADJ", "NOUN"], "", ["NOUN"], ["VERB"], ["ADV"], ["ADP"], ["DET", "NOUN"], ["NOUN", "."]]),
     tiny_scale100=dict(tiny=True, B=2, L=4, K=12, I=2, order="sequential", logit_scale=4.6052),
     full_cfg1=dict(tiny=False, B=1, L=10, K=200, I=10, order="sequential", image="examples/girl.jpg",
                    keep_step_tensors=20),

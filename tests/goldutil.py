@@ -31,7 +31,7 @@ def case_assets(meta):
     bw = synth.make_bert_weights(bcfg, meta["bseed"])
     cw = synth.make_clip_weights(ccfg, meta["cseed"])
     mask = synth.make_token_mask(sv, regular_only=meta["regular_only"])
-    lex = synth.make_lexicon(len(sv.bert_tokens)) if meta["gamma"] is not None else None
+    lex = synth.make_lexicon(len(sv.bert_tokens)) if (meta["gamma"] is not None and not meta.get("pos")) else None
     return sv, bcfg, ccfg, bw, cw, mask, lex
 
 
@@ -40,5 +40,6 @@ def make_oracle(meta):
     from oracle import models as M, step as S, text as T
     sv, bcfg, ccfg, bw, cw, mask, lex = case_assets(meta)
     o = S.Oracle(M.to_torch(bw), bcfg, M.to_torch(cw), ccfg, sv.bert_tokens,
-                 T.ClipBpe(sv.clip_vocab, sv.clip_merges), lexicon=lex)
+                 T.ClipBpe(sv.clip_vocab, sv.clip_merges), lexicon=lex,
+                 pos_tags=synth.make_pos_tags(len(sv.bert_tokens)) if meta.get("pos") else None)
     return o, sv, torch.from_numpy(mask.copy())

@@ -27,7 +27,9 @@ def _objects(meta):
     bt, ct = tokenizers_from_vocab(sv)
     lm = SyntheticLM(bcfg, meta["bseed"])
     clip = CLIP.from_state(ccfg, synth.make_clip_weights(ccfg, meta["cseed"]), ct)
-    if meta["gamma"] is not None:
+    if meta.get("pos"):
+        clip.pos_tags = synth.make_pos_tags(len(sv.bert_tokens))
+    elif meta["gamma"] is not None:
         clip.lexicon = synth.make_lexicon(len(sv.bert_tokens))
     from PIL import Image
     imgs = [Image.fromarray(u) for u in synth.make_images_u8(meta["B"], ccfg.v_image)]
@@ -36,7 +38,7 @@ def _objects(meta):
 
 
 @pytest.mark.parametrize("name", ["tiny_seq", "tiny_shuffle", "tiny_span", "tiny_random", "tiny_senti_seq",
-                                  "tiny_senti_shuffle"])
+                                  "tiny_senti_shuffle", "tiny_pos_seq"])
 def test_generate_caption_dropin_matches_reference(name):
     import utils
     from control_gen_utils import control_generate_caption
@@ -51,6 +53,9 @@ def test_generate_caption_dropin_matches_reference(name):
               generate_order=meta["order"])
     if meta["gamma"] is None:
         texts, scores = generate_caption(names, lm, clip, tok, imgs, mask, logger, **kw)
+    elif meta.get("pos"):
+        texts, scores = control_generate_caption(names, lm, clip, tok, imgs, mask, logger, gamma=meta["gamma"],
+                                                 ctl_type="pos", pos_type=meta["pos"], **kw)
     else:
         texts, scores = control_generate_caption(names, lm, clip, tok, imgs, mask, logger, gamma=meta["gamma"],
                                                  ctl_type="sentiment", style_type=meta["style"], **kw)

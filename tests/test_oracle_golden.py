@@ -14,7 +14,7 @@ from oracle import step as S
 from oracle import text as T
 
 TINY_CASES = ["tiny_seq", "tiny_shuffle", "tiny_span", "tiny_random", "tiny_senti_seq", "tiny_senti_shuffle",
-              "tiny_scale100"]
+              "tiny_scale100", "tiny_pos_seq"]
 
 
 def _run_oracle(meta, arr):
@@ -28,7 +28,7 @@ def _run_oracle(meta, arr):
         kw["random_positions"] = meta["positions"]
     texts, scores, ids = S.generate(o, pix, mask, meta["prompt"], meta["L"], meta["K"], meta["temperature"],
                                     meta["alpha"], meta["beta"], meta["I"], order=meta["order"], gamma=meta["gamma"],
-                                    ctl_signal=meta["style"], trace=trace, **kw)
+                                    ctl_signal=meta["style"], trace=trace, pos_template=meta.get("pos"), **kw)
     return o, texts, scores, ids, trace
 
 

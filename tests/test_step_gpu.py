@@ -26,13 +26,16 @@ _setups = {}
 
 def setup_for(meta, prec):
     key = (meta["tiny"], prec, meta["bseed"], meta["cseed"], round(meta["logit_scale"], 4), meta["regular_only"],
-           meta["gamma"] is not None)
+           meta["gamma"] is not None, bool(meta.get("pos")))
     if key not in _setups:
         if len(_setups) >= 3:  # bound device memory: drop the oldest engines
             k0 = next(iter(_setups))
             _setups.pop(k0).engine.close()
         _setups[key] = harness.build_synthetic(meta["tiny"], prec, meta["bseed"], meta["cseed"], meta["logit_scale"],
                                                meta["regular_only"], lexicon=meta["gamma"] is not None)
+        if meta.get("pos"):
+            _setups[key].engine.set_pos(synth.make_pos_tags(len(_setups[key].sv.bert_tokens)),
+                                        synth.pos_template_masks(meta["pos"]))
     return _setups[key]
 
 
@@ -42,7 +45,22 @@ def gold_final(meta, arr, i, su):
     probs = torch.from_numpy(arr["probs"][i])
     cs = torch.from_numpy(arr["clip_score"][i])
     fin = meta["alpha"] * probs + meta["beta"] * cs
-    if meta["gamma"] is not None:
+    if meta.get("pos"):
+        from oracle import step as S
+        from goldutil import make_oracle
+        o, _, _ = make_oracle(meta)
+        B, K = probs.shape
+        gen_idx = SEED_LEN + meta["positions"][i]
+        inp = torch.from_numpy(arr["inp_before"][i].astype(np.int64))
+        mask = torch.from_numpy(su.token_mask.copy())
+        mask[0, su.bert_tok.vocab["."]] = 1.0 if meta["positions"][i] == meta["L"] - 1 else 0.0
+        idxs = torch.from_numpy(arr["idxs"][i].astype(np.int64))
+        idxs_ = (idxs * mask[0][idxs]).long()
+        rows = inp.unsqueeze(1).repeat(1, K, 1)
+        rows[:, :, gen_idx] = idxs_
+        praw = S.pos_scores(o, rows.view(B * K, -1), meta["pos"]).view(B, K)
+        fin = fin + meta["gamma"] * torch.softmax(praw / 0.1, dim=-1)
+    elif meta["gamma"] is not None:
         B, K = probs.shape
         gen_idx = SEED_LEN + meta["positions"][i]
         inp = torch.from_numpy(arr["inp_before"][i].astype(np.int64))
@@ -114,7 +132,8 @@ def teacher_forced(meta, arr, prec, n_steps=None):
     su = setup_for(meta, prec)
     eng = su.engine
     eng.set_image_embeds(arr["image_embeds"])
-    hp = Engine.hyper(meta["alpha"], meta["beta"], meta["temperature"], meta["gamma"], meta["style"] == "negative")
+    hp = Engine.hyper(meta["alpha"], meta["beta"], meta["temperature"], meta["gamma"], meta["style"] == "negative",
+                      control="pos" if meta.get("pos") else None)
     n = arr["probs"].shape[0] if n_steps is None else min(n_steps, arr["probs"].shape[0])
     soft = 0
     prev_inp = None
@@ -151,7 +170,8 @@ def teacher_forced(meta, arr, prec, n_steps=None):
     return soft, n
 
 
-TINY = ["tiny_seq", "tiny_shuffle", "tiny_span", "tiny_random", "tiny_senti_seq", "tiny_senti_shuffle", "tiny_scale100"]
+TINY = ["tiny_seq", "tiny_shuffle", "tiny_span", "tiny_random", "tiny_senti_seq", "tiny_senti_shuffle", "tiny_scale100",
+        "tiny_pos_seq"]
 
 
 @pytest.mark.parametrize("name", TINY)
@@ -190,7 +210,8 @@ def test_generate_free_running_tiny_f32(name):
     su = setup_for(meta, F32)
     eng = su.engine
     eng.set_image_embeds(arr["image_embeds"])
-    hp = Engine.hyper(meta["alpha"], meta["beta"], meta["temperature"], meta["gamma"], meta["style"] == "negative")
+    hp = Engine.hyper(meta["alpha"], meta["beta"], meta["temperature"], meta["gamma"], meta["style"] == "negative",
+                      control="pos" if meta.get("pos") else None)
     init = su.bert_tok.encode(meta["prompt"] + su.bert_tok.mask_token * meta["L"])
     pos, nm, every = harness.order_positions(meta["order"], meta["L"], meta["I"], order_list=meta["order_list"],
                                              random_positions=meta["positions"])
