@@ -345,3 +345,75 @@ def test_last_layer_pooling_is_exact(prec):
     eng.set_option("pool_last_layer", 1)
     np.testing.assert_allclose(outs[0]["clip_ref"], outs[1]["clip_ref"], atol=1e-6 if prec == F32 else 1e-5)
     np.testing.assert_allclose(outs[0]["final_score"], outs[1]["final_score"], atol=1e-6 if prec == F32 else 1e-5)
+
+
+@pytest.mark.parametrize("prec", [F32, BF16])
+def test_long_ragged_sequences_vs_oracle(prec):
+    """Edge cases in one step, checked against the oracle computed on the fly: a long caption (L=11)
+    whose words are multi-token 'irregular' words, so CLIP sequences are long and ragged, some hit
+    the 77-token truncation (clip/clip.py:71-72), and the branches are too long for the packed
+    attention kernel (generic segment path).  Also K > number of unmasked tokens -> [PAD] candidates."""
+    from oracle import models as M, step as S, text as T
+    meta = dict(tiny=True, bseed=11, cseed=12, logit_scale=2.6592, regular_only=False, gamma=None)
+    su = harness.build_synthetic(True, prec)
+    try:
+        sv = su.sv
+        V = len(sv.bert_tokens)
+        # only multi-token words, digits and pieces stay allowed; leaves fewer than K usable ids
+        mask = np.zeros((1, V), np.float32)
+        irregular = [i for i, t in enumerate(sv.bert_tokens) if t.isalpha() and len(t) >= 6 and i < sv.regular_lo]
+        mask[0, irregular[:20]] = 1.0
+        su.engine.set_token_mask(mask)
+        o = S.Oracle(M.to_torch(synth.make_bert_weights(su.bert_cfg, 11)), su.bert_cfg,
+                     M.to_torch(synth.make_clip_weights(su.clip_cfg, 12)), su.clip_cfg, sv.bert_tokens,
+                     T.ClipBpe(sv.clip_vocab, sv.clip_merges))
+        B, L, K = 2, 11, 32
+        rng = np.random.default_rng(3)
+        inp = np.array(o.init_text("Image of a", L, B), dtype=np.int32)
+        inp[:, 4:4 + L] = rng.choice(irregular, size=(B, L))
+        gen_idx = 4 + 3
+        inp[:, gen_idx] = su.bert_tok.mask_token_id
+        emb = rng.standard_normal((B, su.clip_cfg.proj)).astype(np.float32)
+        su.engine.set_image_embeds(emb)
+        tmask = torch.from_numpy(mask.copy())
+        ref_inp = torch.from_numpy(inp.astype(np.int64))
+        r = S.polish_step(o, ref_inp, torch.from_numpy(emb), tmask, gen_idx, K, 0.1, 0.02, 2.0)
+        res = su.engine.step(inp, gen_idx, K, Engine.hyper(0.02, 2.0, 0.1))
+        lens = r["clip_lens"].numpy()
+        assert lens.max() == 77 and lens.min() < 77, (lens.min(), lens.max())  # truncation really happens
+        np.testing.assert_array_equal(res["idxs"][:, :20], r["idxs"].numpy()[:, :20])
+        assert (res["cand_ids"][:, 20:] == 0).all() and (r["idxs_"].numpy()[:, 20:] == 0).all()  # masked -> [PAD]
+        np.testing.assert_array_equal(res["clip_len"], lens)
+        for row in range(B * K):
+            np.testing.assert_array_equal(res["clip_ids"][row, :lens[row]], r["clip_ids"][row, :lens[row]].numpy())
+        tol = 3e-5 if prec == F32 else 6e-3
+        np.testing.assert_allclose(res["clip_ref"][:, :20], r["clip_ref"].numpy()[:, :20], atol=tol)
+        if prec == F32:
+            np.testing.assert_allclose(res["final_score"], r["final"].numpy(), atol=3e-5)
+            np.testing.assert_array_equal(res["best"], r["best"].numpy())
+    finally:
+        su.engine.close()
+
+
+def test_minimal_shapes_k1_l1():
+    """K=1 / L=1 / B=1 degenerate shapes run and agree with the oracle."""
+    from oracle import models as M, step as S, text as T
+    su = harness.build_synthetic(True, F32)
+    try:
+        sv = su.sv
+        o = S.Oracle(M.to_torch(synth.make_bert_weights(su.bert_cfg, 11)), su.bert_cfg,
+                     M.to_torch(synth.make_clip_weights(su.clip_cfg, 12)), su.clip_cfg, sv.bert_tokens,
+                     T.ClipBpe(sv.clip_vocab, sv.clip_merges))
+        inp = np.array(o.init_text("Image of a", 1, 1), dtype=np.int32)
+        emb = np.random.default_rng(0).standard_normal((1, su.clip_cfg.proj)).astype(np.float32)
+        su.engine.set_image_embeds(emb)
+        tmask = torch.from_numpy(su.token_mask.copy())
+        o.update_token_mask(tmask, 1, 0)
+        r = S.polish_step(o, torch.from_numpy(inp.astype(np.int64)), torch.from_numpy(emb), tmask, 4, 1, 0.1, 0.02, 2.0)
+        res = su.engine.step(inp, 4, 1, Engine.hyper(0.02, 2.0, 0.1), dot_allowed=True)
+        np.testing.assert_array_equal(res["idxs"], r["idxs"].numpy())
+        np.testing.assert_allclose(res["final_score"], r["final"].numpy(), atol=2e-5)
+        assert abs(float(res["clip_score"][0, 0]) - 1.0) < 1e-6  # softmax over a single candidate
+        assert inp[0, 4] == int(r["inp_after"][0, 4])
+    finally:
+        su.engine.close()
