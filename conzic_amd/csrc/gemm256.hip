@@ -210,6 +210,26 @@ __device__ __forceinline__ void tile_of(int t, int tiles_m, int tiles_n, int& tm
   tn = lin - tm * tiles_n;
 }
 
+// Visit order of a persistent work-group.  Default ("legacy"): virtual tiles wg, wg+grid, ... through
+// the XCD-aware map, i.e. the N tiles of an M tile run CONCURRENTLY on neighbouring CUs of one XCD.
+// Alternative (debug bit5): one work-group walks all N tiles of an M tile back to back (A from HBM
+// once, then L2) -- measured 9 % slower (0.684 vs 0.621 ms on the qkv shape), kept for A/B runs.
+__device__ __forceinline__ int tile_count(int tiles_m, int tiles_n, bool legacy) {
+  const int grid = gridDim.x, wg = blockIdx.x;
+  if (legacy) {
+    const int nt = tiles_m * tiles_n;
+    return wg < nt ? (nt - 1 - wg) / grid + 1 : 0;
+  }
+  return wg < tiles_m ? ((tiles_m - 1 - wg) / grid + 1) * tiles_n : 0;
+}
+__device__ __forceinline__ void tile_at(int i, int tiles_m, int tiles_n, bool legacy, int& tm, int& tn) {
+  const int grid = gridDim.x, wg = blockIdx.x;
+  if (legacy) { tile_of(wg + i * grid, tiles_m, tiles_n, tm, tn); return; }
+  const int round = i / tiles_n;
+  tn = i - round * tiles_n;
+  tm = wg + round * grid;
+}
+
 template <int ACT, bool OUT_F32>
 __global__ __launch_bounds__(768) void gemm256p_kernel(GemmArgs g, int tiles_m, int tiles_n, int g_krot_enable) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -217,7 +237,6 @@ __global__ __launch_bounds__(768) void gemm256p_kernel(GemmArgs g, int tiles_m, 
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nk = g.K >> 6;
-  const int ntiles = tiles_m * tiles_n;
   const int lda_b = g.lda * 2, ldw_b = g.ldw * 2;
 
   if (wave >= 8) {
@@ -236,9 +255,11 @@ __global__ __launch_bounds__(768) void gemm256p_kernel(GemmArgs g, int tiles_m, 
     bool first = true;
     const int krot = (g_krot_enable & 1) ? (int)((blockIdx.x >> 3) % (unsigned)nk) : 0;
     const bool dbg_no_dma = g_krot_enable & 4;
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const bool legacy = (g_krot_enable & 32) == 0;  // bit5 selects the (slower, measured) M-major walk
+    const int my_tiles = tile_count(tiles_m, tiles_n, legacy);
+    for (int ti = 0; ti < my_tiles; ++ti) {
       int tm, tn;
-      tile_of(t, tiles_m, tiles_n, tm, tn);
+      tile_at(ti, tiles_m, tiles_n, legacy, tm, tn);
       const int m0 = tm * TM, n0 = tn * TN;
       const unsigned long long pa = (unsigned long long)g.A + (unsigned long long)m0 * lda_b;
       const unsigned long long pw = (unsigned long long)g.W + (unsigned long long)n0 * ldw_b;
@@ -247,6 +268,8 @@ __global__ __launch_bounds__(768) void gemm256p_kernel(GemmArgs g, int tiles_m, 
       rsA.z = (unsigned)(min(TM, g.M - m0) * lda_b); rsA.w = 0x00020000u;
       rsW.x = (unsigned)pw; rsW.y = (unsigned)(pw >> 32) & 0xffffu;
       rsW.z = (unsigned)(min(TN, g.N - n0) * ldw_b); rsW.w = 0x00020000u;
+      if (g_krot_enable & 8) rsA.z = 0;   // debug: out-of-range descriptor -> zeros, no A traffic
+      if (g_krot_enable & 16) rsW.z = 0;  // debug: no W traffic
       for (int kt = 0; kt < nk; ++kt, ++step) {
         if (!first) {
           // previous step's DMA has landed -> publish it; the same barrier proves the stage this
@@ -310,9 +333,11 @@ __global__ __launch_bounds__(768) void gemm256p_kernel(GemmArgs g, int tiles_m, 
   const int brow = wn * 64 + (lane & 31);
   bf16_t* oa = (bf16_t*)g.out_act;
   unsigned step = 0;
-  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+  const bool legacy = (g_krot_enable & 32) == 0;  // bit5 selects the (slower, measured) M-major walk
+  const int my_tiles = tile_count(tiles_m, tiles_n, legacy);
+  for (int ti = 0; ti < my_tiles; ++ti) {
     int tm, tn;
-    tile_of(t, tiles_m, tiles_n, tm, tn);
+    tile_at(ti, tiles_m, tiles_n, legacy, tm, tn);
     const int m0 = tm * TM, n0 = tn * TN;
     f32x16_t acc[4][2];
 #pragma unroll
@@ -455,7 +480,7 @@ int launch_gemm256(const GemmArgs& g, hipStream_t st) {
 #undef CZC_ATTR
     }
     const int tiles_m = cdiv(g.M, TM), tiles_n = cdiv(g.N, TN);
-    const int nt = tiles_m * tiles_n;
+    const int nt = (g_gemm_krot & 32) ? tiles_m : tiles_m * tiles_n;  // work units: tiles, or M tiles for the M-major walk
     dim3 grid(nt < n_cu ? nt : n_cu), block(768);
     const bool f32 = g.out_f32 != nullptr || g.resid != nullptr;
 #define CZC_GO(A_, F_) hipLaunchKernelGGL((gemm256p_kernel<A_, F_>), grid, block, shp, st, g, tiles_m, tiles_n, g_gemm_krot)

@@ -108,3 +108,21 @@ def test_weight_generator_is_order_independent_and_tied():
     assert a["cls.predictions.decoder.weight"] is a["bert.embeddings.word_embeddings.weight"]
     c = synth.make_bert_weights(cfg, 12)
     assert not np.array_equal(a["cls.predictions.bias"], c["cls.predictions.bias"])
+
+
+def test_run_cli_batching_and_result_layout(tmp_path, monkeypatch):
+    """run.py semantics: listdir order, drop_last batching, iter_k.json / best_clipscore.json layout."""
+    import json
+    from conzic_amd import run_cli
+    assert list(run_cli.batches(["a", "b", "c", "d", "e"], 2)) == [["a", "b"], ["c", "d"]]
+    res = [None] * 3
+    res = run_cli.merge_results(res, [["t0a", "t0b"], ["t1a", "t1b"], ["best_a", "best_b"]], ["a", "b"])
+    res = run_cli.merge_results(res, [["t0c", "t0d"], ["t1c", "t1d"], ["best_c", "best_d"]], ["c", "d"])
+    monkeypatch.chdir(tmp_path)
+    args = run_cli.get_args(["--run_type", "caption", "--order", "sequential"])
+    d = run_cli.result_dir(args, "caption", 0)
+    assert d == "results/caption_sequential_len10_topk200_alpha0.020_beta2.000_gamma5.000_lmTemp0.100/sample_0"
+    run_cli.write_results(d, res)
+    assert sorted(os.listdir(d)) == ["best_clipscore.json", "iter_0.json", "iter_1.json"]
+    assert json.load(open(os.path.join(d, "iter_1.json"))) == {"a": "t1a", "b": "t1b", "c": "t1c", "d": "t1d"}
+    assert json.load(open(os.path.join(d, "best_clipscore.json")))["d"] == "best_d"
