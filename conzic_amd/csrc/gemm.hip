@@ -253,7 +253,7 @@ static void launch_t(const GemmArgs& g, int tiles_m, int tiles_n, bool vec, hipS
 #undef CZC_GEMM_LAUNCH
 }
 
-int g_use_gemm256 = 2;  // 0: 128x128 only, 1: gemm256, 2: persistent wave-specialised gemm256p (czc_test_set_option)
+int g_use_gemm256 = 3;  // 0: 128x128 only, 1: gemm256, 2: persistent wave-specialised gemm256p, 3: + 4-stage K ring (gemm256q)
 
 int launch_gemm(int prec, const GemmArgs& g, hipStream_t st) {
   if (g.M <= 0) return 0;

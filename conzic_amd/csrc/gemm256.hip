@@ -210,6 +210,90 @@ __device__ __forceinline__ void tile_of(int t, int tiles_m, int tiles_n, int& tm
   tn = lin - tm * tiles_n;
 }
 
+// Accumulators leave through a wave-private 4 KiB LDS patch that turns the MFMA layout (lane = one
+// row, 4 columns per quad -> 8-byte pieces scattered over 32 rows) into row-major 16-byte pieces:
+// 8 lanes cover one 128-byte line, so every global store / residual load is a full cache line
+// instead of 64 partial ones.
+template <int ACT, bool OUT_F32>
+__device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x16_t (&acc)[4][2], unsigned char* patch, int m0,
+                                              int n0, int wm, int wn, int lane) {
+  const int half = lane >> 5;
+  bf16_t* oa = (bf16_t*)g.out_act;
+    const int l31 = lane & 31;
+    const int rrow = lane >> 3, rslot = lane & 7;  // read side: 8 rows x 8 sixteen-byte slots per pass
+    if (!OUT_F32) {
+      // bf16 output: 32 rows x 64 columns per pass (128-byte rows), 8-byte slots XOR (row & 15)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int cl = j * 32 + 8 * q + 4 * half;  // column inside the wave's 64
+            float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+            if (g.bias) {
+              const int col = min(n0 + wn * 64 + cl, g.N - 4);
+              const float4 b4 = *(const float4*)(g.bias + col);
+              v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+            }
+            v.x = act_fn<ACT>(v.x); v.y = act_fn<ACT>(v.y); v.z = act_fn<ACT>(v.z); v.w = act_fn<ACT>(v.w);
+            const int slot = (cl >> 2) ^ (l31 & 15);
+            *(uint2*)(patch + l31 * 128 + slot * 8) = make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w));
+          }
+        }
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+          const int r = pass * 8 + rrow;
+          const int x = r & 15;
+          // logical 8-byte slots 2*rslot, 2*rslot+1 live in the physical pair ((2*rslot)^x)>>1, swapped if x&1
+          uint4 d = *(const uint4*)(patch + r * 128 + ((((2 * rslot) ^ x) >> 1) << 4));
+          if (x & 1) d = make_uint4(d.z, d.w, d.x, d.y);
+          const int row = m0 + wm * 128 + i * 32 + r;
+          const int col = n0 + wn * 64 + rslot * 8;
+          if (row < g.M && col < g.N) *(uint4*)(oa + (long)row * g.ldc + col) = d;
+        }
+      }
+    } else {
+      // fp32 output (+bias, +fp32 residual, optional bf16 copy): 32 rows x 32 columns per pass
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int col = n0 + wn * 64 + j * 32 + rslot * 4;
+          float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (g.bias && col < g.N) b4 = *(const float4*)(g.bias + col);
+          // residual rows first: four independent 16-byte loads in flight across the LDS round trip
+          float4 r4[4];
+#pragma unroll
+          for (int pass = 0; pass < 4; ++pass) {
+            const int row = m0 + wm * 128 + i * 32 + pass * 8 + rrow;
+            r4[pass] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (g.resid && row < g.M && col < g.N) r4[pass] = *(const float4*)(g.resid + (long)row * g.ldr + col);
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int slot = (2 * q + half) ^ (l31 & 7);
+            *(float4*)(patch + l31 * 128 + slot * 16) =
+                make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+          }
+#pragma unroll
+          for (int pass = 0; pass < 4; ++pass) {
+            const int r = pass * 8 + rrow;
+            float4 v = *(const float4*)(patch + r * 128 + ((rslot ^ (r & 7)) << 4));
+            const int row = m0 + wm * 128 + i * 32 + r;
+            if (row < g.M && col < g.N) {
+              v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+              v.x = act_fn<ACT>(v.x); v.y = act_fn<ACT>(v.y); v.z = act_fn<ACT>(v.z); v.w = act_fn<ACT>(v.w);
+              v.x += r4[pass].x; v.y += r4[pass].y; v.z += r4[pass].z; v.w += r4[pass].w;
+              if (g.out_f32) *(float4*)(g.out_f32 + (long)row * g.ldc + col) = v;
+              if (oa) *(uint2*)(oa + (long)row * g.ldc + col) = make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w));
+            }
+          }
+        }
+      }
+    }
+}
+
 // Visit order of a persistent work-group.  Default ("legacy"): virtual tiles wg, wg+grid, ... through
 // the XCD-aware map, i.e. the N tiles of an M tile run CONCURRENTLY on neighbouring CUs of one XCD.
 // Alternative (debug bit5): one work-group walks all N tiles of an M tile back to back (A from HBM
@@ -368,85 +452,156 @@ __global__ __launch_bounds__(768) void gemm256p_kernel(GemmArgs g, int tiles_m, 
                                                                 __builtin_bit_cast(bf16x8_t, a[i]), acc[i][j], 0, 0, 0);
       }
     }
-    // epilogue (no barrier inside: the loaders are already fetching the next tile's first K step).
-    // Accumulators leave through a wave-private 4 KiB LDS patch (the 32 KiB above the two stages)
-    // that turns the MFMA layout (lane = one row, 4 columns per quad -> 8-byte pieces scattered over
-    // 32 rows) into row-major 16-byte pieces: 8 lanes cover one 128-byte line, so every global
-    // store / residual load is a full cache line instead of 64 partial ones.
-    unsigned char* patch = smem + 2 * STAGE + wave * 4096;
-    const int l31 = lane & 31;
-    const int rrow = lane >> 3, rslot = lane & 7;  // read side: 8 rows x 8 sixteen-byte slots per pass
-    if (!OUT_F32) {
-      // bf16 output: 32 rows x 64 columns per pass (128-byte rows), 8-byte slots XOR (row & 15)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int cl = j * 32 + 8 * q + 4 * half;  // column inside the wave's 64
-            float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
-            if (g.bias) {
-              const int col = min(n0 + wn * 64 + cl, g.N - 4);
-              const float4 b4 = *(const float4*)(g.bias + col);
-              v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
-            }
-            v.x = act_fn<ACT>(v.x); v.y = act_fn<ACT>(v.y); v.z = act_fn<ACT>(v.z); v.w = act_fn<ACT>(v.w);
-            const int slot = (cl >> 2) ^ (l31 & 15);
-            *(uint2*)(patch + l31 * 128 + slot * 8) = make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w));
-          }
-        }
-#pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
-          const int r = pass * 8 + rrow;
-          const int x = r & 15;
-          // logical 8-byte slots 2*rslot, 2*rslot+1 live in the physical pair ((2*rslot)^x)>>1, swapped if x&1
-          uint4 d = *(const uint4*)(patch + r * 128 + ((((2 * rslot) ^ x) >> 1) << 4));
-          if (x & 1) d = make_uint4(d.z, d.w, d.x, d.y);
-          const int row = m0 + wm * 128 + i * 32 + r;
-          const int col = n0 + wn * 64 + rslot * 8;
-          if (row < g.M && col < g.N) *(uint4*)(oa + (long)row * g.ldc + col) = d;
-        }
+    // epilogue (no barrier inside: the loaders are already fetching the next tile's first K step)
+    tile_epilogue<ACT, OUT_F32>(g, acc, smem + 2 * STAGE + wave * 4096, m0, n0, wm, wn, lane);
+  }
+}
+
+// ================================================================================================
+// gemm256q: gemm256p with a 4-deep ring of 32-wide K steps (4 x 32 KiB stages) instead of two
+// 64-wide stages.  The loaders run up to three steps ahead and wait with a COUNTED vmcnt, so a
+// step costs max(DMA issue, DMA latency, MFMA) instead of issue + latency: in gemm256p the 16 DMA
+// issues of a step (~1000 cycles) and the landing of the last one are serialised in front of every
+// barrier.
+//   LDS rows are 64 bytes (32 bf16): 16-byte chunk c of row r sits at chunk c ^ ((r>>2)&3)
+//   (16 distinct rows of a ds_read_b128 lane group -> 16 distinct slots of the 256-byte bank row);
+//   one DMA instruction lands 16 rows.
+// ================================================================================================
+constexpr int QROWB = 64;                      // bytes per tile row per K step (32 bf16)
+constexpr int QA_BYTES = TM * QROWB;           // 16 KiB
+constexpr int QSTAGE = QA_BYTES + TN * QROWB;  // 32 KiB
+constexpr int QS = 4;                          // ring depth
+
+__device__ __forceinline__ int swzq(int row, int chunk) { return row * QROWB + ((chunk ^ ((row >> 2) & 3)) << 4); }
+
+template <int ACT, bool OUT_F32>
+__global__ __launch_bounds__(768) void gemm256q_kernel(GemmArgs g, int tiles_m, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nk = g.K >> 5;  // 32-wide K steps
+  const int lda_b = g.lda * 2, ldw_b = g.ldw * 2;
+  const int my_tiles = tile_count(tiles_m, tiles_n, true);
+  const int total = my_tiles * nk;
+
+  if (wave >= 8) {
+    // ------------------------------- loader waves -------------------------------------------
+    const int lw = wave - 8;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(
+        (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem);
+    // instruction ii (0..3) lands tile rows lw*64 + ii*16 + (lane>>2); physical chunk lane&3
+    const int rbase = lw * 64 + (lane >> 2);
+    const int cq = ((lane & 3) ^ ((lane >> 4) & 3)) << 4;
+    const int a0 = rbase * lda_b + cq, w0 = rbase * ldw_b + cq;
+    const int a16 = 16 * lda_b, w16 = 16 * ldw_b;
+    int cur_ti = -1;
+    u32x4_t rsA, rsW;
+    rsA.x = rsA.y = rsA.z = 0; rsA.w = 0x00020000u;
+    rsW = rsA;
+    auto issue = [&](int s) {
+      const int ti = s / nk, kt = s - ti * nk;
+      if (ti != cur_ti) {
+        cur_ti = ti;
+        int tm, tn;
+        tile_at(ti, tiles_m, tiles_n, true, tm, tn);
+        const int m0 = tm * TM, n0 = tn * TN;
+        const unsigned long long pa = (unsigned long long)g.A + (unsigned long long)m0 * lda_b;
+        const unsigned long long pw = (unsigned long long)g.W + (unsigned long long)n0 * ldw_b;
+        rsA.x = (unsigned)pa; rsA.y = (unsigned)(pa >> 32) & 0xffffu; rsA.z = (unsigned)(min(TM, g.M - m0) * lda_b);
+        rsW.x = (unsigned)pw; rsW.y = (unsigned)(pw >> 32) & 0xffffu; rsW.z = (unsigned)(min(TN, g.N - n0) * ldw_b);
       }
-    } else {
-      // fp32 output (+bias, +fp32 residual, optional bf16 copy): 32 rows x 32 columns per pass
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int col = n0 + wn * 64 + j * 32 + rslot * 4;
-          float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (g.bias && col < g.N) b4 = *(const float4*)(g.bias + col);
-          // residual rows first: four independent 16-byte loads in flight across the LDS round trip
-          float4 r4[4];
-#pragma unroll
-          for (int pass = 0; pass < 4; ++pass) {
-            const int row = m0 + wm * 128 + i * 32 + pass * 8 + rrow;
-            r4[pass] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (g.resid && row < g.M && col < g.N) r4[pass] = *(const float4*)(g.resid + (long)row * g.ldr + col);
-          }
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int slot = (2 * q + half) ^ (l31 & 7);
-            *(float4*)(patch + l31 * 128 + slot * 16) =
-                make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
-          }
-#pragma unroll
-          for (int pass = 0; pass < 4; ++pass) {
-            const int r = pass * 8 + rrow;
-            float4 v = *(const float4*)(patch + r * 128 + ((rslot ^ (r & 7)) << 4));
-            const int row = m0 + wm * 128 + i * 32 + r;
-            if (row < g.M && col < g.N) {
-              v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
-              v.x = act_fn<ACT>(v.x); v.y = act_fn<ACT>(v.y); v.z = act_fn<ACT>(v.z); v.w = act_fn<ACT>(v.w);
-              v.x += r4[pass].x; v.y += r4[pass].y; v.z += r4[pass].z; v.w += r4[pass].w;
-              if (g.out_f32) *(float4*)(g.out_f32 + (long)row * g.ldc + col) = v;
-              if (oa) *(uint2*)(oa + (long)row * g.ldc + col) = make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w));
-            }
-          }
-        }
-      }
+      const unsigned dstA = lds0 + (s & (QS - 1)) * QSTAGE + lw * (64 * QROWB);
+      const unsigned dstW = dstA + QA_BYTES;
+      const unsigned so = kt * QROWB;
+      unsigned keep;
+      asm volatile(
+          "s_mov_b32 %0, m0\n\t"
+          "s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %11, %13 offen lds\n\t"
+          "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %11, %13 offen lds\n\t"
+          "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %5, %11, %13 offen lds\n\t"
+          "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %6, %11, %13 offen lds\n\t"
+          "s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %7, %12, %13 offen lds\n\t"
+          "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %8, %12, %13 offen lds\n\t"
+          "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %9, %12, %13 offen lds\n\t"
+          "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %10, %12, %13 offen lds\n\t"
+          "s_mov_b32 m0, %0"
+          : "=&s"(keep)
+          : "s"(dstA), "s"(dstW), "v"(a0), "v"(a0 + a16), "v"(a0 + 2 * a16), "v"(a0 + 3 * a16), "v"(w0), "v"(w0 + w16),
+            "v"(w0 + 2 * w16), "v"(w0 + 3 * w16), "s"(rsA), "s"(rsW), "s"(so)
+          : "memory", "scc");
+    };
+    const int pro = total < QS ? total : QS;
+    for (int s = 0; s < pro; ++s) issue(s);
+    for (int s = 0; s < total; ++s) {
+      // steps issued so far: 0 .. min(total, QS + max(s-1,0)) - 1; wait until step s has landed, i.e.
+      // at most (issued - 1 - s) later steps (8 DMAs each) may still be in flight
+      const int issued = (s == 0) ? pro : (QS + s - 1 < total ? QS + s - 1 : total);
+      const int later = issued - 1 - s;
+      if (later >= 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+      else if (later == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else if (later == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // publishes step s; proves stage (s-1)%QS has been left
+      if (s >= 1 && s - 1 + QS < total) issue(s - 1 + QS);
     }
+    return;
+  }
+
+  // --------------------------------- MFMA waves ---------------------------------------------
+  const int wm = wave >> 2, wn = wave & 3;
+  const int half = lane >> 5;
+  const int arow = wm * 128 + (lane & 31);
+  const int brow = wn * 64 + (lane & 31);
+  int step = 0;
+  for (int ti = 0; ti < my_tiles; ++ti) {
+    int tm, tn;
+    tile_at(ti, tiles_m, tiles_n, true, tm, tn);
+    const int m0 = tm * TM, n0 = tn * TN;
+    f32x16_t acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int kt = 0; kt < nk; ++kt, ++step) {
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const unsigned char* sA = smem + (step & (QS - 1)) * QSTAGE;
+      const unsigned char* sB = sA + QA_BYTES;
+      // Fragment stream written in software-pipelined order (weights b0,b1 / c0,c1 held, activation
+      // fragments through a two-deep ring).  hipcc re-serialises it to one activation quad + lgkmcnt(0)
+      // per MFMA pair because the kernel sits at the 168-VGPR cap of a 12-wave work-group; pinning the
+      // order with sched_group_barrier produced the intended stream but 19 spills and no net gain
+      // (measured 656 vs 658 TF/s over the four layer shapes), so the order is left to the compiler.
+#define CZC_RA(ks_, i_) (*(const uint4*)(sA + swzq(arow + 32 * (i_), 2 * (ks_) + half)))
+#define CZC_RB(ks_, j_) (*(const uint4*)(sB + swzq(brow + 32 * (j_), 2 * (ks_) + half)))
+#define CZC_MM(b_, a_, i_, j_)                                                                                  \
+  acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, b_), __builtin_bit_cast(bf16x8_t, a_), \
+                                                        acc[i_][j_], 0, 0, 0)
+      uint4 b0 = CZC_RB(0, 0), b1 = CZC_RB(0, 1), a0 = CZC_RA(0, 0), a1;
+      a1 = CZC_RA(0, 1);
+      CZC_MM(b0, a0, 0, 0); CZC_MM(b1, a0, 0, 1);
+      a0 = CZC_RA(0, 2);
+      CZC_MM(b0, a1, 1, 0); CZC_MM(b1, a1, 1, 1);
+      a1 = CZC_RA(0, 3);
+      CZC_MM(b0, a0, 2, 0); CZC_MM(b1, a0, 2, 1);
+      uint4 c0 = CZC_RB(1, 0), c1 = CZC_RB(1, 1);
+      a0 = CZC_RA(1, 0);
+      CZC_MM(b0, a1, 3, 0); CZC_MM(b1, a1, 3, 1);
+      a1 = CZC_RA(1, 1);
+      CZC_MM(c0, a0, 0, 0); CZC_MM(c1, a0, 0, 1);
+      a0 = CZC_RA(1, 2);
+      CZC_MM(c0, a1, 1, 0); CZC_MM(c1, a1, 1, 1);
+      a1 = CZC_RA(1, 3);
+      CZC_MM(c0, a0, 2, 0); CZC_MM(c1, a0, 2, 1);
+      CZC_MM(c0, a1, 3, 0); CZC_MM(c1, a1, 3, 1);
+#undef CZC_RA
+#undef CZC_RB
+#undef CZC_MM
+    }
+    tile_epilogue<ACT, OUT_F32>(g, acc, smem + QS * QSTAGE + wave * 4096, m0, n0, wm, wn, lane);
   }
 }
 
@@ -464,7 +619,7 @@ int launch_gemm256(const GemmArgs& g, hipStream_t st) {
   static bool attr_set = false;
   static int n_cu = 0;
   const int shmem = 2 * STAGE;
-  if (g_use_gemm256 == 2 && g.N % 8 == 0 && g.ldc % 8 == 0) {
+  if (g_use_gemm256 >= 2 && g.N % 8 == 0 && g.ldc % 8 == 0 && g.K % 64 == 0) {
     const int shp = shmem + 8 * 4096;  // + one 4 KiB epilogue patch per MFMA wave = the full 160 KiB
     if (!n_cu) {
       int dev = 0;
@@ -477,12 +632,25 @@ int launch_gemm256(const GemmArgs& g, hipStream_t st) {
       CZC_ATTR((gemm256p_kernel<ACT_NONE, true>));
       CZC_ATTR((gemm256p_kernel<ACT_QUICK_GELU, false>));
       CZC_ATTR((gemm256p_kernel<ACT_QUICK_GELU, true>));
+      CZC_ATTR((gemm256q_kernel<ACT_NONE, false>));
+      CZC_ATTR((gemm256q_kernel<ACT_NONE, true>));
+      CZC_ATTR((gemm256q_kernel<ACT_QUICK_GELU, false>));
+      CZC_ATTR((gemm256q_kernel<ACT_QUICK_GELU, true>));
 #undef CZC_ATTR
     }
     const int tiles_m = cdiv(g.M, TM), tiles_n = cdiv(g.N, TN);
     const int nt = (g_gemm_krot & 32) ? tiles_m : tiles_m * tiles_n;  // work units: tiles, or M tiles for the M-major walk
     dim3 grid(nt < n_cu ? nt : n_cu), block(768);
     const bool f32 = g.out_f32 != nullptr || g.resid != nullptr;
+    if (g_use_gemm256 == 3) {
+      dim3 gq(tiles_m * tiles_n < n_cu ? tiles_m * tiles_n : n_cu);
+#define CZC_GOQ(A_, F_) hipLaunchKernelGGL((gemm256q_kernel<A_, F_>), gq, block, shp, st, g, tiles_m, tiles_n)
+      if (g.act == ACT_QUICK_GELU) { if (f32) CZC_GOQ(ACT_QUICK_GELU, true); else CZC_GOQ(ACT_QUICK_GELU, false); }
+      else { if (f32) CZC_GOQ(ACT_NONE, true); else CZC_GOQ(ACT_NONE, false); }
+#undef CZC_GOQ
+      CZC_HIP_CHECK(hipGetLastError());
+      return 0;
+    }
 #define CZC_GO(A_, F_) hipLaunchKernelGGL((gemm256p_kernel<A_, F_>), grid, block, shp, st, g, tiles_m, tiles_n, g_gemm_krot)
     if (g.act == ACT_QUICK_GELU) { if (f32) CZC_GO(ACT_QUICK_GELU, true); else CZC_GO(ACT_QUICK_GELU, false); }
     else { if (f32) CZC_GO(ACT_NONE, true); else CZC_GO(ACT_NONE, false); }

@@ -233,7 +233,7 @@ def test_combine_first_argmax_on_ties():
     assert best[0] == 0 and np.allclose(fs, fs[0, 0])
 
 
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [1, 2, 3])
 @pytest.mark.parametrize("M,N,K,act,resid", [(2048, 512, 512, 0, True), (3000, 1536, 512, 0, False),
                                              (5000, 2048, 512, 1, False), (2500, 512, 2048, 0, True),
                                              (2304, 320, 192, 1, True), (70000, 512, 512, 0, True)])
@@ -250,7 +250,7 @@ def test_gemm256_variants(variant, M, N, K, act, resid):
         assert lib.czc_test_set_option(b"gemm256", variant) == 0
         C = E.test_gemm(BF16, A, W, bias=bias, resid=R, act=act)
     finally:
-        lib.czc_test_set_option(b"gemm256", 2)
+        lib.czc_test_set_option(b"gemm256", 3)
     pre = (_bf16_round(A).astype(np.float64) @ _bf16_round(W).astype(np.float64).T + bias).astype(np.float32)
     ref = _act(pre, act) + (R if resid else 0)
     err = np.abs(C - ref).max()
