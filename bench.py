@@ -182,7 +182,7 @@ def main():
             tp = os.path.join(ROOT, "profiles", "r01_bench_gemm_traffic.json")
             if os.path.exists(tp) and (B, L, K, I, a.order, a.gamma) == (256, 10, 200, 10, "sequential", None):
                 traffic = json.load(open(tp))["hbm_bytes_per_launch"]
-            roof = dict(bound="mfma", kernel="czc::gemm256p_kernel<bf16> (CLIP-text linear layers)",
+            roof = dict(bound="mfma", kernel="czc::gemm256q_kernel<bf16> (CLIP-text linear layers)",
                         achieved=round(ach, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_BF16_TFLOPS, 4),
                         traffic=traffic, launches=g["launches"], avg_launch_ms=round(g["ms"] / g["launches"], 4),
                         flops_per_launch=g["flops"] / g["launches"])
