@@ -74,10 +74,20 @@ int czc_test_gemm(int precision, int M, int N, int K, const float* A, const floa
   void* dW = up_act(pool, precision, W, (size_t)N * K); T_PTR(dW);
   float* dB = bias ? (float*)pool.up(bias, (size_t)N * 4) : nullptr;
   float* dR = resid ? (float*)pool.up(resid, (size_t)M * N * 4) : nullptr;
-  float* dC = (float*)pool.alloc((size_t)M * N * 4); T_PTR(dC);
+  const bool typed_out = (act & 0x100) != 0;  // store through the activation-typed epilogue (bf16 / split / f32)
+  act &= 0xff;
   GemmArgs g;
-  g.A = dA; g.lda = K; g.W = dW; g.ldw = K; g.bias = dB; g.resid = dR; g.ldr = N; g.out_act = nullptr;
-  g.out_f32 = dC; g.ldc = N; g.M = M; g.N = N; g.K = K; g.act = act;
+  g.A = dA; g.lda = K; g.W = dW; g.ldw = K; g.bias = dB; g.resid = dR; g.ldr = N;
+  g.ldc = N; g.M = M; g.N = N; g.K = K; g.act = act;
+  if (typed_out) {
+    void* dO = pool.alloc((size_t)M * N * prec_bytes(precision)); T_PTR(dO);
+    g.out_act = dO; g.out_f32 = nullptr;
+    T_CHECK(launch_gemm(precision, g, nullptr));
+    T_HIP(hipDeviceSynchronize());
+    return down_act(pool, precision, dO, (size_t)M * N, C);
+  }
+  float* dC = (float*)pool.alloc((size_t)M * N * 4); T_PTR(dC);
+  g.out_act = nullptr; g.out_f32 = dC;
   T_CHECK(launch_gemm(precision, g, nullptr));
   T_HIP(hipDeviceSynchronize());
   T_HIP(hipMemcpy(C, dC, (size_t)M * N * 4, hipMemcpyDeviceToHost));
@@ -109,8 +119,9 @@ int czc_bench_gemm(int precision, int M, int N, int K, int act, int out_mode, in
   GemmArgs g;
   g.A = dA; g.lda = K; g.W = dW; g.ldw = K; g.bias = dB; g.resid = dOf; g.ldr = N; g.out_act = dOa; g.out_f32 = dOf;
   g.ldc = N; g.M = M; g.N = N; g.K = K; g.act = act;
-  const int saved = g_use_gemm256;
-  g_use_gemm256 = use256;
+  const int saved = g_use_gemm256, saved_wreg = g_use_wreg;
+  g_use_gemm256 = use256 == 5 ? 3 : use256;  // 5: weight-stationary kernel where eligible
+  g_use_wreg = use256 == 5;
   hipEvent_t e0, e1;
   T_HIP(hipEventCreate(&e0)); T_HIP(hipEventCreate(&e1));
   for (int i = 0; i < 2; ++i) T_CHECK(launch_gemm(precision, g, nullptr));
@@ -122,6 +133,7 @@ int czc_bench_gemm(int precision, int M, int N, int K, int act, int out_mode, in
   float ms = 0;
   T_HIP(hipEventElapsedTime(&ms, e0, e1));
   g_use_gemm256 = saved;
+  g_use_wreg = saved_wreg;
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   *ms_out = ms / iters;
   return 0;
@@ -130,6 +142,9 @@ int czc_bench_gemm(int precision, int M, int N, int K, int act, int out_mode, in
 int czc_test_set_option(const char* name, int value) {
   if (!strcmp(name, "gemm256")) { g_use_gemm256 = value; return 0; }
   if (!strcmp(name, "gemm_krot")) { g_gemm_krot = value; return 0; }
+  if (!strcmp(name, "skinny")) { g_use_skinny = value; return 0; }
+  if (!strcmp(name, "wreg")) { g_use_wreg = value; return 0; }
+  if (!strcmp(name, "wreg_dbg")) { g_wreg_dbg = value; return 0; }
   if (!strcmp(name, "mfma_attention")) { g_use_mfma_attention = value; return 0; }
   snprintf(czc::g_err, sizeof(czc::g_err), "unknown option %s", name);
   return CZC_ERR_ARG;

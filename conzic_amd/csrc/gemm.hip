@@ -253,6 +253,93 @@ static void launch_t(const GemmArgs& g, int tiles_m, int tiles_n, bool vec, hipS
 #undef CZC_GEMM_LAUNCH
 }
 
+// ---- skinny split-fp16 GEMM for M <= 32 (BERT at batch 1-2: weight streaming, latency bound) ------
+// One work-group per 16 output columns; its 4 waves split K, each streaming its W rows straight
+// from global memory into MFMA fragments (no LDS: every weight byte is used once), 16x16x32 f16
+// MFMA with the weights as the A operand, so a lane ends up with 4 consecutive output columns of
+// one row.  Partial sums meet in LDS; wave 0 applies bias / activation / residual and stores.
+typedef __attribute__((ext_vector_type(4))) float f32x4v_t;
+
+template <int ACT>
+__global__ __launch_bounds__(256) void gemm_skinny_split_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float red[3][2][64][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n0 = blockIdx.x * 16;
+  const int nl = lane & 15, kb = lane >> 4;
+  const int nrow = min(n0 + nl, g.N - 1);
+  const unsigned char* wp = (const unsigned char*)g.W + (long)nrow * g.ldw * 4 + kb * 32;
+  const int m_a = min(nl, g.M - 1), m_b = min(16 + nl, g.M - 1);
+  const unsigned char* xa = (const unsigned char*)g.A + (long)m_a * g.lda * 4 + kb * 32;
+  const unsigned char* xb = (const unsigned char*)g.A + (long)m_b * g.lda * 4 + kb * 32;
+  const bool two = g.M > 16;
+  f32x4v_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  const int steps = g.K >> 5;  // 32 k per MFMA step = 4 groups of (16 B hi + 16 B lo)
+#define CZC_F16(v_) __builtin_bit_cast(f16x8_t, v_)
+  for (int s2 = wave; s2 < steps; s2 += 4) {
+    const long o = (long)s2 * 128;
+    const uint4 wh = *(const uint4*)(wp + o), wl = *(const uint4*)(wp + o + 16);
+    const uint4 ah = *(const uint4*)(xa + o), al = *(const uint4*)(xa + o + 16);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(CZC_F16(wl), CZC_F16(ah), acc0, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(CZC_F16(wh), CZC_F16(al), acc0, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(CZC_F16(wh), CZC_F16(ah), acc0, 0, 0, 0);
+    if (two) {
+      const uint4 bh = *(const uint4*)(xb + o), bl = *(const uint4*)(xb + o + 16);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(CZC_F16(wl), CZC_F16(bh), acc1, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(CZC_F16(wh), CZC_F16(bl), acc1, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(CZC_F16(wh), CZC_F16(bh), acc1, 0, 0, 0);
+    }
+  }
+#undef CZC_F16
+  if (wave > 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { red[wave - 1][0][lane][r] = acc0[r]; red[wave - 1][1][lane][r] = acc1[r]; }
+  }
+  __syncthreads();
+  if (wave != 0) return;
+#pragma unroll
+  for (int w = 0; w < 3; ++w)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { acc0[r] += red[w][0][lane][r]; acc1[r] += red[w][1][lane][r]; }
+  // D[row = n][col = m]: lane holds m = lane&15, n = n0 + 4*(lane>>4) + r
+  split_t* oa = (split_t*)g.out_act;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int m = t * 16 + nl;
+    if (m >= g.M) continue;
+    const f32x4v_t a = t ? acc1 : acc0;
+    const int col = n0 + 4 * kb;
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = min(col + r, g.N - 1);
+      v[r] = apply_act<float, ACT>(a[r] + (g.bias ? g.bias[c] : 0.f));
+      if (g.resid) v[r] += g.resid[(long)m * g.ldr + c];
+    }
+    if (col + 3 < g.N && (g.ldc & 3) == 0) {
+      if (g.out_f32) *(float4*)(g.out_f32 + (long)m * g.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+      if (oa) Act<split_t>::st4(oa, (long)m * g.ldc + col, v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (col + r < g.N) {
+          if (g.out_f32) g.out_f32[(long)m * g.ldc + col + r] = v[r];
+          if (oa) Act<split_t>::st(oa, (long)m * g.ldc + col + r, v[r]);
+        }
+    }
+  }
+}
+
+int g_use_skinny = 1;
+
+static bool launch_skinny(const GemmArgs& g, hipStream_t st) {
+  if (!g_use_skinny || g.M > 32 || (g.K & 31) || (g.lda & 7) || (g.ldw & 7)) return false;
+  dim3 grid(cdiv(g.N, 16)), block(256);
+  if (g.act == ACT_QUICK_GELU) hipLaunchKernelGGL(gemm_skinny_split_kernel<ACT_QUICK_GELU>, grid, block, 0, st, g);
+  else if (g.act == ACT_GELU_ERF) hipLaunchKernelGGL(gemm_skinny_split_kernel<ACT_GELU_ERF>, grid, block, 0, st, g);
+  else hipLaunchKernelGGL(gemm_skinny_split_kernel<ACT_NONE>, grid, block, 0, st, g);
+  return true;
+}
+
 int g_use_gemm256 = 3;  // 0: 128x128 only, 1: gemm256, 2: persistent wave-specialised gemm256p, 3: + 4-stage K ring (gemm256q)
 
 int launch_gemm(int prec, const GemmArgs& g, hipStream_t st) {
@@ -262,7 +349,12 @@ int launch_gemm(int prec, const GemmArgs& g, hipStream_t st) {
     snprintf(g_err, sizeof(g_err), "gemm: K=%d must be a multiple of %d", g.K, kpt);
     return 1;
   }
+  if (prec == PREC_BF16 && gemm_wreg_eligible(g)) return launch_gemm_wreg(g, st);
   if (prec == PREC_BF16 && g_use_gemm256 && gemm256_eligible(g)) return launch_gemm256(g, st);
+  if (prec == PREC_F16X3 && launch_skinny(g, st)) {
+    CZC_HIP_CHECK(hipGetLastError());
+    return 0;
+  }
   const int tiles_m = cdiv(g.M, BM), tiles_n = cdiv(g.N, BN);
   const bool vec = (g.N % 4 == 0) && (g.ldc % 4 == 0) && (!g.resid || g.ldr % 4 == 0);
   if (prec == PREC_BF16) launch_t<bf16_t>(g, tiles_m, tiles_n, vec, st);

@@ -1,0 +1,277 @@
+// Weight-stationary bf16 MFMA GEMM for the K = 512 linear layers of the CLIP text tower
+// (qkv 512->1536, fc1 512->2048 over M = 10^5..10^6 candidate-caption rows):
+//
+//   C[M,N] = act(A[M,512] . W[N,512]^T + bias)        bf16 operands, fp32 accumulate, bf16 out
+//
+// Why another GEMM.  Measured on MI355X (tools/probes/ingest_probe.hip): one CU cannot pull more
+// than ~20 B/clk from L2 and the chip ~10-12 TB/s, whatever the wave count, depth or pattern.  A
+// 256x256-tile GEMM moves 1/128 byte per flop into the CU, so it tops out near 1.4 PFLOP/s before
+// any epilogue, and at K = 512 the tile epilogue and the A/W ring coupling cost another factor 2
+// (gemm256q: 0.67 ms for the qkv shape, 730 TFLOP/s).  Here the weights never move again:
+//   * a work-group owns 256 output columns; each of its 8 waves keeps its 32 columns x 512 k of W
+//     in REGISTERS as 32 MFMA operand fragments (128 VGPRs) for the whole kernel.  The register
+//     file (512 KiB/CU) is the only on-CU memory that holds a 256 x 512 bf16 weight panel.
+//   * only activations stream: 32-row blocks (32 KiB, contiguous in HBM because lda == K) land in a
+//     4-deep LDS ring by LDS-DMA, one full 1 KiB row per DMA instruction.  CU ingest is 1/256 byte
+//     per flop -- half of the tiled kernel -- and there is no weight traffic in steady state.
+//   * every wave multiplies every block against its own columns: one ds_read_b128 + one
+//     v_mfma_f32_32x32x16_bf16 per k16 step (LDS read pipe 50 % busy), two accumulator chains.
+//   * the two waves of a SIMD (w, w+4) run half a block apart: one does MFMA(i) then epilogue(i),
+//     the other epilogue(i-1) then MFMA(i), so bias / quick-GELU / bf16 pack / store of 32x32
+//     outputs always has a partner's MFMAs to hide behind.
+//   * one barrier per block.  Loads, LDS-DMA and stores retire in order on gfx9's vmcnt, and every
+//     VMEM instruction of the loop is issued from inline asm in a fixed number per block, so the
+//     wait for block i is an exact count (two blocks of DMA + three epilogues of stores stay in
+//     flight).  Out-of-range rows / columns are dropped by the buffer descriptors' bounds check.
+//   * LDS row r, 16-byte chunk c lives at chunk c ^ (r & 15): conflict-free for the ds_read_b128 lane
+//     groups, and a pure permutation inside each DMA'd row (the source address carries it).
+//   * the column groups of one row range sit on neighbouring CUs of one XCD and march in step, so
+//     each activation block comes from HBM once and from that XCD's L2 for the other groups.
+#include "kernels.h"
+
+namespace czc {
+
+namespace {
+
+constexpr int WR_K = 512;
+constexpr int WR_ROWB = WR_K * 2;              // 1 KiB per activation row
+constexpr int WR_BLK = 32;                     // rows per block
+constexpr int WR_STAGE = WR_BLK * WR_ROWB;     // 32 KiB
+constexpr int WR_D = 4;                        // ring depth
+constexpr int WR_PATCH = 2048;                 // per-wave epilogue patch (32 rows x 64 bytes)
+constexpr int WR_BIAS = 128;                   // per-wave bias slice (32 floats)
+constexpr int WR_LDS = WR_D * WR_STAGE + 8 * (WR_PATCH + WR_BIAS);
+constexpr int WR_STORES = 2;                   // buffer stores per wave per epilogue
+constexpr int WR_DMAS = 4;
+constexpr int WR_AHEAD = 4;                    // fragment reads in flight ahead of the MFMA that uses them                     // LDS-DMA instructions per wave per block
+
+__device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+
+template <int ACT>
+__device__ __forceinline__ float wr_act(float v) {
+  if (ACT == ACT_QUICK_GELU) return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930156f * v));
+  return v;
+}
+
+template <int ACT, bool DBG_NOLDS>
+__global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, int nsets, int nblk, int dbg) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+
+  // XCD-major linear index: work-group b runs on XCD b % 8
+  const int q = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int set = q / ncg, cg = q - set * ncg;
+  if (set >= nsets) return;
+  const int per = (nblk + nsets - 1) / nsets;
+  const int b0 = set * per;
+  const int nb = min(per, nblk - b0);
+  if (nb <= 0) return;
+
+  // ---- this wave's weight panel: 32 columns x 512 k as 32 MFMA fragments ----
+  const int col0 = cg * 256 + wave * 32;
+  u32x4_t wreg[32];
+  {
+    const int wrow = min(col0 + l31, g.N - 1);
+    const unsigned char* wp = (const unsigned char*)g.W + (long)wrow * g.ldw * 2 + half * 16;
+#pragma unroll
+    for (int t = 0; t < 32; ++t) wreg[t] = *(const u32x4_t*)(wp + t * 32);
+  }
+  // consume the panel here: the compiler then waits for these loads once, before the loop, instead of
+  // placing a vmcnt wait (which would drain the LDS-DMA ring) in front of the first MFMA of every block
+#pragma unroll
+  for (int t = 0; t < 32; t += 8)
+    asm volatile("" ::"v"(wreg[t]), "v"(wreg[t + 1]), "v"(wreg[t + 2]), "v"(wreg[t + 3]), "v"(wreg[t + 4]), "v"(wreg[t + 5]),
+                 "v"(wreg[t + 6]), "v"(wreg[t + 7]));
+  unsigned char* patch = smem + WR_D * WR_STAGE + wave * WR_PATCH;
+  float* bias_s = (float*)(smem + WR_D * WR_STAGE + 8 * WR_PATCH + wave * WR_BIAS);
+  if (lane < 32) bias_s[lane] = (g.bias && col0 + lane < g.N) ? g.bias[col0 + lane] : 0.f;
+
+  // ---- DMA side: this wave lands rows wave*4 + ii (ii 0..3) of every block ----
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(
+      (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem);
+  const int pitch = g.lda * 2;
+  int voff[4];
+#pragma unroll
+  for (int ii = 0; ii < 4; ++ii) {
+    const int r = wave * 4 + ii;
+    voff[ii] = r * pitch + ((lane ^ (r & 15)) << 4);
+  }
+  u32x4_t rsA;
+  rsA.w = 0x00020000u;
+  auto issue = [&](int j) {  // block j of this work-group -> ring slot j % WR_D
+    const long row0 = (long)(b0 + j) * WR_BLK;
+    const unsigned long long pa = (unsigned long long)g.A + (unsigned long long)row0 * pitch;
+    rsA.x = (unsigned)pa; rsA.y = (unsigned)(pa >> 32) & 0xffffu;
+    rsA.z = (unsigned)(min((long)WR_BLK, (long)g.M - row0) * pitch);
+    const unsigned dst = lds0 + (j & (WR_D - 1)) * WR_STAGE + wave * (4 * WR_ROWB);
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %6, 0 offen lds\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %6, 0 offen lds\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %6, 0 offen lds\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %5, %6, 0 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(dst), "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "s"(rsA)
+        : "memory", "scc");
+  };
+
+  // ---- MFMA side ----
+  // fragment t of row l31: logical chunk 2t+half -> physical (2t+half) ^ (l31 & 15); the low four
+  // bits repeat with period 8 in t, the rest is an immediate offset
+  int va[8];
+#pragma unroll
+  for (int tl = 0; tl < 8; ++tl) va[tl] = l31 * WR_ROWB + ((((2 * tl + half) ^ (l31 & 15)) & 15) << 4);
+  f32x16_t acc0, acc1;
+
+  auto mfma_block = [&](int slot) {
+    const unsigned char* sA = smem + slot * WR_STAGE;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+    for (int t = 0; t < 32; t += 2) {
+      const u32x4_t a0 = DBG_NOLDS ? wreg[(t + 5) & 31] : *(const u32x4_t*)(sA + va[t & 7] + (t >> 3) * 256);
+      const u32x4_t a1 = DBG_NOLDS ? wreg[(t + 6) & 31] : *(const u32x4_t*)(sA + va[(t + 1) & 7] + ((t + 1) >> 3) * 256);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wreg[t]), __builtin_bit_cast(bf16x8_t, a0),
+                                                     acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wreg[t + 1]),
+                                                     __builtin_bit_cast(bf16x8_t, a1), acc1, 0, 0, 0);
+    }
+    if (DBG_NOLDS) return;
+    // pin the stream: fragment reads run WR_AHEAD MFMAs ahead of their use (one wave must be able to
+    // keep the matrix pipe fed alone while its SIMD partner is in an epilogue)
+#pragma unroll
+    for (int k = 0; k < WR_AHEAD; ++k) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+    for (int k = 0; k < 32 - WR_AHEAD; ++k) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+#pragma unroll
+    for (int k = 0; k < WR_AHEAD; ++k) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+  };
+
+  // output descriptor is rebased per block; columns past N get an offset no descriptor admits
+  u32x4_t rsC;
+  rsC.w = 0x00020000u;
+  const int rrow = lane >> 2, rs = lane & 3;
+  const int ccol = col0 + rs * 8;
+  const int cpitch = g.ldc * 2;
+  const unsigned coff0 = ccol < g.N ? (unsigned)(rrow * cpitch + ccol * 2) : 0x7ffffff0u;
+  const unsigned coff1 = ccol < g.N ? (unsigned)((16 + rrow) * cpitch + ccol * 2) : 0x7ffffff0u;
+
+  auto epilogue = [&](int j) {  // block j: acc0 + acc1 -> bias, activation, bf16, 64-byte row segments
+    const long row0 = (long)(b0 + j) * WR_BLK;
+    const unsigned long long pc = (unsigned long long)g.out_act + (unsigned long long)row0 * cpitch;
+    rsC.x = (unsigned)pc; rsC.y = (unsigned)(pc >> 32) & 0xffffu;
+    rsC.z = (unsigned)(min((long)WR_BLK, (long)g.M - row0) * cpitch);
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      const float4 b4 = *(const float4*)(bias_s + 8 * qd + 4 * half);
+      float4 v = make_float4(acc0[4 * qd] + acc1[4 * qd] + b4.x, acc0[4 * qd + 1] + acc1[4 * qd + 1] + b4.y,
+                             acc0[4 * qd + 2] + acc1[4 * qd + 2] + b4.z, acc0[4 * qd + 3] + acc1[4 * qd + 3] + b4.w);
+      v.x = wr_act<ACT>(v.x); v.y = wr_act<ACT>(v.y); v.z = wr_act<ACT>(v.z); v.w = wr_act<ACT>(v.w);
+      const int slot = (2 * qd + half) ^ ((l31 >> 1) & 7);  // 8-byte slots of the 64-byte patch row
+      *(uint2*)(patch + l31 * 64 + slot * 8) = make_uint2(pk_bf16(v.x, v.y), pk_bf16(v.z, v.w));
+    }
+    u32x4_t d[2];
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int r = pass * 16 + rrow;
+      const int x = (r >> 1) & 7;
+      const u32x4_t t4 = *(const u32x4_t*)(patch + r * 64 + ((rs ^ (x >> 1)) << 4));
+      const u32x4_t sw = {t4.z, t4.w, t4.x, t4.y};
+      d[pass] = (x & 1) ? sw : t4;
+    }
+    if (!(dbg & 1))
+    asm volatile("buffer_store_dwordx4 %0, %2, %4, 0 offen\n\tbuffer_store_dwordx4 %1, %3, %4, 0 offen"
+                 :
+                 : "v"(d[0]), "v"(d[1]), "v"(coff0), "v"(coff1), "s"(rsC)
+                 : "memory");
+  };
+
+  const int pro = nb < WR_D - 1 ? nb : WR_D - 1;
+  for (int j = 0; j < pro; ++j) issue(j);
+  // waves w and w+4 share a SIMD: the second runs half a block behind  (dbg 32 / 64: other pairings, A/B only)
+  const bool late = (dbg & 32) ? (wave & 1) : (dbg & 64) ? ((wave >> 1) & 1) : ((wave >> 2) & 1);
+
+  for (int i = 0; i < nb; ++i) {
+    // block i must have landed.  VMEM issued after its DMA: the DMA of blocks i+1, i+2 and (from
+    // the fourth block on) three epilogues of stores -- all in order on vmcnt.
+    if (i + 2 >= nb) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (i < 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+    static_assert(2 * WR_DMAS == 8 && 2 * WR_DMAS + 3 * WR_STORES == 14, "wait counts above");
+    if (!(dbg & 256)) __builtin_amdgcn_s_barrier();  // publishes block i; every wave has left block i-1's slot
+    asm volatile("" ::: "memory");
+    // A VMEM instruction blocks its wave until the CU's single vector-memory path takes it (~50 clocks
+    // per KiB), so each wave keeps its memory phase (ring refill, epilogue, stores) away from its MFMA
+    // phase and opposite to its SIMD partner's: one wave of every SIMD always owns the matrix pipe.
+    const bool refill = i + WR_D - 1 < nb && !(dbg & 4);
+    if (!late) {
+      if (dbg & 128) __builtin_amdgcn_s_setprio(3);
+      if (!(dbg & 2)) mfma_block(i & (WR_D - 1));
+      if (dbg & 128) __builtin_amdgcn_s_setprio(0);
+      if (refill) issue(i + WR_D - 1);
+      if (!(dbg & 8)) epilogue(i);
+    } else {
+      if (refill) issue(i + WR_D - 1);
+      if (i > 0 && !(dbg & 8)) epilogue(i - 1);
+      if (dbg & 128) __builtin_amdgcn_s_setprio(3);
+      if (!(dbg & 2)) mfma_block(i & (WR_D - 1));
+      if (dbg & 128) __builtin_amdgcn_s_setprio(0);
+    }
+  }
+  if (late && !(dbg & 8)) epilogue(nb - 1);
+}
+
+}  // namespace
+
+int g_use_wreg = 1;
+int g_wreg_dbg = 0;  // timing ablations only (results invalid): 1 no stores, 2 no MFMA, 4 no DMA refill, 8 no epilogue, 16 MFMA operands from registers only
+
+bool gemm_wreg_eligible(const GemmArgs& g) {
+  return g_use_wreg && g.K == WR_K && g.M >= 2048 && g.N % 8 == 0 && g.ldc % 8 == 0 && g.lda % 8 == 0 && g.ldw % 8 == 0 &&
+         g.out_act && !g.out_f32 && !g.resid && (g.act == ACT_NONE || g.act == ACT_QUICK_GELU) &&
+         (long)g.ldc * 2 * WR_BLK < (1L << 30) && (long)g.lda * 2 * WR_BLK < (1L << 30);
+}
+
+int launch_gemm_wreg(const GemmArgs& g, hipStream_t st) {
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    CZC_HIP_CHECK(hipGetDevice(&dev));
+    CZC_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+    n_cu = prop.multiProcessorCount & ~7;
+    CZC_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_wreg_kernel<ACT_NONE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, WR_LDS));
+    CZC_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_wreg_kernel<ACT_QUICK_GELU, false>, hipFuncAttributeMaxDynamicSharedMemorySize, WR_LDS));
+  }
+  const int ncg = cdiv(g.N, 256);
+  const int nblk = cdiv(g.M, WR_BLK);
+  int nsets = n_cu / ncg;
+  if (nsets < 1) {
+    snprintf(g_err, sizeof(g_err), "gemm_wreg: N=%d needs more column groups than CUs", g.N);
+    return 1;
+  }
+  if (nsets > nblk) nsets = nblk;
+  dim3 grid(n_cu), block(512);
+  if (g_wreg_dbg & 16) {
+    CZC_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_wreg_kernel<ACT_NONE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, WR_LDS));
+    hipLaunchKernelGGL((gemm_wreg_kernel<ACT_NONE, true>), grid, block, WR_LDS, st, g, ncg, nsets, nblk, g_wreg_dbg);
+  } else if (g.act == ACT_QUICK_GELU)
+    hipLaunchKernelGGL((gemm_wreg_kernel<ACT_QUICK_GELU, false>), grid, block, WR_LDS, st, g, ncg, nsets, nblk, g_wreg_dbg);
+  else
+    hipLaunchKernelGGL((gemm_wreg_kernel<ACT_NONE, false>), grid, block, WR_LDS, st, g, ncg, nsets, nblk, g_wreg_dbg);
+  CZC_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+}  // namespace czc

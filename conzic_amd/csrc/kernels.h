@@ -23,6 +23,11 @@ bool gemm256_eligible(const GemmArgs& g);
 int launch_gemm256(const GemmArgs& g, hipStream_t st);  // gemm256.hip: 256x256 LDS-DMA bf16 kernel
 extern int g_use_gemm256;
 extern int g_gemm_krot;
+extern int g_use_skinny;
+bool gemm_wreg_eligible(const GemmArgs& g);
+int launch_gemm_wreg(const GemmArgs& g, hipStream_t st);  // gemm_wreg.hip: weights in registers, K = 512
+extern int g_use_wreg;
+extern int g_wreg_dbg;
 
 // ---- rowops.hip -------------------------------------------------------------------------
 // y = LN(x[row_idx ? row_idx[m] : m]) ; x fp32 [*,H]; outputs optional

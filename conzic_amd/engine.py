@@ -227,8 +227,10 @@ class Engine:
 
 # ---- kernel-level hooks (tests) ----------------------------------------------------------------------
 
-def test_gemm(prec, A, W, bias=None, resid=None, act=0):
+def test_gemm(prec, A, W, bias=None, resid=None, act=0, typed_out=False):
     lib = native.load()
+    if typed_out:
+        act |= 0x100
     A = np.ascontiguousarray(A, np.float32)
     W = np.ascontiguousarray(W, np.float32)
     M, K = A.shape

@@ -187,7 +187,9 @@ int czc_sync(czc_engine* e);
 int czc_stats(czc_engine* e, int64_t* clip_rows, int64_t* clip_seqs, int64_t* bert_rows, int64_t* steps);
 
 /* ---- kernel-level parity hooks (tests only; host pointers, synchronous) -------------------- */
-/* C[M,N] = A[M,K] * W[N,K]^T (+bias) (+activation: 0 none, 1 quick_gelu, 2 gelu_erf) (+resid[M,N]) */
+/* C[M,N] = A[M,K] * W[N,K]^T (+bias) (+activation: 0 none, 1 quick_gelu, 2 gelu_erf) (+resid[M,N]).
+ * act | 0x100: take the result through the activation-typed output path (bf16 / split-fp16 / f32 per
+ * `precision`, resid must be NULL) instead of the fp32 one -- the path the tower-internal layers use. */
 int czc_test_gemm(int precision, int M, int N, int K, const float* A, const float* W, const float* bias,
                   const float* resid, int act, float* C);
 /* GEMM microbenchmark on device-resident data: ms per launch (tools/bench_gemm.py); use256 selects the

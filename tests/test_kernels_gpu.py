@@ -233,7 +233,7 @@ def test_combine_first_argmax_on_ties():
     assert best[0] == 0 and np.allclose(fs, fs[0, 0])
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4])
 @pytest.mark.parametrize("M,N,K,act,resid", [(2048, 512, 512, 0, True), (3000, 1536, 512, 0, False),
                                              (5000, 2048, 512, 1, False), (2500, 512, 2048, 0, True),
                                              (2304, 320, 192, 1, True), (70000, 512, 512, 0, True)])
@@ -257,6 +257,32 @@ def test_gemm256_variants(variant, M, N, K, act, resid):
     assert err < 3e-3 * np.sqrt(K / 64), err
 
 
+@pytest.mark.parametrize("M,N,act", [(2048, 512, 0), (3000, 1536, 0), (5000, 2048, 1), (70001, 512, 1), (2304, 320, 0),
+                                     (2049, 1536, 1), (40000, 2048, 0)])
+def test_gemm_weight_stationary(M, N, act):
+    """K = 512 bf16-output layers (CLIP-text qkv / fc1) take the weights-in-registers kernel: ragged M
+    (partial last 32-row block), N not a multiple of the 256-column group, both activations; compared with
+    the fp64 product of the bf16-rounded operands and with the tiled kernel on the same inputs."""
+    lib = native.load()
+    K = 512
+    rng = np.random.default_rng(M + N + act)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
+    W[:, : K // 2] *= 3.0
+    bias = rng.standard_normal(N).astype(np.float32)
+    C = E.test_gemm(BF16, A, W, bias=bias, act=act, typed_out=True)
+    try:
+        assert lib.czc_test_set_option(b"wreg", 0) == 0
+        C2 = E.test_gemm(BF16, A, W, bias=bias, act=act, typed_out=True)
+    finally:
+        lib.czc_test_set_option(b"wreg", 1)
+    pre = (_bf16_round(A).astype(np.float64) @ _bf16_round(W).astype(np.float64).T + bias).astype(np.float32)
+    ref = _act(pre, act)
+    tol = 2e-3 * np.sqrt(K / 64) + np.abs(ref) * 2.0 ** -8  # + one bf16 rounding of the output
+    assert (np.abs(C - ref) <= tol).all(), np.abs(C - ref).max()
+    assert (np.abs(C - C2) <= np.abs(ref) * 2.0 ** -7 + 1e-3).all(), np.abs(C - C2).max()
+
+
 F16X3 = 3  # internal precision code: split-fp16 storage, three fp16 MFMA passes (BERT tower of the bf16 engine)
 
 
@@ -271,6 +297,31 @@ def test_split_fp16_gemm_is_fp32_class(M, N, K, act):
     ref = _act((A.astype(np.float64) @ W.astype(np.float64).T + bias).astype(np.float32), act)
     err = np.abs(C - ref).max()
     assert err < 1e-5 * np.sqrt(K / 64) * 4, err
+
+
+@pytest.mark.parametrize("M", [1, 15, 16, 17, 30, 32])
+@pytest.mark.parametrize("N,K,act,resid", [(768, 768, 0, True), (2304, 768, 0, False), (3072, 768, 2, False),
+                                           (768, 3072, 0, True), (30522, 768, 0, False), (200, 64, 1, True)])
+def test_split_fp16_skinny_gemm(M, N, K, act, resid):
+    """M <= 32 takes the K-split weight-streaming kernel (BERT at batch 1-2); same fp32-class bound,
+    and agreement with the tiled kernel on the same operands."""
+    rng = np.random.default_rng(M * 31 + N + K)
+    A = (rng.standard_normal((M, K)) * 2).astype(np.float32)
+    W = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
+    W[:, : K // 2] *= 3.0
+    bias = rng.standard_normal(N).astype(np.float32)
+    R = rng.standard_normal((M, N)).astype(np.float32) if resid else None
+    C = E.test_gemm(F16X3, A, W, bias=bias, resid=R, act=act)
+    ref = _act((A.astype(np.float64) @ W.astype(np.float64).T + bias).astype(np.float32), act) + (R if resid else 0)
+    tol = 1e-5 * np.sqrt(K / 64) * 4
+    assert np.abs(C - ref).max() < tol
+    lib = native.load()
+    try:
+        assert lib.czc_test_set_option(b"skinny", 0) == 0
+        C2 = E.test_gemm(F16X3, A, W, bias=bias, resid=R, act=act)
+    finally:
+        lib.czc_test_set_option(b"skinny", 1)
+    assert np.abs(C - C2).max() < tol
 
 
 def test_split_fp16_layernorm_and_attention():

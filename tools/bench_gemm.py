@@ -10,19 +10,22 @@ from conzic_amd import native
 lib = native.load()
 if len(sys.argv) > 2:
     lib.czc_test_set_option(b"gemm_krot", int(sys.argv[2]))
+if len(sys.argv) > 3:
+    lib.czc_test_set_option(b"wreg_dbg", int(sys.argv[3]))
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 768000
 shapes = [("qkv", 1536, 512, 0, 0), ("out", 512, 512, 0, 1), ("fc1", 2048, 512, 1, 0), ("fc2", 512, 2048, 0, 1)]
-tot = {0: 0.0, 1: 0.0, 2: 0.0, 3: 0.0}
+VARIANTS = (3, 5)
+tot = {v: 0.0 for v in VARIANTS}
 fl = 0.0
 for name, N, K, act, mode in shapes:
-    for use256 in (0, 1, 2, 3):
+    for use256 in VARIANTS:
         ms = C.c_double()
         native.check(lib.czc_bench_gemm(0, M, N, K, act, mode, 5, use256, C.byref(ms)), None, "bench")
         tf = 2.0 * M * N * K / (ms.value * 1e-3) / 1e12
         tot[use256] += ms.value
         print(f"{name:4s} M={M} N={N:5d} K={K:5d} use256={use256}: {ms.value:8.3f} ms  {tf:7.1f} TF/s", flush=True)
     fl += 2.0 * M * N * K
-for u in (0, 1, 2, 3):
+for u in VARIANTS:
     print(f"layer GEMMs use256={u}: {tot[u]:.2f} ms -> {fl / (tot[u] * 1e-3) / 1e12:.1f} TF/s")
 sys.stdout.flush()
 if not os.environ.get('CZC_NORMAL_EXIT'):
