@@ -182,7 +182,8 @@ def main():
             tp = os.path.join(ROOT, "profiles", "r01_bench_gemm_traffic.json")
             if os.path.exists(tp) and (B, L, K, I, a.order, a.gamma) == (256, 10, 200, 10, "sequential", None):
                 traffic = json.load(open(tp))["hbm_bytes_per_launch"]
-            roof = dict(bound="mfma", kernel="czc::gemm256q_kernel<bf16> (CLIP-text linear layers)",
+            roof = dict(bound="mfma", kernel="CLIP-text linear layers: czc::gemm_wreg_kernel<bf16> (qkv, fc1; weights in registers) + "
+                               "czc::gemm256q_kernel<bf16> (out-proj, fc2; 256x256 LDS-DMA ring)",
                         achieved=round(ach, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_BF16_TFLOPS, 4),
                         traffic=traffic, launches=g["launches"], avg_launch_ms=round(g["ms"] / g["launches"], 4),
                         flops_per_launch=g["flops"] / g["launches"])

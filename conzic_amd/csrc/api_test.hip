@@ -120,8 +120,8 @@ int czc_bench_gemm(int precision, int M, int N, int K, int act, int out_mode, in
   g.A = dA; g.lda = K; g.W = dW; g.ldw = K; g.bias = dB; g.resid = dOf; g.ldr = N; g.out_act = dOa; g.out_f32 = dOf;
   g.ldc = N; g.M = M; g.N = N; g.K = K; g.act = act;
   const int saved = g_use_gemm256, saved_wreg = g_use_wreg;
-  g_use_gemm256 = use256 == 5 ? 3 : use256;  // 5: weight-stationary kernel where eligible
-  g_use_wreg = use256 == 5;
+  g_use_gemm256 = use256 >= 5 ? 3 : use256;  // 5: weight-stationary kernel where eligible
+  g_use_wreg = use256 == 5 ? 1 : use256 == 6 ? 2 : 0;
   hipEvent_t e0, e1;
   T_HIP(hipEventCreate(&e0)); T_HIP(hipEventCreate(&e1));
   for (int i = 0; i < 2; ++i) T_CHECK(launch_gemm(precision, g, nullptr));

@@ -57,7 +57,7 @@ __device__ __forceinline__ float wr_act(float v) {
   return v;
 }
 
-template <int ACT, bool DBG_NOLDS>
+template <int ACT, bool DBG_NOLDS, bool ILV>
 __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, int nsets, int nblk, int dbg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63;
@@ -158,6 +158,29 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, 
     for (int k = 0; k < WR_AHEAD; ++k) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
   };
 
+  // ---- interleaved form (ILV): the memory work of a block is spread through its MFMA stream ----
+  // A VMEM instruction blocks its wave until the CU's vector-memory path accepts it, and that path is
+  // the busy resource here (HBM-bound output stream).  Issued in a burst, six VMEM per wave per block
+  // keep the wave out of the matrix pipe for about a whole block period; issued one at a time between
+  // groups of four MFMAs, the wave only stalls while the queue is actually full and the partner wave's
+  // MFMAs fill those holes.  The epilogue of block i-1 (kept in accP) rides in block i's stream too.
+  unsigned dma_dst = 0;
+  auto dma_piece = [&](int ii) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "s"(dma_dst + ii * WR_ROWB), "v"(voff[ii]), "s"(rsA)
+                 : "memory");
+  };
+  auto dma_rebase = [&](int j) {
+    const long row0 = (long)(b0 + j) * WR_BLK;
+    const unsigned long long pa = (unsigned long long)g.A + (unsigned long long)row0 * pitch;
+    rsA.x = (unsigned)pa; rsA.y = (unsigned)(pa >> 32) & 0xffffu;
+    rsA.z = (unsigned)(min((long)WR_BLK, (long)g.M - row0) * pitch);
+    dma_dst = lds0 + (j & (WR_D - 1)) * WR_STAGE + wave * (4 * WR_ROWB);
+  };
+  f32x16_t accP;  // finished accumulators of the previous block, waiting for their epilogue
+
   // output descriptor is rebased per block; columns past N get an offset no descriptor admits
   u32x4_t rsC;
   rsC.w = 0x00020000u;
@@ -197,11 +220,94 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, 
                  : "memory");
   };
 
+  auto store_rebase = [&](int j) {
+    const long row0 = (long)(b0 + j) * WR_BLK;
+    const unsigned long long pc = (unsigned long long)g.out_act + (unsigned long long)row0 * cpitch;
+    rsC.x = (unsigned)pc; rsC.y = (unsigned)(pc >> 32) & 0xffffu;
+    rsC.z = (unsigned)(min((long)WR_BLK, (long)g.M - row0) * cpitch);
+  };
+  auto epi_quad = [&](int qd) {  // accP quad qd -> bias, activation, bf16 -> patch
+    const float4 b4 = *(const float4*)(bias_s + 8 * qd + 4 * half);
+    float4 v = make_float4(accP[4 * qd] + b4.x, accP[4 * qd + 1] + b4.y, accP[4 * qd + 2] + b4.z, accP[4 * qd + 3] + b4.w);
+    v.x = wr_act<ACT>(v.x); v.y = wr_act<ACT>(v.y); v.z = wr_act<ACT>(v.z); v.w = wr_act<ACT>(v.w);
+    const int slot = (2 * qd + half) ^ ((l31 >> 1) & 7);
+    *(uint2*)(patch + l31 * 64 + slot * 8) = make_uint2(pk_bf16(v.x, v.y), pk_bf16(v.z, v.w));
+  };
+  auto epi_store = [&](int pass) {  // 16 patch rows -> one buffer store
+    const int r = pass * 16 + rrow;
+    const int x = (r >> 1) & 7;
+    const u32x4_t t4 = *(const u32x4_t*)(patch + r * 64 + ((rs ^ (x >> 1)) << 4));
+    const u32x4_t sw = {t4.z, t4.w, t4.x, t4.y};
+    const u32x4_t d = (x & 1) ? sw : t4;
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" : : "v"(d), "v"(pass ? coff1 : coff0), "s"(rsC) : "memory");
+  };
+  // block in ring slot `slot`: 8 groups of 4 MFMAs (fragments of group s+1 are read during group s), one
+  // auxiliary step pinned after each group.  VMEM order per block: D0 D1 D2 S0 D3 S1.
+  auto mfma_block_ilv = [&](int slot, bool refill, bool prev) {
+    const unsigned char* sA = smem + slot * WR_STAGE;
+    u32x4_t fr[2][4];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) fr[0][k] = *(const u32x4_t*)(sA + va[k & 7] + (k >> 3) * 256);
+#pragma unroll
+    for (int sgm = 0; sgm < 8; ++sgm) {
+      if (sgm < 7) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int t = 4 * (sgm + 1) + k;
+          fr[(sgm + 1) & 1][k] = *(const u32x4_t*)(sA + va[t & 7] + (t >> 3) * 256);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k += 2) {
+        const int t = 4 * sgm + k;
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wreg[t]),
+                                                       __builtin_bit_cast(bf16x8_t, fr[sgm & 1][k]), acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wreg[t + 1]),
+                                                       __builtin_bit_cast(bf16x8_t, fr[sgm & 1][k + 1]), acc1, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (sgm == 0 && refill) dma_piece(0);
+      if (sgm == 1 && prev) epi_quad(0);
+      if (sgm == 2 && refill) dma_piece(1);
+      if (sgm == 2 && prev) epi_quad(1);
+      if (sgm == 3 && prev) epi_quad(2);
+      if (sgm == 4 && refill) dma_piece(2);
+      if (sgm == 4 && prev) epi_quad(3);
+      if (sgm == 5 && prev) epi_store(0);
+      if (sgm == 6 && refill) dma_piece(3);
+      if (sgm == 7 && prev) epi_store(1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
   const int pro = nb < WR_D - 1 ? nb : WR_D - 1;
   for (int j = 0; j < pro; ++j) issue(j);
   // waves w and w+4 share a SIMD: the second runs half a block behind  (dbg 32 / 64: other pairings, A/B only)
   const bool late = (dbg & 32) ? (wave & 1) : (dbg & 64) ? ((wave >> 1) & 1) : ((wave >> 2) & 1);
 
+  if (ILV) {
+    for (int i = 0; i < nb; ++i) {
+      // block i landed?  VMEM issued after its last DMA piece: S1 of that block period, then two full periods
+      // of 4 DMA + 2 stores (stores start with the second block) -- all in order on vmcnt.
+      if (i + 2 >= nb) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (i < 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const bool refill = i + WR_D - 1 < nb;
+      if (refill) dma_rebase(i + WR_D - 1);
+      if (i > 0) store_rebase(i - 1);
+      mfma_block_ilv(i & (WR_D - 1), refill, i > 0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accP[r] = acc0[r] + acc1[r];
+    }
+    store_rebase(nb - 1);
+    epi_quad(0); epi_quad(1); epi_quad(2); epi_quad(3);
+    epi_store(0); epi_store(1);
+    return;
+  }
   for (int i = 0; i < nb; ++i) {
     // block i must have landed.  VMEM issued after its DMA: the DMA of blocks i+1, i+2 and (from
     // the fourth block on) three epilogues of stores -- all in order on vmcnt.
@@ -234,7 +340,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, 
 
 }  // namespace
 
-int g_use_wreg = 1;
+int g_use_wreg = 2;  // 1: memory phase after/before the MFMA phase, 2: memory work interleaved into the MFMA stream
 int g_wreg_dbg = 0;  // timing ablations only (results invalid): 1 no stores, 2 no MFMA, 4 no DMA refill, 8 no epilogue, 16 MFMA operands from registers only
 
 bool gemm_wreg_eligible(const GemmArgs& g) {
@@ -251,8 +357,8 @@ int launch_gemm_wreg(const GemmArgs& g, hipStream_t st) {
     CZC_HIP_CHECK(hipGetDevice(&dev));
     CZC_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
     n_cu = prop.multiProcessorCount & ~7;
-    CZC_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_wreg_kernel<ACT_NONE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, WR_LDS));
-    CZC_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_wreg_kernel<ACT_QUICK_GELU, false>, hipFuncAttributeMaxDynamicSharedMemorySize, WR_LDS));
+    CZC_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_wreg_kernel<ACT_NONE, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, WR_LDS));
+    CZC_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_wreg_kernel<ACT_QUICK_GELU, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, WR_LDS));
   }
   const int ncg = cdiv(g.N, 256);
   const int nblk = cdiv(g.M, WR_BLK);
@@ -263,13 +369,17 @@ int launch_gemm_wreg(const GemmArgs& g, hipStream_t st) {
   }
   if (nsets > nblk) nsets = nblk;
   dim3 grid(n_cu), block(512);
-  if (g_wreg_dbg & 16) {
-    CZC_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_wreg_kernel<ACT_NONE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, WR_LDS));
-    hipLaunchKernelGGL((gemm_wreg_kernel<ACT_NONE, true>), grid, block, WR_LDS, st, g, ncg, nsets, nblk, g_wreg_dbg);
-  } else if (g.act == ACT_QUICK_GELU)
-    hipLaunchKernelGGL((gemm_wreg_kernel<ACT_QUICK_GELU, false>), grid, block, WR_LDS, st, g, ncg, nsets, nblk, g_wreg_dbg);
-  else
-    hipLaunchKernelGGL((gemm_wreg_kernel<ACT_NONE, false>), grid, block, WR_LDS, st, g, ncg, nsets, nblk, g_wreg_dbg);
+#define CZC_WR_GO(A_, N_, I_)                                                                                      \
+  do {                                                                                                             \
+    CZC_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_wreg_kernel<A_, N_, I_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      WR_LDS));                                                                    \
+    hipLaunchKernelGGL((gemm_wreg_kernel<A_, N_, I_>), grid, block, WR_LDS, st, g, ncg, nsets, nblk, g_wreg_dbg);     \
+  } while (0)
+  const bool ilv = g_use_wreg == 2;
+  if (g_wreg_dbg & 16) CZC_WR_GO(ACT_NONE, true, false);
+  else if (g.act == ACT_QUICK_GELU) { if (ilv) CZC_WR_GO(ACT_QUICK_GELU, false, true); else CZC_WR_GO(ACT_QUICK_GELU, false, false); }
+  else { if (ilv) CZC_WR_GO(ACT_NONE, false, true); else CZC_WR_GO(ACT_NONE, false, false); }
+#undef CZC_WR_GO
   CZC_HIP_CHECK(hipGetLastError());
   return 0;
 }

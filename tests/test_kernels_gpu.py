@@ -16,6 +16,7 @@ from goldutil import GOLD
 pytestmark = pytest.mark.gpu
 
 BF16, F32 = native.PREC_BF16, native.PREC_F32
+WREG_DEFAULT = 2  # czc_test_set_option("wreg"): engine default form of the weight-stationary GEMM
 
 
 def _bf16_round(a):
@@ -259,7 +260,8 @@ def test_gemm256_variants(variant, M, N, K, act, resid):
 
 @pytest.mark.parametrize("M,N,act", [(2048, 512, 0), (3000, 1536, 0), (5000, 2048, 1), (70001, 512, 1), (2304, 320, 0),
                                      (2049, 1536, 1), (40000, 2048, 0)])
-def test_gemm_weight_stationary(M, N, act):
+@pytest.mark.parametrize("form", [1, 2])
+def test_gemm_weight_stationary(M, N, act, form):
     """K = 512 bf16-output layers (CLIP-text qkv / fc1) take the weights-in-registers kernel: ragged M
     (partial last 32-row block), N not a multiple of the 256-column group, both activations; compared with
     the fp64 product of the bf16-rounded operands and with the tiled kernel on the same inputs."""
@@ -270,12 +272,13 @@ def test_gemm_weight_stationary(M, N, act):
     W = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
     W[:, : K // 2] *= 3.0
     bias = rng.standard_normal(N).astype(np.float32)
-    C = E.test_gemm(BF16, A, W, bias=bias, act=act, typed_out=True)
     try:
+        assert lib.czc_test_set_option(b"wreg", form) == 0  # 1: separate memory phase, 2: interleaved into the MFMA stream
+        C = E.test_gemm(BF16, A, W, bias=bias, act=act, typed_out=True)
         assert lib.czc_test_set_option(b"wreg", 0) == 0
         C2 = E.test_gemm(BF16, A, W, bias=bias, act=act, typed_out=True)
     finally:
-        lib.czc_test_set_option(b"wreg", 1)
+        lib.czc_test_set_option(b"wreg", WREG_DEFAULT)
     pre = (_bf16_round(A).astype(np.float64) @ _bf16_round(W).astype(np.float64).T + bias).astype(np.float32)
     ref = _act(pre, act)
     tol = 2e-3 * np.sqrt(K / 64) + np.abs(ref) * 2.0 ** -8  # + one bf16 rounding of the output

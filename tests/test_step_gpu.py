@@ -272,9 +272,22 @@ def test_step_rejects_bad_arguments():
         e2.engine.step(inp.copy(), 4, 8, Engine.hyper(0.02, 2.0, 0.1, gamma=5.0))
 
 
+@pytest.fixture
+def one_gemm_family():
+    """The A/B equivalence tests below compare two runs of the SAME step whose CLIP-text row counts differ.  The
+    weight-stationary GEMM only takes M >= 2048 and sums k in two interleaved chains, so letting it serve one run
+    and the tiled kernel the other would add fp32 summation-order noise that has nothing to do with what these
+    tests check (prefix sharing / packing / pooling are the same math).  Its own parity is in test_kernels_gpu.py
+    and every golden-vector test in this file runs with it enabled."""
+    lib = native.load()
+    assert lib.czc_test_set_option(b"wreg", 0) == 0
+    yield
+    lib.czc_test_set_option(b"wreg", 2)
+
+
 @pytest.mark.parametrize("prec", [F32, BF16])
 @pytest.mark.parametrize("name", ["tiny_shuffle", "full_synth_b2"])
-def test_prefix_sharing_is_exact(prec, name):
+def test_prefix_sharing_is_exact(prec, name, one_gemm_family):
     """Encoding the candidates' common causal prefix once (trunk + branches) must not change the
     result: same step with share_prefix on and off."""
     meta, arr = load_case(name)
@@ -307,7 +320,7 @@ def test_prefix_sharing_is_exact(prec, name):
 
 
 @pytest.mark.parametrize("name", ["tiny_shuffle", "full_synth_b2"])
-def test_packed_branch_attention_matches_per_segment(name):
+def test_packed_branch_attention_matches_per_segment(name, one_gemm_family):
     """bf16 engine: packing G candidates into one attention tile vs one wave per candidate."""
     meta, arr = load_case(name)
     su = setup_for(meta, BF16)
@@ -330,7 +343,7 @@ def test_packed_branch_attention_matches_per_segment(name):
 
 
 @pytest.mark.parametrize("prec", [F32, BF16])
-def test_last_layer_pooling_is_exact(prec):
+def test_last_layer_pooling_is_exact(prec, one_gemm_family):
     """Running the last CLIP-text layer's out-projection/MLP on the EOS rows only is the same math."""
     meta, arr = load_case("full_synth_b2")
     su = setup_for(meta, prec)

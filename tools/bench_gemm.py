@@ -14,7 +14,9 @@ if len(sys.argv) > 3:
     lib.czc_test_set_option(b"wreg_dbg", int(sys.argv[3]))
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 768000
 shapes = [("qkv", 1536, 512, 0, 0), ("out", 512, 512, 0, 1), ("fc1", 2048, 512, 1, 0), ("fc2", 512, 2048, 0, 1)]
-VARIANTS = (3, 5)
+VARIANTS = tuple(int(v) for v in os.environ.get('CZC_GEMM_VARIANTS', '3,5,6').split(','))
+if len(sys.argv) > 4:
+    shapes.append(("fc1n", 2048, 512, 0, 0))  # fc1 shape without the activation (epilogue VALU share)
 tot = {v: 0.0 for v in VARIANTS}
 fl = 0.0
 for name, N, K, act, mode in shapes:
