@@ -220,35 +220,51 @@ __global__ __launch_bounds__(256) void attention_branch_kernel(const bf16_t* qkv
   const int nkt_t = (pre_len + 31) >> 5;
   const int Hd = heads * 64;
   const long pitch = 3L * Hd;
-  bf16_t* Vt = (bf16_t*)at_lds + (size_t)wave * 64 * KP;
+  // V image of this wave, ROW-major: 4 sub-tiles of 16 head dims, each [KP key slots][16 dims] (32-byte rows).
+  // Filled with plain 16-byte stores and consumed with ds_read_b64_tr_b16, which hands every lane of a
+  // 16-lane group one COLUMN of a [4 keys][16 dims] block -- the k-contiguous MFMA operand -- so the
+  // transpose costs nothing (the first version scattered 2-byte stores: 64 ds_write_b16 per lane).
+  // KP = 1 (mod 4): the four sub-tiles of one key land on different bank quarters.
+  unsigned char* Vimg = at_lds + (size_t)wave * 128 * KP;
+  const int SUB = KP * 32;
   const int own_slot0 = nkt_t * 32;
-
-  // ---- V^T -> LDS (trunk keys, then the packed own rows), padding slots zeroed ----
-  const int d0 = (lane & 7) * 8;
-  for (int k = lane >> 3; k < own_slot0 + 32; k += 8) {
-    long row = -1;
-    if (k < pre_len) row = (long)pre_off + k;
-    else if (k >= own_slot0 && k - own_slot0 < n_own) row = (long)r0 + (k - own_slot0);
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (row >= 0) v = *(const uint4*)(qkv + row * pitch + 2 * Hd + h * 64 + d0);
-    const unsigned w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int e = 0; e < 8; ++e) Vt[(d0 + e) * KP + k] = (bf16_t)((w[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
-  }
-  __syncthreads();
-
   const int half = lane >> 5, l31 = lane & 31;
   const int q = min(l31, n_own - 1);
+  // the query fragments first: their latency hides behind the V fill
+  const bf16_t* qp = qkv + ((long)r0 + q) * pitch + h * 64 + 8 * half;
+  uint4 qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const uint4*)(qp + 16 * ks);
+  {
+    // 32 key slots per pass, four independent 16-byte loads in flight per lane (a one-load-per-iteration loop
+    // serialises 8-16 L2 round trips in front of everything else; this kernel is latency-bound, not byte-bound)
+    const int sc = lane & 7;
+    unsigned char* wp = Vimg + (sc >> 1) * SUB + (sc & 1) * 16;
+    const bf16_t* vsrc = qkv + 2 * Hd + h * 64 + sc * 8;
+    for (int kb = 0; kb < own_slot0 + 32; kb += 32) {
+      uint4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = kb + 8 * u + (lane >> 3);
+        long row = -1;
+        if (k < pre_len) row = (long)pre_off + k;
+        else if (k >= own_slot0 && k - own_slot0 < n_own) row = (long)r0 + (k - own_slot0);
+        // padding slots must be zero: their P is 0, and 0 * garbage is not
+        v[u] = row >= 0 ? *(const uint4*)(vsrc + row * pitch) : make_uint4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) *(uint4*)(wp + (kb + 8 * u + (lane >> 3)) * 32) = v[u];
+    }
+  }
+  // no barrier: the image is private to this wave and a wave's LDS operations execute in order
+  asm volatile("" ::: "memory");
+
   // first slot of this query's own candidate
   int ss = 0;
   for (int j = 1; j < Gc; ++j) {
     const int o = tab.own_off[s0 + j] - r0;
     if (o <= q) ss = o;
   }
-  const bf16_t* qp = qkv + ((long)r0 + q) * pitch + h * 64 + 8 * half;
-  uint4 qf[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const uint4*)(qp + 16 * ks);
 
   f32x16_t st[AB_MAXT + 1];
 #pragma unroll
@@ -312,14 +328,21 @@ __global__ __launch_bounds__(256) void attention_branch_kernel(const bf16_t* qkv
     f32x16_t o;
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[r] = 0.f;
-    const bf16_t* vrow = Vt + (dt * 32 + l31) * KP;
+    // lane (dim l31 of this 32-dim half, half): keys 16*sstep + 4*half + {0..3} and + 8 + {0..3} of tile t --
+    // the slots its P fragment holds.  Its 16-lane group reads the [4 keys][16 dims] block of sub-tile
+    // 2*dt + (l31>>4); lane i of the group supplies row i>>2, dims 4*(i&3).. and receives column i.
+    typedef __attribute__((ext_vector_type(4))) short tr4_t;
+    typedef __attribute__((address_space(3))) tr4_t* tr4_lds_t;
+    const unsigned char* vbase =
+        Vimg + (dt * 2 + (l31 >> 4)) * SUB + (4 * half + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8;
 #pragma unroll
     for (int t = 0; t <= AB_MAXT; ++t) {
       if (t <= nkt_t) {
 #pragma unroll
         for (int sstep = 0; sstep < 2; ++sstep) {
-          const uint2 lo = *(const uint2*)(vrow + t * 32 + 16 * sstep + 4 * half);
-          const uint2 hi = *(const uint2*)(vrow + t * 32 + 16 * sstep + 8 + 4 * half);
+          const unsigned char* vp = vbase + (t * 32 + 16 * sstep) * 32;
+          const uint2 lo = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr4_lds_t)(vp)));
+          const uint2 hi = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr4_lds_t)(vp + 256)));
           const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
           o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vf),
                                                       __builtin_bit_cast(bf16x8_t, pf[t][sstep]), o, 0, 0, 0);
@@ -353,10 +376,10 @@ int launch_attention_shared(const void* qkv, const SegTable& tab, int B, int K, 
     hipLaunchKernelGGL(attention_mfma_kernel, grid, block, (size_t)wpb * 64 * KPt * 2, st, (const bf16_t*)qkv, trunks,
                        heads, 1, scale, KPt, (bf16_t*)out);
   }
-  const int KP = ((max_keys + 31) & ~31) + 32 + 4;  // trunk tiles + the own tile
+  const int KP = ((max_keys + 31) & ~31) + 32 + 1;  // key slots: trunk tiles + the own tile, padded to 1 (mod 4)
   const int gpi = cdiv(K, G);
   dim3 grid(B * gpi, cdiv(heads, wpb)), block(64 * wpb);
-  hipLaunchKernelGGL(attention_branch_kernel, grid, block, (size_t)wpb * 64 * KP * 2, st, (const bf16_t*)qkv, tab, B, K,
+  hipLaunchKernelGGL(attention_branch_kernel, grid, block, (size_t)wpb * 128 * KP, st, (const bf16_t*)qkv, tab, B, K,
                      G, heads, scale, KP, (bf16_t*)out);
   CZC_HIP_CHECK(hipGetLastError());
   return 0;
