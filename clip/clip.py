@@ -13,7 +13,6 @@ from __future__ import annotations
 import numpy as np
 
 from conzic_amd import native, synth
-from conzic_amd.imageproc import preprocess
 
 
 def _wrap(a: np.ndarray):
@@ -77,9 +76,10 @@ class CLIP:
     def compute_image_representation_from_image_instance(self, image):
         if self.processor is not None:
             pixels = self.processor(images=image, return_tensors="np")['pixel_values'].astype(np.float32)
-        else:
-            pixels = preprocess(image, self._image_size())
-        return _wrap(self._eng().encode_images(pixels))
+            return _wrap(self._eng().encode_images(pixels))
+        # resize / crop / normalise on the device, bit-identical to the PIL image processor (czc_preprocess_u8);
+        # (oracle/imageproc.py is the host statement of the same thing, used by the tests only)
+        return _wrap(self._eng().encode_pil(image))
 
     def compute_image_representation_from_image_path(self, image_path):
         from PIL import Image

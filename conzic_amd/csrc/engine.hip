@@ -77,6 +77,7 @@ struct czc_engine {
   int* h_totals = nullptr;  // pinned: [0]=rows [1]=max len [2]=overflow
   int last_BT = 0;
   int share_prefix = 1;  // encode the candidates' common causal prefix once per image
+  float* d_staged = nullptr; int staged_cap = 0, staged_n = 0;  // czc_preprocess_u8 output slots [cap][3][S][S]
   int pack_branches = 1; // pack several candidates' rows into one attention MFMA tile
   int pool_last_layer = 1; // last CLIP-text layer: out-proj + MLP on the EOS rows only
 
@@ -526,7 +527,7 @@ int czc_destroy(czc_engine* e) {
   (void)hipFree(e->patch_w);
   for (auto& kv : e->ws) if (kv.second.p) (void)hipFree(kv.second.p);
   for (void* p : e->bridge_allocs) (void)hipFree(p);
-  (void)hipFree(e->d_mask); (void)hipFree(e->d_lex); (void)hipFree(e->d_img_n);
+  (void)hipFree(e->d_mask); (void)hipFree(e->d_lex); (void)hipFree(e->d_img_n); (void)hipFree(e->d_staged);
   (void)hipFree(e->d_pos_tags); (void)hipFree(e->d_pos_masks);
   for (auto& kv : e->pk) for (hipEvent_t ev : kv.second.ev) (void)hipEventDestroy(ev);
   if (e->h_totals) (void)hipHostFree(e->h_totals);
@@ -736,6 +737,48 @@ int czc_encode_images(czc_engine* e, const float* pixels, int B, float* out_embe
   if (out_embeds) E_HIP(hipMemcpyAsync(out_embeds, emb, (size_t)B * c.clip_proj * 4, hipMemcpyDefault, e->st));
   E_HIP(hipStreamSynchronize(e->st));
   return CZC_OK;
+}
+
+int czc_preprocess_u8(czc_engine* e, const uint8_t* rgb, int height, int width, const float* mean, const float* stdv,
+                      int slot, float* pixels_out) {
+  if (!e || !rgb || !mean || !stdv || slot < 0) return CZC_ERR_ARG;
+  if (height <= 0 || width <= 0 || (long)height * width > (1L << 28)) return fail(e, CZC_ERR_ARG, "preprocess: bad image size%s");
+  E_HIP(hipSetDevice(e->dev));
+  const int S = e->cfg.vis_image;
+  const size_t img = (size_t)3 * S * S;
+  // staged batch grows by doubling and keeps its contents
+  if (slot >= e->staged_cap) {
+    int cap = e->staged_cap ? e->staged_cap : 8;
+    while (cap <= slot) cap *= 2;
+    float* nb = nullptr;
+    E_HIP(hipMalloc((void**)&nb, (size_t)cap * img * 4));
+    if (e->d_staged) {
+      E_HIP(hipMemcpyAsync(nb, e->d_staged, (size_t)e->staged_cap * img * 4, hipMemcpyDeviceToDevice, e->st));
+      E_HIP(hipStreamSynchronize(e->st));
+      E_HIP(hipFree(e->d_staged));
+    }
+    e->d_staged = nb;
+    e->staged_cap = cap;
+  }
+  unsigned char *d_rgb, *scratch;
+  E_CHECK(ensure(e, "pp_rgb", (size_t)height * width * 3, (void**)&d_rgb));
+  E_CHECK(ensure(e, "pp_scratch", imageproc_scratch_bytes(height, width, S), (void**)&scratch));
+  E_HIP(hipMemcpyAsync(d_rgb, rgb, (size_t)height * width * 3, hipMemcpyDefault, e->st));
+  float* dst = e->d_staged + (size_t)slot * img;
+  {
+    ProfScope ps(e, "rowops", 0);
+    if (launch_clip_preprocess(d_rgb, height, width, S, mean, stdv, scratch, dst, e->st)) return fail(e, CZC_ERR_HIP, "%s", g_err);
+  }
+  if (pixels_out) E_HIP(hipMemcpyAsync(pixels_out, dst, img * 4, hipMemcpyDefault, e->st));
+  E_HIP(hipStreamSynchronize(e->st));
+  if (slot + 1 > e->staged_n) e->staged_n = slot + 1;
+  return CZC_OK;
+}
+
+int czc_encode_staged(czc_engine* e, int B, float* out_embeds) {
+  if (!e || B <= 0) return CZC_ERR_ARG;
+  if (B > e->staged_n) return fail(e, CZC_ERR_STATE, "encode_staged: fewer staged images than requested%s");
+  return czc_encode_images(e, e->d_staged, B, out_embeds);
 }
 
 int czc_encode_text(czc_engine* e, const int32_t* clip_ids, const int32_t* clip_len, int n, float* out_embeds) {

@@ -29,6 +29,12 @@ int launch_gemm_wreg(const GemmArgs& g, hipStream_t st);  // gemm_wreg.hip: weig
 extern int g_use_wreg;
 extern int g_wreg_dbg;
 
+// ---- imageproc.hip ------------------------------------------------------------------------
+// CLIP image geometry on the device, bit-identical to the PIL path of the reference's CLIPProcessor
+size_t imageproc_scratch_bytes(int H, int W, int S);
+int launch_clip_preprocess(const unsigned char* rgb_dev, int H, int W, int S, const float* mean, const float* stdv,
+                           unsigned char* scratch, float* out, hipStream_t st);
+
 // ---- rowops.hip -------------------------------------------------------------------------
 // y = LN(x[row_idx ? row_idx[m] : m]) ; x fp32 [*,H]; outputs optional
 int launch_layernorm(int prec, const float* x, const int* row_idx, const float* gamma, const float* beta, float eps,

@@ -133,6 +133,36 @@ class Engine:
         self._ck(self.lib.czc_encode_images(self.h, _ptr(pixels), B, out.ctypes.data), "czc_encode_images")
         return out
 
+    def preprocess_u8(self, rgb, slot: int = 0, want_pixels: bool = False, mean=None, std=None):
+        """CLIPProcessor geometry on the device (czc_preprocess_u8): rgb uint8 [H,W,3] -> staged slot `slot`;
+        returns the fp32 [3,S,S] pixels when want_pixels."""
+        from .synth import CLIP_MEAN, CLIP_STD
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+        if rgb.ndim != 3 or rgb.shape[2] != 3:
+            raise ValueError("rgb must be uint8 [H, W, 3]")
+        m = np.ascontiguousarray(CLIP_MEAN if mean is None else mean, dtype=np.float32)
+        d = np.ascontiguousarray(CLIP_STD if std is None else std, dtype=np.float32)
+        S = self.clip_cfg.v_image
+        out = np.empty((3, S, S), dtype=np.float32) if want_pixels else None
+        self._ck(self.lib.czc_preprocess_u8(self.h, rgb.ctypes.data, rgb.shape[0], rgb.shape[1], m.ctypes.data, d.ctypes.data,
+                                            int(slot), out.ctypes.data if want_pixels else None), "czc_preprocess_u8")
+        return out
+
+    def encode_staged(self, B: int) -> np.ndarray:
+        out = np.empty((int(B), self.clip_cfg.proj), dtype=np.float32)
+        self._ck(self.lib.czc_encode_staged(self.h, int(B), out.ctypes.data), "czc_encode_staged")
+        return out
+
+    def encode_pil(self, images) -> np.ndarray:
+        """PIL images / uint8 arrays -> image_embeds, geometry and normalisation on the device."""
+        if not isinstance(images, (list, tuple)):
+            images = [images]
+        for i, im in enumerate(images):
+            if not isinstance(im, np.ndarray):
+                im = np.asarray(im.convert("RGB"))
+            self.preprocess_u8(im, i)
+        return self.encode_staged(len(images))
+
     def set_image_embeds(self, embeds):
         e = np.ascontiguousarray(embeds, dtype=np.float32)
         self._ck(self.lib.czc_set_image_embeds(self.h, e.ctypes.data, e.shape[0]), "czc_set_image_embeds")

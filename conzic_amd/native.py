@@ -78,6 +78,8 @@ SIGNATURES = {
     "czc_set_lexicon": (_I, [_P, _P, _I]),
     "czc_set_pos": (_I, [_P, _P, _I, _P, _I]),
     "czc_encode_images": (_I, [_P, _P, _I, _P]),
+    "czc_preprocess_u8": (_I, [_P, _P, _I, _I, _P, _P, _I, _P]),
+    "czc_encode_staged": (_I, [_P, _I, _P]),
     "czc_set_image_embeds": (_I, [_P, _P, _I]),
     "czc_encode_text": (_I, [_P, _P, _P, _I, _P]),
     "czc_step": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, C.POINTER(Hyper), C.POINTER(StepOut)]),

@@ -186,10 +186,26 @@ def make_images_u8(n: int, size: int = 224, seed: int = 1234, first: int = 0) ->
     return out
 
 
+def make_odd_images(S):
+    """Deterministic odd-sized RGB test images for the resize/crop path: smooth gradients + seeded noise, both
+    orientations, down- and up-sampling, one side already S, extreme aspect."""
+    sizes = [(int(S * 1.34) + 1, int(S * 2.01)), (int(S * 2.23), int(S * 1.16) + 1), (S, int(S * 1.8)), (int(S * 2.9), S),
+             (int(S * 0.61), int(S * 0.83)), (S + 1, S + 1), (int(S * 4.3), int(S * 1.05)), (S, S)]
+    out = []
+    for i, (h, w) in enumerate(sizes):
+        rng = np.random.default_rng(7000 + i)
+        yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+        base = np.stack([127 + 120 * np.sin(xx / (3.0 + i) + yy / 7.0), 127 + 120 * np.cos(yy / (2.5 + i) - xx / 11.0),
+                         (xx * 255.0 / max(w - 1, 1) + yy * 255.0 / max(h - 1, 1)) / 2], -1)
+        noise = rng.integers(-40, 41, size=(h, w, 3))
+        out.append(np.clip(base + noise, 0, 255).astype(np.uint8))
+    return out
+
+
 def pixels_from_u8(img_u8: np.ndarray) -> np.ndarray:
     """CLIP image processor on an already 224x224 RGB image: /255, normalise, HWC->CHW
     (clip/clip.py:55-56 with resize/crop being the identity)."""
-    x = img_u8.astype(np.float32) * np.float32(1.0 / 255.0)
+    x = img_u8.astype(np.float32) / np.float32(255.0)  # bit-exact with the HF image processor (fp32 division)
     x = (x - CLIP_MEAN) / CLIP_STD
     return np.ascontiguousarray(np.moveaxis(x, -1, -3)).astype(np.float32)
 

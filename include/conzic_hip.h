@@ -146,6 +146,14 @@ int czc_set_pos(czc_engine* e, const uint8_t* tag_of_token, int vocab, const uin
  * keeps the L2-normalised embeds resident for the following step/generate calls (the north
  * star's "encode once per image and cache"). */
 int czc_encode_images(czc_engine* e, const float* pixels, int B, float* out_embeds);
+/* The image processor itself (clip/clip.py:55-56 -> CLIPProcessor -> HF CLIPImageProcessor, PIL backend): RGB uint8
+ * [height][width][3] (host or device pointer) -> bicubic resize of the shorter side to S (Pillow's 8-bit resampler,
+ * bit-exact) -> centre crop SxS -> /255 -> (x - mean[c]) / std[c] -> CHW fp32, written to slot `slot` of the engine's
+ * staged pixel batch on the device (and to pixels_out [3,S,S], host or device, when not NULL).  mean/std: 3 floats. */
+int czc_preprocess_u8(czc_engine* e, const uint8_t* rgb, int height, int width, const float* mean, const float* stdv,
+                      int slot, float* pixels_out);
+/* czc_encode_images over staged slots 0..B-1 (no host round trip of the pixels). */
+int czc_encode_staged(czc_engine* e, int B, float* out_embeds);
 /* Alternative: hand over image_embeds computed elsewhere (fp32 [B,proj], un-normalised). */
 int czc_set_image_embeds(czc_engine* e, const float* embeds, int B);
 

@@ -1,11 +1,12 @@
-"""CLIP image pre-processing on the host (clip/clip.py:55-56 -> CLIPProcessor): RGB, resize the
-shorter side to S with bicubic resampling, centre crop SxS, /255, normalise, CHW.
-Once per image; the result feeds czc_encode_images."""
+"""TEST INFRASTRUCTURE (oracle): CLIP image pre-processing on the host through PIL itself
+(clip/clip.py:55-56 -> CLIPProcessor -> HF CLIPImageProcessor, PIL backend): RGB, resize the shorter side to S
+with bicubic resampling, centre crop SxS, /255, normalise, CHW.  The product path is czc_preprocess_u8
+(conzic_amd/csrc/imageproc.hip); this is what it is checked against, bit for bit."""
 from __future__ import annotations
 
 import numpy as np
 
-from .synth import CLIP_MEAN, CLIP_STD
+from conzic_amd.synth import CLIP_MEAN, CLIP_STD
 
 
 def preprocess(images, size: int = 224) -> np.ndarray:
@@ -26,7 +27,7 @@ def preprocess(images, size: int = 224) -> np.ndarray:
             im = im.resize((nw, nh), resample=Image.BICUBIC)
             left, top = (nw - size) // 2, (nh - size) // 2
             im = im.crop((left, top, left + size, top + size))
-        x = np.asarray(im, dtype=np.float32) * np.float32(1.0 / 255.0)
+        x = np.asarray(im, dtype=np.float32) / np.float32(255.0)
         x = (x - CLIP_MEAN) / CLIP_STD
         out[i] = np.moveaxis(x, -1, 0)
     return out

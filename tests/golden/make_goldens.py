@@ -340,6 +340,31 @@ def vision_golden(tmp):
         print(f"[golden] vision_{label}", emb.shape)
 
 
+def imageproc_golden(tmp):
+    """Pins the image-processor geometry: synthetic odd-sized images through the reference's own CLIPProcessor
+    (clip/clip.py:55-56); stored as the uint8 crop (pixel_values are an exact fp32 function of it)."""
+    from PIL import Image
+    for label, tiny in (("tiny", True), ("full", False)):
+        sv = synth.make_vocab_tiny() if tiny else synth.make_vocab()
+        bcfg = synth.bert_tiny(len(sv.bert_tokens)) if tiny else synth.bert_base()
+        ccfg = synth.clip_tiny(len(sv.clip_vocab)) if tiny else synth.clip_b32()
+        _, _, clip = build_hf(bcfg, ccfg, sv, 11, 12, tmp)
+        S = ccfg.v_image
+        imgs = synth.make_odd_images(S)
+        if not tiny:
+            imgs = imgs[:4] + imgs[4:6]
+        crops = []
+        for u in imgs:
+            pv = clip.processor(images=Image.fromarray(u), return_tensors="pt")["pixel_values"].numpy()[0]
+            u8 = np.rint((np.moveaxis(pv, 0, -1).astype(np.float64) * synth.CLIP_STD + synth.CLIP_MEAN) * 255.0)
+            u8 = u8.astype(np.uint8)
+            assert np.array_equal(synth.pixels_from_u8(u8[None])[0], pv), "pixel_values must be an exact function of the crop"
+            crops.append(u8)
+        np.savez_compressed(os.path.join(HERE, f"imageproc_{label}.npz"), crops=np.stack(crops),
+                            sizes=np.array([im.shape[:2] for im in imgs], np.int32), n=np.int32(len(imgs)))
+        print(f"[golden] imageproc_{label}", len(imgs), os.path.getsize(os.path.join(HERE, f"imageproc_{label}.npz")) // 1024, "KB")
+
+
 CASES = dict(
     tiny_seq=dict(tiny=True, B=2, L=5, K=12, I=3, order="sequential"),
     tiny_shuffle=dict(tiny=True, B=3, L=6, K=16, I=2, order="shuffle"),
@@ -367,6 +392,8 @@ def main():
             text_bridge_golden()
         if a.only in (None, "vision"):
             vision_golden(tmp)
+        if a.only in (None, "imageproc"):
+            imageproc_golden(tmp)
         for name, kw in CASES.items():
             if a.only not in (None, name):
                 continue

@@ -94,3 +94,14 @@ def test_oracle_full_size_first_step_cfg1():
     np.testing.assert_allclose(r["clip_ref"].numpy(), arr["clip_ref"][0], atol=3e-6)
     np.testing.assert_allclose(r["clip_score"].numpy(), arr["clip_score"][0], atol=1e-6)
     np.testing.assert_array_equal(r["inp_after"].numpy()[:, 4], arr["inp_before"][1][:, 4])
+
+
+@pytest.mark.parametrize("label,S", [("tiny", 32), ("full", 224)])
+def test_oracle_imageproc_matches_reference_processor(label, S):
+    """oracle/imageproc.py (PIL resize + crop + normalise) against pixel_values captured from the reference's own
+    CLIPProcessor on odd-sized synthetic images (tests/golden/make_goldens.py --only imageproc): bit-exact."""
+    from oracle.imageproc import preprocess
+    z = np.load(os.path.join(GOLD, f"imageproc_{label}.npz"))
+    imgs = synth.make_odd_images(S)[: int(z["n"])]
+    assert [list(i.shape[:2]) for i in imgs] == z["sizes"].tolist()
+    np.testing.assert_array_equal(preprocess(imgs, S), synth.pixels_from_u8(z["crops"]))
