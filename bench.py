@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--sentiment", default="positive", choices=["positive", "negative"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event kernel timing (roofline)")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=INT", help="engine option (czc_set_option), A/B runs")
     a = ap.parse_args()
 
     import torch
@@ -123,6 +124,9 @@ def main():
                                  bert_cfg=bcfg, clip_cfg=ccfg, lexicon=a.gamma is not None)
     del bw, cw
     eng = su.engine
+    for kv in a.opt:
+        k, v = kv.split("=")
+        eng.set_option(k, int(v))
     t_setup = time.time() - t0
 
     B, L, K, I = a.images, a.L, a.topk, a.iters

@@ -16,6 +16,8 @@
 //    shuffle, and the probabilities already sit in the B-operand layout of O^T = V^T.P^T; only V
 //    goes through LDS (transposed on the way in).  8 MFMAs per (segment, head) at Tc<=32.
 //  * attention_valu_kernel (f32 engine): exact-fp32 wavefront version, K^T/V/Q in LDS.
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace czc {
@@ -362,6 +364,239 @@ __global__ __launch_bounds__(256) void attention_branch_kernel(const bf16_t* qkv
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// attention_image_kernel: the same packed-branch attention, organised so that HBM latency is never on a
+// wave's critical path.  attention_branch_kernel gives every (group, head) its own wave, and each wave
+// is one chain of dependent round trips (segment table -> Q/V rows -> K rows -> ... -> store): at 16
+// waves per CU the kernel runs at 2.7 TB/s although it only moves 1.3 GB.  Here a work-group owns ONE
+// image and four heads and walks the image's K/G groups itself:
+//   * a group's 32 rows (q, k, v columns of the four heads: 48 KiB) are fetched by LDS-DMA into a two-deep
+//     ring while the previous group is being computed, 12 DMA instructions per wave and group, exact
+//     `vmcnt` accounting as in gemm_wreg.hip (loop VMEM only from inline asm).  (A three-deep ring with the
+//     queries in registers measured the same 0.39 ms: the kernel is bound by the ~80 VMEM instructions a
+//     work-group issues per group, not by how far ahead they are issued.);
+//   * the image's trunk keys / values are loaded once, the K+1 segment offsets once (LDS);
+//   * Q/K tiles are row-major [32][512 B] with 16-byte chunks XOR (row & 15) (conflict-free ds_read_b128),
+//     V goes straight into the [16-dim sub-tile][key][16] image that ds_read_b64_tr_b16 wants: one DMA
+//     instruction gathers one sub-tile (32 keys x 32 B);
+//   * rows past the group (the next group's) are zero-filled by the descriptor and dropped on store.
+// One wave = one head; math identical to attention_branch_kernel (S^T = K Q^T in-lane softmax, P V by MFMA).
+// Needs heads % 4 == 0, trunk <= 32 keys, K <= 1024.
+// ------------------------------------------------------------------------------------------------
+constexpr int A2_ROWB = 512;             // 4 heads x 64 dims x bf16
+constexpr int A2_TILE = 32 * A2_ROWB;    // 16 KiB
+constexpr int A2_STAGE = 3 * A2_TILE;    // q, k, v of one group
+constexpr int A2_RING = 2;               // the next group streams in while this one is computed
+constexpr int A2_META = 4224;            // K + 1 segment offsets (K <= 1024), padded
+constexpr int A2_LDS = A2_RING * A2_STAGE + 2 * A2_TILE + A2_META;
+
+__global__ __launch_bounds__(256) void attention_image_kernel(const bf16_t* qkv, SegTable tab, int B, int K, int G, int heads,
+                                                              float scale, bf16_t* out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char at_lds[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int b = blockIdx.x, hq = blockIdx.y;
+  const int h = hq * 4 + wave;
+  const int Hd = heads * 64;
+  const int pitch = 3 * Hd * 2;  // bytes per qkv row
+  unsigned char* ring = at_lds;
+  unsigned char* Kt = at_lds + A2_RING * A2_STAGE;  // trunk keys, same layout as a K tile
+  unsigned char* Vt = Kt + A2_TILE;                 // trunk values, sub-tile images
+  int* meta = (int*)(Vt + A2_TILE);
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(
+      (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)at_lds);
+
+  const int sb = B + b * K;
+  for (int j = threadIdx.x; j <= K; j += 256)
+    meta[j] = j < K ? tab.own_off[sb + j] : tab.own_off[sb + K - 1] + tab.own_len[sb + K - 1];
+  const int pre_off = tab.pre_off[sb], pre_len = tab.pre_len[sb];
+  __syncthreads();
+
+  // ---- DMA plumbing: per-lane source offsets inside a 32-row block ----
+  // row-major tiles: piece p (0..15) = rows 2p, 2p+1; lane -> row 2p + (lane>>5), physical chunk lane&31
+  // sub-tile images: piece s (0..15) = sub-tile s; lane -> key lane>>1, 16-byte half lane&1
+  int vo_row[4], vo_sub[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int r = 2 * (wave * 4 + u) + (lane >> 5);
+    vo_row[u] = r * pitch + hq * A2_ROWB + (((lane & 31) ^ (r & 15)) << 4);
+    vo_sub[u] = (lane >> 1) * pitch + hq * A2_ROWB + (wave * 4 + u) * 32 + (lane & 1) * 16;
+  }
+  auto dma4 = [&](unsigned dst, const int (&vo)[4], int part, u32x4_t rs) {  // this wave's quarter of one tile
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %6, %7 offen lds\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %6, %7 offen lds\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %6, %7 offen lds\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %5, %6, %7 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(dst + wave * 4096), "v"(vo[0]), "v"(vo[1]), "v"(vo[2]), "v"(vo[3]), "s"(rs), "s"(part * Hd * 2)
+        : "memory", "scc");
+  };
+  auto rows_desc = [&](long row0, int nrows) {  // descriptor over rows [row0, row0 + nrows): the rest reads as zero
+    const unsigned long long pa = (unsigned long long)qkv + (unsigned long long)row0 * pitch;
+    u32x4_t rs;
+    rs.x = __builtin_amdgcn_readfirstlane((unsigned)pa);
+    rs.y = __builtin_amdgcn_readfirstlane((unsigned)(pa >> 32) & 0xffffu);
+    rs.z = __builtin_amdgcn_readfirstlane((unsigned)(nrows * pitch));
+    rs.w = 0x00020000u;
+    return rs;
+  };
+  const int ngroups = (K + G - 1) / G;
+  auto issue_group = [&](int gi) {
+    const int k0 = gi * G, Gc = min(G, K - k0);
+    const int r0 = __builtin_amdgcn_readfirstlane(meta[k0]);
+    const int n_own = min(__builtin_amdgcn_readfirstlane(meta[k0 + Gc]) - r0, 32);
+    const u32x4_t rs = rows_desc(r0, n_own);
+    const unsigned st = lds0 + (gi & 1) * A2_STAGE;
+    dma4(st, vo_row, 0, rs);
+    dma4(st + A2_TILE, vo_row, 1, rs);
+    dma4(st + 2 * A2_TILE, vo_sub, 2, rs);
+  };
+  // trunk (once), then the first group.  VMEM per wave: trunk 8, every group 12 DMA, 4 stores.
+  {
+    const u32x4_t rt = rows_desc(pre_off, min(pre_len, 32));
+    dma4(lds0 + A2_RING * A2_STAGE, vo_row, 1, rt);
+    dma4(lds0 + A2_RING * A2_STAGE + A2_TILE, vo_sub, 2, rt);
+  }
+  issue_group(0);
+
+  const int opitch = Hd * 2;
+  const int nkt_t = pre_len > 0 ? 1 : 0;
+
+  typedef __attribute__((ext_vector_type(4))) short tr4_t;
+  typedef __attribute__((address_space(3))) tr4_t* tr4_lds_t;
+  typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+
+  for (int gi = 0; gi < ngroups; ++gi) {
+    // group gi landed?  issued after its DMA: the 4 stores of group gi-1 (in order on vmcnt)
+    if (gi == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // publishes group gi; every wave has left the other stage
+    asm volatile("" ::: "memory");
+    if (gi + 1 < ngroups) issue_group(gi + 1);
+
+    const int k0 = gi * G, Gc = min(G, K - k0);
+    const int r0 = __builtin_amdgcn_readfirstlane(meta[k0]);
+    const int n_own = min(__builtin_amdgcn_readfirstlane(meta[k0 + Gc]) - r0, 32);
+    const unsigned char* Qs = ring + (gi & 1) * A2_STAGE;
+    const unsigned char* Ks = Qs + A2_TILE;
+    const unsigned char* Vs = Ks + A2_TILE;
+    const int q = min(l31, n_own - 1);
+    int ss = 0;  // first slot of this query's own candidate
+    for (int j = 1; j < Gc; ++j) {
+      const int o = meta[k0 + j] - r0;
+      if (o <= q) ss = o;
+    }
+    // fragments: head `wave` owns chunks 8*wave .. 8*wave+7 of a row; step ks takes chunk 2ks + half
+    const int cq = wave * 8 + half;
+    uint4 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const uint4*)(Qs + q * A2_ROWB + (((cq + 2 * ks) ^ (q & 15)) << 4));
+    f32x16_t st[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const unsigned char* kb = t == 0 ? Kt : Ks;
+      f32x16_t acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const uint4 kf = *(const uint4*)(kb + l31 * A2_ROWB + (((cq + 2 * ks) ^ (l31 & 15)) << 4));
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, kf),
+                                                      __builtin_bit_cast(bf16x8_t, qf[ks]), acc, 0, 0, 0);
+      }
+      st[t] = acc;
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int idx = (r & 3) + 8 * (r >> 2) + 4 * half;
+        const bool ok = t == 0 ? (idx < pre_len) : (idx >= ss && idx <= q);
+        const float v = ok ? st[t][r] * scale : -INFINITY;
+        st[t][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+    uint4 pf[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float e[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        e[r] = __expf(st[t][r] - mx);
+        sum += e[r];
+      }
+#pragma unroll
+      for (int sstep = 0; sstep < 2; ++sstep) {
+        pf[t][sstep].x = (uint32_t)f2bf(e[8 * sstep + 0]) | ((uint32_t)f2bf(e[8 * sstep + 1]) << 16);
+        pf[t][sstep].y = (uint32_t)f2bf(e[8 * sstep + 2]) | ((uint32_t)f2bf(e[8 * sstep + 3]) << 16);
+        pf[t][sstep].z = (uint32_t)f2bf(e[8 * sstep + 4]) | ((uint32_t)f2bf(e[8 * sstep + 5]) << 16);
+        pf[t][sstep].w = (uint32_t)f2bf(e[8 * sstep + 6]) | ((uint32_t)f2bf(e[8 * sstep + 7]) << 16);
+      }
+    }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    u32x4_t rc;  // output descriptor: rows of this group only (the rest is dropped)
+    {
+      const unsigned long long pc = (unsigned long long)out + (unsigned long long)r0 * opitch;
+      rc.x = __builtin_amdgcn_readfirstlane((unsigned)pc);
+      rc.y = __builtin_amdgcn_readfirstlane((unsigned)(pc >> 32) & 0xffffu);
+      rc.z = __builtin_amdgcn_readfirstlane((unsigned)(n_own * opitch));
+      rc.w = 0x00020000u;
+    }
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      f32x16_t o;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[r] = 0.f;
+      // sub-tile (4*wave + 2*dt + (l31>>4)); lane i of a 16-lane group supplies row i>>2, dims 4*(i&3)..
+      const int sub_off = (wave * 4 + dt * 2 + (l31 >> 4)) * 1024 + (4 * half + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        if (t >= 1 - nkt_t) {  // the trunk tile is skipped for an empty trunk
+          const unsigned char* vb = (t == 0 ? Vt : Vs) + sub_off;
+#pragma unroll
+          for (int sstep = 0; sstep < 2; ++sstep) {
+            const unsigned char* vp = vb + 16 * sstep * 32;
+            const uint2 lo = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr4_lds_t)(vp)));
+            const uint2 hi = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr4_lds_t)(vp + 256)));
+            const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vf), __builtin_bit_cast(bf16x8_t, pf[t][sstep]),
+                                                        o, 0, 0, 0);
+          }
+        }
+      }
+      // lane = query row l31, registers = dims 8qd + 4half + e of this 32-dim half.  v_permlane32_swap pairs
+      // quad qd of the lower half-wave with quad qd+2 of the upper one, so that every lane ends up with 8
+      // consecutive dims: two 16-byte stores per lane instead of four 8-byte ones (VMEM issue is what binds).
+      u32x2_t w[4];
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        w[qd].x = (uint32_t)f2bf(o[4 * qd] * inv) | ((uint32_t)f2bf(o[4 * qd + 1] * inv) << 16);
+        w[qd].y = (uint32_t)f2bf(o[4 * qd + 2] * inv) | ((uint32_t)f2bf(o[4 * qd + 3] * inv) << 16);
+      }
+#pragma unroll
+      for (int qa = 0; qa < 2; ++qa) {
+        const u32x2_t sx = __builtin_amdgcn_permlane32_swap(w[qa].x, w[qa + 2].x, false, false);
+        const u32x2_t sy = __builtin_amdgcn_permlane32_swap(w[qa].y, w[qa + 2].y, false, false);
+        const u32x4_t d = {sx.x, sy.x, sx.y, sy.y};  // lower half-wave: quad qa, dims 0..7; upper: quad qa+2
+        const unsigned co = (unsigned)(l31 * opitch + (h * 64 + dt * 32 + 8 * (qa + 2 * half)) * 2);
+        asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" : : "v"(d), "v"(co), "s"(rc) : "memory");
+      }
+    }
+  }
+}
+
+int g_use_attention_image = 1;
+
 // trunks through the generic kernel (n_seg = B), branches packed G per wave
 int launch_attention_shared(const void* qkv, const SegTable& tab, int B, int K, int max_own, int max_keys, int heads,
                             float scale, void* out, hipStream_t st) {
@@ -375,6 +610,17 @@ int launch_attention_shared(const void* qkv, const SegTable& tab, int B, int K, 
     dim3 grid(B, cdiv(heads, wpb)), block(64 * wpb);
     hipLaunchKernelGGL(attention_mfma_kernel, grid, block, (size_t)wpb * 64 * KPt * 2, st, (const bf16_t*)qkv, trunks,
                        heads, 1, scale, KPt, (bf16_t*)out);
+  }
+  if (g_use_attention_image && heads % 4 == 0 && max_keys <= 32 && K <= 1024) {
+    static bool attr = false;
+    if (!attr) {
+      CZC_HIP_CHECK(hipFuncSetAttribute((const void*)attention_image_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, A2_LDS));
+      attr = true;
+    }
+    hipLaunchKernelGGL(attention_image_kernel, dim3(B, heads / 4), dim3(256), A2_LDS, st, (const bf16_t*)qkv, tab, B, K, G, heads,
+                       scale, (bf16_t*)out);
+    CZC_HIP_CHECK(hipGetLastError());
+    return 0;
   }
   const int KP = ((max_keys + 31) & ~31) + 32 + 1;  // key slots: trunk tiles + the own tile, padded to 1 (mod 4)
   const int gpi = cdiv(K, G);

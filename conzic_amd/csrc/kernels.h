@@ -78,6 +78,7 @@ struct SegTable {
 int launch_attention(int prec, const void* qkv, const SegTable& tab, int max_keys, int heads, int causal, float scale,
                      void* out, hipStream_t st);
 extern int g_use_mfma_attention;
+extern int g_use_attention_image;  // per-image persistent branch attention (LDS-DMA ring) where the shapes allow
 // bf16 engine, shared-prefix plan (B trunk segments then B*K branch segments): returns -1 when the
 // shapes do not fit the packed-branch kernel (caller then uses launch_attention)
 int launch_attention_shared(const void* qkv, const SegTable& tab, int B, int K, int max_own, int max_keys, int heads,
