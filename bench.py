@@ -126,7 +126,10 @@ def main():
     eng = su.engine
     for kv in a.opt:
         k, v = kv.split("=")
-        eng.set_option(k, int(v))
+        if k.startswith("test:"):  # kernel-level A/B switches (czc_test_set_option)
+            assert native.load().czc_test_set_option(k[5:].encode(), int(v)) == 0, k
+        else:
+            eng.set_option(k, int(v))
     t_setup = time.time() - t0
 
     B, L, K, I = a.images, a.L, a.topk, a.iters

@@ -147,10 +147,10 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const bf16_t* qkv, 
         }
 #pragma unroll
         for (int sstep = 0; sstep < 2; ++sstep) {
-          pf[kt][sstep].x = (uint32_t)f2bf(e[8 * sstep + 0]) | ((uint32_t)f2bf(e[8 * sstep + 1]) << 16);
-          pf[kt][sstep].y = (uint32_t)f2bf(e[8 * sstep + 2]) | ((uint32_t)f2bf(e[8 * sstep + 3]) << 16);
-          pf[kt][sstep].z = (uint32_t)f2bf(e[8 * sstep + 4]) | ((uint32_t)f2bf(e[8 * sstep + 5]) << 16);
-          pf[kt][sstep].w = (uint32_t)f2bf(e[8 * sstep + 6]) | ((uint32_t)f2bf(e[8 * sstep + 7]) << 16);
+          pf[kt][sstep].x = pack2_bf16(e[8 * sstep + 0], e[8 * sstep + 1]);
+          pf[kt][sstep].y = pack2_bf16(e[8 * sstep + 2], e[8 * sstep + 3]);
+          pf[kt][sstep].z = pack2_bf16(e[8 * sstep + 4], e[8 * sstep + 5]);
+          pf[kt][sstep].w = pack2_bf16(e[8 * sstep + 6], e[8 * sstep + 7]);
         }
       }
     }
@@ -183,8 +183,8 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const bf16_t* qkv, 
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
           uint2 w;
-          w.x = (uint32_t)f2bf(o[4 * qd] * inv) | ((uint32_t)f2bf(o[4 * qd + 1] * inv) << 16);
-          w.y = (uint32_t)f2bf(o[4 * qd + 2] * inv) | ((uint32_t)f2bf(o[4 * qd + 3] * inv) << 16);
+          w.x = pack2_bf16(o[4 * qd] * inv, o[4 * qd + 1] * inv);
+          w.y = pack2_bf16(o[4 * qd + 2] * inv, o[4 * qd + 3] * inv);
           *(uint2*)(op + 8 * qd) = w;
         }
       }
@@ -316,10 +316,10 @@ __global__ __launch_bounds__(256) void attention_branch_kernel(const bf16_t* qkv
       }
 #pragma unroll
       for (int sstep = 0; sstep < 2; ++sstep) {
-        pf[t][sstep].x = (uint32_t)f2bf(e[8 * sstep + 0]) | ((uint32_t)f2bf(e[8 * sstep + 1]) << 16);
-        pf[t][sstep].y = (uint32_t)f2bf(e[8 * sstep + 2]) | ((uint32_t)f2bf(e[8 * sstep + 3]) << 16);
-        pf[t][sstep].z = (uint32_t)f2bf(e[8 * sstep + 4]) | ((uint32_t)f2bf(e[8 * sstep + 5]) << 16);
-        pf[t][sstep].w = (uint32_t)f2bf(e[8 * sstep + 6]) | ((uint32_t)f2bf(e[8 * sstep + 7]) << 16);
+        pf[t][sstep].x = pack2_bf16(e[8 * sstep + 0], e[8 * sstep + 1]);
+        pf[t][sstep].y = pack2_bf16(e[8 * sstep + 2], e[8 * sstep + 3]);
+        pf[t][sstep].z = pack2_bf16(e[8 * sstep + 4], e[8 * sstep + 5]);
+        pf[t][sstep].w = pack2_bf16(e[8 * sstep + 6], e[8 * sstep + 7]);
       }
     }
   }
@@ -356,8 +356,8 @@ __global__ __launch_bounds__(256) void attention_branch_kernel(const bf16_t* qkv
 #pragma unroll
       for (int qd = 0; qd < 4; ++qd) {
         uint2 w;
-        w.x = (uint32_t)f2bf(o[4 * qd] * inv) | ((uint32_t)f2bf(o[4 * qd + 1] * inv) << 16);
-        w.y = (uint32_t)f2bf(o[4 * qd + 2] * inv) | ((uint32_t)f2bf(o[4 * qd + 3] * inv) << 16);
+        w.x = pack2_bf16(o[4 * qd] * inv, o[4 * qd + 1] * inv);
+        w.y = pack2_bf16(o[4 * qd + 2] * inv, o[4 * qd + 3] * inv);
         *(uint2*)(op + 8 * qd) = w;
       }
     }
@@ -536,10 +536,10 @@ __global__ __launch_bounds__(256) void attention_image_kernel(const bf16_t* qkv,
       }
 #pragma unroll
       for (int sstep = 0; sstep < 2; ++sstep) {
-        pf[t][sstep].x = (uint32_t)f2bf(e[8 * sstep + 0]) | ((uint32_t)f2bf(e[8 * sstep + 1]) << 16);
-        pf[t][sstep].y = (uint32_t)f2bf(e[8 * sstep + 2]) | ((uint32_t)f2bf(e[8 * sstep + 3]) << 16);
-        pf[t][sstep].z = (uint32_t)f2bf(e[8 * sstep + 4]) | ((uint32_t)f2bf(e[8 * sstep + 5]) << 16);
-        pf[t][sstep].w = (uint32_t)f2bf(e[8 * sstep + 6]) | ((uint32_t)f2bf(e[8 * sstep + 7]) << 16);
+        pf[t][sstep].x = pack2_bf16(e[8 * sstep + 0], e[8 * sstep + 1]);
+        pf[t][sstep].y = pack2_bf16(e[8 * sstep + 2], e[8 * sstep + 3]);
+        pf[t][sstep].z = pack2_bf16(e[8 * sstep + 4], e[8 * sstep + 5]);
+        pf[t][sstep].w = pack2_bf16(e[8 * sstep + 6], e[8 * sstep + 7]);
       }
     }
     sum += __shfl_xor(sum, 32, 64);
@@ -580,8 +580,8 @@ __global__ __launch_bounds__(256) void attention_image_kernel(const bf16_t* qkv,
       u32x2_t w[4];
 #pragma unroll
       for (int qd = 0; qd < 4; ++qd) {
-        w[qd].x = (uint32_t)f2bf(o[4 * qd] * inv) | ((uint32_t)f2bf(o[4 * qd + 1] * inv) << 16);
-        w[qd].y = (uint32_t)f2bf(o[4 * qd + 2] * inv) | ((uint32_t)f2bf(o[4 * qd + 3] * inv) << 16);
+        w[qd].x = pack2_bf16(o[4 * qd] * inv, o[4 * qd + 1] * inv);
+        w[qd].y = pack2_bf16(o[4 * qd + 2] * inv, o[4 * qd + 3] * inv);
       }
 #pragma unroll
       for (int qa = 0; qa < 2; ++qa) {
@@ -596,6 +596,19 @@ __global__ __launch_bounds__(256) void attention_image_kernel(const bf16_t* qkv,
 }
 
 int g_use_attention_image = 1;
+
+int launch_attention_trunks(const void* qkv, const SegTable& tab, int B, int max_keys, int heads, float scale, void* out,
+                            hipStream_t st) {
+  const int KPt = ((max_keys + 31) & ~31) + 4;
+  const int wpb = heads >= 4 ? 4 : (heads >= 2 ? 2 : 1);
+  SegTable trunks = tab;
+  trunks.n_seg = B;
+  dim3 grid(B, cdiv(heads, wpb)), block(64 * wpb);
+  hipLaunchKernelGGL(attention_mfma_kernel, grid, block, (size_t)wpb * 64 * KPt * 2, st, (const bf16_t*)qkv, trunks, heads, 1,
+                     scale, KPt, (bf16_t*)out);
+  CZC_HIP_CHECK(hipGetLastError());
+  return 0;
+}
 
 // trunks through the generic kernel (n_seg = B), branches packed G per wave
 int launch_attention_shared(const void* qkv, const SegTable& tab, int B, int K, int max_own, int max_keys, int heads,

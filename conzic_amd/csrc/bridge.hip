@@ -241,8 +241,10 @@ int launch_prefix_plan(const int* clip_ids, const int* clip_len, int B, int K, i
   return 0;
 }
 
-__global__ void prefix_finish_kernel(const int* own_off, const int* own_len, int B, int K, int* pre_off, int* eos_idx) {
+__global__ void prefix_finish_kernel(const int* own_off, const int* own_len, int B, int K, int* pre_off, int* eos_idx,
+                                     int* n_trunk_rows) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0 && n_trunk_rows) *n_trunk_rows = own_off[B];  // the B trunk segments come first
   if (i < B) pre_off[i] = 0;
   if (i < B * K) {
     const int s = B + i;
@@ -252,9 +254,9 @@ __global__ void prefix_finish_kernel(const int* own_off, const int* own_len, int
 }
 
 int launch_prefix_finish(const int* own_off, const int* own_len, int B, int K, int* pre_off, int* eos_idx,
-                         hipStream_t st) {
+                         int* n_trunk_rows, hipStream_t st) {
   hipLaunchKernelGGL(prefix_finish_kernel, dim3(cdiv((long)B * K, 256)), dim3(256), 0, st, own_off, own_len, B, K,
-                     pre_off, eos_idx);
+                     pre_off, eos_idx, n_trunk_rows);
   CZC_HIP_CHECK(hipGetLastError());
   return 0;
 }

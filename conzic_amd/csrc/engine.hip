@@ -78,6 +78,8 @@ struct czc_engine {
   int last_BT = 0;
   int share_prefix = 1;  // encode the candidates' common causal prefix once per image
   float* d_staged = nullptr; int staged_cap = 0, staged_n = 0;  // czc_preprocess_u8 output slots [cap][3][S][S]
+  int fuse_qkv_attn = 0;  // branch rows: q/k/v projection and attention in one kernel (qkv_attn.hip); same speed as the
+                          // two-kernel path on configs[2] today (0.78 vs 0.75 ms per layer), kept opt-in
   int pack_branches = 1; // pack several candidates' rows into one attention MFMA tile
   int pool_last_layer = 1; // last CLIP-text layer: out-proj + MLP on the EOS rows only
 
@@ -236,7 +238,8 @@ int gemm(czc_engine* e, int prec, const char* kind, const void* A, int lda, cons
 // are still produced); the pooled residual rows are returned in *pooled (fp32 [n_pool, H]).
 int clip_stack(czc_engine* e, const char* gk, std::vector<LayerW>& L, float* x, int M, int H, int I, int heads,
                float eps, const SegTable& tab, int max_keys, int causal, int plan_B = 0, int plan_K = 0,
-               int plan_max_own = 0, const int* pool_idx = nullptr, int n_pool = 0, float** pooled = nullptr) {
+               int plan_max_own = 0, const int* pool_idx = nullptr, int n_pool = 0, float** pooled = nullptr,
+               int plan_trunk_rows = 0) {
   const int P = e->pc;
   void *y, *qkv, *ctx, *hbuf;
   E_CHECK(ensure(e, "cs_y", (size_t)M * H * e->esz, &y));
@@ -247,6 +250,16 @@ int clip_stack(czc_engine* e, const char* gk, std::vector<LayerW>& L, float* x, 
   for (size_t n = 0; n < L.size(); ++n) {
     LayerW& l = L[n];
     { ProfScope ps(e, "rowops", 0); E_CHECK(launch_layernorm(P, x, nullptr, l.ln1_g, l.ln1_b, eps, M, H, y, nullptr, e->st)); }
+    const bool fused = plan_B > 0 && plan_trunk_rows > 0 && P == PREC_BF16 && g_use_mfma_attention && e->pack_branches &&
+                       e->fuse_qkv_attn && qkv_attn_eligible(H, heads, max_keys, plan_max_own, plan_K);
+    if (fused) {
+      // trunk rows (B*T of them) through the ordinary kernels; the B*K branches never write q,k,v to HBM
+      E_CHECK(gemm(e, P, gk, y, H, l.qkv_w, H, l.qkv_b, nullptr, 0, qkv, nullptr, 3 * H, plan_trunk_rows, 3 * H, H, ACT_NONE));
+      { ProfScope ps(e, "attention", 0);
+        E_CHECK(launch_attention_trunks(qkv, tab, plan_B, max_keys, heads, scale, ctx, e->st)); }
+      { ProfScope ps(e, gk, 2.0 * (M - plan_trunk_rows) * 3.0 * H * H);
+        E_CHECK(launch_qkv_attn(y, H, l.qkv_w, l.qkv_b, qkv, tab, plan_B, plan_K, plan_max_own, heads, scale, ctx, e->st)); }
+    } else {
     E_CHECK(gemm(e, P, gk, y, H, l.qkv_w, H, l.qkv_b, nullptr, 0, qkv, nullptr, 3 * H, M, 3 * H, H, ACT_NONE));
     { ProfScope ps(e, "attention", 0);
       int rc = -1;
@@ -254,6 +267,7 @@ int clip_stack(czc_engine* e, const char* gk, std::vector<LayerW>& L, float* x, 
         rc = launch_attention_shared(qkv, tab, plan_B, plan_K, plan_max_own, max_keys, heads, scale, ctx, e->st);
       if (rc > 0) E_CHECK(rc);
       if (rc < 0) E_CHECK(launch_attention(P, qkv, tab, max_keys, heads, causal, scale, ctx, e->st)); }
+    }
     if (pool_idx && n + 1 == L.size() && e->pool_last_layer) {
       void *ctx_e, *y_e, *h_e; float* x_e;
       E_CHECK(ensure(e, "cs_ctx_e", (size_t)n_pool * H * e->esz, &ctx_e));
@@ -365,10 +379,10 @@ int clip_text_forward(czc_engine* e, const int* cids, const int* clen, int B, in
   { ProfScope ps(e, "bridge", 0);
     E_CHECK(launch_prefix_plan(cids, clen, B, K, share, own_len, pre_len, src, pos0, totals + 3, e->st));
     E_CHECK(launch_scan(own_len, S, own_off, totals, e->st));
-    E_CHECK(launch_prefix_finish(own_off, own_len, B, K, pre_off, eidx, e->st)); }
+    E_CHECK(launch_prefix_finish(own_off, own_len, B, K, pre_off, eidx, totals + 6, e->st)); }
   E_HIP(hipMemcpyAsync(e->h_totals, totals, 32, hipMemcpyDeviceToHost, e->st));
   E_HIP(hipStreamSynchronize(e->st));  // the one host round trip per step (the reference has one too, gen_utils.py:81)
-  const int M = e->h_totals[0], max_len = e->h_totals[3], max_branch = e->h_totals[4];
+  const int M = e->h_totals[0], max_len = e->h_totals[3], max_branch = e->h_totals[4], n_trunk = e->h_totals[6];
   if (e->h_totals[2]) return fail(e, CZC_ERR_OVERFLOW, "text bridge overflow (row text > CZC_BRIDGE_MAX_BYTES)%s");
   if (max_len > c.clip_max_pos || max_len > CZC_CLIP_MAX_LEN)
     return fail(e, CZC_ERR_ARG, "CLIP sequence longer than max_position_embeddings%s");
@@ -386,7 +400,7 @@ int clip_text_forward(czc_engine* e, const int* cids, const int* clen, int B, in
   SegTable tab{pre_off, pre_len, own_off, own_len, S, 0};
   float* pooled = nullptr;
   E_CHECK(clip_stack(e, "gemm_clip_text", e->ctext, x, M, H, c.clip_inter, c.clip_heads, c.clip_eps, tab, max_len, 1, B,
-                     K, max_branch, eidx, n_seq, &pooled));
+                     K, max_branch, eidx, n_seq, &pooled, share ? n_trunk : 0));
   { ProfScope ps(e, "rowops", 0);
     if (pooled) E_CHECK(launch_layernorm(P, pooled, nullptr, fg, fb, c.clip_eps, n_seq, H, pa, nullptr, e->st));
     else E_CHECK(launch_layernorm(P, x, eidx, fg, fb, c.clip_eps, n_seq, H, pa, nullptr, e->st)); }
@@ -866,6 +880,7 @@ int czc_set_option(czc_engine* e, const char* name, int value) {
   if (!strcmp(name, "share_prefix")) { e->share_prefix = value ? 1 : 0; return CZC_OK; }
   if (!strcmp(name, "pack_branches")) { e->pack_branches = value ? 1 : 0; return CZC_OK; }
   if (!strcmp(name, "pool_last_layer")) { e->pool_last_layer = value ? 1 : 0; return CZC_OK; }
+  if (!strcmp(name, "fuse_qkv_attn")) { e->fuse_qkv_attn = value ? 1 : 0; return CZC_OK; }
   return fail(e, CZC_ERR_ARG, "unknown option %s", name);
 }
 

@@ -203,6 +203,19 @@ def test_step_parity_full_size_bf16(name):
     teacher_forced(meta, arr, BF16, n_steps=10)
 
 
+@pytest.mark.parametrize("name", ["full_synth_b2", "full_regular"])
+def test_step_parity_full_size_bf16_fused_qkv_attention(name):
+    """Same bar (fused score within 1e-3 of the reference goldens) with the opt-in fused q/k/v projection +
+    branch attention kernel (qkv_attn.hip) serving the branch rows."""
+    meta, arr = load_case(name)
+    eng = setup_for(meta, BF16).engine
+    eng.set_option("fuse_qkv_attn", 1)
+    try:
+        teacher_forced(meta, arr, BF16, n_steps=10)
+    finally:
+        eng.set_option("fuse_qkv_attn", 0)
+
+
 @pytest.mark.parametrize("name", TINY)
 def test_generate_free_running_tiny_f32(name):
     """czc_generate (no host round trips) reproduces the reference trajectory id-for-id."""
@@ -342,6 +355,32 @@ def test_packed_branch_attention_matches_per_segment(name, one_gemm_family):
         np.testing.assert_allclose(ra["final_score"], rb["final_score"], atol=2e-4)
 
 
+def test_fused_qkv_attention_matches_unfused():
+    """Branch rows through qkv_attn.hip (projection + attention in one kernel, q/k/v never in HBM) against the
+    two-kernel path on the same step: same bf16 roundings of q/k/v and the same attention arithmetic, so only the
+    30 trunk rows (a different GEMM kernel at M = 30) can differ, at fp32 summation-order level."""
+    meta, arr = load_case("full_synth_b2")
+    su = setup_for(meta, BF16)
+    eng = su.engine
+    eng.set_image_embeds(arr["image_embeds"])
+    hp = Engine.hyper(meta["alpha"], meta["beta"], meta["temperature"])
+    outs = []
+    for fuse in (1, 0):
+        eng.set_option("fuse_qkv_attn", fuse)
+        rows = []
+        for i in (0, 2, 5, arr["probs"].shape[0] - 1):
+            inp = np.ascontiguousarray(arr["inp_before"][i], dtype=np.int32)
+            rows.append(eng.step(inp, SEED_LEN + meta["positions"][i], meta["K"], hp,
+                                 dot_allowed=(meta["positions"][i] == meta["L"] - 1)))
+        outs.append(rows)
+    eng.set_option("fuse_qkv_attn", 0)
+    for ra, rb in zip(*outs):
+        np.testing.assert_array_equal(ra["clip_ids"], rb["clip_ids"])
+        np.testing.assert_allclose(ra["clip_ref"], rb["clip_ref"], atol=1e-3)
+        np.testing.assert_allclose(ra["final_score"], rb["final_score"], atol=2e-4)
+        assert np.isfinite(ra["final_score"]).all()
+
+
 @pytest.mark.parametrize("prec", [F32, BF16])
 def test_last_layer_pooling_is_exact(prec, one_gemm_family):
     """Running the last CLIP-text layer's out-projection/MLP on the EOS rows only is the same math."""
@@ -356,8 +395,10 @@ def test_last_layer_pooling_is_exact(prec, one_gemm_family):
         inp = np.ascontiguousarray(arr["inp_before"][4], dtype=np.int32)
         outs.append(eng.step(inp, SEED_LEN + meta["positions"][4], meta["K"], hp))
     eng.set_option("pool_last_layer", 1)
-    np.testing.assert_allclose(outs[0]["clip_ref"], outs[1]["clip_ref"], atol=1e-6 if prec == F32 else 1e-5)
-    np.testing.assert_allclose(outs[0]["final_score"], outs[1]["final_score"], atol=1e-6 if prec == F32 else 1e-5)
+    # bf16: the 400 pooled rows take the 128x128 GEMM whose quick-GELU uses __expf/__frcp_rn, the full batch the
+    # 256x256 one with raw v_exp/v_rcp -- a last-bit difference in fc1, not in what is being tested
+    np.testing.assert_allclose(outs[0]["clip_ref"], outs[1]["clip_ref"], atol=1e-6 if prec == F32 else 5e-5)
+    np.testing.assert_allclose(outs[0]["final_score"], outs[1]["final_score"], atol=1e-6 if prec == F32 else 5e-5)
 
 
 @pytest.mark.parametrize("prec", [F32, BF16])
