@@ -143,6 +143,7 @@ int czc_test_set_option(const char* name, int value) {
   if (!strcmp(name, "gemm256")) { g_use_gemm256 = value; return 0; }
   if (!strcmp(name, "gemm_krot")) { g_gemm_krot = value; return 0; }
   if (!strcmp(name, "skinny")) { g_use_skinny = value; return 0; }
+  if (!strcmp(name, "splitk")) { g_use_splitk = value; return 0; }
   if (!strcmp(name, "wreg")) { g_use_wreg = value; return 0; }
   if (!strcmp(name, "wreg_dbg")) { g_wreg_dbg = value; return 0; }
   if (!strcmp(name, "mfma_attention")) { g_use_mfma_attention = value; return 0; }

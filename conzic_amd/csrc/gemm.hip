@@ -117,8 +117,17 @@ __device__ __forceinline__ void epilogue(const GemmArgs& g, f32x16_t (&acc)[2][2
 }
 
 template <typename T, int ACT, bool VEC>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, int tiles_m, int tiles_n) {
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, int tiles_m, int tiles_n, int kchunk) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE_BYTES];
+  // split-K launch (gridDim.y > 1): slice z multiplies k in [z*kchunk, (z+1)*kchunk) into its own fp32 slab
+  // out_f32 + z*M*ldc (no bias / activation / residual: splitk_reduce_kernel adds them in a fixed order)
+  if (gridDim.y > 1) {
+    const int z = blockIdx.y;
+    g.A = (const unsigned char*)g.A + (size_t)z * kchunk * sizeof(T);
+    g.W = (const unsigned char*)g.W + (size_t)z * kchunk * sizeof(T);
+    g.out_f32 += (size_t)z * g.M * g.ldc;
+    g.K = kchunk;
+  }
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -238,9 +247,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, int tiles_m, int 
 }
 
 template <typename T>
-static void launch_t(const GemmArgs& g, int tiles_m, int tiles_n, bool vec, hipStream_t st) {
-  dim3 grid(tiles_m * tiles_n), block(256);
-#define CZC_GEMM_LAUNCH(ACT_, VEC_) hipLaunchKernelGGL((gemm_kernel<T, ACT_, VEC_>), grid, block, 0, st, g, tiles_m, tiles_n)
+static void launch_t(const GemmArgs& g, int tiles_m, int tiles_n, bool vec, hipStream_t st, int ksplit = 1) {
+  dim3 grid(tiles_m * tiles_n, ksplit), block(256);
+  const int kchunk = g.K / ksplit;
+#define CZC_GEMM_LAUNCH(ACT_, VEC_) \
+  hipLaunchKernelGGL((gemm_kernel<T, ACT_, VEC_>), grid, block, 0, st, g, tiles_m, tiles_n, kchunk)
   if (vec) {
     if (g.act == ACT_QUICK_GELU) CZC_GEMM_LAUNCH(ACT_QUICK_GELU, true);
     else if (g.act == ACT_GELU_ERF) CZC_GEMM_LAUNCH(ACT_GELU_ERF, true);
@@ -340,6 +351,57 @@ static bool launch_skinny(const GemmArgs& g, hipStream_t st) {
   return true;
 }
 
+// ---- deterministic split-K for small-M, long-K fp32-output layers (BERT out-proj / fc2 at a few thousand rows) ----
+// 128x128 tiles give only M/128 * N/128 work-groups (180 for 3840 x 768) and each walks K through a two-stage
+// pipeline whose step time is an L2/HBM round trip, not its 24 MFMAs: the kernel is latency-bound at 0.7
+// work-groups per CU.  Splitting K over 2-4 work-groups per tile shortens the chain and fills the chip; the
+// slabs are summed in slice order by one small kernel, so results do not depend on scheduling.
+__global__ void splitk_reduce_kernel(const float* slabs, int nslab, long slab_stride, const float* bias, const float* resid,
+                                     int ldr, float* out, int ldc, int M, int N) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // one float4 of the output
+  const int n4 = N >> 2;
+  if (i >= (long)M * n4) return;
+  const int m = (int)(i / n4), n = (int)(i - (long)m * n4) * 4;
+  float4 v = *(const float4*)(slabs + (long)m * ldc + n);
+  for (int z = 1; z < nslab; ++z) {
+    const float4 p = *(const float4*)(slabs + z * slab_stride + (long)m * ldc + n);
+    v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+  }
+  if (bias) { const float4 b = *(const float4*)(bias + n); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+  if (resid) { const float4 r = *(const float4*)(resid + (long)m * ldr + n); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+  *(float4*)(out + (long)m * ldc + n) = v;
+}
+
+int g_use_splitk = 1;
+static float* g_splitk_ws = nullptr;
+static size_t g_splitk_bytes = 0;
+
+// returns 0 when the shape does not want split-K, else the slice count it launched with
+template <typename T>
+static int try_splitk(const GemmArgs& g, int tiles_m, int tiles_n, hipStream_t st, int* rc) {
+  *rc = 0;
+  if (!g_use_splitk || g.out_act || !g.out_f32 || g.act != ACT_NONE || g.N % 4 || g.ldc % 4 || (g.resid && g.ldr % 4)) return 0;
+  const int tiles = tiles_m * tiles_n;
+  if (tiles >= 384 || g.M < 256) return 0;
+  int ks = 0;
+  for (int c = 4; c >= 2; --c)
+    if (g.K % (c * Mma<T>::KPT) == 0 && g.K / c >= 256 && tiles * c <= 1024) { ks = c; break; }
+  if (!ks) return 0;
+  const size_t need = (size_t)ks * g.M * g.ldc * 4;
+  if (need > g_splitk_bytes) {
+    if (g_splitk_ws) { (void)hipStreamSynchronize(st); (void)hipFree(g_splitk_ws); g_splitk_ws = nullptr; g_splitk_bytes = 0; }
+    if (hipMalloc((void**)&g_splitk_ws, need + need / 4) != hipSuccess) { *rc = 1; snprintf(g_err, sizeof(g_err), "split-K workspace allocation failed"); return ks; }
+    g_splitk_bytes = need + need / 4;
+  }
+  GemmArgs p = g;
+  p.bias = nullptr; p.resid = nullptr; p.out_f32 = g_splitk_ws;
+  launch_t<T>(p, tiles_m, tiles_n, true, st, ks);
+  const long n4 = (long)g.M * (g.N >> 2);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv(n4, 256)), dim3(256), 0, st, g_splitk_ws, ks, (long)g.M * g.ldc,
+                     g.bias, g.resid, g.ldr, g.out_f32, g.ldc, g.M, g.N);
+  return ks;
+}
+
 int g_use_gemm256 = 3;  // 0: 128x128 only, 1: gemm256, 2: persistent wave-specialised gemm256p, 3: + 4-stage K ring (gemm256q)
 
 int launch_gemm(int prec, const GemmArgs& g, hipStream_t st) {
@@ -357,6 +419,12 @@ int launch_gemm(int prec, const GemmArgs& g, hipStream_t st) {
   }
   const int tiles_m = cdiv(g.M, BM), tiles_n = cdiv(g.N, BN);
   const bool vec = (g.N % 4 == 0) && (g.ldc % 4 == 0) && (!g.resid || g.ldr % 4 == 0);
+  int rc = 0;
+  if (prec == PREC_F16X3 && try_splitk<split_t>(g, tiles_m, tiles_n, st, &rc)) {
+    if (rc) return rc;
+    CZC_HIP_CHECK(hipGetLastError());
+    return 0;
+  }
   if (prec == PREC_BF16) launch_t<bf16_t>(g, tiles_m, tiles_n, vec, st);
   else if (prec == PREC_F16X3) launch_t<split_t>(g, tiles_m, tiles_n, vec, st);
   else launch_t<float>(g, tiles_m, tiles_n, vec, st);

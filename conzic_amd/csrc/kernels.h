@@ -24,6 +24,7 @@ int launch_gemm256(const GemmArgs& g, hipStream_t st);  // gemm256.hip: 256x256 
 extern int g_use_gemm256;
 extern int g_gemm_krot;
 extern int g_use_skinny;
+extern int g_use_splitk;
 bool gemm_wreg_eligible(const GemmArgs& g);
 int launch_gemm_wreg(const GemmArgs& g, hipStream_t st);  // gemm_wreg.hip: weights in registers, K = 512
 extern int g_use_wreg;

@@ -327,6 +327,32 @@ def test_split_fp16_skinny_gemm(M, N, K, act, resid):
     assert np.abs(C - C2).max() < tol
 
 
+@pytest.mark.parametrize("M,N,K,resid", [(3840, 768, 768, True), (3840, 768, 3072, True), (1000, 512, 1024, False),
+                                         (300, 768, 3072, True)])
+def test_split_fp16_gemm_split_k(M, N, K, resid):
+    """Few-tile, long-K fp32-output layers (BERT out-proj / fc2 at B = 256) run split-K with a fixed-order
+    reduction: fp32-class accuracy, bit-identical from run to run, and equal to the unsplit kernel up to
+    fp32 summation order."""
+    lib = native.load()
+    rng = np.random.default_rng(M + N + K)
+    A = (rng.standard_normal((M, K)) * 2).astype(np.float32)
+    W = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    R = rng.standard_normal((M, N)).astype(np.float32) if resid else None
+    C = E.test_gemm(F16X3, A, W, bias=bias, resid=R)
+    C_again = E.test_gemm(F16X3, A, W, bias=bias, resid=R)
+    np.testing.assert_array_equal(C, C_again)
+    ref = (A.astype(np.float64) @ W.astype(np.float64).T + bias).astype(np.float32) + (R if resid else 0)
+    tol = 1e-5 * np.sqrt(K / 64) * 4
+    assert np.abs(C - ref).max() < tol
+    try:
+        assert lib.czc_test_set_option(b"splitk", 0) == 0
+        C1 = E.test_gemm(F16X3, A, W, bias=bias, resid=R)
+    finally:
+        lib.czc_test_set_option(b"splitk", 1)
+    assert np.abs(C - C1).max() < tol
+
+
 def test_split_fp16_layernorm_and_attention():
     rng = np.random.default_rng(5)
     x = (rng.standard_normal((33, 768)) * 2).astype(np.float32)
