@@ -194,12 +194,20 @@ def main():
                         achieved=round(ach, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_BF16_TFLOPS, 4),
                         traffic=traffic, launches=g["launches"], avg_launch_ms=round(g["ms"] / g["launches"], 4),
                         flops_per_launch=g["flops"] / g["launches"])
+        if (L, K, I, a.order, a.gamma) == (10, 200, 10, "sequential", None):
+            cfg_name = "BASELINE configs[2]"
+        elif (L, K, a.order, a.gamma) == (15, 512, "shuffle", None):
+            cfg_name = "BASELINE configs[3] shape (per-GPU shard)"
+        elif a.gamma is not None and L == 12 and K == 200:
+            cfg_name = "BASELINE configs[4] shape (per-GPU shard)"
+        else:
+            cfg_name = "custom shape"
         f_cap = caption_flops(L, K, I)
         out = dict(metric="captions/sec (L=10, K=200, seq order)", value=round(value, 4), unit="captions/s",
                    n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(dt / a.steps * 1e3, 2),
                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype="bf16" if prec == 0 else "f32",
                    data="synthetic",
-                   config=dict(workload=f"BASELINE configs[2]: {B} random-pixel 224x224 images per GPU, {a.order}, "
+                   config=dict(workload=f"{cfg_name}: {B} random-pixel 224x224 images per GPU, {a.order}, "
                                         f"L={L}, K={K}, I={I}, alpha=0.02 beta=2.0 tau=0.1, bert-base + CLIP ViT-B/32 shapes, "
                                         "random-init weights, synthetic vocab (1 CLIP token per word)",
                                images_per_gpu=B, sentence_len=L, candidate_k=K, num_iterations=I, order=a.order,
