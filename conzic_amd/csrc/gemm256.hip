@@ -606,220 +606,6 @@ __global__ __launch_bounds__(768) void gemm256q_kernel(GemmArgs g, int tiles_m, 
 }
 
 
-// ================================================================================================
-// gemm256s ("staggered"): TWO independent 4-wave work-groups per CU, each owning 256x128 tiles.
-// In gemm256p/q all eight MFMA waves of a CU reach the epilogue together, so the matrix pipe idles
-// while 64K outputs get bias/activation/convert/store (one full-rate VALU instruction per output
-// element costs 6 % of a K=512 tile's MFMA time; quick-GELU ~9 of them).  Two small work-groups
-// drift apart by themselves: while one is in its epilogue (VALU + LDS patch + stores) the other
-// one's waves have the MFMA pipe of every SIMD to themselves.
-//   * 256 threads, no loader waves: each wave issues its quarter of a stage (6 LDS-DMA
-//     instructions per 32-wide K step) right after the step's barrier, two steps ahead
-//     (3 x 24 KiB ring), and waits with a counted vmcnt(6).
-//   * 2 waves / SIMD -> 256 VGPRs per wave: 128 accumulators + room for the fragment pipeline.
-//   * LDS: 3 x 24 KiB + 4 x 2 KiB epilogue patches = exactly half of the 160 KiB.
-//   * Stores and loads share vmcnt on gfx9 and may retire out of order with each other, so the
-//     first K step after an epilogue drains with vmcnt(0) (the stage it needs landed long ago).
-// ================================================================================================
-constexpr int SN = 128;                          // W rows (output columns) per tile
-constexpr int S_STAGE = (TM + SN) * QROWB;       // 24 KiB
-constexpr int SS = 3;                            // ring depth
-constexpr int S_PATCH = 2048;                    // per-wave epilogue patch
-constexpr int S_LDS = SS * S_STAGE + 4 * S_PATCH;  // 80 KiB
-
-// 32 rows x 64 bytes per pass (32 bf16 columns, or 16 fp32 columns): every global access is a 64-byte
-// row segment; the two segments of a 128-byte line are written back to back by the same wave.
-template <int ACT, bool OUT_F32>
-__device__ __forceinline__ void tile_epilogue_s(const GemmArgs& g, f32x16_t (&acc)[4][2], unsigned char* patch, int m0,
-                                                int n0, int wm, int wn, int lane) {
-  const int half = lane >> 5, l31 = lane & 31;
-  const int rrow = lane >> 2, rs = lane & 3;  // read side: 16 rows x 4 sixteen-byte slots per pass
-  bf16_t* oa = (bf16_t*)g.out_act;
-  if (!OUT_F32) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int cbase = n0 + wn * 64 + j * 32;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
-          if (g.bias) {
-            const float4 b4 = *(const float4*)(g.bias + min(cbase + 8 * q + 4 * half, g.N - 4));
-            v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
-          }
-          v.x = act_fn<ACT>(v.x); v.y = act_fn<ACT>(v.y); v.z = act_fn<ACT>(v.z); v.w = act_fn<ACT>(v.w);
-          const int slot = (2 * q + half) ^ ((l31 >> 1) & 7);  // 8-byte slots of the 64-byte patch row
-          *(uint2*)(patch + l31 * 64 + slot * 8) = make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w));
-        }
-#pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-          const int r = pass * 16 + rrow;
-          const int x = (r >> 1) & 7;
-          uint4 d = *(const uint4*)(patch + r * 64 + ((rs ^ (x >> 1)) << 4));
-          if (x & 1) d = make_uint4(d.z, d.w, d.x, d.y);
-          const int row = m0 + wm * 128 + i * 32 + r;
-          const int col = cbase + rs * 8;
-          if (row < g.M && col < g.N) *(uint4*)(oa + (long)row * g.ldc + col) = d;
-        }
-      }
-    }
-  } else {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int col = n0 + wn * 64 + j * 32 + 16 * h + rs * 4;
-          float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (g.bias && col < g.N) b4 = *(const float4*)(g.bias + col);
-          float4 r4[2];
-#pragma unroll
-          for (int pass = 0; pass < 2; ++pass) {
-            const int row = m0 + wm * 128 + i * 32 + pass * 16 + rrow;
-            r4[pass] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (g.resid && row < g.M && col < g.N) r4[pass] = *(const float4*)(g.resid + (long)row * g.ldr + col);
-          }
-#pragma unroll
-          for (int qq = 0; qq < 2; ++qq) {
-            const int q = 2 * h + qq;
-            const int slot = (2 * qq + half) ^ ((l31 >> 1) & 3);  // 16-byte slots of the 64-byte patch row
-            *(float4*)(patch + l31 * 64 + slot * 16) =
-                make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
-          }
-#pragma unroll
-          for (int pass = 0; pass < 2; ++pass) {
-            const int r = pass * 16 + rrow;
-            float4 v = *(const float4*)(patch + r * 64 + ((rs ^ ((r >> 1) & 3)) << 4));
-            const int row = m0 + wm * 128 + i * 32 + r;
-            if (row < g.M && col < g.N) {
-              v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
-              v.x = act_fn<ACT>(v.x); v.y = act_fn<ACT>(v.y); v.z = act_fn<ACT>(v.z); v.w = act_fn<ACT>(v.w);
-              v.x += r4[pass].x; v.y += r4[pass].y; v.z += r4[pass].z; v.w += r4[pass].w;
-              if (g.out_f32) *(float4*)(g.out_f32 + (long)row * g.ldc + col) = v;
-              if (oa) *(uint2*)(oa + (long)row * g.ldc + col) = make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w));
-            }
-          }
-        }
-      }
-    }
-  }
-}
-
-template <int ACT, bool OUT_F32>
-__global__ __launch_bounds__(256, 2) void gemm256s_kernel(GemmArgs g, int tiles_m, int tiles_n) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int nk = g.K >> 5;  // 32-wide K steps
-  const int lda_b = g.lda * 2, ldw_b = g.ldw * 2;
-  const int my_tiles = tile_count(tiles_m, tiles_n, true);
-  if (my_tiles == 0) return;
-  const int total = my_tiles * nk;
-
-  // ---- DMA side: this wave lands A rows wave*64 + ii*16 + (lane>>2) (ii 0..3) and W rows
-  //      wave*32 + ii*16 + (lane>>2) (ii 0..1) of every stage; physical 16-byte chunk lane&3 ----
-  const unsigned lds0 = __builtin_amdgcn_readfirstlane(
-      (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem);
-  const int cq = ((lane & 3) ^ ((lane >> 4) & 3)) << 4;
-  const int a0 = (wave * 64 + (lane >> 2)) * lda_b + cq, w0 = (wave * 32 + (lane >> 2)) * ldw_b + cq;
-  const int a16 = 16 * lda_b, w16 = 16 * ldw_b;
-  u32x4_t rsA, rsW;
-  rsA.x = rsA.y = rsA.z = 0; rsA.w = 0x00020000u;
-  rsW = rsA;
-  int i_ti = 0, i_kt = 0, i_stage = 0;  // issue cursor
-  auto issue = [&]() {
-    if (i_kt == 0) {
-      int tm, tn;
-      tile_at(i_ti, tiles_m, tiles_n, true, tm, tn);
-      const int m0 = tm * TM, n0 = tn * SN;
-      const unsigned long long pa = (unsigned long long)g.A + (unsigned long long)m0 * lda_b;
-      const unsigned long long pw = (unsigned long long)g.W + (unsigned long long)n0 * ldw_b;
-      rsA.x = (unsigned)pa; rsA.y = (unsigned)(pa >> 32) & 0xffffu; rsA.z = (unsigned)(min(TM, g.M - m0) * lda_b);
-      rsW.x = (unsigned)pw; rsW.y = (unsigned)(pw >> 32) & 0xffffu; rsW.z = (unsigned)(min(SN, g.N - n0) * ldw_b);
-    }
-    const unsigned dstA = lds0 + i_stage * S_STAGE + wave * (64 * QROWB);
-    const unsigned dstW = lds0 + i_stage * S_STAGE + QA_BYTES + wave * (32 * QROWB);
-    const unsigned so = i_kt * QROWB;
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %9, %11 offen lds\n\t"
-        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %9, %11 offen lds\n\t"
-        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %5, %9, %11 offen lds\n\t"
-        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %6, %9, %11 offen lds\n\t"
-        "s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %7, %10, %11 offen lds\n\t"
-        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %8, %10, %11 offen lds\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "s"(dstA), "s"(dstW), "v"(a0), "v"(a0 + a16), "v"(a0 + 2 * a16), "v"(a0 + 3 * a16), "v"(w0), "v"(w0 + w16),
-          "s"(rsA), "s"(rsW), "s"(so)
-        : "memory", "scc");
-    if (++i_kt == nk) { i_kt = 0; ++i_ti; }
-    i_stage = (i_stage == SS - 1) ? 0 : i_stage + 1;
-  };
-  issue();
-  if (total > 1) issue();
-
-  // ---- MFMA side ----
-  const int wm = wave >> 1, wn = wave & 1;
-  const int half = lane >> 5;
-  const int arow = wm * 128 + (lane & 31);
-  const int brow = wn * 64 + (lane & 31);
-  int s = 0, stage = 0;
-  for (int ti = 0; ti < my_tiles; ++ti) {
-    int tm, tn;
-    tile_at(ti, tiles_m, tiles_n, true, tm, tn);
-    const int m0 = tm * TM, n0 = tn * SN;
-    f32x16_t acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    for (int kt = 0; kt < nk; ++kt, ++s) {
-      // step s must have landed: one later step (6 DMAs) may stay in flight, except behind an
-      // epilogue (stores share the counter) and at the very end
-      if ((kt == 0 && ti > 0) || s + 1 >= total) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      __builtin_amdgcn_s_barrier();  // publishes step s; proves stage (s-1)%SS has been left
-      asm volatile("" ::: "memory");
-      if (s + 2 < total) issue();
-      const unsigned char* sA = smem + stage * S_STAGE;
-      const unsigned char* sB = sA + QA_BYTES;
-      stage = (stage == SS - 1) ? 0 : stage + 1;
-#define CZC_RA(ks_, i_) (*(const uint4*)(sA + swzq(arow + 32 * (i_), 2 * (ks_) + half)))
-#define CZC_RB(ks_, j_) (*(const uint4*)(sB + swzq(brow + 32 * (j_), 2 * (ks_) + half)))
-#define CZC_MM(b_, a_, i_, j_)                                                                                  \
-  acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, b_), __builtin_bit_cast(bf16x8_t, a_), \
-                                                        acc[i_][j_], 0, 0, 0)
-      uint4 b0 = CZC_RB(0, 0), b1 = CZC_RB(0, 1), a0 = CZC_RA(0, 0), a1;
-      a1 = CZC_RA(0, 1);
-      CZC_MM(b0, a0, 0, 0); CZC_MM(b1, a0, 0, 1);
-      a0 = CZC_RA(0, 2);
-      CZC_MM(b0, a1, 1, 0); CZC_MM(b1, a1, 1, 1);
-      a1 = CZC_RA(0, 3);
-      CZC_MM(b0, a0, 2, 0); CZC_MM(b1, a0, 2, 1);
-      uint4 c0 = CZC_RB(1, 0), c1 = CZC_RB(1, 1);
-      a0 = CZC_RA(1, 0);
-      CZC_MM(b0, a1, 3, 0); CZC_MM(b1, a1, 3, 1);
-      a1 = CZC_RA(1, 1);
-      CZC_MM(c0, a0, 0, 0); CZC_MM(c1, a0, 0, 1);
-      a0 = CZC_RA(1, 2);
-      CZC_MM(c0, a1, 1, 0); CZC_MM(c1, a1, 1, 1);
-      a1 = CZC_RA(1, 3);
-      CZC_MM(c0, a0, 2, 0); CZC_MM(c1, a0, 2, 1);
-      CZC_MM(c0, a1, 3, 0); CZC_MM(c1, a1, 3, 1);
-#undef CZC_RA
-#undef CZC_RB
-#undef CZC_MM
-    }
-    tile_epilogue_s<ACT, OUT_F32>(g, acc, smem + SS * S_STAGE + wave * S_PATCH, m0, n0, wm, wn, lane);
-  }
-}
-
 }  // namespace
 
 int g_gemm_krot = 0;  // bit0: rotate K order per work-group (no gain measured); bits1-2: debug (skip MFMA / skip DMA)
@@ -852,27 +638,6 @@ int launch_gemm256(const GemmArgs& g, hipStream_t st) {
       CZC_ATTR((gemm256q_kernel<ACT_QUICK_GELU, false>));
       CZC_ATTR((gemm256q_kernel<ACT_QUICK_GELU, true>));
 #undef CZC_ATTR
-    }
-    if (g_use_gemm256 == 4) {
-      static bool s_attr = false;
-      if (!s_attr) {
-#define CZC_ATTR(K_) CZC_HIP_CHECK(hipFuncSetAttribute((const void*)K_, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS))
-        CZC_ATTR((gemm256s_kernel<ACT_NONE, false>));
-        CZC_ATTR((gemm256s_kernel<ACT_NONE, true>));
-        CZC_ATTR((gemm256s_kernel<ACT_QUICK_GELU, false>));
-        CZC_ATTR((gemm256s_kernel<ACT_QUICK_GELU, true>));
-#undef CZC_ATTR
-        s_attr = true;
-      }
-      const int tm_ = cdiv(g.M, TM), tn_ = cdiv(g.N, SN);
-      const bool f32o = g.out_f32 != nullptr || g.resid != nullptr;
-      dim3 gs(tm_ * tn_ < 2 * n_cu ? tm_ * tn_ : 2 * n_cu), bs(256);
-#define CZC_GOS(A_, F_) hipLaunchKernelGGL((gemm256s_kernel<A_, F_>), gs, bs, S_LDS, st, g, tm_, tn_)
-      if (g.act == ACT_QUICK_GELU) { if (f32o) CZC_GOS(ACT_QUICK_GELU, true); else CZC_GOS(ACT_QUICK_GELU, false); }
-      else { if (f32o) CZC_GOS(ACT_NONE, true); else CZC_GOS(ACT_NONE, false); }
-#undef CZC_GOS
-      CZC_HIP_CHECK(hipGetLastError());
-      return 0;
     }
     const int tiles_m = cdiv(g.M, TM), tiles_n = cdiv(g.N, TN);
     const int nt = (g_gemm_krot & 32) ? tiles_m : tiles_m * tiles_n;  // work units: tiles, or M tiles for the M-major walk

@@ -27,6 +27,8 @@
 //     groups, and a pure permutation inside each DMA'd row (the source address carries it).
 //   * the column groups of one row range sit on neighbouring CUs of one XCD and march in step, so
 //     each activation block comes from HBM once and from that XCD's L2 for the other groups.
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace czc {
@@ -243,7 +245,9 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, 
   };
   // block in ring slot `slot`: 8 groups of 4 MFMAs (fragments of group s+1 are read during group s), one
   // auxiliary step pinned after each group.  VMEM order per block: D0 D1 D2 S0 D3 S1.
-  auto mfma_block_ilv = [&](int slot, bool refill, bool prev) {
+  auto mfma_block_ilv = [&](int slot, auto steady_c, bool refill_rt, bool prev_rt, int jd, int js) {
+    constexpr bool STEADY = decltype(steady_c)::value;  // steady state: refill and epilogue unconditional
+    const bool refill = STEADY || refill_rt, prev = STEADY || prev_rt;
     const unsigned char* sA = smem + slot * WR_STAGE;
     u32x4_t fr[2][4];
 #pragma unroll
@@ -268,13 +272,15 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, 
                                                        __builtin_bit_cast(bf16x8_t, fr[sgm & 1][k + 1]), acc1, 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (sgm == 0 && refill) dma_piece(0);
+      // descriptor arithmetic (a few dozen SALU) rides in the slots too: nothing but the wait and the barrier
+      // stands between two blocks' MFMA streams
+      if (sgm == 0 && refill) { dma_rebase(jd); dma_piece(0); }
       if (sgm == 1 && prev) epi_quad(0);
       if (sgm == 2 && refill) dma_piece(1);
       if (sgm == 2 && prev) epi_quad(1);
       if (sgm == 3 && prev) epi_quad(2);
       if (sgm == 4 && refill) dma_piece(2);
-      if (sgm == 4 && prev) epi_quad(3);
+      if (sgm == 4 && prev) { epi_quad(3); store_rebase(js); }
       if (sgm == 5 && prev) epi_store(0);
       if (sgm == 6 && refill) dma_piece(3);
       if (sgm == 7 && prev) epi_store(1);
@@ -288,21 +294,27 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, 
   const bool late = (dbg & 32) ? (wave & 1) : (dbg & 64) ? ((wave >> 1) & 1) : ((wave >> 2) & 1);
 
   if (ILV) {
-    for (int i = 0; i < nb; ++i) {
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    auto step = [&](int i, auto steady_c) {
       // block i landed?  VMEM issued after its last DMA piece: S1 of that block period, then two full periods
       // of 4 DMA + 2 stores (stores start with the second block) -- all in order on vmcnt.
-      if (i + 2 >= nb) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      constexpr bool STEADY = decltype(steady_c)::value;
+      if (STEADY) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+      else if (i + 2 >= nb) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else if (i < 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      const bool refill = i + WR_D - 1 < nb;
-      if (refill) dma_rebase(i + WR_D - 1);
-      if (i > 0) store_rebase(i - 1);
-      mfma_block_ilv(i & (WR_D - 1), refill, i > 0);
+      mfma_block_ilv(i & (WR_D - 1), steady_c, i + WR_D - 1 < nb, i > 0, i + WR_D - 1, i - 1);
 #pragma unroll
       for (int r = 0; r < 16; ++r) accP[r] = acc0[r] + acc1[r];
-    }
+    };
+    // head (short store history: conservative waits), branch-free steady state, tail (no more refills)
+    int i = 0;
+    for (; i < nb && i < 4; ++i) step(i, F_());
+    for (; i + WR_D - 1 < nb; ++i) step(i, T_());
+    for (; i < nb; ++i) step(i, F_());
     store_rebase(nb - 1);
     epi_quad(0); epi_quad(1); epi_quad(2); epi_quad(3);
     epi_store(0); epi_store(1);
