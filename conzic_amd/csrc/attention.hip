@@ -595,7 +595,7 @@ __global__ __launch_bounds__(256) void attention_image_kernel(const bf16_t* qkv,
   }
 }
 
-int g_use_attention_image = 1;
+int g_use_attention_image = 1;  // 0 off, 1 when the batch fills the chip, 2 always (tests)
 
 int launch_attention_trunks(const void* qkv, const SegTable& tab, int B, int max_keys, int heads, float scale, void* out,
                             hipStream_t st) {
@@ -624,7 +624,10 @@ int launch_attention_shared(const void* qkv, const SegTable& tab, int B, int K, 
     hipLaunchKernelGGL(attention_mfma_kernel, grid, block, (size_t)wpb * 64 * KPt * 2, st, (const bf16_t*)qkv, trunks,
                        heads, 1, scale, KPt, (bf16_t*)out);
   }
-  if (g_use_attention_image && heads % 4 == 0 && max_keys <= 32 && K <= 1024) {
+  // one work-group per (image, 4 heads) walking the image's groups in sequence: needs enough images to fill the
+  // chip (a single image would leave 2 work-groups doing 40 groups each; the per-group kernel spreads those)
+  if (g_use_attention_image && heads % 4 == 0 && max_keys <= 32 && K <= 1024 &&
+      (B * (heads / 4) >= 128 || g_use_attention_image == 2)) {
     static bool attr = false;
     if (!attr) {
       CZC_HIP_CHECK(hipFuncSetAttribute((const void*)attention_image_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, A2_LDS));

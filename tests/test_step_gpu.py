@@ -204,6 +204,19 @@ def test_step_parity_full_size_bf16(name):
 
 
 @pytest.mark.parametrize("name", ["full_synth_b2", "full_regular"])
+def test_step_parity_full_size_bf16_per_image_attention(name):
+    """Same bar with the per-image persistent branch attention kernel forced on (the B = 2 goldens are below
+    the batch size at which the engine selects it)."""
+    meta, arr = load_case(name)
+    lib = native.load()
+    assert lib.czc_test_set_option(b"attention_image", 2) == 0
+    try:
+        teacher_forced(meta, arr, BF16, n_steps=10)
+    finally:
+        lib.czc_test_set_option(b"attention_image", 1)
+
+
+@pytest.mark.parametrize("name", ["full_synth_b2", "full_regular"])
 def test_step_parity_full_size_bf16_fused_qkv_attention(name):
     """Same bar (fused score within 1e-3 of the reference goldens) with the opt-in fused q/k/v projection +
     branch attention kernel (qkv_attn.hip) serving the branch rows."""
@@ -332,10 +345,24 @@ def test_prefix_sharing_is_exact(prec, name, one_gemm_family):
             np.testing.assert_array_equal(ia, ib)
 
 
+@pytest.mark.parametrize("kernel", ["per_group", "per_image"])
 @pytest.mark.parametrize("name", ["tiny_shuffle", "full_synth_b2"])
-def test_packed_branch_attention_matches_per_segment(name, one_gemm_family):
-    """bf16 engine: packing G candidates into one attention tile vs one wave per candidate."""
+def test_packed_branch_attention_matches_per_segment(name, kernel, one_gemm_family):
+    """bf16 engine: packing G candidates into one attention tile vs one wave per candidate -- through the
+    per-(group, head) kernel and through the per-image persistent kernel (which the engine only picks by itself
+    once the batch fills the chip, B >= 64; forced here)."""
     meta, arr = load_case(name)
+    if kernel == "per_image" and meta["tiny"]:
+        pytest.skip("needs heads % 4 == 0")
+    lib = native.load()
+    assert lib.czc_test_set_option(b"attention_image", 2 if kernel == "per_image" else 0) == 0
+    try:
+        _packed_vs_per_segment(meta, arr)
+    finally:
+        lib.czc_test_set_option(b"attention_image", 1)
+
+
+def _packed_vs_per_segment(meta, arr):
     su = setup_for(meta, BF16)
     eng = su.engine
     eng.set_image_embeds(arr["image_embeds"])
