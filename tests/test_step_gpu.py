@@ -543,3 +543,47 @@ def test_config3_shape_k512_l15_kernel_families_agree():
     finally:
         lib.czc_test_set_option(b"attention_image", 1)
         su.engine.close()
+
+
+def test_large_batch_kernel_families_agree():
+    """B = 64 images x K = 200 candidates (78 k packed CLIP rows, ~58 blocks per work-group of the weight-stationary
+    GEMM, the per-image attention kernel selected by the engine itself): the exact-count vmcnt pipelines of
+    gemm_wreg / attention_image / qkv_attn against the kernels that do not rely on them, on the same step.
+    A mis-counted wait would show up here as a handful of wildly wrong rows, not as rounding noise."""
+    su = harness.build_synthetic(False, BF16)
+    lib = native.load()
+    try:
+        from oracle import step as S, models as M, text as T
+        B, L, K = 64, 10, 200
+        rng = np.random.default_rng(11)
+        o = S.Oracle(M.to_torch(synth.make_bert_weights(su.bert_cfg, 11)), su.bert_cfg,
+                     M.to_torch(synth.make_clip_weights(su.clip_cfg, 12)), su.clip_cfg, su.sv.bert_tokens,
+                     T.ClipBpe(su.sv.clip_vocab, su.sv.clip_merges))
+        inp = np.array(o.init_text("Image of a", L, B), dtype=np.int32)
+        regular = np.nonzero(su.token_mask[0] > 0)[0]
+        inp[:, SEED_LEN:SEED_LEN + L] = rng.choice(regular, size=(B, L))  # a later sweep: every position filled
+        gen_idx = SEED_LEN + 6
+        su.engine.set_image_embeds(rng.standard_normal((B, su.clip_cfg.proj)).astype(np.float32))
+        hp = Engine.hyper(0.02, 2.0, 0.1)
+        outs = {}
+        for name, wreg, att, fuse in (("default", 2, 1, 0), ("tiled_gemm", 0, 1, 0), ("per_group_attention", 2, 0, 0),
+                                      ("wreg_phase_separated", 1, 1, 0), ("fused_qkv_attention", 2, 1, 1)):
+            assert lib.czc_test_set_option(b"wreg", wreg) == 0
+            assert lib.czc_test_set_option(b"attention_image", att) == 0
+            su.engine.set_option("fuse_qkv_attn", fuse)
+            outs[name] = su.engine.step(inp.copy(), gen_idx, K, hp)
+        ref = outs["tiled_gemm"]
+        for name, res in outs.items():
+            np.testing.assert_array_equal(res["idxs"], ref["idxs"], err_msg=name)
+            assert np.isfinite(res["final_score"]).all(), name
+            # different fp32 summation orders under bf16 roundings: ~1e-4 typical, ~1e-3 in the tail of 12 800 cosines
+            np.testing.assert_allclose(res["clip_ref"], ref["clip_ref"], atol=3e-3, err_msg=name)
+            assert np.abs(res["clip_ref"] - ref["clip_ref"]).mean() < 2e-4, name
+            np.testing.assert_allclose(res["final_score"], ref["final_score"], atol=1e-3, err_msg=name)
+        # bit-reproducible from run to run
+        again = su.engine.step(inp.copy(), gen_idx, K, hp)
+        np.testing.assert_array_equal(again["final_score"], outs["fused_qkv_attention"]["final_score"])
+    finally:
+        lib.czc_test_set_option(b"wreg", 2)
+        lib.czc_test_set_option(b"attention_image", 1)
+        su.engine.close()
