@@ -180,8 +180,12 @@ int czc_generate(czc_engine* e, int B, int T, int L, int seed_len, const int32_t
                  int n_steps, const int32_t* positions_host, const int32_t* n_mask_host, int snapshot_every,
                  const czc_hyper* hp, int32_t* out_ids, float* out_cos);
 
-/* Engine options.  "share_prefix" (default 1): encode the causal prefix common to an image's K
- * candidates once per step instead of K times (results are identical). */
+/* Engine options (all are exact work reductions / kernel choices; results agree within the engine precision):
+ *   "share_prefix"    (1) encode the causal prefix common to an image's K candidates once per step instead of K
+ *                         times
+ *   "pack_branches"   (1) attention of the branch rows with G candidates packed per 32-query MFMA tile
+ *   "pool_last_layer" (1) last CLIP-text layer: out-projection + MLP on the EOS rows only
+ *   "fuse_qkv_attn"   (0) branch rows: q/k/v projection and attention in one kernel (q, k, v never in HBM) */
 int czc_set_option(czc_engine* e, const char* name, int value);
 
 /* ---- measurement ------------------------------------------------------------------------- */
@@ -200,10 +204,12 @@ int czc_stats(czc_engine* e, int64_t* clip_rows, int64_t* clip_seqs, int64_t* be
  * `precision`, resid must be NULL) instead of the fp32 one -- the path the tower-internal layers use. */
 int czc_test_gemm(int precision, int M, int N, int K, const float* A, const float* W, const float* bias,
                   const float* resid, int act, float* C);
-/* GEMM microbenchmark on device-resident data: ms per launch (tools/bench_gemm.py); use256 selects the
- * 256x256 LDS-DMA kernel where eligible.  czc_test_set_option("gemm256", 0|1) is the same A/B switch
- * for whole-engine runs. */
+/* GEMM microbenchmark on device-resident data: ms per launch (tools/bench_gemm.py); use256: 0 128x128 kernel,
+ * 1-3 the 256x256 LDS-DMA kernels (plain / persistent / persistent + K ring), 5-6 the weight-stationary kernel
+ * (memory phase separate / interleaved into the MFMA stream) where eligible. */
 int czc_bench_gemm(int precision, int M, int N, int K, int act, int out_mode, int iters, int use256, double* ms_out);
+/* Process-wide kernel A/B switches for tests and tools: "gemm256" 0..3, "wreg" 0|1|2, "skinny", "splitk",
+ * "mfma_attention", "attention_image" 0|1|2 (2 = force), "qkv_attn"; "*_dbg" are timing ablations (results invalid). */
 int czc_test_set_option(const char* name, int value);
 int czc_test_layernorm(int precision, int M, int H, const float* x, const float* gamma, const float* beta, float eps,
                        float* y);
