@@ -587,3 +587,42 @@ def test_large_batch_kernel_families_agree():
         lib.czc_test_set_option(b"wreg", 2)
         lib.czc_test_set_option(b"attention_image", 1)
         su.engine.close()
+
+
+def test_first_sweep_large_batch_kernel_families_agree():
+    """The whole first sweep (captions growing from 0 to L filled positions: trunk length, rows per candidate and the
+    packing factor G all change from step to step) at B = 64, K = 200, teacher-forced on the default kernels'
+    own write-backs: default kernels vs the tiled-GEMM / per-group-attention family at every position."""
+    su = harness.build_synthetic(False, BF16)
+    lib = native.load()
+    try:
+        from oracle import step as S, models as M, text as T
+        B, L, K = 64, 10, 200
+        rng = np.random.default_rng(21)
+        o = S.Oracle(M.to_torch(synth.make_bert_weights(su.bert_cfg, 11)), su.bert_cfg,
+                     M.to_torch(synth.make_clip_weights(su.clip_cfg, 12)), su.clip_cfg, su.sv.bert_tokens,
+                     T.ClipBpe(su.sv.clip_vocab, su.sv.clip_merges))
+        inp = np.array(o.init_text("Image of a", L, B), dtype=np.int32)
+        su.engine.set_image_embeds(rng.standard_normal((B, su.clip_cfg.proj)).astype(np.float32))
+        hp = Engine.hyper(0.02, 2.0, 0.1)
+        flips = 0
+        for pos in range(L):
+            gen_idx = SEED_LEN + pos
+            res = {}
+            for name, wreg, att in (("conservative", 0, 0), ("default", 2, 1)):
+                assert lib.czc_test_set_option(b"wreg", wreg) == 0
+                assert lib.czc_test_set_option(b"attention_image", att) == 0
+                cur = inp.copy()
+                res[name] = (su.engine.step(cur, gen_idx, K, hp, dot_allowed=(pos == L - 1)), cur)
+            a, b = res["default"][0], res["conservative"][0]
+            np.testing.assert_array_equal(a["idxs"], b["idxs"])
+            np.testing.assert_array_equal(a["clip_ids"], b["clip_ids"])
+            assert np.isfinite(a["final_score"]).all()
+            np.testing.assert_allclose(a["final_score"], b["final_score"], atol=1e-3, err_msg=f"position {pos}")
+            flips += int((a["best"] != b["best"]).sum())
+            inp = res["default"][1]  # the step wrote the winners back
+        assert flips <= 3, flips  # near-ties may flip between kernel families in bf16
+    finally:
+        lib.czc_test_set_option(b"wreg", 2)
+        lib.czc_test_set_option(b"attention_image", 1)
+        su.engine.close()
