@@ -707,11 +707,14 @@ __global__ __launch_bounds__(256) void attention_valu_kernel(const T* qkv, SegTa
     const float sum = wave_sum(e0 + e1);
     Ps[j0] = e0 / sum;
     Ps[j1] = e1 / sum;
-    __syncthreads();
+    // every LDS region here is private to this wave and a wave's LDS operations execute in order: no barrier,
+    // only keep the compiler from moving the reads above the writes (two block-wide barriers per query used
+    // to serialise the four heads of a work-group: 30 barriers per sequence at T = 15)
+    asm volatile("" ::: "memory");
     float o = 0.f;
     for (int j = 0; j < vis; ++j) o += Ps[j] * Vs[j * 64 + lane];
     if (live) Act<T>::st(out, ((long)g.own_off + i) * (long)Hd + h * 64 + lane, o);
-    __syncthreads();
+    asm volatile("" ::: "memory");
   }
 }
 
