@@ -72,9 +72,33 @@ class CLIP:
             return self.czc_cfg.v_image
         return self.model.config.vision_config.image_size
 
+    def _device_processor_params(self):
+        """(mean, std) when the HF image processor is the geometry czc_preprocess_u8 implements (RGB, bicubic
+        resize of the shorter side to S, centre crop SxS, 1/255 rescale, normalise), else None."""
+        ip = getattr(self.processor, "image_processor", None)
+        if ip is None:
+            return None
+        S = self._image_size()
+        try:
+            def field(obj, key):  # plain dict (older transformers) or SizeDict
+                return obj.get(key) if isinstance(obj, dict) else getattr(obj, key, None)
+            size, crop = getattr(ip, "size", None), getattr(ip, "crop_size", None)
+            ok = (field(size, "shortest_edge") == S and field(crop, "height") == S and field(crop, "width") == S
+                  and int(getattr(ip, "resample", -1)) == 3
+                  and all(bool(getattr(ip, k, False)) for k in ("do_resize", "do_center_crop", "do_rescale", "do_normalize"))
+                  and abs(float(getattr(ip, "rescale_factor", 0.0)) - 1.0 / 255.0) < 1e-12)
+            if not ok:
+                return None
+            return (np.asarray(ip.image_mean, np.float32), np.asarray(ip.image_std, np.float32))
+        except (TypeError, ValueError, AttributeError):
+            return None
+
     # ---- clip/clip.py:48-62 ------------------------------------------------------------------
     def compute_image_representation_from_image_instance(self, image):
         if self.processor is not None:
+            std_cfg = self._device_processor_params()
+            if std_cfg is not None:  # the checkpoint's processor is the standard CLIP one: run it on the device
+                return _wrap(self._eng().encode_pil(image, mean=std_cfg[0], std=std_cfg[1]))
             pixels = self.processor(images=image, return_tensors="np")['pixel_values'].astype(np.float32)
             return _wrap(self._eng().encode_images(pixels))
         # resize / crop / normalise on the device, bit-identical to the PIL image processor (czc_preprocess_u8);

@@ -153,14 +153,14 @@ class Engine:
         self._ck(self.lib.czc_encode_staged(self.h, int(B), out.ctypes.data), "czc_encode_staged")
         return out
 
-    def encode_pil(self, images) -> np.ndarray:
+    def encode_pil(self, images, mean=None, std=None) -> np.ndarray:
         """PIL images / uint8 arrays -> image_embeds, geometry and normalisation on the device."""
         if not isinstance(images, (list, tuple)):
             images = [images]
         for i, im in enumerate(images):
             if not isinstance(im, np.ndarray):
                 im = np.asarray(im.convert("RGB"))
-            self.preprocess_u8(im, i)
+            self.preprocess_u8(im, i, mean=mean, std=std)
         return self.encode_staged(len(images))
 
     def set_image_embeds(self, embeds):

@@ -126,3 +126,29 @@ def test_run_cli_batching_and_result_layout(tmp_path, monkeypatch):
     assert sorted(os.listdir(d)) == ["best_clipscore.json", "iter_0.json", "iter_1.json"]
     assert json.load(open(os.path.join(d, "iter_1.json"))) == {"a": "t1a", "b": "t1b", "c": "t1c", "d": "t1d"}
     assert json.load(open(os.path.join(d, "best_clipscore.json")))["d"] == "best_d"
+
+
+def test_dropin_clip_recognises_the_standard_image_processor():
+    """clip/clip.py hands images to the device processor only when the checkpoint's HF image processor is the
+    geometry czc_preprocess_u8 implements; anything else keeps the HF path."""
+    import types
+    from clip.clip import CLIP
+    from conzic_amd import synth
+    try:
+        from transformers.models.clip.image_processing_pil_clip import CLIPImageProcessorPil
+    except ImportError:
+        pytest.skip("transformers PIL image processor unavailable")
+    c = CLIP(None)
+    c.czc_cfg = synth.clip_tiny(300)
+    S = c.czc_cfg.v_image
+    c.processor = types.SimpleNamespace(image_processor=CLIPImageProcessorPil(size={"shortest_edge": S},
+                                                                             crop_size={"height": S, "width": S}))
+    mean, std = c._device_processor_params()
+    np.testing.assert_allclose(mean, synth.CLIP_MEAN, rtol=0, atol=1e-7)
+    np.testing.assert_allclose(std, synth.CLIP_STD, rtol=0, atol=1e-7)
+    c.processor = types.SimpleNamespace(image_processor=CLIPImageProcessorPil(size={"shortest_edge": S}, resample=2,
+                                                                             crop_size={"height": S, "width": S}))
+    assert c._device_processor_params() is None  # bilinear: not ours
+    c.processor = types.SimpleNamespace(image_processor=CLIPImageProcessorPil(size={"shortest_edge": S + 8},
+                                                                             crop_size={"height": S, "width": S}))
+    assert c._device_processor_params() is None

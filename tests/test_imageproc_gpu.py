@@ -63,3 +63,27 @@ def test_bad_arguments_are_errors(setups):
         eng.preprocess_u8(np.zeros((4, 4), np.uint8))
     with pytest.raises(native.NativeError):
         eng.encode_staged(10_000)
+
+
+def test_dropin_clip_with_hf_processor_uses_device_path_bit_exactly(setups):
+    """A drop-in `CLIP` that carries the checkpoint's own HF image processor (the real-checkpoint route) sends raw
+    RGB to czc_preprocess_u8; the embeddings equal those of HF's pixel_values pushed through czc_encode_images."""
+    import types
+    from PIL import Image
+    from clip.clip import CLIP
+    try:
+        from transformers.models.clip.image_processing_pil_clip import CLIPImageProcessorPil
+    except ImportError:
+        pytest.skip("transformers PIL image processor unavailable")
+    su = setups[32]
+    S = su.clip_cfg.v_image
+    c = CLIP(None)
+    c.czc_cfg = su.clip_cfg
+    c._engine = su.engine
+    ip = CLIPImageProcessorPil(size={"shortest_edge": S}, crop_size={"height": S, "width": S})
+    c.processor = types.SimpleNamespace(image_processor=ip)
+    imgs = [Image.fromarray(u) for u in synth.make_odd_images(S)[:5]]
+    got = np.asarray(c.compute_image_representation_from_image_instance(imgs))
+    pv = ip(images=imgs, return_tensors="np")["pixel_values"].astype(np.float32)
+    want = su.engine.encode_images(pv)
+    np.testing.assert_array_equal(got, want)
