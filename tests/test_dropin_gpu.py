@@ -87,3 +87,32 @@ def test_clip_wrapper_methods():
     np.testing.assert_allclose(np.asarray(ref), rr.numpy(), atol=5e-6)
     np.testing.assert_allclose(np.asarray(score), rs.numpy(), atol=5e-6)
     assert abs(float(np.asarray(score).sum()) - 1.0) < 1e-5
+
+
+def test_engine_from_checkpoint_directories_matches_in_memory_engine(tmp_path):
+    """Real-checkpoint route on synthetic weights laid out as Hugging Face directories:
+    same step results as the engine fed from memory."""
+    from conzic_amd import checkpoint, harness, native, synth
+    from conzic_amd.engine import Engine
+    su = harness.build_synthetic(True, native.PREC_F32)
+    sv = su.sv
+    bw, cw = synth.make_bert_weights(su.bert_cfg, 11), synth.make_clip_weights(su.clip_cfg, 12)
+    bdir, cdir = checkpoint.write_checkpoint_dirs(str(tmp_path), su.bert_cfg, bw, su.clip_cfg, cw, sv)
+    eng, bcfg, ccfg, bt, ct = checkpoint.engine_from_checkpoints(bdir, cdir, native.PREC_F32)
+    try:
+        assert bcfg == su.bert_cfg
+        eng.set_token_mask(su.token_mask)
+        rng = np.random.default_rng(3)
+        emb = rng.standard_normal((2, su.clip_cfg.proj)).astype(np.float32)
+        inp = np.array([bt.encode("Image of a" + bt.mask_token * 5)] * 2, dtype=np.int32)
+        hp = Engine.hyper(0.02, 2.0, 0.1)
+        outs = []
+        for e in (eng, su.engine):
+            e.set_image_embeds(emb)
+            outs.append(e.step(inp.copy(), 4, 12, hp))
+        for k in ("idxs", "clip_ids", "best"):
+            np.testing.assert_array_equal(outs[0][k], outs[1][k])
+        np.testing.assert_array_equal(outs[0]["final_score"], outs[1]["final_score"])
+    finally:
+        eng.close()
+        su.engine.close()

@@ -152,3 +152,29 @@ def test_dropin_clip_recognises_the_standard_image_processor():
     c.processor = types.SimpleNamespace(image_processor=CLIPImageProcessorPil(size={"shortest_edge": S + 8},
                                                                              crop_size={"height": S, "width": S}))
     assert c._device_processor_params() is None
+
+
+def test_checkpoint_directories_round_trip(tmp_path):
+    """conzic_amd/checkpoint.py: Hugging Face style directories (config.json, model.safetensors, vocab files)
+    -> configs, fp32 tensors under their HF names, tokenizers; no torch modules involved."""
+    from conzic_amd import checkpoint
+    sv = synth.make_vocab_tiny()
+    bcfg, ccfg = synth.bert_tiny(len(sv.bert_tokens)), synth.clip_tiny(len(sv.clip_vocab))
+    bw, cw = synth.make_bert_weights(bcfg, 11), synth.make_clip_weights(ccfg, 12)
+    bdir, cdir = checkpoint.write_checkpoint_dirs(str(tmp_path), bcfg, bw, ccfg, cw, sv)
+    with open(os.path.join(bdir, "config.json")) as f:
+        assert checkpoint.bert_cfg_from_json(json.load(f)) == bcfg
+    with open(os.path.join(cdir, "config.json")) as f:
+        got = checkpoint.clip_cfg_from_json(json.load(f))
+    assert got == ccfg
+    rb, rc = checkpoint.read_safetensors(bdir), checkpoint.read_safetensors(os.path.join(cdir, "model.safetensors"))
+    assert set(rb) == set(bw) and set(rc) == set(cw)
+    for k in bw:
+        np.testing.assert_array_equal(rb[k], np.asarray(bw[k], np.float32))
+    bt, ct = checkpoint.load_tokenizers(bdir, cdir)
+    bt0, ct0 = tokenizers_from_vocab(sv)
+    text = "image of a " + " ".join(sv.bert_tokens[sv.regular_lo:sv.regular_lo + 5])
+    assert bt.encode(text) == bt0.encode(text)
+    assert ct(text)["input_ids"] == ct0(text)["input_ids"]
+    with pytest.raises(FileNotFoundError):
+        checkpoint.read_safetensors(str(tmp_path / "nothing_here"))
