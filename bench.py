@@ -83,7 +83,8 @@ def main():
     ap.add_argument("--topk", type=int, default=200)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--order", default="sequential", choices=["sequential", "shuffle"])
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32", "split"])
+    ap.add_argument("--logit-scale", type=float, default=2.6592, help="CLIP logit_scale (HF init 2.6592; published checkpoint ln 100 = 4.6052)")
     ap.add_argument("--gamma", type=float, default=None, help="sentiment control weight (BASELINE configs[4]: 5.0)")
     ap.add_argument("--sentiment", default="positive", choices=["positive", "negative"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -110,8 +111,9 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    prec = native.PREC_BF16 if a.precision == "bf16" else native.PREC_F32
+    prec = {"bf16": native.PREC_BF16, "f32": native.PREC_F32, "split": native.PREC_SPLIT}[a.precision]
     bcfg, ccfg = synth.bert_base(), synth.clip_b32()
+    ccfg.logit_scale = a.logit_scale  # make_clip_weights writes it into the "logit_scale" tensor
     # frozen weights: generated on rank 0, broadcast once over RCCL (xGMI), consumed in place
     t0 = time.time()
     if world > 1:
@@ -120,7 +122,7 @@ def main():
         torch.cuda.synchronize()
     else:
         bw, cw = synth.make_bert_weights(bcfg, 11), synth.make_clip_weights(ccfg, 12)
-    su = harness.build_synthetic(False, prec, regular_only=True, device=local, bert_w=bw, clip_w=cw,
+    su = harness.build_synthetic(False, prec, logit_scale=a.logit_scale, regular_only=True, device=local, bert_w=bw, clip_w=cw,
                                  bert_cfg=bcfg, clip_cfg=ccfg, lexicon=a.gamma is not None)
     del bw, cw
     eng = su.engine
@@ -205,7 +207,7 @@ def main():
         f_cap = caption_flops(L, K, I)
         out = dict(metric="captions/sec (L=10, K=200, seq order)", value=round(value, 4), unit="captions/s",
                    n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(dt / a.steps * 1e3, 2),
-                   higher_is_better=True, scaling="weak", vs_baseline=None, dtype="bf16" if prec == 0 else "f32",
+                   higher_is_better=True, scaling="weak", vs_baseline=None, dtype={0: "bf16", 1: "f32", 3: "split-fp16 (fp16 hi+lo planes, 3 MFMA passes, fp32 accumulate)"}[prec],
                    data="synthetic",
                    config=dict(workload=f"{cfg_name}: {B} random-pixel 224x224 images per GPU, {a.order}, "
                                         f"L={L}, K={K}, I={I}, alpha=0.02 beta=2.0 tau=0.1, bert-base + CLIP ViT-B/32 shapes, "

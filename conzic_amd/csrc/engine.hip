@@ -494,7 +494,8 @@ int czc_create(const czc_config* cfg, int device_id, czc_engine** out) {
     snprintf(czc::g_err, sizeof(czc::g_err), "czc_create: head_dim must be 64 for all towers");
     return CZC_ERR_ARG;
   }
-  if (cfg->precision != CZC_PREC_BF16 && cfg->precision != CZC_PREC_F32 && cfg->precision != CZC_PREC_ALL_BF16) {
+  if (cfg->precision != CZC_PREC_BF16 && cfg->precision != CZC_PREC_F32 && cfg->precision != CZC_PREC_ALL_BF16 &&
+      cfg->precision != CZC_PREC_SPLIT) {
     snprintf(czc::g_err, sizeof(czc::g_err), "czc_create: unknown precision");
     return CZC_ERR_ARG;
   }
@@ -512,9 +513,10 @@ int czc_create(const czc_config* cfg, int device_id, czc_engine** out) {
   e->dev = device_id;
   // precision 0: CLIP towers on bf16 MFMA; BERT on split-fp16 MFMA (hi+lo planes, three fp16 passes,
   // ~22 mantissa bits: the tau=0.1 softmax amplifies logit error tenfold, and BERT is 1.4% of the
-  // FLOPs); 1: everything on f32 MFMA; 2: everything bf16 (experiments)
-  e->pc = cfg->precision == CZC_PREC_F32 ? PREC_F32 : PREC_BF16;
-  e->pb = cfg->precision == CZC_PREC_ALL_BF16 ? PREC_BF16 : (cfg->precision == CZC_PREC_BF16 ? PREC_F16X3 : PREC_F32);
+  // FLOPs); 1: everything on f32 MFMA; 2: everything bf16 (experiments); 3: every tower on split-fp16 MFMA
+  e->pc = cfg->precision == CZC_PREC_F32 ? PREC_F32 : (cfg->precision == CZC_PREC_SPLIT ? PREC_F16X3 : PREC_BF16);
+  e->pb = cfg->precision == CZC_PREC_ALL_BF16 ? PREC_BF16
+                                              : (cfg->precision == CZC_PREC_F32 ? PREC_F32 : PREC_F16X3);
   e->esz = e->pc == PREC_BF16 ? 2 : 4;
   e->eb = e->pb == PREC_BF16 ? 2 : 4;
   if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&e->st) != hipSuccess ||

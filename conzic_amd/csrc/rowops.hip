@@ -199,6 +199,8 @@ int launch_im2col(int prec, const float* pixels, int B, int S, int p, void* out,
   dim3 grid((unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192)), block(256);
   if (prec == PREC_BF16)
     hipLaunchKernelGGL(im2col_kernel<bf16_t>, grid, block, 0, st, pixels, B, S, p, (bf16_t*)out);
+  else if (prec == PREC_F16X3)
+    hipLaunchKernelGGL(im2col_kernel<split_t>, grid, block, 0, st, pixels, B, S, p, (split_t*)out);
   else
     hipLaunchKernelGGL(im2col_kernel<float>, grid, block, 0, st, pixels, B, S, p, (float*)out);
   CZC_HIP_CHECK(hipGetLastError());

@@ -49,6 +49,23 @@ def make_config(bert_cfg, clip_cfg, special: Dict[str, int], precision: int) -> 
     return c
 
 
+def normalize_state_name(name: str) -> Optional[str]:
+    """Checkpoint key -> the name the engine knows, or None for tensors the path never reads.
+    `from_pretrained` renames the legacy TF-style `LayerNorm.gamma` / `LayerNorm.beta` of old BERT checkpoints to
+    `.weight` / `.bias` on load; a safetensors file read directly still carries the old names.  The pooler and the
+    next-sentence head are not on the masked-LM path (HF:bert/modeling_bert.py:939-982); `position_ids` is a
+    buffer; the MLM decoder weight is tied to the word embeddings (HF:bert/modeling_bert.py:910-913)."""
+    if name.endswith(".gamma"):
+        name = name[:-len(".gamma")] + ".weight"
+    elif name.endswith(".beta"):
+        name = name[:-len(".beta")] + ".bias"
+    if name.endswith("position_ids") or name == "cls.predictions.decoder.weight":
+        return None
+    if name.startswith("bert.pooler.") or name.startswith("cls.seq_relationship."):
+        return None
+    return name
+
+
 class Engine:
     def __init__(self, bert_cfg, clip_cfg, special: Dict[str, int], precision: int = native.PREC_BF16, device: int = 0):
         self.lib = native.load()
@@ -83,8 +100,9 @@ class Engine:
             for name, t in sd.items():
                 if names is not None and name not in names:
                     continue
-                if name.endswith("position_ids") or name == "cls.predictions.decoder.weight":
-                    continue  # decoder weight is tied to the word embeddings (HF:bert/modeling_bert.py:910-913)
+                name = normalize_state_name(name)
+                if name is None:
+                    continue
                 if name == "cls.predictions.decoder.bias" and "cls.predictions.bias" in sd:
                     continue
                 if hasattr(t, "detach"):

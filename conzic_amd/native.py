@@ -16,6 +16,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "conzic_hip.h")
 PREC_BF16 = 0
 PREC_F32 = 1
 PREC_ALL_BF16 = 2
+PREC_SPLIT = 3
 CLIP_MAX_LEN = 77
 
 

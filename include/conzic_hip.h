@@ -41,6 +41,11 @@ extern "C" {
                         /* BERT is only 1.4% of the step's FLOPs                                          */
 #define CZC_PREC_F32 1  /* f32-input MFMA everywhere (verification mode, ~1e-6 of the CPU reference) */
 #define CZC_PREC_ALL_BF16 2 /* bf16 MFMA in every tower (experiments only) */
+#define CZC_PREC_SPLIT 3 /* every tower on split-fp16 MFMA (hi+lo fp16 planes, three passes, ~22 mantissa bits,  */
+                         /* fp32 accumulate): fp32-class results at 3/16 of the f32-MFMA cost.  The mode for     */
+                         /* checkpoints whose logit_scale.exp() is large (clip/clip.py:95-98: x100 for the       */
+                         /* published clip-vit-base-patch32), where a bf16 cosine error would be multiplied by   */
+                         /* 100 ahead of softmax_K and leave the 1e-3 fused-score budget                          */
 
 #define CZC_BRIDGE_MAX_BYTES 512 /* decoded caption text per candidate row */
 #define CZC_CLIP_MAX_LEN 77       /* clip/clip.py:71-72 (max_length = 77, truncation) */

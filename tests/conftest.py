@@ -28,3 +28,19 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if "gpu" in it.keywords:
             it.add_marker(skip)
+
+
+def pytest_terminal_summary(terminalreporter):
+    """Measured parity errors of the golden step tests (tests/test_step_gpu.py::ERR_LOG), worst per case and
+    engine precision, so that a GPU run leaves the numbers DESIGN.md quotes in its log."""
+    mod = sys.modules.get("test_step_gpu")
+    log = getattr(mod, "ERR_LOG", None) if mod else None
+    if not log:
+        return
+    worst = {}
+    for name, prec, efin, ecos in log:
+        w = worst.setdefault((name, prec), [0.0, 0.0, 0])
+        w[0], w[1], w[2] = max(w[0], efin), max(w[1], ecos), w[2] + 1
+    terminalreporter.write_line("golden parity, worst over image-steps (case, precision: |d final_score|, |d cosine|, n):")
+    for (name, prec), (efin, ecos, n) in sorted(worst.items()):
+        terminalreporter.write_line(f"  {name:22s} prec={prec}: {efin:.3e} {ecos:.3e} n={n}")

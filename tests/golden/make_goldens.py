@@ -379,6 +379,12 @@ CASES = dict(
                    keep_step_tensors=20),
     full_synth_b2=dict(tiny=False, B=2, L=10, K=200, I=1, order="shuffle", image="synthetic"),
     full_regular=dict(tiny=False, B=2, L=10, K=200, I=1, order="sequential", image="synthetic", regular_only=True),
+    # published-checkpoint logit scale (ln 100, clip/clip.py:95-98) on full-size towers
+    full_scale100=dict(tiny=False, B=2, L=10, K=200, I=1, order="sequential", image="synthetic", logit_scale=4.6052),
+    # BASELINE configs[3] shape: shuffle order, L=15, K=512 (gen_utils.py:98-146)
+    full_shuffle_k512=dict(tiny=False, B=2, L=15, K=512, I=1, order="shuffle", image="synthetic"),
+    # BASELINE configs[4] shape: sentiment control, gamma=5, L=12, K=200 (control_gen_utils.py:30-80)
+    full_senti=dict(tiny=False, B=2, L=12, K=200, I=1, order="sequential", image="synthetic", gamma=5.0, style="positive"),
 )
 
 

@@ -105,3 +105,25 @@ def test_oracle_imageproc_matches_reference_processor(label, S):
     imgs = synth.make_odd_images(S)[: int(z["n"])]
     assert [list(i.shape[:2]) for i in imgs] == z["sizes"].tolist()
     np.testing.assert_array_equal(preprocess(imgs, S), synth.pixels_from_u8(z["crops"]))
+
+
+@pytest.mark.parametrize("name,step", [("full_scale100", 6), ("full_senti", 7), ("full_shuffle_k512", 3)])
+def test_oracle_full_size_mid_trajectory_step(name, step):
+    """The oracle on the full-size goldens added for the published logit scale (x100, clip/clip.py:95-98), the
+    sentiment control path at configs[4] shape (gamma=5, L=12; control_gen_utils.py:53-63) and configs[3] shape
+    (K=512, L=15, shuffle): one mid-trajectory position-step each, against what the reference produced."""
+    meta, arr = load_case(name)
+    o, sv, mask = make_oracle(meta)
+    pos = meta["positions"][step]
+    gen_idx = 4 + pos
+    inp = torch.from_numpy(arr["inp_before"][step].astype(np.int64))
+    emb = torch.from_numpy(arr["image_embeds"])
+    o.update_token_mask(mask, meta["L"], pos)
+    r = S.polish_step(o, inp, emb, mask, gen_idx, meta["K"], meta["temperature"], meta["alpha"], meta["beta"],
+                      gamma=meta["gamma"], ctl_signal=meta["style"])
+    np.testing.assert_array_equal(r["idxs"].numpy(), arr["idxs"][step])
+    np.testing.assert_allclose(r["probs"].numpy(), arr["probs"][step], rtol=2e-4, atol=1e-7)
+    np.testing.assert_allclose(r["clip_ref"].numpy(), arr["clip_ref"][step], atol=3e-6)
+    np.testing.assert_allclose(r["clip_score"].numpy(), arr["clip_score"][step], atol=2e-6, rtol=2e-4)
+    if step + 1 < arr["inp_before"].shape[0]:
+        np.testing.assert_array_equal(r["inp_after"].numpy()[:, gen_idx], arr["inp_before"][step + 1][:, gen_idx])

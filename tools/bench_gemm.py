@@ -14,6 +14,7 @@ if len(sys.argv) > 3:
     lib.czc_test_set_option(b"wreg_dbg", int(sys.argv[3]))
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 768000
 shapes = [("qkv", 1536, 512, 0, 0), ("out", 512, 512, 0, 1), ("fc1", 2048, 512, 1, 0), ("fc2", 512, 2048, 0, 1)]
+PREC = int(os.environ.get('CZC_GEMM_PREC', '0'))  # 0 bf16, 1 f32, 3 split-fp16 (use CZC_GEMM_VARIANTS=0)
 VARIANTS = tuple(int(v) for v in os.environ.get('CZC_GEMM_VARIANTS', '3,5,6').split(','))
 if len(sys.argv) > 4:
     shapes.append(("fc1n", 2048, 512, 0, 0))  # fc1 shape without the activation (epilogue VALU share)
@@ -22,7 +23,7 @@ fl = 0.0
 for name, N, K, act, mode in shapes:
     for use256 in VARIANTS:
         ms = C.c_double()
-        native.check(lib.czc_bench_gemm(0, M, N, K, act, mode, 5, use256, C.byref(ms)), None, "bench")
+        native.check(lib.czc_bench_gemm(PREC, M, N, K, act, mode, 5, use256, C.byref(ms)), None, "bench")
         tf = 2.0 * M * N * K / (ms.value * 1e-3) / 1e12
         tot[use256] += ms.value
         print(f"{name:4s} M={M} N={N:5d} K={K:5d} use256={use256}: {ms.value:8.3f} ms  {tf:7.1f} TF/s", flush=True)
