@@ -34,6 +34,9 @@ struct LayerW {
   void* fc1_w = nullptr; float* fc1_b = nullptr;
   void* fc2_w = nullptr; float* fc2_b = nullptr;
   float *ln2_g = nullptr, *ln2_b = nullptr;
+  // bf16 CLIP-text tower: LayerNorm folded into the q/k/v and fc1 weights (GemmArgs::ln_*, rowops.hip fold_ln_kernel)
+  void* qkv_wf = nullptr; float* qkv_sf = nullptr; float* qkv_bf = nullptr;
+  void* fc1_wf = nullptr; float* fc1_sf = nullptr; float* fc1_bf = nullptr;
 };
 
 struct Buf {
@@ -82,6 +85,8 @@ struct czc_engine {
                           // two-kernel path on configs[2] today (0.78 vs 0.75 ms per layer), kept opt-in
   int pack_branches = 1; // pack several candidates' rows into one attention MFMA tile
   int pool_last_layer = 1; // last CLIP-text layer: out-proj + MLP on the EOS rows only
+  int fold_ln = 0;         // bf16 CLIP-text tower: LayerNorm applied inside the GEMM epilogues (no LayerNorm pass over HBM);
+                           // measured slower than the LayerNorm kernel while out-proj / fc2 pay for the bf16 copy
 
   bool prof = false;
   std::map<std::string, ProfKind> pk;
@@ -217,6 +222,23 @@ int build_layers(czc_engine* e, std::vector<LayerW>& L, int n_layers, int H, int
     E_CHECK(need(e, fc2 + ".weight", (size_t)H * I, &t)); E_CHECK(to_act(e, prec, t, (size_t)H * I, &l.fc2_w));
     E_CHECK(need(e, fc2 + ".bias", H, &l.fc2_b));
     E_CHECK(need(e, ln2 + ".weight", H, &l.ln2_g)); E_CHECK(need(e, ln2 + ".bias", H, &l.ln2_b));
+    if (!bert_style && prec == PREC_BF16 && H == 512 && prefix.compare(0, 5, "text_") == 0) {
+      // pre-LN block: LN1 feeds q/k/v, LN2 feeds fc1 (HF:clip/modeling_clip.py:368-383)
+      float* fc1m;
+      E_CHECK(need(e, fc1 + ".weight", (size_t)I * H, &fc1m));
+      E_HIP(hipMalloc(&l.qkv_wf, (size_t)3 * H * H * 2));
+      E_HIP(hipMalloc((void**)&l.qkv_sf, (size_t)3 * H * 4));
+      E_HIP(hipMalloc((void**)&l.qkv_bf, (size_t)3 * H * 4));
+      E_HIP(hipMalloc(&l.fc1_wf, (size_t)I * H * 2));
+      E_HIP(hipMalloc((void**)&l.fc1_sf, (size_t)I * 4));
+      E_HIP(hipMalloc((void**)&l.fc1_bf, (size_t)I * 4));
+      const float* ws[3] = {qw, kw, vw};
+      const float* bs[3] = {qb, kb, vb};
+      for (int t3 = 0; t3 < 3; ++t3)
+        E_CHECK(launch_fold_ln(ws[t3], bs[t3], l.ln1_g, l.ln1_b, H, H, (char*)l.qkv_wf + (size_t)t3 * H * H * 2,
+                               l.qkv_sf + t3 * H, l.qkv_bf + t3 * H, e->st));
+      E_CHECK(launch_fold_ln(fc1m, l.fc1_b, l.ln2_g, l.ln2_b, I, H, l.fc1_wf, l.fc1_sf, l.fc1_bf, e->st));
+    }
   }
   return 0;
 }
@@ -227,6 +249,12 @@ int gemm(czc_engine* e, int prec, const char* kind, const void* A, int lda, cons
   g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.resid = resid; g.ldr = ldr;
   g.out_act = out_act; g.out_f32 = out_f32; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.act = act;
   ProfScope ps(e, kind, 2.0 * M * (double)N * K);
+  E_CHECK(launch_gemm(prec, g, e->st));
+  return 0;
+}
+
+int gemm_ex(czc_engine* e, int prec, const char* kind, const GemmArgs& g) {
+  ProfScope ps(e, kind, 2.0 * g.M * (double)g.N * g.K);
   E_CHECK(launch_gemm(prec, g, e->st));
   return 0;
 }
@@ -247,11 +275,38 @@ int clip_stack(czc_engine* e, const char* gk, std::vector<LayerW>& L, float* x, 
   E_CHECK(ensure(e, "cs_ctx", (size_t)M * H * e->esz, &ctx));
   E_CHECK(ensure(e, "cs_h", (size_t)M * I * e->esz, &hbuf));
   const float scale = 1.0f / sqrtf(64.0f);
+  // LayerNorm folding (bf16 text tower, big batches): the fp32-output GEMMs (out-proj, fc2) also leave a bf16 copy
+  // of the new residual stream in `y` and its per-row statistics partials in `stats`; the K = 512 GEMMs that follow
+  // a LayerNorm (q/k/v, fc1) read that copy with gain-folded weights and finish the LayerNorm in their epilogue.
+  // Layer 0's LN1 (input = embeddings) and everything on pooled rows still run the LayerNorm kernel.
+  const bool fold = P == PREC_BF16 && e->fold_ln && H == 512 && M >= 2048 && !L.empty() && L[0].qkv_wf &&
+                    g_use_wreg == 2 && g_use_gemm256 == 3 && !e->fuse_qkv_attn;
+  float* stats = nullptr;
+  if (fold) E_CHECK(ensure(e, "cs_stats", (size_t)M * (H / 64) * 2 * 4, (void**)&stats));
+  bool have_stats = false;
+  auto lnf_gemm = [&](const void* Wf, const float* bf, const float* sf, void* out, int N, int act) -> int {
+    GemmArgs g;
+    g.A = y; g.lda = H; g.W = Wf; g.ldw = H; g.bias = bf; g.resid = nullptr; g.ldr = 0; g.out_act = out; g.out_f32 = nullptr;
+    g.ldc = N; g.M = M; g.N = N; g.K = H; g.act = act;
+    g.ln_stats = stats; g.ln_s = sf; g.ln_groups = H / 64; g.ln_eps = eps;
+    if (!gemm_wreg_eligible(g)) return fail(e, CZC_ERR_STATE, "folded LayerNorm GEMM not eligible%s");
+    return gemm_ex(e, P, gk, g);
+  };
+  auto resid_gemm = [&](const void* A, int lda, const void* W, const float* b, int K) -> int {  // x += A.W^T + b (+ copy, stats)
+    GemmArgs g;
+    g.A = A; g.lda = lda; g.W = W; g.ldw = K; g.bias = b; g.resid = x; g.ldr = H; g.out_act = fold ? y : nullptr; g.out_f32 = x;
+    g.ldc = H; g.M = M; g.N = H; g.K = K; g.act = ACT_NONE;
+    g.row_stats = fold ? stats : nullptr;
+    return gemm_ex(e, P, gk, g);
+  };
   for (size_t n = 0; n < L.size(); ++n) {
     LayerW& l = L[n];
-    { ProfScope ps(e, "rowops", 0); E_CHECK(launch_layernorm(P, x, nullptr, l.ln1_g, l.ln1_b, eps, M, H, y, nullptr, e->st)); }
     const bool fused = plan_B > 0 && plan_trunk_rows > 0 && P == PREC_BF16 && g_use_mfma_attention && e->pack_branches &&
                        e->fuse_qkv_attn && qkv_attn_eligible(H, heads, max_keys, plan_max_own, plan_K);
+    if (!(fold && have_stats)) {
+      ProfScope ps(e, "rowops", 0);
+      E_CHECK(launch_layernorm(P, x, nullptr, l.ln1_g, l.ln1_b, eps, M, H, y, nullptr, e->st));
+    }
     if (fused) {
       // trunk rows (B*T of them) through the ordinary kernels; the B*K branches never write q,k,v to HBM
       E_CHECK(gemm(e, P, gk, y, H, l.qkv_w, H, l.qkv_b, nullptr, 0, qkv, nullptr, 3 * H, plan_trunk_rows, 3 * H, H, ACT_NONE));
@@ -260,7 +315,8 @@ int clip_stack(czc_engine* e, const char* gk, std::vector<LayerW>& L, float* x, 
       { ProfScope ps(e, gk, 2.0 * (M - plan_trunk_rows) * 3.0 * H * H);
         E_CHECK(launch_qkv_attn(y, H, l.qkv_w, l.qkv_b, qkv, tab, plan_B, plan_K, plan_max_own, heads, scale, ctx, e->st)); }
     } else {
-    E_CHECK(gemm(e, P, gk, y, H, l.qkv_w, H, l.qkv_b, nullptr, 0, qkv, nullptr, 3 * H, M, 3 * H, H, ACT_NONE));
+    if (fold && have_stats) E_CHECK(lnf_gemm(l.qkv_wf, l.qkv_bf, l.qkv_sf, qkv, 3 * H, ACT_NONE));
+    else E_CHECK(gemm(e, P, gk, y, H, l.qkv_w, H, l.qkv_b, nullptr, 0, qkv, nullptr, 3 * H, M, 3 * H, H, ACT_NONE));
     { ProfScope ps(e, "attention", 0);
       int rc = -1;
       if (plan_B > 0 && P == PREC_BF16 && g_use_mfma_attention && e->pack_branches)
@@ -285,10 +341,15 @@ int clip_stack(czc_engine* e, const char* gk, std::vector<LayerW>& L, float* x, 
       *pooled = x_e;
       return 0;
     }
-    E_CHECK(gemm(e, P, gk, ctx, H, l.o_w, H, l.o_b, x, H, nullptr, x, H, M, H, H, ACT_NONE));
-    { ProfScope ps(e, "rowops", 0); E_CHECK(launch_layernorm(P, x, nullptr, l.ln2_g, l.ln2_b, eps, M, H, y, nullptr, e->st)); }
-    E_CHECK(gemm(e, P, gk, y, H, l.fc1_w, H, l.fc1_b, nullptr, 0, hbuf, nullptr, I, M, I, H, ACT_QUICK_GELU));
-    E_CHECK(gemm(e, P, gk, hbuf, I, l.fc2_w, I, l.fc2_b, x, H, nullptr, x, H, M, H, I, ACT_NONE));
+    E_CHECK(resid_gemm(ctx, H, l.o_w, l.o_b, H));
+    if (fold) {
+      E_CHECK(lnf_gemm(l.fc1_wf, l.fc1_bf, l.fc1_sf, hbuf, I, ACT_QUICK_GELU));
+    } else {
+      { ProfScope ps(e, "rowops", 0); E_CHECK(launch_layernorm(P, x, nullptr, l.ln2_g, l.ln2_b, eps, M, H, y, nullptr, e->st)); }
+      E_CHECK(gemm(e, P, gk, y, H, l.fc1_w, H, l.fc1_b, nullptr, 0, hbuf, nullptr, I, M, I, H, ACT_QUICK_GELU));
+    }
+    E_CHECK(resid_gemm(hbuf, I, l.fc2_w, l.fc2_b, I));
+    have_stats = fold;
   }
   return 0;
 }
@@ -536,7 +597,11 @@ int czc_destroy(czc_engine* e) {
   (void)hipStreamSynchronize(e->st);
   for (auto& kv : e->w) if (kv.second.p) (void)hipFree(kv.second.p);
   auto free_layers = [](std::vector<LayerW>& L) {
-    for (auto& l : L) { (void)hipFree(l.qkv_w); (void)hipFree(l.qkv_b); (void)hipFree(l.o_w); (void)hipFree(l.fc1_w); (void)hipFree(l.fc2_w); }
+    for (auto& l : L) {
+      (void)hipFree(l.qkv_w); (void)hipFree(l.qkv_b); (void)hipFree(l.o_w); (void)hipFree(l.fc1_w); (void)hipFree(l.fc2_w);
+      (void)hipFree(l.qkv_wf); (void)hipFree(l.qkv_sf); (void)hipFree(l.qkv_bf);
+      (void)hipFree(l.fc1_wf); (void)hipFree(l.fc1_sf); (void)hipFree(l.fc1_bf);
+    }
   };
   free_layers(e->bert); free_layers(e->ctext); free_layers(e->cvis);
   (void)hipFree(e->mlm_dense_w); (void)hipFree(e->decoder_w); (void)hipFree(e->tproj_w); (void)hipFree(e->vproj_w);
@@ -883,6 +948,7 @@ int czc_set_option(czc_engine* e, const char* name, int value) {
   if (!strcmp(name, "pack_branches")) { e->pack_branches = value ? 1 : 0; return CZC_OK; }
   if (!strcmp(name, "pool_last_layer")) { e->pool_last_layer = value ? 1 : 0; return CZC_OK; }
   if (!strcmp(name, "fuse_qkv_attn")) { e->fuse_qkv_attn = value ? 1 : 0; return CZC_OK; }
+  if (!strcmp(name, "fold_ln")) { e->fold_ln = value ? 1 : 0; return CZC_OK; }
   return fail(e, CZC_ERR_ARG, "unknown option %s", name);
 }
 

@@ -15,6 +15,9 @@
 //
 // Work-group -> tile map is XCD-aware: consecutive ids inside one XCD's share walk the N tiles
 // of the same M tile, so the activation tile is fetched into one L2 only.
+#include <map>
+#include <mutex>
+
 #include "kernels.h"
 
 namespace czc {
@@ -373,8 +376,10 @@ __global__ void splitk_reduce_kernel(const float* slabs, int nslab, long slab_st
 }
 
 int g_use_splitk = 1;
-static float* g_splitk_ws = nullptr;
-static size_t g_splitk_bytes = 0;
+// slab workspace per stream (two engines, or the two half-batch lanes of one engine, run split-K GEMMs concurrently)
+struct SplitkWs { float* p = nullptr; size_t bytes = 0; };
+static std::map<hipStream_t, SplitkWs> g_splitk_map;
+static std::mutex g_splitk_mu;
 
 // returns 0 when the shape does not want split-K, else the slice count it launched with
 template <typename T>
@@ -388,16 +393,22 @@ static int try_splitk(const GemmArgs& g, int tiles_m, int tiles_n, hipStream_t s
     if (g.K % (c * Mma<T>::KPT) == 0 && g.K / c >= 256 && tiles * c <= 1024) { ks = c; break; }
   if (!ks) return 0;
   const size_t need = (size_t)ks * g.M * g.ldc * 4;
-  if (need > g_splitk_bytes) {
-    if (g_splitk_ws) { (void)hipStreamSynchronize(st); (void)hipFree(g_splitk_ws); g_splitk_ws = nullptr; g_splitk_bytes = 0; }
-    if (hipMalloc((void**)&g_splitk_ws, need + need / 4) != hipSuccess) { *rc = 1; snprintf(g_err, sizeof(g_err), "split-K workspace allocation failed"); return ks; }
-    g_splitk_bytes = need + need / 4;
+  float* ws = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_splitk_mu);
+    SplitkWs& w = g_splitk_map[st];
+    if (need > w.bytes) {
+      if (w.p) { (void)hipStreamSynchronize(st); (void)hipFree(w.p); w.p = nullptr; w.bytes = 0; }
+      if (hipMalloc((void**)&w.p, need + need / 4) != hipSuccess) { *rc = 1; snprintf(g_err, sizeof(g_err), "split-K workspace allocation failed"); return ks; }
+      w.bytes = need + need / 4;
+    }
+    ws = w.p;
   }
   GemmArgs p = g;
-  p.bias = nullptr; p.resid = nullptr; p.out_f32 = g_splitk_ws;
+  p.bias = nullptr; p.resid = nullptr; p.out_f32 = ws;
   launch_t<T>(p, tiles_m, tiles_n, true, st, ks);
   const long n4 = (long)g.M * (g.N >> 2);
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv(n4, 256)), dim3(256), 0, st, g_splitk_ws, ks, (long)g.M * g.ldc,
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv(n4, 256)), dim3(256), 0, st, ws, ks, (long)g.M * g.ldc,
                      g.bias, g.resid, g.ldr, g.out_f32, g.ldc, g.M, g.N);
   return ks;
 }

@@ -214,7 +214,18 @@ __device__ __forceinline__ void tile_of(int t, int tiles_m, int tiles_n, int& tm
 // row, 4 columns per quad -> 8-byte pieces scattered over 32 rows) into row-major 16-byte pieces:
 // 8 lanes cover one 128-byte line, so every global store / residual load is a full cache line
 // instead of 64 partial ones.
-template <int ACT, bool OUT_F32>
+// sum over the 8 lanes that share (lane >> 3): two quad-permute DPP steps, then the mirrored half row
+__device__ __forceinline__ float sum8_dpp(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));  // row_half_mirror
+  return v;
+}
+
+// STATS (fp32 path only): besides the fp32 result and its bf16 copy, every wave leaves the per-row (sum, sum of
+// squares) of its 64 result columns in g.row_stats[row][n/64][2] -- the LayerNorm statistics of the next layer in
+// eight fixed-order partials per 512-wide row, so the consumer GEMM can apply the LayerNorm in its epilogue.
+template <int ACT, bool OUT_F32, bool STATS = false>
 __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x16_t (&acc)[4][2], unsigned char* patch, int m0,
                                               int n0, int wm, int wn, int lane) {
   const int half = lane >> 5;
@@ -257,6 +268,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x16_t (&acc)
       // fp32 output (+bias, +fp32 residual, optional bf16 copy): 32 rows x 32 columns per pass
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
+        float ps[4] = {0.f, 0.f, 0.f, 0.f}, pq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int col = n0 + wn * 64 + j * 32 + rslot * 4;
@@ -276,19 +288,56 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x16_t (&acc)
             *(float4*)(patch + l31 * 128 + slot * 16) =
                 make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
           }
+          uint2 pk[4];
 #pragma unroll
           for (int pass = 0; pass < 4; ++pass) {
             const int r = pass * 8 + rrow;
             float4 v = *(const float4*)(patch + r * 128 + ((rslot ^ (r & 7)) << 4));
             const int row = m0 + wm * 128 + i * 32 + r;
+            v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+            v.x = act_fn<ACT>(v.x); v.y = act_fn<ACT>(v.y); v.z = act_fn<ACT>(v.z); v.w = act_fn<ACT>(v.w);
+            v.x += r4[pass].x; v.y += r4[pass].y; v.z += r4[pass].z; v.w += r4[pass].w;
             if (row < g.M && col < g.N) {
-              v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
-              v.x = act_fn<ACT>(v.x); v.y = act_fn<ACT>(v.y); v.z = act_fn<ACT>(v.z); v.w = act_fn<ACT>(v.w);
-              v.x += r4[pass].x; v.y += r4[pass].y; v.z += r4[pass].z; v.w += r4[pass].w;
               if (g.out_f32) *(float4*)(g.out_f32 + (long)row * g.ldc + col) = v;
-              if (oa) *(uint2*)(oa + (long)row * g.ldc + col) = make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w));
+              if (STATS) {
+                ps[pass] += (v.x + v.y) + (v.z + v.w);
+                pq[pass] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+              }
+            }
+            pk[pass] = make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w));
+          }
+          if (oa && !(STATS && (g.ln_groups & 2))) {
+            // bf16 copy in 16-byte stores (the epilogue is store-ISSUE bound): lanes rslot, rslot^1 hold adjacent
+            // 4-column pieces of the same row; swapping one piece per pass pair leaves the even lane with 8
+            // columns of the first pass's row and the odd lane with 8 columns of the second pass's row
+            const bool odd = rslot & 1;
+#pragma unroll
+            for (int pp = 0; pp < 4; pp += 2) {
+              const uint2 send = odd ? pk[pp] : pk[pp + 1];
+              uint2 recv;
+              recv.x = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send.x, 0xB1, 0xf, 0xf, true);
+              recv.y = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send.y, 0xB1, 0xf, 0xf, true);
+              const uint4 d = odd ? make_uint4(recv.x, recv.y, pk[pp + 1].x, pk[pp + 1].y)
+                                  : make_uint4(pk[pp].x, pk[pp].y, recv.x, recv.y);
+              const int row = m0 + wm * 128 + i * 32 + (pp + (odd ? 1 : 0)) * 8 + rrow;
+              const int c8 = n0 + wn * 64 + j * 32 + (rslot & 6) * 4;
+              if (row < g.M && c8 < g.N) *(uint4*)(oa + (long)row * g.ldc + c8) = d;
             }
           }
+        }
+        if (STATS && !(g.ln_groups & 4)) {
+          // the 8 lanes of a row (rslot 0..7) hold 8 columns each: reduce, then lane rslot == pass keeps pass's
+          // row, so that one 8-byte store per lane covers the 32 rows of this block
+          float ks = 0.f, kq = 0.f;
+#pragma unroll
+          for (int pass = 0; pass < 4; ++pass) {
+            const float s8 = sum8_dpp(ps[pass]), q8 = sum8_dpp(pq[pass]);
+            if (rslot == pass) { ks = s8; kq = q8; }
+          }
+          const int row = m0 + wm * 128 + i * 32 + rslot * 8 + rrow;
+          const int grp = (n0 >> 6) + wn;
+          if (rslot < 4 && row < g.M && n0 + wn * 64 < g.N && !(g.ln_groups & 1))
+            *(float2*)(g.row_stats + ((long)row * (g.N >> 6) + grp) * 2) = make_float2(ks, kq);
         }
       }
     }
@@ -474,7 +523,7 @@ constexpr int QS = 4;                          // ring depth
 
 __device__ __forceinline__ int swzq(int row, int chunk) { return row * QROWB + ((chunk ^ ((row >> 2) & 3)) << 4); }
 
-template <int ACT, bool OUT_F32>
+template <int ACT, bool OUT_F32, bool STATS = false>
 __global__ __launch_bounds__(768) void gemm256q_kernel(GemmArgs g, int tiles_m, int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
@@ -601,7 +650,7 @@ __global__ __launch_bounds__(768) void gemm256q_kernel(GemmArgs g, int tiles_m, 
 #undef CZC_RB
 #undef CZC_MM
     }
-    tile_epilogue<ACT, OUT_F32>(g, acc, smem + QS * QSTAGE + wave * 4096, m0, n0, wm, wn, lane);
+    tile_epilogue<ACT, OUT_F32, STATS>(g, acc, smem + QS * QSTAGE + wave * 4096, m0, n0, wm, wn, lane);
   }
 }
 
@@ -637,14 +686,24 @@ int launch_gemm256(const GemmArgs& g, hipStream_t st) {
       CZC_ATTR((gemm256q_kernel<ACT_NONE, true>));
       CZC_ATTR((gemm256q_kernel<ACT_QUICK_GELU, false>));
       CZC_ATTR((gemm256q_kernel<ACT_QUICK_GELU, true>));
+      CZC_ATTR((gemm256q_kernel<ACT_NONE, true, true>));
 #undef CZC_ATTR
     }
     const int tiles_m = cdiv(g.M, TM), tiles_n = cdiv(g.N, TN);
     const int nt = (g_gemm_krot & 32) ? tiles_m : tiles_m * tiles_n;  // work units: tiles, or M tiles for the M-major walk
     dim3 grid(nt < n_cu ? nt : n_cu), block(768);
     const bool f32 = g.out_f32 != nullptr || g.resid != nullptr;
+    if (g.row_stats && !(g_use_gemm256 == 3 && f32 && g.act == ACT_NONE && g.N % 64 == 0)) {
+      snprintf(g_err, sizeof(g_err), "gemm256: row_stats needs the fp32-output ring kernel, no activation, N %% 64 == 0");
+      return 1;
+    }
     if (g_use_gemm256 == 3) {
       dim3 gq(tiles_m * tiles_n < n_cu ? tiles_m * tiles_n : n_cu);
+      if (g.row_stats) {
+        hipLaunchKernelGGL((gemm256q_kernel<ACT_NONE, true, true>), gq, block, shp, st, g, tiles_m, tiles_n);
+        CZC_HIP_CHECK(hipGetLastError());
+        return 0;
+      }
 #define CZC_GOQ(A_, F_) hipLaunchKernelGGL((gemm256q_kernel<A_, F_>), gq, block, shp, st, g, tiles_m, tiles_n)
       if (g.act == ACT_QUICK_GELU) { if (f32) CZC_GOQ(ACT_QUICK_GELU, true); else CZC_GOQ(ACT_QUICK_GELU, false); }
       else { if (f32) CZC_GOQ(ACT_NONE, true); else CZC_GOQ(ACT_NONE, false); }

@@ -41,8 +41,16 @@ constexpr int WR_BLK = 32;                     // rows per block
 constexpr int WR_STAGE = WR_BLK * WR_ROWB;     // 32 KiB
 constexpr int WR_D = 4;                        // ring depth
 constexpr int WR_PATCH = 2048;                 // per-wave epilogue patch (32 rows x 64 bytes)
-constexpr int WR_BIAS = 128;                   // per-wave bias slice (32 floats)
+constexpr int WR_BIAS = 256;                   // per-wave bias slice (32 floats) + folded-LayerNorm column sums (32 floats)
 constexpr int WR_LDS = WR_D * WR_STAGE + 8 * (WR_PATCH + WR_BIAS);
+// LayerNorm folded into the epilogue (LNF): the per-row statistics partials of a block (32 rows x 16 floats) ride
+// an LDS ring of their own, five deep: the statistics of block b are read during block b+1's MFMA stream while
+// the refill of block b+4 is already being issued, so the ring of four that serves the activation rows (whose
+// slot is free as soon as the block's MFMAs are done) would be overwritten one block too early.
+constexpr int WR_SD = 5;
+constexpr int WR_SSLOT = 32 * 16 * 4;          // 2 KiB
+constexpr int WR_LDS_LNF = WR_LDS + WR_SD * WR_SSLOT;
+static_assert(WR_LDS_LNF <= 160 * 1024, "LDS budget");
 constexpr int WR_STORES = 2;                   // buffer stores per wave per epilogue
 constexpr int WR_DMAS = 4;
 constexpr int WR_AHEAD = 4;                    // fragment reads in flight ahead of the MFMA that uses them                     // LDS-DMA instructions per wave per block
@@ -59,8 +67,9 @@ __device__ __forceinline__ float wr_act(float v) {
   return v;
 }
 
-template <int ACT, bool DBG_NOLDS, bool ILV>
+template <int ACT, bool DBG_NOLDS, bool ILV, bool LNF = false>
 __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, int nsets, int nblk, int dbg) {
+  static_assert(!LNF || ILV, "the folded-LayerNorm epilogue exists in the interleaved form only");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -93,6 +102,8 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, 
   unsigned char* patch = smem + WR_D * WR_STAGE + wave * WR_PATCH;
   float* bias_s = (float*)(smem + WR_D * WR_STAGE + 8 * WR_PATCH + wave * WR_BIAS);
   if (lane < 32) bias_s[lane] = (g.bias && col0 + lane < g.N) ? g.bias[col0 + lane] : 0.f;
+  if (LNF && lane < 32) bias_s[32 + lane] = col0 + lane < g.N ? g.ln_s[col0 + lane] : 0.f;
+  unsigned char* stat_ring = smem + WR_LDS;  // LNF only
 
   // ---- DMA side: this wave lands rows wave*4 + ii (ii 0..3) of every block ----
   const unsigned lds0 = __builtin_amdgcn_readfirstlane(
@@ -104,6 +115,23 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, 
     const int r = wave * 4 + ii;
     voff[ii] = r * pitch + ((lane ^ (r & 15)) << 4);
   }
+  // LNF: one more DMA per wave and block -- its four rows' statistics partials (4 x 64 bytes = one dword per lane)
+  u32x4_t rsS;
+  rsS.w = 0x00020000u;
+  const int spitch = g.ln_groups * 8;  // bytes of partials per row (64 for the 512-wide residual stream)
+  auto stat_piece = [&](int j) {
+    const long row0 = (long)(b0 + j) * WR_BLK;
+    const unsigned long long ps = (unsigned long long)g.ln_stats + (unsigned long long)row0 * spitch;
+    rsS.x = (unsigned)ps; rsS.y = (unsigned)(ps >> 32) & 0xffffu;
+    rsS.z = (unsigned)(min((long)WR_BLK, (long)g.M - row0) * spitch);
+    const unsigned dst = lds0 + WR_LDS + (j % WR_SD) * WR_SSLOT + wave * 256;
+    const int vo = wave * 256 + lane * 4;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dword %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "s"(dst), "v"(vo), "s"(rsS)
+                 : "memory");
+  };
   u32x4_t rsA;
   rsA.w = 0x00020000u;
   auto issue = [&](int j) {  // block j of this work-group -> ring slot j % WR_D
@@ -123,6 +151,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, 
         : "=&s"(keep)
         : "s"(dst), "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "s"(rsA)
         : "memory", "scc");
+    if (LNF) stat_piece(j);
   };
 
   // ---- MFMA side ----
@@ -228,9 +257,30 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, 
     rsC.x = (unsigned)pc; rsC.y = (unsigned)(pc >> 32) & 0xffffu;
     rsC.z = (unsigned)(min((long)WR_BLK, (long)g.M - row0) * cpitch);
   };
+  // LNF: this lane's row of the block whose epilogue is running: rstd and -mean*rstd
+  float ln_r = 1.f, ln_nm = 0.f;
+  auto ln_row = [&](int j) {
+    const float4* sp = (const float4*)(stat_ring + (j % WR_SD) * WR_SSLOT + l31 * 64);
+    const float4 p0 = sp[0], p1 = sp[1], p2 = sp[2], p3 = sp[3];  // (s,q) x 8 column groups, summed in group order
+    const float sm = ((p0.x + p0.z) + (p1.x + p1.z)) + ((p2.x + p2.z) + (p3.x + p3.z));
+    const float sq = ((p0.y + p0.w) + (p1.y + p1.w)) + ((p2.y + p2.w) + (p3.y + p3.w));
+    const float inv = 1.0f / (float)WR_K;
+    const float mean = sm * inv;
+    const float var = fmaxf(sq * inv - mean * mean, 0.f);
+    ln_r = __builtin_amdgcn_rsqf(var + g.ln_eps);
+    ln_r = ln_r * (1.5f - 0.5f * (var + g.ln_eps) * ln_r * ln_r);  // one Newton step: v_rsq_f32 is ~1 ulp, LN wants better
+    ln_nm = -mean * ln_r;
+  };
   auto epi_quad = [&](int qd) {  // accP quad qd -> bias, activation, bf16 -> patch
     const float4 b4 = *(const float4*)(bias_s + 8 * qd + 4 * half);
-    float4 v = make_float4(accP[4 * qd] + b4.x, accP[4 * qd + 1] + b4.y, accP[4 * qd + 2] + b4.z, accP[4 * qd + 3] + b4.w);
+    float4 v;
+    if (LNF) {
+      const float4 s4 = *(const float4*)(bias_s + 32 + 8 * qd + 4 * half);
+      v = make_float4(fmaf(ln_r, accP[4 * qd], fmaf(ln_nm, s4.x, b4.x)), fmaf(ln_r, accP[4 * qd + 1], fmaf(ln_nm, s4.y, b4.y)),
+                      fmaf(ln_r, accP[4 * qd + 2], fmaf(ln_nm, s4.z, b4.z)), fmaf(ln_r, accP[4 * qd + 3], fmaf(ln_nm, s4.w, b4.w)));
+    } else {
+      v = make_float4(accP[4 * qd] + b4.x, accP[4 * qd + 1] + b4.y, accP[4 * qd + 2] + b4.z, accP[4 * qd + 3] + b4.w);
+    }
     v.x = wr_act<ACT>(v.x); v.y = wr_act<ACT>(v.y); v.z = wr_act<ACT>(v.z); v.w = wr_act<ACT>(v.w);
     const int slot = (2 * qd + half) ^ ((l31 >> 1) & 7);
     *(uint2*)(patch + l31 * 64 + slot * 8) = make_uint2(pk_bf16(v.x, v.y), pk_bf16(v.z, v.w));
@@ -275,6 +325,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, 
       // descriptor arithmetic (a few dozen SALU) rides in the slots too: nothing but the wait and the barrier
       // stands between two blocks' MFMA streams
       if (sgm == 0 && refill) { dma_rebase(jd); dma_piece(0); }
+      if (LNF && sgm == 0 && prev) ln_row(js);
       if (sgm == 1 && prev) epi_quad(0);
       if (sgm == 2 && refill) dma_piece(1);
       if (sgm == 2 && prev) epi_quad(1);
@@ -282,7 +333,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, 
       if (sgm == 4 && refill) dma_piece(2);
       if (sgm == 4 && prev) { epi_quad(3); store_rebase(js); }
       if (sgm == 5 && prev) epi_store(0);
-      if (sgm == 6 && refill) dma_piece(3);
+      if (sgm == 6 && refill) { dma_piece(3); if (LNF) stat_piece(jd); }
       if (sgm == 7 && prev) epi_store(1);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -300,6 +351,14 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, 
       // block i landed?  VMEM issued after its last DMA piece: S1 of that block period, then two full periods
       // of 4 DMA + 2 stores (stores start with the second block) -- all in order on vmcnt.
       constexpr bool STEADY = decltype(steady_c)::value;
+      // LNF: one more DMA per block (the statistics piece, issued right after the block's last row piece):
+      // 5 per prologue block, 7 per steady period -> 10 / 15 instead of 8 / 13
+      if (LNF) {
+        if (STEADY) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+        else if (i + 2 >= nb) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (i < 4) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+      } else
       if (STEADY) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
       else if (i + 2 >= nb) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else if (i < 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -316,6 +375,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, 
     for (; i + WR_D - 1 < nb; ++i) step(i, T_());
     for (; i < nb; ++i) step(i, F_());
     store_rebase(nb - 1);
+    if (LNF) ln_row(nb - 1);
     epi_quad(0); epi_quad(1); epi_quad(2); epi_quad(3);
     epi_store(0); epi_store(1);
     return;
@@ -356,6 +416,7 @@ int g_use_wreg = 2;  // 1: memory phase after/before the MFMA phase, 2: memory w
 int g_wreg_dbg = 0;  // timing ablations only (results invalid): 1 no stores, 2 no MFMA, 4 no DMA refill, 8 no epilogue, 16 MFMA operands from registers only
 
 bool gemm_wreg_eligible(const GemmArgs& g) {
+  if (g.ln_stats && (g_use_wreg != 2 || !g.ln_s || g.ln_groups != 8 || (g_wreg_dbg & 16))) return false;
   return g_use_wreg && g.K == WR_K && g.M >= 2048 && g.N % 8 == 0 && g.ldc % 8 == 0 && g.lda % 8 == 0 && g.ldw % 8 == 0 &&
          g.out_act && !g.out_f32 && !g.resid && (g.act == ACT_NONE || g.act == ACT_QUICK_GELU) &&
          (long)g.ldc * 2 * WR_BLK < (1L << 30) && (long)g.lda * 2 * WR_BLK < (1L << 30);
@@ -388,6 +449,20 @@ int launch_gemm_wreg(const GemmArgs& g, hipStream_t st) {
     hipLaunchKernelGGL((gemm_wreg_kernel<A_, N_, I_>), grid, block, WR_LDS, st, g, ncg, nsets, nblk, g_wreg_dbg);     \
   } while (0)
   const bool ilv = g_use_wreg == 2;
+  if (g.ln_stats) {
+    dim3 gridl(n_cu);
+#define CZC_WR_GOL(A_)                                                                                                 \
+  do {                                                                                                                 \
+    CZC_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_wreg_kernel<A_, false, true, true>,                            \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, WR_LDS_LNF));                       \
+    hipLaunchKernelGGL((gemm_wreg_kernel<A_, false, true, true>), gridl, block, WR_LDS_LNF, st, g, ncg, nsets, nblk,  \
+                       g_wreg_dbg);                                                                                    \
+  } while (0)
+    if (g.act == ACT_QUICK_GELU) CZC_WR_GOL(ACT_QUICK_GELU); else CZC_WR_GOL(ACT_NONE);
+#undef CZC_WR_GOL
+    CZC_HIP_CHECK(hipGetLastError());
+    return 0;
+  }
   if (g_wreg_dbg & 16) CZC_WR_GO(ACT_NONE, true, false);
   else if (g.act == ACT_QUICK_GELU) { if (ilv) CZC_WR_GO(ACT_QUICK_GELU, false, true); else CZC_WR_GO(ACT_QUICK_GELU, false, false); }
   else { if (ilv) CZC_WR_GO(ACT_NONE, false, true); else CZC_WR_GO(ACT_NONE, false, false); }

@@ -17,6 +17,18 @@ struct GemmArgs {
   void* out_act; float* out_f32; int ldc;
   int M, N, K;
   int act;
+  // LayerNorm folded into the GEMMs around it (bf16 CLIP-text tower).
+  // Producer side (fp32-output 256x256 kernel): per-row partial sums of the fp32 result over each 64-column
+  // group, row_stats[m][N/64][2] = (sum, sum of squares); together with out_act (bf16 copy of the result)
+  // this is everything the next layer's LayerNorm needs, so the LayerNorm kernel and its HBM pass disappear.
+  float* row_stats = nullptr;
+  // Consumer side (weight-stationary K = 512 kernel): A holds the bf16 copy of the RAW residual stream, W the
+  // weights pre-multiplied by the LayerNorm gain, ln_s[n] = sum_k W'[n,k], bias the folded bias; the epilogue
+  // turns acc = x.W'^T into LN(x).W^T + b = rstd*(acc - mean*ln_s[n]) + bias'[n] with mean/rstd from ln_stats.
+  const float* ln_stats = nullptr;  // [M][ln_groups][2]
+  const float* ln_s = nullptr;      // [N]
+  int ln_groups = 0;
+  float ln_eps = 0.f;
 };
 int launch_gemm(int prec, const GemmArgs& g, hipStream_t st);
 bool gemm256_eligible(const GemmArgs& g);
@@ -54,6 +66,9 @@ int launch_im2col(int prec, const float* pixels, int B, int S, int p, void* out,
 int launch_vision_assemble(const float* patch_out, int B, int P, int H, const float* cls, const float* pos, float* x,
                            hipStream_t st);
 int launch_convert(int prec, const float* src, void* dst, long n, hipStream_t st);  // fp32 -> act type
+// bf16 weights with the preceding LayerNorm's gain folded in, their row sums and the folded bias (GemmArgs::ln_*)
+int launch_fold_ln(const float* W, const float* bias, const float* gamma, const float* beta, int N, int K, void* Wf, float* s,
+                   float* bf, hipStream_t st);
 int launch_act_to_f32(int prec, const void* src, float* dst, long n, hipStream_t st);  // act type -> fp32
 // gather rows: dst[m] = src[idx[m]]  (fp32 rows of width H)
 int launch_gather_rows_f32(const float* src, const int* idx, int M, int H, float* dst, hipStream_t st);

@@ -7,6 +7,7 @@ calling generate_caption / control_generate_caption.
     python -m conzic_amd.demo_cli --lm_model <dir> --match_model <dir> --caption_img_path img.jpg ...
 """
 import argparse
+import json
 import os
 import sys
 import time
@@ -26,7 +27,12 @@ def get_args(argv=None):
     p.add_argument('--run_type', default='controllable', nargs='?', choices=['caption', 'controllable'])
     p.add_argument('--prompt', default='Image of a', type=str)
     p.add_argument('--order', default='shuffle', nargs='?', choices=['sequential', 'shuffle', 'span', 'random'])
-    p.add_argument('--control_type', default='sentiment', nargs='?', choices=["sentiment"])
+    p.add_argument('--control_type', default='sentiment', nargs='?', choices=["sentiment", "pos"])
+    # demo.py:40-45 declares this with type=list (unusable from a shell); here: a JSON list of tag lists
+    p.add_argument('--pos_type', type=json.loads,
+                   default=[['DET'], ['ADJ', 'NOUN'], ['NOUN'], ['VERB'], ['VERB'], ['ADV'], ['ADP'], ['DET', 'NOUN'],
+                            ['NOUN'], ['NOUN', '.'], ['.', 'NOUN'], ['.', 'NOUN']],
+                   help="predefined part-of-speech template (JSON)")
     p.add_argument('--sentiment_type', default="positive", nargs='?', choices=["positive", "negative"])
     p.add_argument('--samples_num', default=2, type=int)
     p.add_argument("--sentence_len", type=int, default=10)
@@ -67,6 +73,7 @@ def main(argv=None):
         lm_model = SyntheticLM(bcfg)
         clip = CLIP.from_state(ccfg, synth.make_clip_weights(ccfg, 12), clip_tok)
         clip.lexicon = synth.make_lexicon(len(sv.bert_tokens))
+        clip.pos_tags = synth.make_pos_tags(len(sv.bert_tokens))
         token_mask = synth.make_token_mask(sv)
         from PIL import Image
         images = [Image.fromarray(u) for u in synth.make_images_u8(args.batch_size, ccfg.v_image)]
@@ -94,7 +101,8 @@ def main(argv=None):
             generate_caption(img_name, lm_model, clip, lm_tokenizer, image_instance, token_mask, logger, **kw)
         else:
             control_generate_caption(img_name, lm_model, clip, lm_tokenizer, image_instance, token_mask, logger,
-                                     gamma=args.gamma, ctl_type=args.control_type, style_type=args.sentiment_type, **kw)
+                                     gamma=args.gamma, ctl_type=args.control_type, style_type=args.sentiment_type,
+                                     pos_type=args.pos_type, **kw)
     logger.info("total %.2fs" % (time.time() - t0))
 
 

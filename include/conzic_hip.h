@@ -190,7 +190,10 @@ int czc_generate(czc_engine* e, int B, int T, int L, int seed_len, const int32_t
  *                         times
  *   "pack_branches"   (1) attention of the branch rows with G candidates packed per 32-query MFMA tile
  *   "pool_last_layer" (1) last CLIP-text layer: out-projection + MLP on the EOS rows only
- *   "fuse_qkv_attn"   (0) branch rows: q/k/v projection and attention in one kernel (q, k, v never in HBM) */
+ *   "fuse_qkv_attn"   (0) branch rows: q/k/v projection and attention in one kernel (q, k, v never in HBM)
+ *   "fold_ln"         (0) bf16 CLIP-text tower at >= 2048 packed rows: LayerNorm applied inside the GEMM epilogues
+ *                         (out-proj / fc2 emit a bf16 copy of the residual stream + row statistics; q/k/v / fc1 run
+ *                         on gain-folded weights and finish the normalisation), no LayerNorm pass over HBM */
 int czc_set_option(czc_engine* e, const char* name, int value);
 
 /* ---- measurement ------------------------------------------------------------------------- */
@@ -209,6 +212,13 @@ int czc_stats(czc_engine* e, int64_t* clip_rows, int64_t* clip_seqs, int64_t* be
  * `precision`, resid must be NULL) instead of the fp32 one -- the path the tower-internal layers use. */
 int czc_test_gemm(int precision, int M, int N, int K, const float* A, const float* W, const float* bias,
                   const float* resid, int act, float* C);
+/* The folded-LayerNorm GEMM pair of the bf16 CLIP-text tower (hidden 512) on host data:
+ *   x_out[M,512] = resid + A[M,K1] * Wo[512,K1]^T + bo;  h[M,N] = act(LN(x_out; gamma, beta, eps) * W1[N,512]^T + b1)
+ * through the producer kernel (fp32 result + bf16 copy + per-row statistics) and the weight-stationary consumer
+ * kernel that finishes the LayerNorm in its epilogue.  M >= 2048, K1 % 64 == 0, N % 8 == 0. */
+int czc_test_lnf_pair(int M, int K1, int N, const float* A, const float* Wo, const float* bo, const float* resid,
+                      const float* gamma, const float* beta, float eps, const float* W1, const float* b1, int act,
+                      float* x_out, float* h_out);
 /* GEMM microbenchmark on device-resident data: ms per launch (tools/bench_gemm.py); use256: 0 128x128 kernel,
  * 1-3 the 256x256 LDS-DMA kernels (plain / persistent / persistent + K ring), 5-6 the weight-stationary kernel
  * (memory phase separate / interleaved into the MFMA stream) where eligible. */

@@ -365,3 +365,43 @@ def test_split_fp16_layernorm_and_attention():
     qkv = rng.standard_normal((sum(lens), 3 * 12 * 64)).astype(np.float32)
     out = E.test_attention(F16X3, qkv, lens, 12, False, 0.125)
     assert np.abs(out - _attn_ref(qkv, lens, 12, False, 0.125)).max() < 3e-5
+
+
+@pytest.mark.parametrize("M,K1,N,act,mean_shift", [(2048, 512, 1536, 0, 0.0), (4100, 2048, 2048, 1, 0.0),
+                                                   (2048 + 37, 512, 2048, 1, 3.0), (40000, 512, 1536, 0, 0.5)])
+def test_folded_layernorm_gemm_pair(M, K1, N, act, mean_shift):
+    """LayerNorm folded into the GEMMs around it (bf16 CLIP-text tower, HF:clip/modeling_clip.py:368-383): the
+    fp32-output kernel leaves x, a bf16 copy and per-row (sum, sum^2) partials; the weight-stationary kernel
+    multiplies the raw bf16 copy with gain-folded weights and applies rstd / mean in its epilogue.  Reference:
+    fp64 LayerNorm + linear on the kernel's own fp32 x (so the comparison isolates the folded LayerNorm), with
+    bf16-level tolerance; ragged M, a row mean far from zero (the cancellation case) and K1 = 2048 covered."""
+    import ctypes as C
+    lib = native.load()
+    rng = np.random.default_rng(M + N)
+    A = rng.standard_normal((M, K1)).astype(np.float32)
+    Wo = (rng.standard_normal((512, K1)) * 0.03).astype(np.float32)
+    bo = (rng.standard_normal(512) * 0.1).astype(np.float32)
+    resid = (rng.standard_normal((M, 512)) * 1.5 + mean_shift).astype(np.float32)
+    gamma = (1.0 + 0.3 * rng.standard_normal(512)).astype(np.float32)
+    beta = (0.2 * rng.standard_normal(512)).astype(np.float32)
+    W1 = (rng.standard_normal((N, 512)) * 0.04).astype(np.float32)
+    b1 = (rng.standard_normal(N) * 0.1).astype(np.float32)
+    x_out = np.empty((M, 512), np.float32)
+    h = np.empty((M, N), np.float32)
+    p = lambda a: a.ctypes.data
+    native.check(lib.czc_test_lnf_pair(M, K1, N, p(A), p(Wo), p(bo), p(resid), p(gamma), p(beta), C.c_float(1e-5),
+                                       p(W1), p(b1), act, p(x_out), p(h)), None, "czc_test_lnf_pair")
+    bf = lambda a: torch.from_numpy(a).to(torch.bfloat16).to(torch.float64).numpy()
+    x_ref = resid.astype(np.float64) + bf(A) @ bf(Wo).T + bo
+    assert np.abs(x_out - x_ref).max() < 2e-4 * np.sqrt(K1 / 512)
+    x64 = x_out.astype(np.float64)
+    mu = x64.mean(1, keepdims=True)
+    y = (x64 - mu) / np.sqrt(x64.var(1, keepdims=True) + 1e-5) * gamma + beta
+    ref = y @ W1.astype(np.float64).T + b1
+    if act == 1:
+        ref = ref / (1.0 + np.exp(-1.702 * ref))
+    err = np.abs(h - ref)
+    # bf16 operands (2^-9 relative, K = 512 products of |y| ~ 1 and |w| ~ 0.04) + bf16 output rounding
+    tol = 0.02 * (1.0 + abs(mean_shift)) + 2 ** -8 * np.abs(ref)
+    assert (err < tol).all(), (err.max(), np.abs(ref).max())
+    assert err.mean() < 4e-3 * (1.0 + abs(mean_shift))

@@ -237,6 +237,26 @@ def test_step_parity_full_size_bf16(name):
     teacher_forced(meta, arr, BF16, n_steps=10)
 
 
+@pytest.mark.parametrize("prec", [F32, BF16, SPLIT])
+@pytest.mark.parametrize("name", ["full_cfg1", "full_senti", "tiny_seq"])
+def test_bert_logits_row_vs_reference(name, prec):
+    """A4 directly: czc_step_out.logits (the masked row of BertForMaskedLM(inp).logits, gen_utils.py:69,42) against
+    the row captured from the reference's own forward at the first step.  The bf16 and split engines both run the
+    BERT tower on split-fp16 MFMA; tau = 0.1 multiplies a logit error by ten, hence the tight bar."""
+    meta, arr = load_case(name)
+    su = setup_for(meta, prec)
+    su.engine.set_image_embeds(arr["image_embeds"])
+    hp = Engine.hyper(meta["alpha"], meta["beta"], meta["temperature"], meta["gamma"], meta["style"] == "negative")
+    inp = np.ascontiguousarray(arr["inp_before"][0], dtype=np.int32)
+    res = su.engine.step(inp, SEED_LEN + meta["positions"][0], meta["K"], hp, dot_allowed=(meta["positions"][0] == meta["L"] - 1),
+                         want=("logits", "idxs"))
+    ref = arr["logits_row0"]
+    assert res["logits"].shape == ref.shape
+    err = np.abs(res["logits"] - ref).max()
+    assert err < (5e-5 if prec == F32 else 2e-4), err
+    assert (res["logits"].argmax(1) == ref.argmax(1)).all()
+
+
 def test_precision_selected_from_logit_scale():
     """conzic_amd.runtime.choose_precision: bf16 towers only where exp(logit_scale) keeps them inside the
     budget; the published checkpoints' scale (100) gets the split-fp16 engine."""
@@ -478,6 +498,34 @@ def test_fused_qkv_attention_matches_unfused():
         np.testing.assert_allclose(ra["clip_ref"], rb["clip_ref"], atol=1e-3)
         np.testing.assert_allclose(ra["final_score"], rb["final_score"], atol=2e-4)
         assert np.isfinite(ra["final_score"]).all()
+
+
+@pytest.mark.parametrize("name,steps", [("full_synth_b2", (4, 7, 9)), ("full_shuffle_k512", (2, 9)), ("full_senti", (6, 11))])
+def test_folded_layernorm_matches_layernorm_kernel(name, steps):
+    """bf16 engine: LayerNorm applied inside the GEMM epilogues (option fold_ln, applies above 2048 packed rows)
+    against the stand-alone LayerNorm kernel on the same steps: same math, bf16 rounding of the raw residual
+    stream instead of the normalised one."""
+    meta, arr = load_case(name)
+    su = setup_for(meta, BF16)
+    eng = su.engine
+    eng.set_image_embeds(arr["image_embeds"])
+    hp = Engine.hyper(meta["alpha"], meta["beta"], meta["temperature"], meta["gamma"], meta["style"] == "negative")
+    outs = []
+    for fold in (1, 0):
+        eng.set_option("fold_ln", fold)
+        rows = []
+        for i in steps:
+            inp = np.ascontiguousarray(arr["inp_before"][i], dtype=np.int32)
+            rows.append(eng.step(inp, SEED_LEN + meta["positions"][i], meta["K"], hp,
+                                 dot_allowed=(meta["positions"][i] == meta["L"] - 1)))
+        outs.append((rows, eng.profile_get("rowops")))
+    eng.set_option("fold_ln", 0)
+    for ra, rb in zip(outs[0][0], outs[1][0]):
+        np.testing.assert_array_equal(ra["clip_ids"], rb["clip_ids"])
+        assert np.isfinite(ra["final_score"]).all()
+        np.testing.assert_allclose(ra["clip_ref"], rb["clip_ref"], atol=3e-3)
+        assert np.abs(ra["clip_ref"] - rb["clip_ref"]).mean() < 4e-4
+        np.testing.assert_allclose(ra["final_score"], rb["final_score"], atol=1e-3)
 
 
 @pytest.mark.parametrize("prec", [F32, BF16])
