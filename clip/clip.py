@@ -23,6 +23,15 @@ def _wrap(a: np.ndarray):
         return a
 
 
+class ImageEmbeds:
+    """Image embeddings computed earlier (`CLIP.compute_image_representation_from_image_instance`), handed back in
+    place of the images: the north star's "ViT image encode once per image, cached" across `samples_num` passes
+    (the reference re-encodes on every call, demo.py:83-85 -> gen_utils.py:58).  `embeds`: fp32 [B, proj]."""
+
+    def __init__(self, embeds):
+        self.embeds = np.ascontiguousarray(np.asarray(embeds, dtype=np.float32))
+
+
 class CLIP:
     def __init__(self, model_name=None):
         self.model = None
@@ -95,6 +104,27 @@ class CLIP:
 
     # ---- clip/clip.py:48-62 ------------------------------------------------------------------
     def compute_image_representation_from_image_instance(self, image):
+        if isinstance(image, ImageEmbeds):  # cached from an earlier sample: no second pass through the ViT
+            self._eng().set_image_embeds(image.embeds)
+            return _wrap(image.embeds)
+        # one-entry cache on the identity of the image objects: the same PIL image(s) polished again
+        # (demo.py:83 loops samples_num times over one image) are encoded once
+        imgs = image if isinstance(image, (list, tuple)) else [image]
+        key = tuple(id(im) for im in imgs)
+        cached = getattr(self, "_img_cache", None)
+        if cached is not None and cached[0] == key and all(a is b for a, b in zip(cached[1], imgs)):
+            self._eng().set_image_embeds(cached[2])
+            return _wrap(cached[2])
+        emb = self._encode_images_uncached(image)
+        self._img_cache = (key, list(imgs), np.ascontiguousarray(np.asarray(emb, dtype=np.float32)))
+        return emb
+
+    def last_image_embeds(self):
+        """fp32 [B, proj] of the most recent image encode (to be handed back as `ImageEmbeds` on later samples)."""
+        cached = getattr(self, "_img_cache", None)
+        return None if cached is None else cached[2].copy()
+
+    def _encode_images_uncached(self, image):
         if self.processor is not None:
             std_cfg = self._device_processor_params()
             if std_cfg is not None:  # the checkpoint's processor is the standard CLIP one: run it on the device

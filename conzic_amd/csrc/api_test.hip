@@ -199,6 +199,7 @@ int czc_test_set_option(const char* name, int value) {
   if (!strcmp(name, "skinny")) { g_use_skinny = value; return 0; }
   if (!strcmp(name, "splitk")) { g_use_splitk = value; return 0; }
   if (!strcmp(name, "wreg")) { g_use_wreg = value; return 0; }
+  if (!strcmp(name, "gemm256s")) { g_use_gemm256s = value; return 0; }
   if (!strcmp(name, "wreg_dbg")) { g_wreg_dbg = value; return 0; }
   if (!strcmp(name, "lnf_dbg")) { g_lnf_dbg = value; return 0; }
   if (!strcmp(name, "mfma_attention")) { g_use_mfma_attention = value; return 0; }
@@ -296,7 +297,7 @@ int czc_test_bridge(const czc_bridge_tables* t, const czc_config* cfg, int n_row
   int* dovf = (int*)pool.alloc(4); T_PTR(dovf);
   T_HIP(hipMemset(dovf, 0, 4));
   PosDev nopos{nullptr, nullptr, 0};
-  T_CHECK(launch_bridge(bd, drows, n_rows, T, -1, nullptr, 1, nullptr, 0, nopos, dids, dlen, nullptr, nullptr, dovf, nullptr));
+  T_CHECK(launch_bridge(bd, drows, n_rows, T, -1, nullptr, 1, nullptr, nullptr, nullptr, 0, nopos, dids, dlen, nullptr, nullptr, dovf, nullptr));
   T_HIP(hipDeviceSynchronize());
   int ovf = 0;
   T_HIP(hipMemcpy(&ovf, dovf, 4, hipMemcpyDeviceToHost));

@@ -193,6 +193,169 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const bf16_t* qkv, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// split-fp16 MFMA kernel (split engine precision): attention_mfma_kernel's structure with every product as three
+// v_mfma_f32_32x32x16_f16 passes over fp16 hi/lo planes -- q, k, v arrive as split_t (common.h), the softmax
+// probabilities are split into hi + lo before the PV product, V^T sits in LDS as two fp16 planes.  fp32-class
+// accuracy (the split engine's bar is 1e-4 on the fused score) at MFMA speed instead of the VALU kernel's.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned pack2_f16(float a, float b) {
+  typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+  const h2 v = {(_Float16)a, (_Float16)b};
+  return __builtin_bit_cast(unsigned, v);
+}
+
+__global__ __launch_bounds__(256) void attention_mfma_split_kernel(const split_t* qkv, SegTable tab, int heads, int causal,
+                                                                   float scale, int KP, split_t* out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char at_lds[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int wpb = blockDim.x >> 6;
+  const int s = blockIdx.x;
+  int h = blockIdx.y * wpb + wave;
+  const bool live = h < heads;
+  if (!live) h = heads - 1;
+  const Seg g = load_seg(tab, s);
+  const int nk = g.pre_len + g.own_len, nq = g.own_len;
+  if (nq <= 0) return;  // uniform per block
+  const int Hd = heads * 64;
+  const long pitchb = 3L * Hd * 4;  // bytes per qkv row (split_t: 4 bytes per element)
+  const unsigned char* base = (const unsigned char*)qkv;
+  _Float16* Vh = (_Float16*)at_lds + (size_t)wave * 2 * 64 * KP;  // [64 d][KP keys] hi plane, then lo plane
+  _Float16* Vl = Vh + 64 * KP;
+  // byte offset of the 8-element group that starts at element e0 (e0 % 8 == 0) of a row: hi 16 bytes, lo at +16
+#define CZC_GRP(e0) ((long)((e0) >> 3) * 32)
+
+  for (int k0 = 0; k0 < nk; k0 += 8) {
+    const int k = k0 + (lane >> 3);
+    if (k < nk) {
+      const int d0 = (lane & 7) * 8;
+      const unsigned char* vp = base + key_row(g, k) * pitchb + CZC_GRP(2 * Hd + h * 64 + d0);
+      const uint4 vh = *(const uint4*)vp, vl = *(const uint4*)(vp + 16);
+      const unsigned wh[4] = {vh.x, vh.y, vh.z, vh.w}, wl[4] = {vl.x, vl.y, vl.z, vl.w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const unsigned short a = (unsigned short)((wh[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+        const unsigned short b = (unsigned short)((wl[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+        Vh[(d0 + e) * KP + k] = __builtin_bit_cast(_Float16, a);
+        Vl[(d0 + e) * KP + k] = __builtin_bit_cast(_Float16, b);
+      }
+    }
+  }
+  const int nkt_all = (nk + 31) >> 5;
+  for (int i = lane; i < 64 * (nkt_all * 32 - nk); i += 64) {
+    const int d = i / (nkt_all * 32 - nk), k = nk + i % (nkt_all * 32 - nk);
+    Vh[d * KP + k] = (_Float16)0.f;
+    Vl[d * KP + k] = (_Float16)0.f;
+  }
+  __syncthreads();
+
+#define CZC_F16(v_) __builtin_bit_cast(f16x8_t, v_)
+  const int half = lane >> 5, l31 = lane & 31;
+  for (int q0 = 0; q0 < nq; q0 += 32) {
+    const int q = min(q0 + l31, nq - 1);
+    const unsigned char* qp = base + ((long)g.own_off + q) * pitchb + CZC_GRP(h * 64 + 8 * half);
+    uint4 qh[4], ql[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {  // step ks: elements 16ks + 8half .. +7 -> group 2ks + half
+      qh[ks] = *(const uint4*)(qp + ks * 64);
+      ql[ks] = *(const uint4*)(qp + ks * 64 + 16);
+    }
+    const int kmax = causal ? min(nk, g.pre_len + min(q0 + 32, nq)) : nk;
+    const int nkt = (kmax + 31) >> 5;
+    const int vis = causal ? g.pre_len + q : nk - 1;
+
+    f32x16_t st[AT_MAXKT];
+#pragma unroll
+    for (int kt = 0; kt < AT_MAXKT; ++kt) {
+      if (kt < nkt) {
+        const int kk = min(kt * 32 + l31, nk - 1);
+        const unsigned char* kp = base + key_row(g, kk) * pitchb + CZC_GRP(Hd + h * 64 + 8 * half);
+        f32x16_t acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const uint4 kh = *(const uint4*)(kp + ks * 64), kl = *(const uint4*)(kp + ks * 64 + 16);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(CZC_F16(kl), CZC_F16(qh[ks]), acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(CZC_F16(kh), CZC_F16(ql[ks]), acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(CZC_F16(kh), CZC_F16(qh[ks]), acc, 0, 0, 0);
+        }
+        st[kt] = acc;
+      }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < AT_MAXKT; ++kt) {
+      if (kt < nkt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          const float v = key <= vis && key < nk ? st[kt][r] * scale : -INFINITY;
+          st[kt][r] = v;
+          mx = fmaxf(mx, v);
+        }
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+    uint4 ph[AT_MAXKT][2], pl[AT_MAXKT][2];
+#pragma unroll
+    for (int kt = 0; kt < AT_MAXKT; ++kt) {
+      if (kt < nkt) {
+        float e[16], el[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          e[r] = expf(st[kt][r] - mx);
+          sum += e[r];
+          el[r] = e[r] - (float)(_Float16)e[r];
+        }
+#pragma unroll
+        for (int sstep = 0; sstep < 2; ++sstep) {
+          ph[kt][sstep] = make_uint4(pack2_f16(e[8 * sstep + 0], e[8 * sstep + 1]), pack2_f16(e[8 * sstep + 2], e[8 * sstep + 3]),
+                                     pack2_f16(e[8 * sstep + 4], e[8 * sstep + 5]), pack2_f16(e[8 * sstep + 6], e[8 * sstep + 7]));
+          pl[kt][sstep] = make_uint4(pack2_f16(el[8 * sstep + 0], el[8 * sstep + 1]), pack2_f16(el[8 * sstep + 2], el[8 * sstep + 3]),
+                                     pack2_f16(el[8 * sstep + 4], el[8 * sstep + 5]), pack2_f16(el[8 * sstep + 6], el[8 * sstep + 7]));
+        }
+      }
+    }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      f32x16_t o;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[r] = 0.f;
+      const _Float16* vrh = Vh + (dt * 32 + l31) * KP;
+      const _Float16* vrl = Vl + (dt * 32 + l31) * KP;
+#pragma unroll
+      for (int kt = 0; kt < AT_MAXKT; ++kt) {
+        if (kt < nkt) {
+#pragma unroll
+          for (int sstep = 0; sstep < 2; ++sstep) {
+            const int ko = kt * 32 + 16 * sstep + 4 * half;
+            const uint2 h0 = *(const uint2*)(vrh + ko), h1 = *(const uint2*)(vrh + ko + 8);
+            const uint2 l0 = *(const uint2*)(vrl + ko), l1 = *(const uint2*)(vrl + ko + 8);
+            const uint4 vh = make_uint4(h0.x, h0.y, h1.x, h1.y), vl = make_uint4(l0.x, l0.y, l1.x, l1.y);
+            o = __builtin_amdgcn_mfma_f32_32x32x16_f16(CZC_F16(vl), CZC_F16(ph[kt][sstep]), o, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_f32_32x32x16_f16(CZC_F16(vh), CZC_F16(pl[kt][sstep]), o, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_f32_32x32x16_f16(CZC_F16(vh), CZC_F16(ph[kt][sstep]), o, 0, 0, 0);
+          }
+        }
+      }
+      if (live && q0 + l31 < nq) {
+        const long eo = ((long)g.own_off + q0 + l31) * Hd + h * 64 + dt * 32 + 4 * half;
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd)
+          Act<split_t>::st4(out, eo + 8 * qd, o[4 * qd] * inv, o[4 * qd + 1] * inv, o[4 * qd + 2] * inv, o[4 * qd + 3] * inv);
+      }
+    }
+  }
+#undef CZC_F16
+#undef CZC_GRP
+}
+
+// ------------------------------------------------------------------------------------------------
 // bf16 MFMA kernel for the BRANCH segments of a shared-prefix plan.
 // The K candidates of an image own only a handful of rows each (the rows from the first differing
 // token on) and are laid out back to back, so one wave packs G consecutive candidates of one image
@@ -734,6 +897,20 @@ int launch_attention(int prec, const void* qkv, const SegTable& tab, int max_key
     dim3 grid(tab.n_seg, cdiv(heads, wpb)), block(64 * wpb);
     hipLaunchKernelGGL(attention_mfma_kernel, grid, block, shmem, st, (const bf16_t*)qkv, tab, heads, causal, scale, KP,
                        (bf16_t*)out);
+    CZC_HIP_CHECK(hipGetLastError());
+    return 0;
+  }
+  if (prec == PREC_F16X3 && g_use_mfma_attention) {
+    const int KP = ((max_keys + 31) & ~31) + 4;
+    int wpb = heads >= 4 ? 4 : (heads >= 2 ? 2 : 1);
+    while (wpb > 1 && (size_t)wpb * 2 * 64 * KP * 2 > 150 * 1024) wpb >>= 1;
+    const size_t shmem = (size_t)wpb * 2 * 64 * KP * 2;
+    if (shmem > 64 * 1024)
+      CZC_HIP_CHECK(hipFuncSetAttribute((const void*)attention_mfma_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)shmem));
+    dim3 grid(tab.n_seg, cdiv(heads, wpb)), block(64 * wpb);
+    hipLaunchKernelGGL(attention_mfma_split_kernel, grid, block, shmem, st, (const split_t*)qkv, tab, heads, causal, scale, KP,
+                       (split_t*)out);
     CZC_HIP_CHECK(hipGetLastError());
     return 0;
   }

@@ -41,8 +41,8 @@ __device__ __forceinline__ bool merge_lookup(const BridgeDev& bd, int l, int r, 
 }
 
 __global__ __launch_bounds__(BR_THREADS) void bridge_kernel(BridgeDev bd, const int* inp, int B, int T, int gen_idx,
-                                                            const int* cand, int K, const float* lexicon, int negative,
-                                                            PosDev pos, int* clip_ids, int* clip_len, float* senti_raw,
+                                                            const int* cand, int K, const float* lexicon, const float* lex_pos,
+                                                            const uint8_t* lex_cls, int negative, PosDev pos, int* clip_ids, int* clip_len, float* senti_raw,
                                                             float* repeats, int* overflow) {
   extern __shared__ __attribute__((aligned(16))) unsigned char br_lds[];
   unsigned char* txt = br_lds + (size_t)threadIdx.x * BR_MAXB;
@@ -65,7 +65,14 @@ __global__ __launch_bounds__(BR_THREADS) void bridge_kernel(BridgeDev bd, const 
     if (cand && id == cid) ++rep;
     const unsigned fl = bd.piece_flags[id];
     if (fl & 1u) continue;  // special token: skipped
-    if (lexicon) senti += lexicon[id];
+    if (lex_pos) {
+      // (word, coarse POS) keyed table -- sentiments_classifer.py:14-30 scores each WORD by the mean of its
+      // SentiWordNet synsets under the word's coarse POS class ('' n v a r): the word is addressed by its first
+      // piece, the class comes from a per-token tag table (context-free stand-in for nltk.pos_tag)
+      if (first || !(fl & 2u)) senti += lex_pos[id * 5 + lex_cls[id]];
+    } else if (lexicon) {
+      senti += lexicon[id];
+    }
     if (pos.tag_of_token && (first || !(fl & 2u))) {
       if (n_words < pos.n) {
         const unsigned m = pos.masks[n_words];
@@ -150,14 +157,14 @@ __global__ __launch_bounds__(BR_THREADS) void bridge_kernel(BridgeDev bd, const 
 }
 
 int launch_bridge(const BridgeDev& bd, const int* inp, int B, int T, int gen_idx, const int* cand, int K,
-                  const float* lexicon, int negative, const PosDev& pos, int* clip_ids, int* clip_len, float* senti_raw,
+                  const float* lexicon, const float* lex_pos, const uint8_t* lex_cls, int negative, const PosDev& pos, int* clip_ids, int* clip_len, float* senti_raw,
                   float* repeats, int* overflow_flag, hipStream_t st) {
   const long rows = (long)B * K;
   if (rows <= 0) return 0;
   const size_t shmem = (size_t)BR_THREADS * (2 * BR_MAXB + BR_MAXSYM * 4);
   CZC_HIP_CHECK(hipFuncSetAttribute((const void*)bridge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
   hipLaunchKernelGGL(bridge_kernel, dim3(cdiv(rows, BR_THREADS)), dim3(BR_THREADS), shmem, st, bd, inp, B, T, gen_idx,
-                     cand, K, lexicon, negative, pos, clip_ids, clip_len, senti_raw, repeats, overflow_flag);
+                     cand, K, lexicon, lex_pos, lex_cls, negative, pos, clip_ids, clip_len, senti_raw, repeats, overflow_flag);
   CZC_HIP_CHECK(hipGetLastError());
   return 0;
 }

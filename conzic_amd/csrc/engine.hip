@@ -72,6 +72,7 @@ struct czc_engine {
   std::map<std::string, Buf> ws;
   float* d_mask = nullptr; int mask_vocab = 0;
   float* d_lex = nullptr;
+  float* d_lex_pos = nullptr; uint8_t* d_lex_cls = nullptr;  // (word-start piece, coarse POS class) keyed table [V][5] + class per token
   uint8_t* d_pos_tags = nullptr; uint16_t* d_pos_masks = nullptr; int pos_n = 0;
   BridgeDev bd; bool has_bridge = false;
   std::vector<void*> bridge_allocs;
@@ -484,7 +485,7 @@ int step_device(czc_engine* e, int* d_inp, int B, int T, int gen_idx, int n_mask
   if (!e->d_img_n || e->img_B != B) return fail(e, CZC_ERR_STATE, "image embeds not set for this batch size%s");
   if (T > CZC_MAX_BERT_LEN || gen_idx < 0 || gen_idx >= T || K > CZC_MAX_TOPK)
     return fail(e, CZC_ERR_ARG, "step: bad T/gen_idx/K%s");
-  if (hp->control == 1 && !e->d_lex) return fail(e, CZC_ERR_STATE, "sentiment path needs a lexicon%s");
+  if (hp->control == 1 && !e->d_lex && !e->d_lex_pos) return fail(e, CZC_ERR_STATE, "sentiment path needs a lexicon%s");
   if (hp->control == 2 && !e->d_pos_tags) return fail(e, CZC_ERR_STATE, "POS path needs czc_set_pos%s");
   const int n_seq = B * K;
 
@@ -512,7 +513,8 @@ int step_device(czc_engine* e, int* d_inp, int B, int T, int gen_idx, int n_mask
   E_HIP(hipMemsetAsync(totals, 0, 32, e->st));
   { ProfScope ps(e, "bridge", 0);
     PosDev pos{hp->control == 2 ? e->d_pos_tags : nullptr, e->d_pos_masks, e->pos_n};
-    E_CHECK(launch_bridge(e->bd, d_inp, B, T, gen_idx, cand, K, hp->control == 1 ? e->d_lex : nullptr, hp->negative,
+    E_CHECK(launch_bridge(e->bd, d_inp, B, T, gen_idx, cand, K, hp->control == 1 ? e->d_lex : nullptr,
+                          hp->control == 1 ? e->d_lex_pos : nullptr, e->d_lex_cls, hp->negative,
                           pos, cids, clen, senti, reps, totals + 2, e->st)); }
   float* feat;
   E_CHECK(clip_text_forward(e, cids, clen, B, K, e->share_prefix, totals, &feat));
@@ -608,7 +610,7 @@ int czc_destroy(czc_engine* e) {
   (void)hipFree(e->patch_w);
   for (auto& kv : e->ws) if (kv.second.p) (void)hipFree(kv.second.p);
   for (void* p : e->bridge_allocs) (void)hipFree(p);
-  (void)hipFree(e->d_mask); (void)hipFree(e->d_lex); (void)hipFree(e->d_img_n); (void)hipFree(e->d_staged);
+  (void)hipFree(e->d_mask); (void)hipFree(e->d_lex); (void)hipFree(e->d_lex_pos); (void)hipFree(e->d_lex_cls); (void)hipFree(e->d_img_n); (void)hipFree(e->d_staged);
   (void)hipFree(e->d_pos_tags); (void)hipFree(e->d_pos_masks);
   for (auto& kv : e->pk) for (hipEvent_t ev : kv.second.ev) (void)hipEventDestroy(ev);
   if (e->h_totals) (void)hipHostFree(e->h_totals);
@@ -695,6 +697,24 @@ int czc_set_lexicon(czc_engine* e, const float* lex, int vocab) {
   E_HIP(hipSetDevice(e->dev));
   if (!e->d_lex) E_HIP(hipMalloc((void**)&e->d_lex, (size_t)vocab * 4));
   E_HIP(hipMemcpy(e->d_lex, lex, (size_t)vocab * 4, hipMemcpyDefault));
+  return CZC_OK;
+}
+
+int czc_set_lexicon_pos(czc_engine* e, const float* table, const uint8_t* class_of_token, int vocab) {
+  if (!e) return CZC_ERR_ARG;
+  E_HIP(hipSetDevice(e->dev));
+  if (!table) {  // back to the per-token lexicon of czc_set_lexicon
+    (void)hipFree(e->d_lex_pos); (void)hipFree(e->d_lex_cls);
+    e->d_lex_pos = nullptr; e->d_lex_cls = nullptr;
+    return CZC_OK;
+  }
+  if (!class_of_token || vocab != e->cfg.bert_vocab) return fail(e, CZC_ERR_ARG, "lexicon table size != bert_vocab%s");
+  std::vector<uint8_t> cls(class_of_token, class_of_token + vocab);
+  for (uint8_t c : cls) if (c > 4) return fail(e, CZC_ERR_ARG, "coarse POS class must be 0..4 ('' n v a r)%s");
+  if (!e->d_lex_pos) E_HIP(hipMalloc((void**)&e->d_lex_pos, (size_t)vocab * 5 * 4));
+  if (!e->d_lex_cls) E_HIP(hipMalloc((void**)&e->d_lex_cls, (size_t)vocab));
+  E_HIP(hipMemcpy(e->d_lex_pos, table, (size_t)vocab * 5 * 4, hipMemcpyDefault));
+  E_HIP(hipMemcpy(e->d_lex_cls, cls.data(), (size_t)vocab, hipMemcpyHostToDevice));
   return CZC_OK;
 }
 

@@ -424,6 +424,7 @@ int launch_gemm(int prec, const GemmArgs& g, hipStream_t st) {
   }
   if (prec == PREC_BF16 && gemm_wreg_eligible(g)) return launch_gemm_wreg(g, st);
   if (prec == PREC_BF16 && g_use_gemm256 && gemm256_eligible(g)) return launch_gemm256(g, st);
+  if (prec == PREC_F16X3 && gemm256s_eligible(g)) return launch_gemm256s(g, st);
   if (prec == PREC_F16X3 && launch_skinny(g, st)) {
     CZC_HIP_CHECK(hipGetLastError());
     return 0;

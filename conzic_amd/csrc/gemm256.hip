@@ -343,6 +343,70 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x16_t (&acc)
     }
 }
 
+
+// Split-fp16 activation output (qkv / fc1 of the split engine): same 32x32 fp32 round trip through the patch as the
+// fp32 path, then lanes rslot / rslot^1 swap one 4-column piece per pass pair so that every lane holds the 8
+// consecutive columns of one split_t group (16 bytes of fp16 hi parts followed by 16 bytes of lo parts).
+template <int ACT>
+__device__ __forceinline__ void tile_epilogue_split(const GemmArgs& g, f32x16_t (&acc)[4][2], unsigned char* patch, int m0,
+                                                    int n0, int wm, int wn, int lane) {
+  const int half = lane >> 5;
+  const int l31 = lane & 31;
+  const int rrow = lane >> 3, rslot = lane & 7;
+  unsigned char* oa = (unsigned char*)g.out_act;
+  const bool odd = rslot & 1;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + rslot * 4;
+      float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (g.bias && col < g.N) b4 = *(const float4*)(g.bias + col);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int slot = (2 * q + half) ^ (l31 & 7);
+        *(float4*)(patch + l31 * 128 + slot * 16) =
+            make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+      }
+      float4 v[4];
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        const int r = pass * 8 + rrow;
+        float4 t = *(const float4*)(patch + r * 128 + ((rslot ^ (r & 7)) << 4));
+        t.x += b4.x; t.y += b4.y; t.z += b4.z; t.w += b4.w;
+        t.x = act_fn<ACT>(t.x); t.y = act_fn<ACT>(t.y); t.z = act_fn<ACT>(t.z); t.w = act_fn<ACT>(t.w);
+        v[pass] = t;
+      }
+#pragma unroll
+      for (int pp = 0; pp < 4; pp += 2) {
+        const float4 send = odd ? v[pp] : v[pp + 1];
+        float4 recv;
+        recv.x = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send.x), 0xB1, 0xf, 0xf, true));
+        recv.y = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send.y), 0xB1, 0xf, 0xf, true));
+        recv.z = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send.z), 0xB1, 0xf, 0xf, true));
+        recv.w = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send.w), 0xB1, 0xf, 0xf, true));
+        const float4 lo4 = odd ? recv : v[pp];      // columns c8 .. c8+3
+        const float4 hi4 = odd ? v[pp + 1] : recv;  // columns c8+4 .. c8+7
+        const float e[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+        typedef __attribute__((ext_vector_type(8))) _Float16 h8;
+        h8 hh, ll;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          hh[t] = (_Float16)e[t];
+          ll[t] = (_Float16)(e[t] - (float)hh[t]);
+        }
+        const int row = m0 + wm * 128 + i * 32 + (pp + (odd ? 1 : 0)) * 8 + rrow;
+        const int c8 = n0 + wn * 64 + j * 32 + (rslot & 6) * 4;
+        if (row < g.M && c8 < g.N) {
+          unsigned char* dst = oa + ((long)row * g.ldc + c8) * 4;  // group of 8 elements = 32 bytes: hi plane, lo plane
+          *(h8*)dst = hh;
+          *(h8*)(dst + 16) = ll;
+        }
+      }
+    }
+  }
+}
+
 // Visit order of a persistent work-group.  Default ("legacy"): virtual tiles wg, wg+grid, ... through
 // the XCD-aware map, i.e. the N tiles of an M tile run CONCURRENTLY on neighbouring CUs of one XCD.
 // Alternative (debug bit5): one work-group walks all N tiles of an M tile back to back (A from HBM
@@ -655,6 +719,152 @@ __global__ __launch_bounds__(768) void gemm256q_kernel(GemmArgs g, int tiles_m, 
 }
 
 
+
+// ================================================================================================
+// gemm256s: the persistent wave-specialised 256x256 kernel (gemm256p structure: 8 MFMA waves + 4 LDS-DMA loader
+// waves, two 64 KiB stages of 128-byte rows) for the SPLIT-fp16 engine precision.  A 128-byte tile row is 32
+// elements as four groups of [8 fp16 hi | 8 fp16 lo] (common.h split_t), so one stage feeds two k16 MFMA steps, and
+// every product is three v_mfma_f32_32x32x16_f16 passes (hi*hi + lo*hi + hi*lo): 48 MFMAs per stage and wave on
+// 24 ds_read_b128 -- three times the matrix work of the bf16 kernel on twice the bytes, which moves these layers
+// from the HBM / CU-ingest bound of the bf16 tower towards the MFMA bound.
+// ================================================================================================
+template <int ACT, bool OUT_F32>
+__global__ __launch_bounds__(768) void gemm256s_kernel(GemmArgs g, int tiles_m, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nk = g.K >> 5;  // 32 elements (128 bytes of split_t) per stage
+  const int lda_b = g.lda * 4, ldw_b = g.ldw * 4;
+  const int my_tiles = tile_count(tiles_m, tiles_n, true);
+
+  if (wave >= 8) {
+    // ------------------------------- loader waves (as gemm256p) -----------------------------
+    const int lw = wave - 8;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(
+        (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem);
+    const int rbase = lw * 64 + (lane >> 3);
+    const int ce = ((lane & 7) ^ ((lane >> 4) & 7)) << 4;
+    const int co = ((lane & 7) ^ (((lane >> 4) + 4) & 7)) << 4;
+    const int a_e = rbase * lda_b + ce, a_o = (rbase + 8) * lda_b + co;
+    const int w_e = rbase * ldw_b + ce, w_o = (rbase + 8) * ldw_b + co;
+    const int a16 = 16 * lda_b, w16 = 16 * ldw_b;
+    unsigned step = 0;
+    bool first = true;
+    for (int ti = 0; ti < my_tiles; ++ti) {
+      int tm, tn;
+      tile_at(ti, tiles_m, tiles_n, true, tm, tn);
+      const int m0 = tm * TM, n0 = tn * TN;
+      const unsigned long long pa = (unsigned long long)g.A + (unsigned long long)m0 * lda_b;
+      const unsigned long long pw = (unsigned long long)g.W + (unsigned long long)n0 * ldw_b;
+      u32x4_t rsA, rsW;
+      rsA.x = (unsigned)pa; rsA.y = (unsigned)(pa >> 32) & 0xffffu;
+      rsA.z = (unsigned)(min(TM, g.M - m0) * lda_b); rsA.w = 0x00020000u;
+      rsW.x = (unsigned)pw; rsW.y = (unsigned)(pw >> 32) & 0xffffu;
+      rsW.z = (unsigned)(min(TN, g.N - n0) * ldw_b); rsW.w = 0x00020000u;
+      for (int kt = 0; kt < nk; ++kt, ++step) {
+        if (!first) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+        }
+        first = false;
+        const unsigned dstA = lds0 + (step & 1) * STAGE + lw * (64 * ROWB);
+        const unsigned dstW = dstA + A_BYTES;
+        const unsigned so = kt * ROWB;
+        unsigned keep;
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %11, %13 offen lds\n\t"
+            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %11, %13 offen lds\n\t"
+            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %5, %11, %13 offen lds\n\t"
+            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %6, %11, %13 offen lds\n\t"
+            "s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %7, %12, %13 offen lds\n\t"
+            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %8, %12, %13 offen lds\n\t"
+            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %9, %12, %13 offen lds\n\t"
+            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %10, %12, %13 offen lds\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "s"(dstA), "s"(dstW), "v"(a_e), "v"(a_o), "v"(a_e + a16), "v"(a_o + a16), "v"(w_e), "v"(w_o),
+              "v"(w_e + w16), "v"(w_o + w16), "s"(rsA), "s"(rsW), "s"(so)
+            : "memory", "scc");
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %11, %13 offen lds\n\t"
+            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %11, %13 offen lds\n\t"
+            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %5, %11, %13 offen lds\n\t"
+            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %6, %11, %13 offen lds\n\t"
+            "s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %7, %12, %13 offen lds\n\t"
+            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %8, %12, %13 offen lds\n\t"
+            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %9, %12, %13 offen lds\n\t"
+            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %10, %12, %13 offen lds\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "s"(dstA + 32 * ROWB), "s"(dstW + 32 * ROWB), "v"(a_e + 2 * a16), "v"(a_o + 2 * a16), "v"(a_e + 3 * a16),
+              "v"(a_o + 3 * a16), "v"(w_e + 2 * w16), "v"(w_o + 2 * w16), "v"(w_e + 3 * w16), "v"(w_o + 3 * w16),
+              "s"(rsA), "s"(rsW), "s"(so)
+            : "memory", "scc");
+      }
+    }
+    if (!first) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    return;
+  }
+
+  // --------------------------------- MFMA waves ---------------------------------------------
+  const int wm = wave >> 2, wn = wave & 3;
+  const int half = lane >> 5;
+  const int arow = wm * 128 + (lane & 31);
+  const int brow = wn * 64 + (lane & 31);
+  unsigned step = 0;
+  for (int ti = 0; ti < my_tiles; ++ti) {
+    int tm, tn;
+    tile_at(ti, tiles_m, tiles_n, true, tm, tn);
+    const int m0 = tm * TM, n0 = tn * TN;
+    f32x16_t acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int kt = 0; kt < nk; ++kt, ++step) {
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const unsigned char* sA = smem + (step & 1) * STAGE;
+      const unsigned char* sB = sA + A_BYTES;
+#define CZC_F16(v_) __builtin_bit_cast(f16x8_t, v_)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int ch = 2 * (2 * s2 + half);  // chunk 2g = hi plane, 2g+1 = lo plane of k-group g = 2*s2 + half
+        uint4 bh[2], bl[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          bh[j] = *(const uint4*)(sB + swz(brow + 32 * j, ch));
+          bl[j] = *(const uint4*)(sB + swz(brow + 32 * j, ch + 1));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const uint4 ah = *(const uint4*)(sA + swz(arow + 32 * i, ch));
+          const uint4 al = *(const uint4*)(sA + swz(arow + 32 * i, ch + 1));
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            // (a_hi + a_lo)(w_hi + w_lo) ~ a_hi w_hi + a_lo w_hi + a_hi w_lo   (lo*lo ~ 2^-22, dropped); small terms first
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(CZC_F16(bl[j]), CZC_F16(ah), acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(CZC_F16(bh[j]), CZC_F16(al), acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(CZC_F16(bh[j]), CZC_F16(ah), acc[i][j], 0, 0, 0);
+          }
+        }
+      }
+#undef CZC_F16
+    }
+    unsigned char* patch = smem + 2 * STAGE + wave * 4096;
+    if (OUT_F32) tile_epilogue<ACT, true>(g, acc, patch, m0, n0, wm, wn, lane);
+    else tile_epilogue_split<ACT>(g, acc, patch, m0, n0, wm, wn, lane);
+  }
+}
+
 }  // namespace
 
 int g_gemm_krot = 0;  // bit0: rotate K order per work-group (no gain measured); bits1-2: debug (skip MFMA / skip DMA)
@@ -731,6 +941,42 @@ int launch_gemm256(const GemmArgs& g, hipStream_t st) {
     hipLaunchKernelGGL(gemm256_kernel<ACT_QUICK_GELU>, grid, block, shmem, st, g, tiles_m, tiles_n);
   else
     hipLaunchKernelGGL(gemm256_kernel<ACT_NONE>, grid, block, shmem, st, g, tiles_m, tiles_n);
+  CZC_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int g_use_gemm256s = 1;
+
+// split-fp16 operands; big-M layers only (BERT at a few thousand rows stays on the 128x128 + split-K path)
+bool gemm256s_eligible(const GemmArgs& g) {
+  return g_use_gemm256s && g.M >= 16384 && g.N % 8 == 0 && g.K % 32 == 0 && g.ldc % 8 == 0 && g.lda % 8 == 0 && g.ldw % 8 == 0 &&
+         (!g.resid || g.ldr % 4 == 0) && (g.act == ACT_NONE || g.act == ACT_QUICK_GELU) && !g.row_stats && !g.ln_stats &&
+         !(g.out_act && g.out_f32) && (long)256 * g.lda * 4 < (1L << 31) && (long)256 * g.ldw * 4 < (1L << 31);
+}
+
+int launch_gemm256s(const GemmArgs& g, hipStream_t st) {
+  static int n_cu = 0;
+  const int shp = 2 * STAGE + 8 * 4096;
+  if (!n_cu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    CZC_HIP_CHECK(hipGetDevice(&dev));
+    CZC_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+    n_cu = prop.multiProcessorCount;
+#define CZC_ATTR(K_) CZC_HIP_CHECK(hipFuncSetAttribute((const void*)K_, hipFuncAttributeMaxDynamicSharedMemorySize, shp))
+    CZC_ATTR((gemm256s_kernel<ACT_NONE, false>));
+    CZC_ATTR((gemm256s_kernel<ACT_NONE, true>));
+    CZC_ATTR((gemm256s_kernel<ACT_QUICK_GELU, false>));
+    CZC_ATTR((gemm256s_kernel<ACT_QUICK_GELU, true>));
+#undef CZC_ATTR
+  }
+  const int tiles_m = cdiv(g.M, TM), tiles_n = cdiv(g.N, TN);
+  dim3 grid(tiles_m * tiles_n < n_cu ? tiles_m * tiles_n : n_cu), block(768);
+  const bool f32 = g.out_f32 != nullptr || g.resid != nullptr;
+#define CZC_GOS(A_, F_) hipLaunchKernelGGL((gemm256s_kernel<A_, F_>), grid, block, shp, st, g, tiles_m, tiles_n)
+  if (g.act == ACT_QUICK_GELU) { if (f32) CZC_GOS(ACT_QUICK_GELU, true); else CZC_GOS(ACT_QUICK_GELU, false); }
+  else { if (f32) CZC_GOS(ACT_NONE, true); else CZC_GOS(ACT_NONE, false); }
+#undef CZC_GOS
   CZC_HIP_CHECK(hipGetLastError());
   return 0;
 }

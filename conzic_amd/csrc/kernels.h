@@ -34,6 +34,9 @@ int launch_gemm(int prec, const GemmArgs& g, hipStream_t st);
 bool gemm256_eligible(const GemmArgs& g);
 int launch_gemm256(const GemmArgs& g, hipStream_t st);  // gemm256.hip: 256x256 LDS-DMA bf16 kernel
 extern int g_use_gemm256;
+bool gemm256s_eligible(const GemmArgs& g);  // split-fp16 operands, same 256x256 persistent structure
+int launch_gemm256s(const GemmArgs& g, hipStream_t st);
+extern int g_use_gemm256s;
 extern int g_gemm_krot;
 extern int g_use_skinny;
 extern int g_use_splitk;
@@ -129,6 +132,8 @@ struct BridgeDev {
 };
 // rows: inp[b,:] with column gen_idx replaced by cand[b,k] (cand==null: rows are taken verbatim,
 // n_rows = B, K = 1).  Writes clip_ids [B*K,77], clip_len, and optionally senti/repeats.
+// Sentiment score of a row: sum of lexicon[id] over its non-special pieces, or -- when lex_pos [V][5] and
+// lex_cls [V] are given -- sum of lex_pos[id][lex_cls[id]] over its word-start pieces.
 // POS template for the control score (null tags = no POS score)
 struct PosDev {
   const uint8_t* tag_of_token;  // [V]
@@ -136,7 +141,7 @@ struct PosDev {
   int n;
 };
 int launch_bridge(const BridgeDev& bd, const int* inp, int B, int T, int gen_idx, const int* cand, int K,
-                  const float* lexicon, int negative, const PosDev& pos, int* clip_ids, int* clip_len, float* senti_raw,
+                  const float* lexicon, const float* lex_pos, const uint8_t* lex_cls, int negative, const PosDev& pos, int* clip_ids, int* clip_len, float* senti_raw,
                   float* repeats, int* overflow_flag, hipStream_t st);
 // exclusive scan of len[n] -> off[n+1]; totals[0] = sum, totals[1] = max
 int launch_scan(const int* len, int n, int* off, int* totals, hipStream_t st);

@@ -129,6 +129,17 @@ class Engine:
         m = np.ascontiguousarray(np.asarray(mask, dtype=np.float32).reshape(-1))
         self._ck(self.lib.czc_set_token_mask(self.h, m.ctypes.data, m.size), "czc_set_token_mask")
 
+    def set_lexicon_pos(self, table, class_of_token):
+        """(word-start piece, coarse POS class) keyed sentiment table [V,5] + class per token [V] (None: back to
+        the per-token lexicon).  See conzic_amd/sentiment.py."""
+        if table is None:
+            self._ck(self.lib.czc_set_lexicon_pos(self.h, None, None, 0), "czc_set_lexicon_pos")
+            return
+        t = np.ascontiguousarray(table, dtype=np.float32)
+        c = np.ascontiguousarray(class_of_token, dtype=np.uint8)
+        assert t.ndim == 2 and t.shape[1] == 5 and c.shape == (t.shape[0],)
+        self._ck(self.lib.czc_set_lexicon_pos(self.h, t.ctypes.data, c.ctypes.data, t.shape[0]), "czc_set_lexicon_pos")
+
     def set_lexicon(self, lex):
         m = np.ascontiguousarray(np.asarray(lex, dtype=np.float32).reshape(-1))
         self._ck(self.lib.czc_set_lexicon(self.h, m.ctypes.data, m.size), "czc_set_lexicon")

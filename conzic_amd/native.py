@@ -77,6 +77,7 @@ SIGNATURES = {
     "czc_set_token_mask": (_I, [_P, _P, _I]),
     "czc_set_bridge": (_I, [_P, C.POINTER(BridgeTables)]),
     "czc_set_lexicon": (_I, [_P, _P, _I]),
+    "czc_set_lexicon_pos": (_I, [_P, _P, _P, _I]),
     "czc_set_pos": (_I, [_P, _P, _I, _P, _I]),
     "czc_encode_images": (_I, [_P, _P, _I, _P]),
     "czc_preprocess_u8": (_I, [_P, _P, _I, _I, _P, _P, _I, _P]),

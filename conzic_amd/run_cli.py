@@ -76,6 +76,7 @@ def main(argv=None):
         lm_model = SyntheticLM(bcfg)
         clip = CLIP.from_state(ccfg, synth.make_clip_weights(ccfg, 12), clip_tok)
         clip.lexicon = synth.make_lexicon(len(sv.bert_tokens))
+        clip.pos_tags = synth.make_pos_tags(len(sv.bert_tokens))
         token_mask = synth.make_token_mask(sv)
     else:
         from transformers import AutoModelForMaskedLM, AutoTokenizer
@@ -89,12 +90,36 @@ def main(argv=None):
             token_mask[0, sid] = 0
     img_dir = args.caption_img_path
     names = os.listdir(img_dir)
+    # One process per GPU (torchrun): batches are block-partitioned over the ranks (conzic_amd/dist.py); every rank
+    # walks ALL (sample, batch) pairs in the reference's order and advances the order RNG for the batches it skips,
+    # so an N-rank run produces the single-process run's captions batch for batch.  No collective while polishing;
+    # one gather of the caption dicts at the end of each sample.
+    from conzic_amd import dist as czd
+    from conzic_amd.runtime import advance_order_rng
+    from clip.clip import ImageEmbeds
+    rank, world, local = czd.env_rank_world()
+    if world > 1:
+        import torch
+        import torch.distributed as tdist
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local % torch.cuda.device_count())
+        if not tdist.is_initialized():
+            tdist.init_process_group(os.environ.get("CZC_DIST_BACKEND", "nccl"))
+    all_batches = list(batches(names, args.batch_size))
+    own_lo, own_hi = czd.shard_range(len(all_batches), rank, world)
+    embed_cache = {}  # batch index -> image_embeds [B, proj]: the ViT runs once per image, not once per sample
     for sample_id in range(args.samples_num):
         all_results = [None] * (args.num_iterations + 1)
         logger.info(f"Sample {sample_id + 1}: ")
-        for batch_idx, name_batch in enumerate(batches(names, args.batch_size)):
+        for batch_idx, name_batch in enumerate(all_batches):
+            if not (own_lo <= batch_idx < own_hi):
+                advance_order_rng(args.order, args.sentence_len, args.num_iterations)
+                continue
             logger.info(f"The {batch_idx + 1}-th batch:")
-            imgs = [Image.open(os.path.join(img_dir, n)).convert("RGB") for n in name_batch]
+            if batch_idx in embed_cache:
+                imgs = ImageEmbeds(embed_cache[batch_idx])
+            else:
+                imgs = [Image.open(os.path.join(img_dir, n)).convert("RGB") for n in name_batch]
             kw = dict(prompt=args.prompt, batch_size=args.batch_size, max_len=args.sentence_len,
                       top_k=args.candidate_k, temperature=args.lm_temperature, max_iter=args.num_iterations,
                       alpha=args.alpha, beta=args.beta, generate_order=args.order)
@@ -103,9 +128,21 @@ def main(argv=None):
             else:
                 gen_texts, _ = control_generate_caption(name_batch, lm_model, clip, lm_tokenizer, imgs, token_mask,
                                                         logger, gamma=args.gamma, ctl_type=args.control_type,
-                                                        style_type=args.sentiment_type, **kw)
+                                                        style_type=args.sentiment_type, pos_type=args.pos_type, **kw)
+            if batch_idx not in embed_cache:
+                embed_cache[batch_idx] = clip.last_image_embeds()
             all_results = merge_results(all_results, gen_texts, name_batch)
-        write_results(result_dir(args, run_type, sample_id), all_results)
+        if world > 1:
+            import torch.distributed as tdist
+            parts = [None] * world
+            tdist.all_gather_object(parts, all_results)
+            all_results = [None] * (args.num_iterations + 1)
+            for part in parts:  # rank order == batch order
+                for it, d in enumerate(part):
+                    if d is not None:
+                        all_results[it] = {**(all_results[it] or {}), **d}
+        if rank == 0:
+            write_results(result_dir(args, run_type, sample_id), all_results)
 
 
 if __name__ == "__main__":

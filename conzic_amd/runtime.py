@@ -169,6 +169,18 @@ def clip_only_engine(clip, device: int = 0) -> Engine:
     return eng
 
 
+def advance_order_rng(order: str, max_len: int, max_iters: int) -> None:
+    """Consume from the process-global RNG streams exactly what one *_generation call would (gen_utils.py:110-111
+    shuffle: one `random.shuffle`; :210 random: one `np.random.randint` per iteration).  A rank of an image-sharded
+    run calls this for the batches it does NOT own, so that every batch sees the visiting order it would have seen
+    in the single-process run (SURVEY.md §8e parity caveat)."""
+    if order == "shuffle":
+        random.shuffle(list(range(max_len)))
+    elif order == "random":
+        for _ in range(max_iters):
+            np.random.randint(0, max_len)
+
+
 def _mask_to_numpy(token_mask) -> np.ndarray:
     if hasattr(token_mask, "detach"):
         return token_mask.detach().float().cpu().numpy()
@@ -191,9 +203,14 @@ def run_generation(order: str, img_name, model, clip, tokenizer, image_instance,
             raise RuntimeError("the POS path needs a per-token tag table: set clip.pos_tags (see DESIGN.md)")
         eng.set_pos(clip.pos_tags, synth.pos_template_masks(pos_template))
     elif gamma is not None:
-        if getattr(clip, "lexicon", None) is None:
-            raise RuntimeError("the sentiment path needs a per-token lexicon: set clip.lexicon (see DESIGN.md)")
-        eng.set_lexicon(clip.lexicon)
+        if getattr(clip, "lexicon_pos", None) is not None:   # (table [V,5], class_of_token [V]): conzic_amd/sentiment.py
+            eng.set_lexicon_pos(*clip.lexicon_pos)
+        elif getattr(clip, "lexicon", None) is not None:
+            eng.set_lexicon_pos(None, None)
+            eng.set_lexicon(clip.lexicon)
+        else:
+            raise RuntimeError("the sentiment path needs a sentiment table: set clip.lexicon (per token) or "
+                               "clip.lexicon_pos (per word-start piece and coarse POS, conzic_amd/sentiment.py)")
     order_list = random_positions = None
     if order == "shuffle":
         order_list = list(range(max_len))

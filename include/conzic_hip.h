@@ -141,6 +141,13 @@ int czc_set_bridge(czc_engine* e, const czc_bridge_tables* t);
 /* Per-BERT-token sentiment score (stand-in for sentiments_classifer.py:9-33). */
 int czc_set_lexicon(czc_engine* e, const float* lexicon, int vocab);
 
+/* The same score keyed the way the reference scores (sentiments_classifer.py:14-30: per WORD and coarse POS class,
+ * mean of pos_score - neg_score over the word's SentiWordNet synsets): table fp32 [V][5] over the classes
+ * 0 '' | 1 n | 2 v | 3 a | 4 r, addressed by a word's FIRST piece ('##' continuations add nothing), and
+ * class_of_token uint8 [V] = the class a context-free tagger gives that token (host pointer).  Where nltk and its
+ * corpora exist, conzic_amd/sentiment.py fills both from SentiWordNet; table == NULL returns to czc_set_lexicon. */
+int czc_set_lexicon_pos(czc_engine* e, const float* table, const uint8_t* class_of_token, int vocab);
+
 /* POS control (control_gen_utils.py:136-195 / POS_classifier.py:6-31): per-BERT-token universal-tagset id
  * (stand-in for nltk.pos_tag) and the template as one bit mask of accepted tag ids per word
  * position (0xFFFF = the reference's "" wildcard); n_template <= 32. */

@@ -45,6 +45,7 @@ class Oracle:
     bpe: T.ClipBpe
     lexicon: Optional[np.ndarray] = None
     pos_tags: Optional[np.ndarray] = None
+    lexicon_pos: Optional[tuple] = None  # (table [V,5], class_of_token [V]): score keyed per word and coarse POS
     vocab: Dict[str, int] = field(default_factory=dict)
 
     def __post_init__(self):
@@ -100,6 +101,22 @@ def generate_caption_step(logits_row: torch.Tensor, mask: torch.Tensor, temperat
 
 def senti_scores(o: Oracle, rows: torch.Tensor, ctl_signal: str) -> torch.Tensor:
     """Stand-in for sentiments_classifer.py:35-45 (see module docstring): [N] scores."""
+    if o.lexicon_pos is not None:
+        # per word (addressed by its first piece; '##' continuations add nothing) under the coarse POS class of that
+        # piece: sentiments_classifer.py:14-30 with a context-free tagger
+        table, cls = o.lexicon_pos
+        per_tok = torch.from_numpy(np.asarray(table, np.float32)[np.arange(len(cls)), np.asarray(cls, np.int64)])
+        cont = torch.tensor([t.startswith("##") for t in o.id2tok])
+        sc = torch.zeros(rows.shape[0])
+        for r in range(rows.shape[0]):
+            first = True
+            for i in rows[r].tolist():
+                if i in o.special:
+                    continue
+                if first or not bool(cont[i]):
+                    sc[r] += per_tok[i]
+                first = False
+        return -sc if ctl_signal == "negative" else sc
     lex = torch.from_numpy(o.lexicon)
     keep = torch.ones_like(rows, dtype=torch.bool)
     for s in o.special:

@@ -1,0 +1,143 @@
+"""-m gpu: the N>1 path on ONE GPU -- two ranks (gloo rendezvous on 127.0.0.1, both engines on cuda:0) do what two
+GPUs would: receive the frozen weights through `dist.broadcast_state`, polish their own image shard with the
+visiting order every rank agrees on, gather.  Images are independent (gen_utils.py:65-81 has no cross-image term)
+and the order is an explicit input, so the 2-rank result must equal the 1-rank run image for image.
+The f32 engine is used because its kernels do not depend on the batch size, which makes "equal" mean bit-equal."""
+import json
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rank_main(rank, world, port, B, L, K, I, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0")
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    from conzic_amd import dist as czd, harness, native, synth
+    from conzic_amd.engine import Engine
+    from oracle import step as S
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda", 0)
+        sv = harness.cached_vocab(True)
+        bcfg, ccfg = synth.bert_tiny(len(sv.bert_tokens)), synth.clip_tiny(len(sv.clip_vocab))
+        bw = czd.broadcast_state(synth.make_bert_weights(bcfg, 11) if rank == 0 else None, dev)
+        cw = czd.broadcast_state(synth.make_clip_weights(ccfg, 12) if rank == 0 else None, dev)
+        su = harness.build_synthetic(True, native.PREC_F32, device=0, bert_w=bw, clip_w=cw, bert_cfg=bcfg, clip_cfg=ccfg)
+        lo, hi = czd.shard_range(B, rank, world)
+        pix = synth.pixels_from_u8(synth.make_images_u8(hi - lo, ccfg.v_image, first=lo))
+        su.engine.encode_images(pix)
+        # one shuffle order per call for the whole job: rank 0 draws it, every rank uses it
+        order = [S.shuffle_order(L, seed=42) if rank == 0 else None]
+        dist.broadcast_object_list(order, src=0)
+        pos, nm, every = harness.order_positions("shuffle", L, I, order_list=order[0])
+        init = su.bert_tok.encode("Image of a" + su.bert_tok.mask_token * L)
+        ids, cos = su.engine.generate(hi - lo, init, L, 4, K, pos, Engine.hyper(0.02, 2.0, 0.1), n_mask=nm, snapshot_every=every)
+        full = czd.gather_ids(ids, world)
+        q.put((rank, full.tolist(), order[0]))
+        su.engine.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_equal_one_rank_image_for_image():
+    import torch.multiprocessing as mp
+    from conzic_amd import harness, native, synth
+    from conzic_amd.engine import Engine
+    from oracle import step as S
+    B, L, K, I = 6, 5, 12, 2
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, B, L, K, I, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+    assert [r[0] for r in res] == [0, 1]
+    assert res[0][1] == res[1][1], "every rank must hold the same gathered result"
+    gathered = np.array(res[0][1], dtype=np.int32)
+    order = res[0][2]
+    assert order == S.shuffle_order(L, seed=42)
+    # the single-process run of the same job
+    su = harness.build_synthetic(True, native.PREC_F32)
+    try:
+        su.engine.encode_images(synth.pixels_from_u8(synth.make_images_u8(B, su.clip_cfg.v_image)))
+        pos, nm, every = harness.order_positions("shuffle", L, I, order_list=order)
+        init = su.bert_tok.encode("Image of a" + su.bert_tok.mask_token * L)
+        ids, _ = su.engine.generate(B, init, L, 4, K, pos, Engine.hyper(0.02, 2.0, 0.1), n_mask=nm, snapshot_every=every)
+    finally:
+        su.engine.close()
+    assert gathered.shape == ids.shape
+    np.testing.assert_array_equal(gathered, ids)
+
+
+def _run_cli(rank, world, port, img_dir, out_dir, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", CZC_DIST_BACKEND="gloo", CZC_PRECISION="f32")
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    os.chdir(out_dir)
+    from conzic_amd import run_cli
+    run_cli.main(["--synthetic", "--tiny", "--caption_img_path", img_dir, "--run_type", "caption", "--order", "shuffle",
+                  "--batch_size", "2", "--samples_num", "2", "--sentence_len", "5", "--candidate_k", "12",
+                  "--num_iterations", "2"])
+    q.put(rank)
+
+
+def test_run_cli_sharded_over_two_ranks_matches_single_process(tmp_path):
+    """The run.py-shaped harness: 3 batches x 2 samples, shuffle order (one draw per call from the process-global
+    stream, gen_utils.py:110-111).  Two ranks -- which skip each other's batches but advance the order stream for
+    them -- must write the JSON files the single process writes; the second sample reuses the cached image
+    embeddings (ViT once per image)."""
+    import torch.multiprocessing as mp
+    from PIL import Image
+    from conzic_amd import synth
+    img_dir = tmp_path / "imgs"
+    img_dir.mkdir()
+    for j, u in enumerate(synth.make_images_u8(6, 40)):
+        Image.fromarray(u).save(img_dir / f"im{j}.png")
+    outs = {}
+    ctx = mp.get_context("spawn")
+    for world in (1, 2):
+        out_dir = tmp_path / f"w{world}"
+        out_dir.mkdir()
+        port = _free_port()
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_run_cli, args=(r, world, port, str(img_dir), str(out_dir), q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        done = sorted(q.get(timeout=600) for _ in range(world))
+        for p in procs:
+            p.join(timeout=120)
+        assert done == list(range(world))
+        files = {}
+        for root, _, fs in os.walk(out_dir / "results"):
+            for f in fs:
+                files[os.path.relpath(os.path.join(root, f), out_dir)] = json.load(open(os.path.join(root, f)))
+        outs[world] = files
+    assert outs[1] and set(outs[1]) == set(outs[2])
+    assert any("sample_1" in k for k in outs[1]) and any(k.endswith("best_clipscore.json") for k in outs[1])
+    for k in outs[1]:
+        assert outs[1][k] == outs[2][k], k
+        assert len(outs[1][k]) == 6

@@ -66,6 +66,34 @@ def test_generate_caption_dropin_matches_reference(name):
     assert mask[0, tok.vocab["."]] == (1.0 if last == meta["L"] - 1 else 0.0)
 
 
+def test_image_embeds_cached_across_samples():
+    """North star: the ViT encode happens once per image.  The same image objects polished again (the samples_num
+    loop of demo.py:83) and `ImageEmbeds` handed back in their place must not go through the vision tower again,
+    and must give the captions a fresh encode gives."""
+    import utils
+    from clip.clip import ImageEmbeds
+    from gen_utils import generate_caption
+    meta, arr = load_case("tiny_seq")
+    lm, clip, tok, imgs, mask = _objects(meta)
+    logger = logging.getLogger("dropin-test")
+    names = [f"img{j}" for j in range(meta["B"])]
+    kw = dict(prompt=meta["prompt"], batch_size=meta["B"], max_len=meta["L"], top_k=meta["K"],
+              temperature=meta["temperature"], max_iter=meta["I"], alpha=meta["alpha"], beta=meta["beta"],
+              generate_order="sequential")
+    utils.set_seed(meta["seed"])
+    t1, s1 = generate_caption(names, lm, clip, tok, imgs, mask.copy(), logger, **kw)
+    eng = clip._engine
+    eng.profile_reset()
+    eng.profile(True)
+    t2, s2 = generate_caption(names, lm, clip, tok, imgs, mask.copy(), logger, **kw)                     # same objects
+    t3, s3 = generate_caption(names, lm, clip, tok, ImageEmbeds(clip.last_image_embeds()), mask.copy(), logger, **kw)
+    eng.profile(False)
+    assert eng.profile_get("gemm_vision")["launches"] == 0, "the vision tower ran again"
+    assert t1 == t2 == t3 == meta["texts"]
+    np.testing.assert_allclose(np.array(s2), np.array(s1), atol=1e-6)
+    np.testing.assert_allclose(np.array(s3), np.array(s1), atol=1e-6)
+
+
 def test_clip_wrapper_methods():
     from oracle import models as M
     import torch

@@ -178,3 +178,55 @@ def test_checkpoint_directories_round_trip(tmp_path):
     assert ct(text)["input_ids"] == ct0(text)["input_ids"]
     with pytest.raises(FileNotFoundError):
         checkpoint.read_safetensors(str(tmp_path / "nothing_here"))
+
+
+def test_advance_order_rng_consumes_what_a_generation_call_would():
+    """A rank that skips a batch must leave the process-global streams where a real call would (gen_utils.py:110-111
+    one random.shuffle per shuffle call; :210 one np.random.randint per iteration of the random order)."""
+    import random
+    from conzic_amd.runtime import advance_order_rng
+    random.seed(42)
+    np.random.seed(42)
+    lst = list(range(10))
+    random.shuffle(lst)          # what a shuffle_generation call draws
+    after_real = random.random()
+    random.seed(42)
+    advance_order_rng("shuffle", 10, 7)
+    assert random.random() == after_real
+    np.random.seed(5)
+    [np.random.randint(0, 10) for _ in range(7)]
+    after_real = np.random.randint(0, 1 << 30)
+    np.random.seed(5)
+    advance_order_rng("random", 10, 7)
+    assert np.random.randint(0, 1 << 30) == after_real
+    random.seed(1)
+    a = random.random()
+    random.seed(1)
+    advance_order_rng("sequential", 10, 7)   # draws nothing
+    assert random.random() == a
+
+
+def test_sentiwordnet_table_builder_with_stand_in_nltk():
+    """conzic_amd/sentiment.py against sentiments_classifer.py:14-30 arithmetic with a stand-in nltk (the real one and
+    its corpora are absent here): per (word, class) mean of pos-neg over the synsets, 0 without synsets; class of a
+    token from the Penn tag map; '##' pieces and specials never start a word."""
+    import types
+    from conzic_amd import sentiment
+
+    class Syn:
+        def __init__(self, p, n): self.p, self.n = p, n
+        def pos_score(self): return self.p
+        def neg_score(self): return self.n
+    db = {("good", "a"): [Syn(0.75, 0.0), Syn(0.5, 0.25)], ("good", "n"): [Syn(0.5, 0.0)], ("bad", "a"): [Syn(0.0, 0.625)],
+          ("run", "v"): [Syn(0.125, 0.125)]}
+    tags = {"good": "JJ", "bad": "JJ", "run": "VB", "dog": "NN", "the": "DT"}
+    fake = types.SimpleNamespace(
+        corpus=types.SimpleNamespace(sentiwordnet=types.SimpleNamespace(senti_synsets=lambda w, c: db.get((w, c), []))),
+        pos_tag=lambda ws: [(w, tags.get(w, "XX")) for w in ws])
+    toks = ["[PAD]", "[CLS]", "good", "bad", "run", "dog", "the", "##ly"]
+    table, cls = sentiment.build_sentiwordnet_tables(toks, nltk_module=fake)
+    assert table.shape == (8, 5) and cls.tolist() == [0, 0, 3, 3, 2, 1, 0, 0]
+    assert table[2, 3] == np.float32((0.75 + 0.25) / 2) and table[2, 1] == np.float32(0.5) and table[2, 2] == 0
+    assert table[3, 3] == np.float32(-0.625) and table[4, 2] == 0.0 and not table[[0, 1, 7]].any()
+    with pytest.raises(ImportError, match="nltk"):
+        sentiment.build_sentiwordnet_tables(toks)

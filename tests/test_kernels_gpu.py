@@ -405,3 +405,48 @@ def test_folded_layernorm_gemm_pair(M, K1, N, act, mean_shift):
     tol = 0.02 * (1.0 + abs(mean_shift)) + 2 ** -8 * np.abs(ref)
     assert (err < tol).all(), (err.max(), np.abs(ref).max())
     assert err.mean() < 4e-3 * (1.0 + abs(mean_shift))
+
+
+@pytest.mark.parametrize("M,N,K,act,mode", [(16384 + 37, 1536, 512, 0, "typed"), (20000, 2048, 512, 1, "typed"),
+                                            (16500, 512, 2048, 0, "resid"), (16384, 512, 512, 0, "resid")])
+def test_split_fp16_gemm_256_tile_kernel(M, N, K, act, mode):
+    """gemm256s: the persistent 256x256 LDS-DMA kernel with three fp16 MFMA passes per product (the CLIP-text linear
+    layers of the split engine, M >= 16384).  fp32-class against an fp64 reference, ragged M, both epilogues
+    (split_t activation output incl. quick-GELU, fp32 output + fp32 residual), and agreement with the 128x128
+    register-staged kernel it replaces."""
+    rng = np.random.default_rng(N + K)
+    A = (rng.standard_normal((M, K)) * 1.5).astype(np.float32)
+    W = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    R = rng.standard_normal((M, N)).astype(np.float32) if mode == "resid" else None
+    C = E.test_gemm(F16X3, A, W, bias=bias, resid=R, act=act, typed_out=(mode == "typed"))
+    ref = _act((A.astype(np.float64) @ W.astype(np.float64).T + bias).astype(np.float32), act) + (R if R is not None else 0)
+    tol = 1e-5 * np.sqrt(K / 64) * 4 + (2e-6 * np.abs(ref).max() if mode == "typed" else 0)  # typed: hi+lo storage ~2^-22
+    assert np.abs(C - ref).max() < tol, np.abs(C - ref).max()
+    lib = native.load()
+    try:
+        assert lib.czc_test_set_option(b"gemm256s", 0) == 0
+        C2 = E.test_gemm(F16X3, A, W, bias=bias, resid=R, act=act, typed_out=(mode == "typed"))
+    finally:
+        lib.czc_test_set_option(b"gemm256s", 1)
+    assert np.abs(C - C2).max() < tol
+
+
+@pytest.mark.parametrize("causal", [False, True])
+def test_split_fp16_mfma_attention(causal):
+    """attention_mfma_split_kernel (three fp16 MFMA passes for QK^T and PV) on packed ragged segments up to 77 rows,
+    8 and 12 heads: fp32-class, and equal to the exact-fp32 VALU kernel it replaces within that class."""
+    rng = np.random.default_rng(9)
+    for heads in (8, 12):
+        lens = [15, 1, 7, 16, 20, 77, 50, 64, 65, 2, 33]
+        qkv = rng.standard_normal((sum(lens), 3 * heads * 64)).astype(np.float32)
+        out = E.test_attention(F16X3, qkv, lens, heads, causal, 0.125)
+        ref = _attn_ref(qkv, lens, heads, causal, 0.125)
+        assert np.abs(out - ref).max() < 3e-5, np.abs(out - ref).max()
+        lib = native.load()
+        try:
+            assert lib.czc_test_set_option(b"mfma_attention", 0) == 0
+            out2 = E.test_attention(F16X3, qkv, lens, heads, causal, 0.125)
+        finally:
+            lib.czc_test_set_option(b"mfma_attention", 1)
+        assert np.abs(out - out2).max() < 3e-5

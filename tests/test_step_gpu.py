@@ -257,6 +257,47 @@ def test_bert_logits_row_vs_reference(name, prec):
     assert (res["logits"].argmax(1) == ref.argmax(1)).all()
 
 
+@pytest.mark.parametrize("prec", [F32, BF16])
+def test_sentiment_table_keyed_by_word_and_pos(prec):
+    """czc_set_lexicon_pos: the sentence score summed per WORD (first piece; '##' continuations add nothing) under
+    the coarse POS class of that piece (sentiments_classifer.py:14-30), fused into the bridge kernel -- against the
+    oracle on the same random table, through a whole sentiment step (gamma = 5, control_gen_utils.py:53-63)."""
+    from oracle import step as S
+    from goldutil import make_oracle
+    meta, arr = load_case("tiny_senti_seq")
+    su = harness.build_synthetic(True, prec, lexicon=True)
+    try:
+        V = len(su.sv.bert_tokens)
+        rng = np.random.default_rng(7)
+        table = rng.uniform(-1, 1, size=(V, 5)).astype(np.float32)
+        cls = rng.integers(0, 5, size=V).astype(np.uint8)
+        su.engine.set_lexicon_pos(table, cls)
+        su.engine.set_image_embeds(arr["image_embeds"])
+        o, _, mask = make_oracle(meta)
+        o.lexicon_pos = (table, cls)
+        i = 3
+        gen_idx = SEED_LEN + meta["positions"][i]
+        inp = np.ascontiguousarray(arr["inp_before"][i], dtype=np.int32)
+        # put a '##' continuation piece into the row so that the word-start rule matters
+        cont = next(j for j, t in enumerate(su.sv.bert_tokens) if t.startswith("##") and su.token_mask[0, j] >= 0)
+        inp[:, SEED_LEN] = cont if gen_idx != SEED_LEN else inp[:, SEED_LEN]
+        inp[:, SEED_LEN + 1] = cont if gen_idx != SEED_LEN + 1 else inp[:, SEED_LEN + 1]
+        hp = Engine.hyper(meta["alpha"], meta["beta"], meta["temperature"], meta["gamma"], False)
+        res = su.engine.step(inp.copy(), gen_idx, meta["K"], hp, want=("idxs", "senti_raw", "final_score", "best"))
+        o.update_token_mask(mask, meta["L"], meta["positions"][i])
+        r = S.polish_step(o, torch.from_numpy(inp.astype(np.int64)), torch.from_numpy(arr["image_embeds"]), mask, gen_idx,
+                          meta["K"], meta["temperature"], meta["alpha"], meta["beta"], gamma=meta["gamma"])
+        np.testing.assert_array_equal(res["idxs"], r["idxs"].numpy())
+        np.testing.assert_allclose(res["senti_raw"], r["senti_raw"].numpy(), atol=1e-5)
+        np.testing.assert_allclose(res["final_score"], r["final"].numpy(), atol=2e-5 if prec == F32 else 2.5e-2)
+        # and back to the per-token lexicon
+        su.engine.set_lexicon_pos(None, None)
+        res2 = su.engine.step(inp.copy(), gen_idx, meta["K"], hp, want=("senti_raw",))
+        assert np.abs(res2["senti_raw"] - res["senti_raw"]).max() > 1e-3
+    finally:
+        su.engine.close()
+
+
 def test_precision_selected_from_logit_scale():
     """conzic_amd.runtime.choose_precision: bf16 towers only where exp(logit_scale) keeps them inside the
     budget; the published checkpoints' scale (100) gets the split-fp16 engine."""
