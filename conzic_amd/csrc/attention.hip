@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void attention_mfma_split_kernel(const split_t
         float e[16], el[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          e[r] = expf(st[kt][r] - mx);
+          e[r] = pin(expf(st[kt][r] - mx));  // one fp32 value behind hi and lo (common.h pin())
           sum += e[r];
           el[r] = e[r] - (float)(_Float16)e[r];
         }
@@ -525,6 +525,172 @@ __global__ __launch_bounds__(256) void attention_branch_kernel(const bf16_t* qkv
       }
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// split-fp16 form of attention_branch_kernel (split engine precision): G candidates of one image packed into one
+// 32-query tile, shared trunk keys + block-diagonal own keys, every product three v_mfma_f32_32x32x16_f16 passes.
+// q / k / v rows are split_t (16 bytes of fp16 hi parts + 16 bytes of lo parts per 8 elements); the V image in LDS
+// is two fp16 planes in the [sub-tile][key slot][16 dims] layout ds_read_b64_tr_b16 reads as the k-contiguous operand.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attention_branch_split_kernel(const split_t* qkv, SegTable tab, int B, int K, int G,
+                                                                     int heads, float scale, int KP, split_t* out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char at_lds[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int wpb = blockDim.x >> 6;
+  int h = blockIdx.y * wpb + wave;
+  const bool live = h < heads;
+  if (!live) h = heads - 1;
+  const int gpi = (K + G - 1) / G;
+  const int b = blockIdx.x / gpi, k0 = (blockIdx.x - b * gpi) * G;
+  const int Gc = min(G, K - k0);
+  const int s0 = B + b * K + k0;
+  const int pre_off = tab.pre_off[s0], pre_len = tab.pre_len[s0];
+  const int r0 = tab.own_off[s0];
+  const int n_own = tab.own_off[s0 + Gc - 1] + tab.own_len[s0 + Gc - 1] - r0;  // <= 32 by construction
+  const int nkt_t = (pre_len + 31) >> 5;
+  const int Hd = heads * 64;
+  const long pitchb = 3L * Hd * 4;
+  const unsigned char* base = (const unsigned char*)qkv;
+#define CZC_GRP(e0) ((long)((e0) >> 3) * 32)
+#define CZC_F16(v_) __builtin_bit_cast(f16x8_t, v_)
+  unsigned char* Vh = at_lds + (size_t)wave * 2 * 128 * KP;  // hi plane, then lo plane (128*KP bytes each)
+  unsigned char* Vl = Vh + 128 * KP;
+  const int SUB = KP * 32;
+  const int own_slot0 = nkt_t * 32;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int q = min(l31, n_own - 1);
+  const unsigned char* qp = base + ((long)r0 + q) * pitchb + CZC_GRP(h * 64 + 8 * half);
+  uint4 qh[4], ql[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    qh[ks] = *(const uint4*)(qp + ks * 64);
+    ql[ks] = *(const uint4*)(qp + ks * 64 + 16);
+  }
+  {
+    const int sc = lane & 7;  // 8 head dims sc*8.. of one key: sub-tile sc>>1, half row (sc&1)*16 bytes
+    const int wo = (sc >> 1) * SUB + (sc & 1) * 16;
+    const unsigned char* vsrc = base + CZC_GRP(2 * Hd + h * 64 + sc * 8);
+    for (int kb = 0; kb < own_slot0 + 32; kb += 32) {
+      uint4 vh[4], vl[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = kb + 8 * u + (lane >> 3);
+        long row = -1;
+        if (k < pre_len) row = (long)pre_off + k;
+        else if (k >= own_slot0 && k - own_slot0 < n_own) row = (long)r0 + (k - own_slot0);
+        vh[u] = row >= 0 ? *(const uint4*)(vsrc + row * pitchb) : make_uint4(0, 0, 0, 0);
+        vl[u] = row >= 0 ? *(const uint4*)(vsrc + row * pitchb + 16) : make_uint4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        *(uint4*)(Vh + wo + (kb + 8 * u + (lane >> 3)) * 32) = vh[u];
+        *(uint4*)(Vl + wo + (kb + 8 * u + (lane >> 3)) * 32) = vl[u];
+      }
+    }
+  }
+  asm volatile("" ::: "memory");  // the image is private to this wave; a wave's LDS operations execute in order
+
+  int ss = 0;
+  for (int j = 1; j < Gc; ++j) {
+    const int o = tab.own_off[s0 + j] - r0;
+    if (o <= q) ss = o;
+  }
+
+  f32x16_t st[AB_MAXT + 1];
+#pragma unroll
+  for (int t = 0; t <= AB_MAXT; ++t) {
+    if (t <= nkt_t) {
+      long krow;
+      if (t < nkt_t) krow = (long)pre_off + min(t * 32 + l31, pre_len - 1);
+      else krow = (long)r0 + min(l31, n_own - 1);
+      const unsigned char* kp = base + krow * pitchb + CZC_GRP(Hd + h * 64 + 8 * half);
+      f32x16_t acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const uint4 kh = *(const uint4*)(kp + ks * 64), kl = *(const uint4*)(kp + ks * 64 + 16);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(CZC_F16(kl), CZC_F16(qh[ks]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(CZC_F16(kh), CZC_F16(ql[ks]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(CZC_F16(kh), CZC_F16(qh[ks]), acc, 0, 0, 0);
+      }
+      st[t] = acc;
+    }
+  }
+  float mx = -INFINITY;
+#pragma unroll
+  for (int t = 0; t <= AB_MAXT; ++t) {
+    if (t <= nkt_t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int idx = (r & 3) + 8 * (r >> 2) + 4 * half;
+        const bool ok = t < nkt_t ? (t * 32 + idx < pre_len) : (idx >= ss && idx <= q);
+        const float v = ok ? st[t][r] * scale : -INFINITY;
+        st[t][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    }
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  float sum = 0.f;
+  uint4 ph[AB_MAXT + 1][2], pl[AB_MAXT + 1][2];
+#pragma unroll
+  for (int t = 0; t <= AB_MAXT; ++t) {
+    if (t <= nkt_t) {
+      float e[16], el[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        e[r] = pin(expf(st[t][r] - mx));
+        sum += e[r];
+        el[r] = e[r] - (float)(_Float16)e[r];
+      }
+#pragma unroll
+      for (int sstep = 0; sstep < 2; ++sstep) {
+        ph[t][sstep] = make_uint4(pack2_f16(e[8 * sstep + 0], e[8 * sstep + 1]), pack2_f16(e[8 * sstep + 2], e[8 * sstep + 3]),
+                                  pack2_f16(e[8 * sstep + 4], e[8 * sstep + 5]), pack2_f16(e[8 * sstep + 6], e[8 * sstep + 7]));
+        pl[t][sstep] = make_uint4(pack2_f16(el[8 * sstep + 0], el[8 * sstep + 1]), pack2_f16(el[8 * sstep + 2], el[8 * sstep + 3]),
+                                  pack2_f16(el[8 * sstep + 4], el[8 * sstep + 5]), pack2_f16(el[8 * sstep + 6], el[8 * sstep + 7]));
+      }
+    }
+  }
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = 1.0f / sum;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt) {
+    f32x16_t o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+    typedef __attribute__((ext_vector_type(4))) short tr4_t;
+    typedef __attribute__((address_space(3))) tr4_t* tr4_lds_t;
+    const int voff = (dt * 2 + (l31 >> 4)) * SUB + (4 * half + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8;
+#pragma unroll
+    for (int t = 0; t <= AB_MAXT; ++t) {
+      if (t <= nkt_t) {
+#pragma unroll
+        for (int sstep = 0; sstep < 2; ++sstep) {
+          const int vo = voff + (t * 32 + 16 * sstep) * 32;
+          const uint2 h0 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr4_lds_t)(Vh + vo)));
+          const uint2 h1 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr4_lds_t)(Vh + vo + 256)));
+          const uint2 l0 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr4_lds_t)(Vl + vo)));
+          const uint2 l1 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr4_lds_t)(Vl + vo + 256)));
+          const uint4 vh = make_uint4(h0.x, h0.y, h1.x, h1.y), vl = make_uint4(l0.x, l0.y, l1.x, l1.y);
+          o = __builtin_amdgcn_mfma_f32_32x32x16_f16(CZC_F16(vl), CZC_F16(ph[t][sstep]), o, 0, 0, 0);
+          o = __builtin_amdgcn_mfma_f32_32x32x16_f16(CZC_F16(vh), CZC_F16(pl[t][sstep]), o, 0, 0, 0);
+          o = __builtin_amdgcn_mfma_f32_32x32x16_f16(CZC_F16(vh), CZC_F16(ph[t][sstep]), o, 0, 0, 0);
+        }
+      }
+    }
+    if (live && l31 < n_own) {
+      const long eo = ((long)r0 + l31) * Hd + h * 64 + dt * 32 + 4 * half;
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd)
+        Act<split_t>::st4(out, eo + 8 * qd, o[4 * qd] * inv, o[4 * qd + 1] * inv, o[4 * qd + 2] * inv, o[4 * qd + 3] * inv);
+    }
+  }
+#undef CZC_F16
+#undef CZC_GRP
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -806,6 +972,38 @@ int launch_attention_shared(const void* qkv, const SegTable& tab, int B, int K, 
   dim3 grid(B * gpi, cdiv(heads, wpb)), block(64 * wpb);
   hipLaunchKernelGGL(attention_branch_kernel, grid, block, (size_t)wpb * 128 * KP, st, (const bf16_t*)qkv, tab, B, K,
                      G, heads, scale, KP, (bf16_t*)out);
+  CZC_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// split engine precision, shared-prefix plan: trunks through attention_mfma_split_kernel, branches packed G per tile
+int launch_attention_shared_split(const void* qkv, const SegTable& tab, int B, int K, int max_own, int max_keys, int heads,
+                                  float scale, void* out, hipStream_t st) {
+  if (max_keys > 96 || max_own > 32 || max_own <= 0) return -1;  // caller falls back to the generic path
+  const int G = 32 / max_own;
+  const int KPt = ((max_keys + 31) & ~31) + 4;
+  int wpb = heads >= 4 ? 4 : (heads >= 2 ? 2 : 1);
+  {
+    SegTable trunks = tab;
+    trunks.n_seg = B;
+    int wt = wpb;
+    while (wt > 1 && (size_t)wt * 2 * 64 * KPt * 2 > 150 * 1024) wt >>= 1;
+    const size_t shm = (size_t)wt * 2 * 64 * KPt * 2;
+    if (shm > 64 * 1024)
+      CZC_HIP_CHECK(hipFuncSetAttribute((const void*)attention_mfma_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    dim3 grid(B, cdiv(heads, wt)), block(64 * wt);
+    hipLaunchKernelGGL(attention_mfma_split_kernel, grid, block, shm, st, (const split_t*)qkv, trunks, heads, 1, scale, KPt,
+                       (split_t*)out);
+  }
+  const int KP = ((max_keys + 31) & ~31) + 32 + 1;
+  const int gpi = cdiv(K, G);
+  while (wpb > 1 && (size_t)wpb * 2 * 128 * KP > 150 * 1024) wpb >>= 1;
+  const size_t shm = (size_t)wpb * 2 * 128 * KP;
+  if (shm > 64 * 1024)
+    CZC_HIP_CHECK(hipFuncSetAttribute((const void*)attention_branch_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+  dim3 grid(B * gpi, cdiv(heads, wpb)), block(64 * wpb);
+  hipLaunchKernelGGL(attention_branch_split_kernel, grid, block, shm, st, (const split_t*)qkv, tab, B, K, G, heads, scale, KP,
+                     (split_t*)out);
   CZC_HIP_CHECK(hipGetLastError());
   return 0;
 }

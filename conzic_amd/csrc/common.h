@@ -61,6 +61,16 @@ template <> struct Act<float> {
     *(float4*)(b + i) = make_float4(x, y, z, w);
   }
 };
+// Splitting v into fp16 hi + lo needs ONE fp32 value behind both parts.  HIP compiles with -ffp-contract=fast: when v is
+// the result of a multiply or add that is still visible (o * inv, acc + bias, x * sigmoid), the compiler derives the
+// hi that feeds `v - hi` with a single-rounding v_fma_mix*_f16 from the exact product, but the STORED hi with
+// v_cvt_pk_f16_f32 from the fp32-rounded one; at near-ties (about 1 value in 8000) the two differ by one fp16 ulp and
+// hi + lo is off by 2^-11 relative.  pin() makes the fp32 value opaque so that both conversions start from it.
+__device__ __forceinline__ float pin(float v) {
+  asm("" : "+v"(v));
+  return v;
+}
+
 template <> struct Act<split_t> {
   __device__ static __forceinline__ long off(long i) { return (i >> 3) * 32 + (i & 7) * 2; }
   __device__ static __forceinline__ float ld(const split_t* b, long i) {
@@ -69,6 +79,7 @@ template <> struct Act<split_t> {
   }
   __device__ static __forceinline__ void st(split_t* b, long i, float v) {
     unsigned char* p = (unsigned char*)b + off(i);
+    v = pin(v);
     const _Float16 hi = (_Float16)v;
     *(_Float16*)p = hi;
     *(_Float16*)(p + 16) = (_Float16)(v - (float)hi);
@@ -76,6 +87,7 @@ template <> struct Act<split_t> {
   __device__ static __forceinline__ void st4(split_t* b, long i, float x, float y, float z, float w) {  // i % 4 == 0
     unsigned char* p = (unsigned char*)b + off(i);
     typedef __attribute__((ext_vector_type(4))) _Float16 h4;
+    x = pin(x); y = pin(y); z = pin(z); w = pin(w);
     h4 hi = {(_Float16)x, (_Float16)y, (_Float16)z, (_Float16)w};
     h4 lo = {(_Float16)(x - (float)hi[0]), (_Float16)(y - (float)hi[1]), (_Float16)(z - (float)hi[2]),
              (_Float16)(w - (float)hi[3])};

@@ -322,6 +322,8 @@ int clip_stack(czc_engine* e, const char* gk, std::vector<LayerW>& L, float* x, 
       int rc = -1;
       if (plan_B > 0 && P == PREC_BF16 && g_use_mfma_attention && e->pack_branches)
         rc = launch_attention_shared(qkv, tab, plan_B, plan_K, plan_max_own, max_keys, heads, scale, ctx, e->st);
+      else if (plan_B > 0 && P == PREC_F16X3 && g_use_mfma_attention && e->pack_branches)
+        rc = launch_attention_shared_split(qkv, tab, plan_B, plan_K, plan_max_own, max_keys, heads, scale, ctx, e->st);
       if (rc > 0) E_CHECK(rc);
       if (rc < 0) E_CHECK(launch_attention(P, qkv, tab, max_keys, heads, causal, scale, ctx, e->st)); }
     }

@@ -387,7 +387,7 @@ __device__ __forceinline__ void tile_epilogue_split(const GemmArgs& g, f32x16_t 
         recv.w = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send.w), 0xB1, 0xf, 0xf, true));
         const float4 lo4 = odd ? recv : v[pp];      // columns c8 .. c8+3
         const float4 hi4 = odd ? v[pp + 1] : recv;  // columns c8+4 .. c8+7
-        const float e[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+        const float e[8] = {pin(lo4.x), pin(lo4.y), pin(lo4.z), pin(lo4.w), pin(hi4.x), pin(hi4.y), pin(hi4.z), pin(hi4.w)};
         typedef __attribute__((ext_vector_type(8))) _Float16 h8;
         h8 hh, ll;
 #pragma unroll
@@ -721,6 +721,139 @@ __global__ __launch_bounds__(768) void gemm256q_kernel(GemmArgs g, int tiles_m, 
 
 
 // ================================================================================================
+// gemm256sq: gemm256q's 4-deep ring of 32 KiB stages for the SPLIT-fp16 precision.  A 64-byte tile row holds 16
+// elements ([8 hi | 8 lo] x 2 groups) = one k16 MFMA step, three fp16 passes per product: 24 MFMAs per stage and
+// wave on 12 ds_read_b128, loaders up to three stages ahead with counted vmcnt.  (gemm256s below, the two-stage
+// form, waits for every stage's DMA latency in front of its barrier: 0.37 of MFMA peak; kept for A/B.)
+// ================================================================================================
+template <int ACT, bool OUT_F32>
+__global__ __launch_bounds__(768) void gemm256sq_kernel(GemmArgs g, int tiles_m, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nk = g.K >> 4;  // one k16 MFMA step per stage: a 64-byte row = two split_t groups = 16 elements
+  const int lda_b = g.lda * 4, ldw_b = g.ldw * 4;
+  const int my_tiles = tile_count(tiles_m, tiles_n, true);
+  const int total = my_tiles * nk;
+
+  if (wave >= 8) {
+    // ------------------------------- loader waves -------------------------------------------
+    const int lw = wave - 8;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(
+        (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem);
+    // instruction ii (0..3) lands tile rows lw*64 + ii*16 + (lane>>2); physical chunk lane&3
+    const int rbase = lw * 64 + (lane >> 2);
+    const int cq = ((lane & 3) ^ ((lane >> 4) & 3)) << 4;
+    const int a0 = rbase * lda_b + cq, w0 = rbase * ldw_b + cq;
+    const int a16 = 16 * lda_b, w16 = 16 * ldw_b;
+    int cur_ti = -1;
+    u32x4_t rsA, rsW;
+    rsA.x = rsA.y = rsA.z = 0; rsA.w = 0x00020000u;
+    rsW = rsA;
+    auto issue = [&](int s) {
+      const int ti = s / nk, kt = s - ti * nk;
+      if (ti != cur_ti) {
+        cur_ti = ti;
+        int tm, tn;
+        tile_at(ti, tiles_m, tiles_n, true, tm, tn);
+        const int m0 = tm * TM, n0 = tn * TN;
+        const unsigned long long pa = (unsigned long long)g.A + (unsigned long long)m0 * lda_b;
+        const unsigned long long pw = (unsigned long long)g.W + (unsigned long long)n0 * ldw_b;
+        rsA.x = (unsigned)pa; rsA.y = (unsigned)(pa >> 32) & 0xffffu; rsA.z = (unsigned)(min(TM, g.M - m0) * lda_b);
+        rsW.x = (unsigned)pw; rsW.y = (unsigned)(pw >> 32) & 0xffffu; rsW.z = (unsigned)(min(TN, g.N - n0) * ldw_b);
+      }
+      const unsigned dstA = lds0 + (s & (QS - 1)) * QSTAGE + lw * (64 * QROWB);
+      const unsigned dstW = dstA + QA_BYTES;
+      const unsigned so = kt * QROWB;
+      unsigned keep;
+      asm volatile(
+          "s_mov_b32 %0, m0\n\t"
+          "s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %11, %13 offen lds\n\t"
+          "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %11, %13 offen lds\n\t"
+          "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %5, %11, %13 offen lds\n\t"
+          "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %6, %11, %13 offen lds\n\t"
+          "s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %7, %12, %13 offen lds\n\t"
+          "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %8, %12, %13 offen lds\n\t"
+          "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %9, %12, %13 offen lds\n\t"
+          "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %10, %12, %13 offen lds\n\t"
+          "s_mov_b32 m0, %0"
+          : "=&s"(keep)
+          : "s"(dstA), "s"(dstW), "v"(a0), "v"(a0 + a16), "v"(a0 + 2 * a16), "v"(a0 + 3 * a16), "v"(w0), "v"(w0 + w16),
+            "v"(w0 + 2 * w16), "v"(w0 + 3 * w16), "s"(rsA), "s"(rsW), "s"(so)
+          : "memory", "scc");
+    };
+    const int pro = total < QS ? total : QS;
+    for (int s = 0; s < pro; ++s) issue(s);
+    for (int s = 0; s < total; ++s) {
+      // steps issued so far: 0 .. min(total, QS + max(s-1,0)) - 1; wait until step s has landed, i.e.
+      // at most (issued - 1 - s) later steps (8 DMAs each) may still be in flight
+      const int issued = (s == 0) ? pro : (QS + s - 1 < total ? QS + s - 1 : total);
+      const int later = issued - 1 - s;
+      if (later >= 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+      else if (later == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else if (later == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // publishes step s; proves stage (s-1)%QS has been left
+      if (s >= 1 && s - 1 + QS < total) issue(s - 1 + QS);
+    }
+    return;
+  }
+
+  // --------------------------------- MFMA waves ---------------------------------------------
+  const int wm = wave >> 2, wn = wave & 3;
+  const int half = lane >> 5;
+  const int arow = wm * 128 + (lane & 31);
+  const int brow = wn * 64 + (lane & 31);
+  int step = 0;
+  for (int ti = 0; ti < my_tiles; ++ti) {
+    int tm, tn;
+    tile_at(ti, tiles_m, tiles_n, true, tm, tn);
+    const int m0 = tm * TM, n0 = tn * TN;
+    f32x16_t acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int kt = 0; kt < nk; ++kt, ++step) {
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const unsigned char* sA = smem + (step & (QS - 1)) * QSTAGE;
+      const unsigned char* sB = sA + QA_BYTES;
+      // row = [hi g0 | lo g0 | hi g1 | lo g1] (16-byte chunks); lane half h contracts group h: chunks 2h (hi), 2h+1 (lo)
+#define CZC_F16(v_) __builtin_bit_cast(f16x8_t, v_)
+      uint4 bh[2], bl[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        bh[j] = *(const uint4*)(sB + swzq(brow + 32 * j, 2 * half));
+        bl[j] = *(const uint4*)(sB + swzq(brow + 32 * j, 2 * half + 1));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint4 ah = *(const uint4*)(sA + swzq(arow + 32 * i, 2 * half));
+        const uint4 al = *(const uint4*)(sA + swzq(arow + 32 * i, 2 * half + 1));
+        // pass-major over the two column tiles: consecutive MFMAs never share an accumulator
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(CZC_F16(bl[j]), CZC_F16(ah), acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(CZC_F16(bh[j]), CZC_F16(al), acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(CZC_F16(bh[j]), CZC_F16(ah), acc[i][j], 0, 0, 0);
+      }
+#undef CZC_F16
+    }
+    unsigned char* patch = smem + QS * QSTAGE + wave * 4096;
+    if (OUT_F32) tile_epilogue<ACT, true>(g, acc, patch, m0, n0, wm, wn, lane);
+    else tile_epilogue_split<ACT>(g, acc, patch, m0, n0, wm, wn, lane);
+  }
+}
+
+
+
+
+// ================================================================================================
 // gemm256s: the persistent wave-specialised 256x256 kernel (gemm256p structure: 8 MFMA waves + 4 LDS-DMA loader
 // waves, two 64 KiB stages of 128-byte rows) for the SPLIT-fp16 engine precision.  A 128-byte tile row is 32
 // elements as four groups of [8 fp16 hi | 8 fp16 lo] (common.h split_t), so one stage feeds two k16 MFMA steps, and
@@ -848,13 +981,14 @@ __global__ __launch_bounds__(768) void gemm256s_kernel(GemmArgs g, int tiles_m, 
         for (int i = 0; i < 4; ++i) {
           const uint4 ah = *(const uint4*)(sA + swz(arow + 32 * i, ch));
           const uint4 al = *(const uint4*)(sA + swz(arow + 32 * i, ch + 1));
+          // (a_hi + a_lo)(w_hi + w_lo) ~ a_hi w_hi + a_lo w_hi + a_hi w_lo   (lo*lo ~ 2^-22, dropped); small terms first,
+          // pass-major over the two column tiles so that consecutive MFMAs never share an accumulator
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            // (a_hi + a_lo)(w_hi + w_lo) ~ a_hi w_hi + a_lo w_hi + a_hi w_lo   (lo*lo ~ 2^-22, dropped); small terms first
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(CZC_F16(bl[j]), CZC_F16(ah), acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(CZC_F16(bh[j]), CZC_F16(al), acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(CZC_F16(bh[j]), CZC_F16(ah), acc[i][j], 0, 0, 0);
-          }
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(CZC_F16(bl[j]), CZC_F16(ah), acc[i][j], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(CZC_F16(bh[j]), CZC_F16(al), acc[i][j], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(CZC_F16(bh[j]), CZC_F16(ah), acc[i][j], 0, 0, 0);
         }
       }
 #undef CZC_F16
@@ -945,7 +1079,7 @@ int launch_gemm256(const GemmArgs& g, hipStream_t st) {
   return 0;
 }
 
-int g_use_gemm256s = 1;
+int g_use_gemm256s = 1;  // 1: four-stage ring (gemm256sq), 2: two-stage form (gemm256s), 0: 128x128 kernel
 
 // split-fp16 operands; big-M layers only (BERT at a few thousand rows stays on the 128x128 + split-K path)
 bool gemm256s_eligible(const GemmArgs& g) {
@@ -968,11 +1102,23 @@ int launch_gemm256s(const GemmArgs& g, hipStream_t st) {
     CZC_ATTR((gemm256s_kernel<ACT_NONE, true>));
     CZC_ATTR((gemm256s_kernel<ACT_QUICK_GELU, false>));
     CZC_ATTR((gemm256s_kernel<ACT_QUICK_GELU, true>));
+    CZC_ATTR((gemm256sq_kernel<ACT_NONE, false>));
+    CZC_ATTR((gemm256sq_kernel<ACT_NONE, true>));
+    CZC_ATTR((gemm256sq_kernel<ACT_QUICK_GELU, false>));
+    CZC_ATTR((gemm256sq_kernel<ACT_QUICK_GELU, true>));
 #undef CZC_ATTR
   }
   const int tiles_m = cdiv(g.M, TM), tiles_n = cdiv(g.N, TN);
   dim3 grid(tiles_m * tiles_n < n_cu ? tiles_m * tiles_n : n_cu), block(768);
   const bool f32 = g.out_f32 != nullptr || g.resid != nullptr;
+  if (g_use_gemm256s == 1 && g.K % 16 == 0) {
+#define CZC_GOSQ(A_, F_) hipLaunchKernelGGL((gemm256sq_kernel<A_, F_>), grid, block, shp, st, g, tiles_m, tiles_n)
+    if (g.act == ACT_QUICK_GELU) { if (f32) CZC_GOSQ(ACT_QUICK_GELU, true); else CZC_GOSQ(ACT_QUICK_GELU, false); }
+    else { if (f32) CZC_GOSQ(ACT_NONE, true); else CZC_GOSQ(ACT_NONE, false); }
+#undef CZC_GOSQ
+    CZC_HIP_CHECK(hipGetLastError());
+    return 0;
+  }
 #define CZC_GOS(A_, F_) hipLaunchKernelGGL((gemm256s_kernel<A_, F_>), grid, block, shp, st, g, tiles_m, tiles_n)
   if (g.act == ACT_QUICK_GELU) { if (f32) CZC_GOS(ACT_QUICK_GELU, true); else CZC_GOS(ACT_QUICK_GELU, false); }
   else { if (f32) CZC_GOS(ACT_NONE, true); else CZC_GOS(ACT_NONE, false); }

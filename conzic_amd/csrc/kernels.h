@@ -112,6 +112,10 @@ extern int g_qkv_attn_dbg;  // per-image persistent branch attention (LDS-DMA ri
 int launch_attention_shared(const void* qkv, const SegTable& tab, int B, int K, int max_own, int max_keys, int heads,
                             float scale, void* out, hipStream_t st);
 
+// the same for the split engine precision (qkv / out are split_t)
+int launch_attention_shared_split(const void* qkv, const SegTable& tab, int B, int K, int max_own, int max_keys, int heads,
+                                  float scale, void* out, hipStream_t st);
+
 // ---- topk.hip -----------------------------------------------------------------------------
 int launch_softmax_mask_topk(const float* logits, int B, int V, int K, const float* mask, float temperature, int dot_id,
                              int dot_allowed, float* probs, int* idxs, int* cand, hipStream_t st);
