@@ -202,6 +202,8 @@ int czc_test_set_option(const char* name, int value) {
   if (!strcmp(name, "gemm256s")) { g_use_gemm256s = value; return 0; }
   if (!strcmp(name, "wreg_dbg")) { g_wreg_dbg = value; return 0; }
   if (!strcmp(name, "lnf_dbg")) { g_lnf_dbg = value; return 0; }
+  if (!strcmp(name, "wreg_min_m")) { g_wreg_min_m = value; return 0; }
+  if (!strcmp(name, "gemm256_min_m")) { g_gemm256_min_m = value; return 0; }
   if (!strcmp(name, "mfma_attention")) { g_use_mfma_attention = value; return 0; }
   if (!strcmp(name, "attention_image")) { g_use_attention_image = value; return 0; }
   if (!strcmp(name, "qkv_attn")) { g_use_qkv_attn = value; return 0; }

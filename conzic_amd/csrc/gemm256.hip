@@ -1001,10 +1001,11 @@ __global__ __launch_bounds__(768) void gemm256s_kernel(GemmArgs g, int tiles_m, 
 
 }  // namespace
 
+int g_gemm256_min_m = 2048;
 int g_gemm_krot = 0;  // bit0: rotate K order per work-group (no gain measured); bits1-2: debug (skip MFMA / skip DMA)
 
 bool gemm256_eligible(const GemmArgs& g) {
-  return g.M >= 2048 && g.N % 4 == 0 && g.K % 64 == 0 && g.ldc % 4 == 0 && (!g.resid || g.ldr % 4 == 0) &&
+  return g.M >= g_gemm256_min_m && g.N % 4 == 0 && g.K % 64 == 0 && g.ldc % 4 == 0 && (!g.resid || g.ldr % 4 == 0) &&
          (g.act == ACT_NONE || g.act == ACT_QUICK_GELU) && (long)256 * g.lda * 2 < (1L << 31) &&
          (long)256 * g.ldw * 2 < (1L << 31);
 }

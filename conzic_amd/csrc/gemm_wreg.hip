@@ -413,11 +413,12 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, 
 }  // namespace
 
 int g_use_wreg = 2;  // 1: memory phase after/before the MFMA phase, 2: memory work interleaved into the MFMA stream
+int g_wreg_min_m = 2048;  // below this the 128x128 kernel wins (few blocks per work-group); tests lower it to pin the kernel family
 int g_wreg_dbg = 0;  // timing ablations only (results invalid): 1 no stores, 2 no MFMA, 4 no DMA refill, 8 no epilogue, 16 MFMA operands from registers only
 
 bool gemm_wreg_eligible(const GemmArgs& g) {
   if (g.ln_stats && (g_use_wreg != 2 || !g.ln_s || g.ln_groups != 8 || (g_wreg_dbg & 16))) return false;
-  return g_use_wreg && g.K == WR_K && g.M >= 2048 && g.N % 8 == 0 && g.ldc % 8 == 0 && g.lda % 8 == 0 && g.ldw % 8 == 0 &&
+  return g_use_wreg && g.K == WR_K && g.M >= g_wreg_min_m && g.N % 8 == 0 && g.ldc % 8 == 0 && g.lda % 8 == 0 && g.ldw % 8 == 0 &&
          g.out_act && !g.out_f32 && !g.resid && (g.act == ACT_NONE || g.act == ACT_QUICK_GELU) &&
          (long)g.ldc * 2 * WR_BLK < (1L << 30) && (long)g.lda * 2 * WR_BLK < (1L << 30);
 }

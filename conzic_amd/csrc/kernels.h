@@ -44,6 +44,7 @@ bool gemm_wreg_eligible(const GemmArgs& g);
 int launch_gemm_wreg(const GemmArgs& g, hipStream_t st);  // gemm_wreg.hip: weights in registers, K = 512
 extern int g_use_wreg;
 extern int g_wreg_dbg;
+extern int g_wreg_min_m, g_gemm256_min_m;  // row-count thresholds of the two big-batch GEMM families
 
 // ---- imageproc.hip ------------------------------------------------------------------------
 // CLIP image geometry on the device, bit-identical to the PIL path of the reference's CLIPProcessor
