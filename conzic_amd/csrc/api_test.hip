@@ -11,6 +11,7 @@
 using namespace czc;
 
 static int g_lnf_dbg = 0;
+static int g_option_epoch = 0;  // bumped by every czc_test_set_option: engines drop their cached step graphs
 
 namespace {
 
@@ -193,7 +194,10 @@ int czc_test_lnf_pair(int M, int K1, int N, const float* A, const float* Wo, con
   return down_act(pool, PREC_BF16, dh, (size_t)M * N, h_out);
 }
 
+int czc_option_epoch(void) { return g_option_epoch; }
+
 int czc_test_set_option(const char* name, int value) {
+  ++g_option_epoch;
   if (!strcmp(name, "gemm256")) { g_use_gemm256 = value; return 0; }
   if (!strcmp(name, "gemm_krot")) { g_gemm_krot = value; return 0; }
   if (!strcmp(name, "skinny")) { g_use_skinny = value; return 0; }

@@ -89,6 +89,14 @@ struct czc_engine {
   int fold_ln = 0;         // bf16 CLIP-text tower: LayerNorm applied inside the GEMM epilogues (no LayerNorm pass over HBM);
                            // measured slower than the LayerNorm kernel while out-proj / fc2 pay for the bf16 copy
 
+  // hipGraph replay of the two halves of a position-step (before / after the one size read), small batches only
+  int use_graphs = 0;   // 0 off (default: measured no faster than eager launches), 1 on, -1 czc_generate with B <= 4
+  bool graphs_now = false, capturing = false, capture_broken = false;
+  int option_epoch = 0;
+  std::map<std::vector<int>, hipGraphExec_t> graphs;
+  std::map<std::vector<int>, int> graph_seen;
+  int64_t stat_graph_launches = 0, stat_graph_captures = 0;
+
   bool prof = false;
   std::map<std::string, ProfKind> pk;
   int64_t stat_clip_rows = 0, stat_clip_seqs = 0, stat_bert_rows = 0, stat_steps = 0;
@@ -120,9 +128,20 @@ int fail(czc_engine* e, int code, const char* fmt, const char* a = "") {
   return code;
 }
 
+void invalidate_graphs(czc_engine* e) {
+  for (auto& kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
+  e->graphs.clear();
+  e->graph_seen.clear();
+}
+
 int ensure(czc_engine* e, const char* name, size_t bytes, void** out) {
   Buf& b = e->ws[name];
   if (b.bytes < bytes) {
+    if (e->capturing) {  // no allocation inside a capture: give the capture up, the caller reruns the phase eagerly
+      e->capture_broken = true;
+      return fail(e, CZC_ERR_STATE, "workspace growth during graph capture%s");
+    }
+    invalidate_graphs(e);  // cached graphs hold the old pointers
     if (b.p) {
       E_HIP(hipStreamSynchronize(e->st));
       E_HIP(hipFree(b.p));
@@ -389,8 +408,6 @@ int bert_forward(czc_engine* e, const int* d_inp, int B, int T) {
     E_CHECK(gemm(e, P, "gemm_bert", hbuf, I, l.fc2_w, I, l.fc2_b, x, H, nullptr, tmp, H, M, H, I, ACT_NONE));
     { ProfScope ps(e, "rowops", 0); E_CHECK(launch_layernorm(P, tmp, nullptr, l.ln2_g, l.ln2_b, c.bert_eps, M, H, xa, x, e->st)); }
   }
-  e->stat_bert_rows += M;
-  e->last_BT = M;
   return 0;
 }
 
@@ -425,32 +442,42 @@ int mlm_head(czc_engine* e, int B, int T, int gen_idx, float** logits_out) {
 // CLIP text tower (clip/clip.py:78-83) on B x K candidate sequences: ids [B*K,77] + len -> feat fp32
 // [B*K, proj].  With `share` the causal prefix common to an image's K candidates is encoded once
 // (trunk segment) and every candidate only carries the rows from its first differing token on.
-// Contains the step's single host round trip: 16 bytes of totals (rows, longest sequence, overflow).
-int clip_text_forward(czc_engine* e, const int* cids, const int* clen, int B, int K, int share, int* totals,
-                      float** feat_out) {
+// Two halves around the step's single host round trip (32 bytes of totals: rows, longest sequence, overflow):
+// clip_plan builds the segment table on the device and starts the read, clip_tower runs on the sizes it returned.
+struct PlanBufs { int *own_len, *pre_len, *src, *pos0, *own_off, *pre_off, *eidx; };
+
+int plan_bufs(czc_engine* e, int B, int K, PlanBufs* p) {
+  const int n_seq = B * K, S = B + n_seq;
+  E_CHECK(ensure(e, "p_own_len", (size_t)S * 4, (void**)&p->own_len));
+  E_CHECK(ensure(e, "p_pre_len", (size_t)S * 4, (void**)&p->pre_len));
+  E_CHECK(ensure(e, "p_src", (size_t)S * 4, (void**)&p->src));
+  E_CHECK(ensure(e, "p_pos0", (size_t)S * 4, (void**)&p->pos0));
+  E_CHECK(ensure(e, "p_own_off", (size_t)(S + 1) * 4, (void**)&p->own_off));
+  E_CHECK(ensure(e, "p_pre_off", (size_t)S * 4, (void**)&p->pre_off));
+  E_CHECK(ensure(e, "s_eidx", (size_t)n_seq * 4, (void**)&p->eidx));
+  return 0;
+}
+
+int clip_plan(czc_engine* e, const int* cids, const int* clen, int B, int K, int share, int* totals) {
+  PlanBufs p;
+  E_CHECK(plan_bufs(e, B, K, &p));
+  const int S = B + B * K;
+  { ProfScope ps(e, "bridge", 0);
+    E_CHECK(launch_prefix_plan(cids, clen, B, K, share, p.own_len, p.pre_len, p.src, p.pos0, totals + 3, e->st));
+    E_CHECK(launch_scan(p.own_len, S, p.own_off, totals, e->st));
+    E_CHECK(launch_prefix_finish(p.own_off, p.own_len, B, K, p.pre_off, p.eidx, totals + 6, e->st)); }
+  E_HIP(hipMemcpyAsync(e->h_totals, totals, 32, hipMemcpyDeviceToHost, e->st));
+  return 0;
+}
+
+int clip_tower(czc_engine* e, const int* cids, int B, int K, int share, int M, int max_len, int max_branch, int n_trunk,
+               float** feat_out) {
   const czc_config& c = e->cfg;
   const int P = e->pc;
   const int H = c.clip_hidden;
   const int n_seq = B * K, S = B + n_seq;
-  int *own_len, *pre_len, *src, *pos0, *own_off, *pre_off, *eidx;
-  E_CHECK(ensure(e, "p_own_len", (size_t)S * 4, (void**)&own_len));
-  E_CHECK(ensure(e, "p_pre_len", (size_t)S * 4, (void**)&pre_len));
-  E_CHECK(ensure(e, "p_src", (size_t)S * 4, (void**)&src));
-  E_CHECK(ensure(e, "p_pos0", (size_t)S * 4, (void**)&pos0));
-  E_CHECK(ensure(e, "p_own_off", (size_t)(S + 1) * 4, (void**)&own_off));
-  E_CHECK(ensure(e, "p_pre_off", (size_t)S * 4, (void**)&pre_off));
-  E_CHECK(ensure(e, "s_eidx", (size_t)n_seq * 4, (void**)&eidx));
-  { ProfScope ps(e, "bridge", 0);
-    E_CHECK(launch_prefix_plan(cids, clen, B, K, share, own_len, pre_len, src, pos0, totals + 3, e->st));
-    E_CHECK(launch_scan(own_len, S, own_off, totals, e->st));
-    E_CHECK(launch_prefix_finish(own_off, own_len, B, K, pre_off, eidx, totals + 6, e->st)); }
-  E_HIP(hipMemcpyAsync(e->h_totals, totals, 32, hipMemcpyDeviceToHost, e->st));
-  E_HIP(hipStreamSynchronize(e->st));  // the one host round trip per step (the reference has one too, gen_utils.py:81)
-  const int M = e->h_totals[0], max_len = e->h_totals[3], max_branch = e->h_totals[4], n_trunk = e->h_totals[6];
-  if (e->h_totals[2]) return fail(e, CZC_ERR_OVERFLOW, "text bridge overflow (row text > CZC_BRIDGE_MAX_BYTES)%s");
-  if (max_len > c.clip_max_pos || max_len > CZC_CLIP_MAX_LEN)
-    return fail(e, CZC_ERR_ARG, "CLIP sequence longer than max_position_embeddings%s");
-
+  PlanBufs p;
+  E_CHECK(plan_bufs(e, B, K, &p));
   float *x, *feat, *tok, *pos, *fg, *fb; void* pa;
   E_CHECK(ensure(e, "c_x", (size_t)M * H * 4, (void**)&x));
   E_CHECK(ensure(e, "c_pa", (size_t)n_seq * H * e->esz, &pa));
@@ -460,23 +487,153 @@ int clip_text_forward(czc_engine* e, const int* cids, const int* clen, int B, in
   E_CHECK(need(e, "text_model.final_layer_norm.weight", H, &fg));
   E_CHECK(need(e, "text_model.final_layer_norm.bias", H, &fb));
   { ProfScope ps(e, "rowops", 0);
-    E_CHECK(launch_clip_embed(cids, CZC_CLIP_MAX_LEN, src, pos0, own_off, own_len, S, max_len, H, tok, pos, x, e->st)); }
-  SegTable tab{pre_off, pre_len, own_off, own_len, S, 0};
+    E_CHECK(launch_clip_embed(cids, CZC_CLIP_MAX_LEN, p.src, p.pos0, p.own_off, p.own_len, S, max_len, H, tok, pos, x, e->st)); }
+  SegTable tab{p.pre_off, p.pre_len, p.own_off, p.own_len, S, 0};
   float* pooled = nullptr;
   E_CHECK(clip_stack(e, "gemm_clip_text", e->ctext, x, M, H, c.clip_inter, c.clip_heads, c.clip_eps, tab, max_len, 1, B,
-                     K, max_branch, eidx, n_seq, &pooled, share ? n_trunk : 0));
+                     K, max_branch, p.eidx, n_seq, &pooled, share ? n_trunk : 0));
   { ProfScope ps(e, "rowops", 0);
     if (pooled) E_CHECK(launch_layernorm(P, pooled, nullptr, fg, fb, c.clip_eps, n_seq, H, pa, nullptr, e->st));
-    else E_CHECK(launch_layernorm(P, x, eidx, fg, fb, c.clip_eps, n_seq, H, pa, nullptr, e->st)); }
+    else E_CHECK(launch_layernorm(P, x, p.eidx, fg, fb, c.clip_eps, n_seq, H, pa, nullptr, e->st)); }
   E_CHECK(gemm(e, P, "gemm_clip_text", pa, H, e->tproj_w, H, nullptr, nullptr, 0, nullptr, feat, c.clip_proj, n_seq,
                c.clip_proj, H, ACT_NONE));
-  e->stat_clip_rows += M;
-  e->stat_clip_seqs += n_seq;
   *feat_out = feat;
   return 0;
 }
 
-// one position-step on the device-resident d_inp (gen_utils.py:66-81)
+// sizes of the tower from the totals the plan read back (after the stream has been synchronised)
+int read_totals(czc_engine* e, int* M, int* max_len, int* max_branch, int* n_trunk) {
+  const czc_config& c = e->cfg;
+  *M = e->h_totals[0]; *max_len = e->h_totals[3]; *max_branch = e->h_totals[4]; *n_trunk = e->h_totals[6];
+  if (e->h_totals[2]) return fail(e, CZC_ERR_OVERFLOW, "text bridge overflow (row text > CZC_BRIDGE_MAX_BYTES)%s");
+  if (*max_len > c.clip_max_pos || *max_len > CZC_CLIP_MAX_LEN)
+    return fail(e, CZC_ERR_ARG, "CLIP sequence longer than max_position_embeddings%s");
+  return 0;
+}
+
+int clip_text_forward(czc_engine* e, const int* cids, const int* clen, int B, int K, int share, int* totals,
+                      float** feat_out) {
+  E_CHECK(clip_plan(e, cids, clen, B, K, share, totals));
+  E_HIP(hipStreamSynchronize(e->st));  // the one host round trip per step (the reference has one too, gen_utils.py:81)
+  int M, max_len, max_branch, n_trunk;
+  E_CHECK(read_totals(e, &M, &max_len, &max_branch, &n_trunk));
+  E_CHECK(clip_tower(e, cids, B, K, share, M, max_len, max_branch, n_trunk, feat_out));
+  e->stat_clip_rows += M;
+  e->stat_clip_seqs += B * K;
+  return 0;
+}
+
+// ---- one position-step on the device-resident d_inp (gen_utils.py:66-81), in two halves around the size read ----
+struct StepArgs {
+  int* d_inp; int B, T, gen_idx, n_mask, dot_allowed, K;
+  czc_hyper hp;
+};
+struct StepBufs { float *probs, *senti, *reps; int *idxs, *cand, *cids, *clen, *totals; };
+
+int step_bufs(czc_engine* e, int n_seq, StepBufs* b) {
+  E_CHECK(ensure(e, "s_probs", (size_t)n_seq * 4, (void**)&b->probs));
+  E_CHECK(ensure(e, "s_idxs", (size_t)n_seq * 4, (void**)&b->idxs));
+  E_CHECK(ensure(e, "s_cand", (size_t)n_seq * 4, (void**)&b->cand));
+  E_CHECK(ensure(e, "s_cids", (size_t)n_seq * CZC_CLIP_MAX_LEN * 4, (void**)&b->cids));
+  E_CHECK(ensure(e, "s_clen", (size_t)n_seq * 4, (void**)&b->clen));
+  E_CHECK(ensure(e, "s_tot", 32, (void**)&b->totals));
+  E_CHECK(ensure(e, "s_senti", (size_t)n_seq * 4, (void**)&b->senti));
+  E_CHECK(ensure(e, "s_reps", (size_t)n_seq * 4, (void**)&b->reps));
+  return 0;
+}
+
+// mask -> BERT -> MLM head -> softmax/top-K -> text bridge -> segment plan -> start of the 32-byte size read
+int step_phase_a(czc_engine* e, const StepArgs& a) {
+  const czc_config& c = e->cfg;
+  const czc_hyper* hp = &a.hp;
+  if (a.n_mask > 0) {
+    E_CHECK(launch_mask_positions(a.d_inp, a.B, a.T, a.gen_idx, a.n_mask, c.mask_id, e->st));
+    E_CHECK(bert_forward(e, a.d_inp, a.B, a.T));
+  }
+  float* logits;
+  E_CHECK(mlm_head(e, a.B, a.T, a.gen_idx, &logits));
+  StepBufs b;
+  E_CHECK(step_bufs(e, a.B * a.K, &b));
+  { ProfScope ps(e, "topk", 0);
+    E_CHECK(launch_softmax_mask_topk(logits, a.B, c.bert_vocab, a.K, e->d_mask, hp->temperature, c.dot_id, a.dot_allowed,
+                                     b.probs, b.idxs, b.cand, e->st)); }
+  E_HIP(hipMemsetAsync(b.totals, 0, 32, e->st));
+  { ProfScope ps(e, "bridge", 0);
+    PosDev pos{hp->control == 2 ? e->d_pos_tags : nullptr, e->d_pos_masks, e->pos_n};
+    E_CHECK(launch_bridge(e->bd, a.d_inp, a.B, a.T, a.gen_idx, b.cand, a.K, hp->control == 1 ? e->d_lex : nullptr,
+                          hp->control == 1 ? e->d_lex_pos : nullptr, e->d_lex_cls, hp->negative,
+                          pos, b.cids, b.clen, b.senti, b.reps, b.totals + 2, e->st)); }
+  E_CHECK(clip_plan(e, b.cids, b.clen, a.B, a.K, e->share_prefix, b.totals));
+  return 0;
+}
+
+// CLIP text tower on the planned rows -> cosine / softmax_K / fusion / argmax / write-back
+int step_phase_b(czc_engine* e, const StepArgs& a, int M, int max_len, int max_branch, int n_trunk) {
+  const czc_config& c = e->cfg;
+  const czc_hyper* hp = &a.hp;
+  const int n_seq = a.B * a.K;
+  StepBufs b;
+  E_CHECK(step_bufs(e, n_seq, &b));
+  float* feat;
+  E_CHECK(clip_tower(e, b.cids, a.B, a.K, e->share_prefix, M, max_len, max_branch, n_trunk, &feat));
+  float *cscore, *cref, *fin, *bcos; int* best;
+  E_CHECK(ensure(e, "s_cscore", (size_t)n_seq * 4, (void**)&cscore));
+  E_CHECK(ensure(e, "s_cref", (size_t)n_seq * 4, (void**)&cref));
+  E_CHECK(ensure(e, "s_fin", (size_t)n_seq * 4, (void**)&fin));
+  E_CHECK(ensure(e, "s_best", (size_t)a.B * 4, (void**)&best));
+  E_CHECK(ensure(e, "s_bcos", (size_t)a.B * 4, (void**)&bcos));
+  CombineArgs ca;
+  ca.text_feat = feat; ca.img_n = e->d_img_n; ca.logit_scale_exp = e->logit_scale_exp; ca.probs = b.probs; ca.cand = b.cand;
+  ca.senti_raw = b.senti; ca.repeats = b.reps; ca.alpha = hp->alpha; ca.beta = hp->beta; ca.gamma = hp->gamma;
+  ca.use_senti = hp->control; ca.B = a.B; ca.K = a.K; ca.D = c.clip_proj; ca.clip_score = cscore; ca.clip_ref = cref;
+  ca.final_score = fin; ca.best = best; ca.best_cos = bcos; ca.inp = a.d_inp; ca.T = a.T; ca.gen_idx = a.gen_idx;
+  { ProfScope ps(e, "combine", 0); E_CHECK(launch_combine(ca, e->st)); }
+  return 0;
+}
+
+// Launch-bound small batches (configs[1]: one image is ~250 launches of 5-20 us kernels per step): each half of the
+// step is captured into a hipGraph the SECOND time its key is seen (the first pass runs eagerly and sizes the
+// workspace) and replayed afterwards.  Key = everything a kernel argument or a kernel choice depends on: shapes,
+// position, hyper-parameters, engine options, the process-wide kernel switches' epoch, and for the second half the
+// sizes the plan produced.  Any workspace growth or pointer-changing setter drops all graphs (ensure()).
+extern "C" int czc_option_epoch(void);
+
+template <typename F>
+int run_phase(czc_engine* e, std::vector<int> key, F fn) {
+  if (!e->graphs_now || e->prof) return fn();
+  if (e->option_epoch != czc_option_epoch()) { invalidate_graphs(e); e->option_epoch = czc_option_epoch(); }
+  auto it = e->graphs.find(key);
+  if (it != e->graphs.end()) {
+    E_HIP(hipGraphLaunch(it->second, e->st));
+    e->stat_graph_launches += 1;
+    return 0;
+  }
+  if (e->graph_seen[key]++ == 0) return fn();
+  e->capturing = true;
+  e->capture_broken = false;
+  hipGraph_t g = nullptr;
+  int rc = 0;
+  if (hipStreamBeginCapture(e->st, hipStreamCaptureModeThreadLocal) != hipSuccess) { e->capturing = false; return fn(); }
+  rc = fn();
+  const hipError_t he = hipStreamEndCapture(e->st, &g);
+  e->capturing = false;
+  hipGraphExec_t ex = nullptr;
+  if (rc || he != hipSuccess || e->capture_broken || !g ||
+      hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) != hipSuccess) {
+    if (g) (void)hipGraphDestroy(g);
+    (void)hipGetLastError();
+    e->err[0] = 0;
+    e->graph_seen[key] = -1000000;  // do not try this key again
+    return fn();
+  }
+  (void)hipGraphDestroy(g);
+  e->graphs[key] = ex;
+  e->stat_graph_captures += 1;
+  E_HIP(hipGraphLaunch(ex, e->st));
+  e->stat_graph_launches += 1;
+  return 0;
+}
+
 int step_device(czc_engine* e, int* d_inp, int B, int T, int gen_idx, int n_mask, int dot_allowed, int K,
                 const czc_hyper* hp) {
   const czc_config& c = e->cfg;
@@ -489,50 +646,22 @@ int step_device(czc_engine* e, int* d_inp, int B, int T, int gen_idx, int n_mask
     return fail(e, CZC_ERR_ARG, "step: bad T/gen_idx/K%s");
   if (hp->control == 1 && !e->d_lex && !e->d_lex_pos) return fail(e, CZC_ERR_STATE, "sentiment path needs a lexicon%s");
   if (hp->control == 2 && !e->d_pos_tags) return fail(e, CZC_ERR_STATE, "POS path needs czc_set_pos%s");
-  const int n_seq = B * K;
-
-  if (n_mask > 0) {
-    E_CHECK(launch_mask_positions(d_inp, B, T, gen_idx, n_mask, c.mask_id, e->st));
-    E_CHECK(bert_forward(e, d_inp, B, T));
-  } else if (e->last_BT != B * T) {
-    return fail(e, CZC_ERR_STATE, "n_mask=0 needs a previous forward of the same shape%s");
-  }
-  float* logits;
-  E_CHECK(mlm_head(e, B, T, gen_idx, &logits));
-
-  float *probs, *senti, *reps; int *idxs, *cand, *cids, *clen, *totals;
-  E_CHECK(ensure(e, "s_probs", (size_t)n_seq * 4, (void**)&probs));
-  E_CHECK(ensure(e, "s_idxs", (size_t)n_seq * 4, (void**)&idxs));
-  E_CHECK(ensure(e, "s_cand", (size_t)n_seq * 4, (void**)&cand));
-  E_CHECK(ensure(e, "s_cids", (size_t)n_seq * CZC_CLIP_MAX_LEN * 4, (void**)&cids));
-  E_CHECK(ensure(e, "s_clen", (size_t)n_seq * 4, (void**)&clen));
-  E_CHECK(ensure(e, "s_tot", 32, (void**)&totals));
-  E_CHECK(ensure(e, "s_senti", (size_t)n_seq * 4, (void**)&senti));
-  E_CHECK(ensure(e, "s_reps", (size_t)n_seq * 4, (void**)&reps));
-  { ProfScope ps(e, "topk", 0);
-    E_CHECK(launch_softmax_mask_topk(logits, B, c.bert_vocab, K, e->d_mask, hp->temperature, c.dot_id, dot_allowed,
-                                     probs, idxs, cand, e->st)); }
-  E_HIP(hipMemsetAsync(totals, 0, 32, e->st));
-  { ProfScope ps(e, "bridge", 0);
-    PosDev pos{hp->control == 2 ? e->d_pos_tags : nullptr, e->d_pos_masks, e->pos_n};
-    E_CHECK(launch_bridge(e->bd, d_inp, B, T, gen_idx, cand, K, hp->control == 1 ? e->d_lex : nullptr,
-                          hp->control == 1 ? e->d_lex_pos : nullptr, e->d_lex_cls, hp->negative,
-                          pos, cids, clen, senti, reps, totals + 2, e->st)); }
-  float* feat;
-  E_CHECK(clip_text_forward(e, cids, clen, B, K, e->share_prefix, totals, &feat));
-
-  float *cscore, *cref, *fin, *bcos; int* best;
-  E_CHECK(ensure(e, "s_cscore", (size_t)n_seq * 4, (void**)&cscore));
-  E_CHECK(ensure(e, "s_cref", (size_t)n_seq * 4, (void**)&cref));
-  E_CHECK(ensure(e, "s_fin", (size_t)n_seq * 4, (void**)&fin));
-  E_CHECK(ensure(e, "s_best", (size_t)B * 4, (void**)&best));
-  E_CHECK(ensure(e, "s_bcos", (size_t)B * 4, (void**)&bcos));
-  CombineArgs a;
-  a.text_feat = feat; a.img_n = e->d_img_n; a.logit_scale_exp = e->logit_scale_exp; a.probs = probs; a.cand = cand;
-  a.senti_raw = senti; a.repeats = reps; a.alpha = hp->alpha; a.beta = hp->beta; a.gamma = hp->gamma;
-  a.use_senti = hp->control; a.B = B; a.K = K; a.D = c.clip_proj; a.clip_score = cscore; a.clip_ref = cref;
-  a.final_score = fin; a.best = best; a.best_cos = bcos; a.inp = d_inp; a.T = T; a.gen_idx = gen_idx;
-  { ProfScope ps(e, "combine", 0); E_CHECK(launch_combine(a, e->st)); }
+  if (n_mask <= 0 && e->last_BT != B * T) return fail(e, CZC_ERR_STATE, "n_mask=0 needs a previous forward of the same shape%s");
+  StepArgs a{d_inp, B, T, gen_idx, n_mask, dot_allowed, K, *hp};
+  auto fbits = [](float f) { int i; memcpy(&i, &f, 4); return i; };
+  std::vector<int> key = {0, B, T, gen_idx, n_mask, dot_allowed, K, fbits(hp->alpha), fbits(hp->beta), fbits(hp->gamma),
+                          fbits(hp->temperature), hp->control, hp->negative, e->share_prefix, e->pack_branches,
+                          e->pool_last_layer, e->fold_ln, e->fuse_qkv_attn, (int)(((uintptr_t)d_inp) >> 4)};
+  E_CHECK(run_phase(e, key, [&]() { return step_phase_a(e, a); }));
+  if (n_mask > 0) { e->stat_bert_rows += B * T; e->last_BT = B * T; }
+  E_HIP(hipStreamSynchronize(e->st));  // the one host round trip per step (the reference has one too, gen_utils.py:81)
+  int M, max_len, max_branch, n_trunk;
+  E_CHECK(read_totals(e, &M, &max_len, &max_branch, &n_trunk));
+  key[0] = 1;
+  key.insert(key.end(), {M, max_len, max_branch, n_trunk});
+  E_CHECK(run_phase(e, key, [&]() { return step_phase_b(e, a, M, max_len, max_branch, n_trunk); }));
+  e->stat_clip_rows += M;
+  e->stat_clip_seqs += B * K;
   e->stat_steps += 1;
   return 0;
 }
@@ -599,6 +728,7 @@ int czc_destroy(czc_engine* e) {
   if (!e) return CZC_OK;
   (void)hipSetDevice(e->dev);
   (void)hipStreamSynchronize(e->st);
+  invalidate_graphs(e);
   for (auto& kv : e->w) if (kv.second.p) (void)hipFree(kv.second.p);
   auto free_layers = [](std::vector<LayerW>& L) {
     for (auto& l : L) {
@@ -688,7 +818,7 @@ int czc_finalize_weights(czc_engine* e) {
 int czc_set_token_mask(czc_engine* e, const float* mask, int vocab) {
   if (!e || !mask || vocab != e->cfg.bert_vocab) return e ? fail(e, CZC_ERR_ARG, "token mask size != bert_vocab%s") : CZC_ERR_ARG;
   E_HIP(hipSetDevice(e->dev));
-  if (!e->d_mask) E_HIP(hipMalloc((void**)&e->d_mask, (size_t)vocab * 4));
+  if (!e->d_mask) { invalidate_graphs(e); E_HIP(hipMalloc((void**)&e->d_mask, (size_t)vocab * 4)); }
   E_HIP(hipMemcpy(e->d_mask, mask, (size_t)vocab * 4, hipMemcpyDefault));
   e->mask_vocab = vocab;
   return CZC_OK;
@@ -697,12 +827,13 @@ int czc_set_token_mask(czc_engine* e, const float* mask, int vocab) {
 int czc_set_lexicon(czc_engine* e, const float* lex, int vocab) {
   if (!e || !lex || vocab != e->cfg.bert_vocab) return e ? fail(e, CZC_ERR_ARG, "lexicon size != bert_vocab%s") : CZC_ERR_ARG;
   E_HIP(hipSetDevice(e->dev));
-  if (!e->d_lex) E_HIP(hipMalloc((void**)&e->d_lex, (size_t)vocab * 4));
+  if (!e->d_lex) { invalidate_graphs(e); E_HIP(hipMalloc((void**)&e->d_lex, (size_t)vocab * 4)); }
   E_HIP(hipMemcpy(e->d_lex, lex, (size_t)vocab * 4, hipMemcpyDefault));
   return CZC_OK;
 }
 
 int czc_set_lexicon_pos(czc_engine* e, const float* table, const uint8_t* class_of_token, int vocab) {
+  if (e) invalidate_graphs(e);  // kernel arguments of cached step graphs may point at what this call replaces
   if (!e) return CZC_ERR_ARG;
   E_HIP(hipSetDevice(e->dev));
   if (!table) {  // back to the per-token lexicon of czc_set_lexicon
@@ -721,6 +852,7 @@ int czc_set_lexicon_pos(czc_engine* e, const float* table, const uint8_t* class_
 }
 
 int czc_set_pos(czc_engine* e, const uint8_t* tag_of_token, int vocab, const uint16_t* template_masks, int n_template) {
+  if (e) invalidate_graphs(e);  // kernel arguments of cached step graphs may point at what this call replaces
   if (!e || !tag_of_token || !template_masks) return CZC_ERR_ARG;
   if (vocab != e->cfg.bert_vocab || n_template <= 0 || n_template > 32) return fail(e, CZC_ERR_ARG, "bad POS tables%s");
   E_HIP(hipSetDevice(e->dev));
@@ -776,6 +908,7 @@ static int build_bridge(czc_engine* e, const czc_bridge_tables* t, BridgeDev* bd
 }
 
 int czc_set_bridge(czc_engine* e, const czc_bridge_tables* t) {
+  if (e) invalidate_graphs(e);  // kernel arguments of cached step graphs may point at what this call replaces
   if (!e || !t) return CZC_ERR_ARG;
   if (t->bert_vocab != e->cfg.bert_vocab) return fail(e, CZC_ERR_ARG, "bridge bert_vocab != config%s");
   E_HIP(hipSetDevice(e->dev));
@@ -793,7 +926,7 @@ int czc_set_image_embeds(czc_engine* e, const float* embeds, int B) {
   float* raw;
   E_CHECK(ensure(e, "img_raw", (size_t)B * D * 4, (void**)&raw));
   E_HIP(hipMemcpyAsync(raw, embeds, (size_t)B * D * 4, hipMemcpyDefault, e->st));
-  if (e->img_B < B) { if (e->d_img_n) (void)hipFree(e->d_img_n); e->d_img_n = nullptr; E_HIP(hipMalloc((void**)&e->d_img_n, (size_t)B * D * 4)); }
+  if (e->img_B < B) { invalidate_graphs(e); if (e->d_img_n) (void)hipFree(e->d_img_n); e->d_img_n = nullptr; E_HIP(hipMalloc((void**)&e->d_img_n, (size_t)B * D * 4)); }
   E_CHECK(launch_l2_normalize(raw, B, D, e->d_img_n, e->st));
   e->img_B = B;
   E_HIP(hipStreamSynchronize(e->st));
@@ -834,7 +967,7 @@ int czc_encode_images(czc_engine* e, const float* pixels, int B, float* out_embe
     E_CHECK(launch_make_row_index(idx, B, T, 0, e->st));
     E_CHECK(launch_layernorm(P, x, idx, g1, b1, c.clip_eps, B, H, ca, nullptr, e->st)); }
   E_CHECK(gemm(e, P, "gemm_vision", ca, H, e->vproj_w, H, nullptr, nullptr, 0, nullptr, emb, c.clip_proj, B, c.clip_proj, H, ACT_NONE));
-  if (e->img_B < B) { if (e->d_img_n) (void)hipFree(e->d_img_n); e->d_img_n = nullptr; E_HIP(hipMalloc((void**)&e->d_img_n, (size_t)B * c.clip_proj * 4)); }
+  if (e->img_B < B) { invalidate_graphs(e); if (e->d_img_n) (void)hipFree(e->d_img_n); e->d_img_n = nullptr; E_HIP(hipMalloc((void**)&e->d_img_n, (size_t)B * c.clip_proj * 4)); }
   E_CHECK(launch_l2_normalize(emb, B, c.clip_proj, e->d_img_n, e->st));
   e->img_B = B;
   if (out_embeds) E_HIP(hipMemcpyAsync(out_embeds, emb, (size_t)B * c.clip_proj * 4, hipMemcpyDefault, e->st));
@@ -908,6 +1041,7 @@ int czc_step(czc_engine* e, int32_t* inp, int B, int T, int gen_idx, int n_mask,
   if (!e || !inp || !hp || B <= 0) return CZC_ERR_ARG;
   E_HIP(hipSetDevice(e->dev));
   e->err[0] = 0;
+  e->graphs_now = e->use_graphs == 1;
   int* d_inp;
   E_CHECK(ensure(e, "g_inp", (size_t)B * T * 4, (void**)&d_inp));
   E_HIP(hipMemcpyAsync(d_inp, inp, (size_t)B * T * 4, hipMemcpyDefault, e->st));
@@ -941,6 +1075,7 @@ int czc_generate(czc_engine* e, int B, int T, int L, int seed_len, const int32_t
   if (seed_len + L > T) return fail(e, CZC_ERR_ARG, "generate: seed_len + L > T%s");
   E_HIP(hipSetDevice(e->dev));
   e->err[0] = 0;
+  e->graphs_now = e->use_graphs == 1 || (e->use_graphs < 0 && B <= 4);  // launch-bound batches only
   int *d_inp, *d_row;
   E_CHECK(ensure(e, "g_inp", (size_t)B * T * 4, (void**)&d_inp));
   E_CHECK(ensure(e, "g_row", (size_t)T * 4, (void**)&d_row));
@@ -971,6 +1106,7 @@ int czc_set_option(czc_engine* e, const char* name, int value) {
   if (!strcmp(name, "pool_last_layer")) { e->pool_last_layer = value ? 1 : 0; return CZC_OK; }
   if (!strcmp(name, "fuse_qkv_attn")) { e->fuse_qkv_attn = value ? 1 : 0; return CZC_OK; }
   if (!strcmp(name, "fold_ln")) { e->fold_ln = value ? 1 : 0; return CZC_OK; }
+  if (!strcmp(name, "graphs")) { e->use_graphs = value; invalidate_graphs(e); return CZC_OK; }
   return fail(e, CZC_ERR_ARG, "unknown option %s", name);
 }
 
@@ -1014,6 +1150,14 @@ int czc_profile_get(czc_engine* e, const char* kind, double* total_ms, int64_t* 
   if (total_ms) *total_ms = ms;
   if (launches) *launches = n;
   if (flops) *flops = fl;
+  return CZC_OK;
+}
+
+int czc_graph_stats(czc_engine* e, int64_t* launches, int64_t* captures, int64_t* cached) {
+  if (!e) return CZC_ERR_ARG;
+  if (launches) *launches = e->stat_graph_launches;
+  if (captures) *captures = e->stat_graph_captures;
+  if (cached) *cached = (int64_t)e->graphs.size();
   return CZC_OK;
 }
 

@@ -198,6 +198,10 @@ int czc_generate(czc_engine* e, int B, int T, int L, int seed_len, const int32_t
  *   "pack_branches"   (1) attention of the branch rows with G candidates packed per 32-query MFMA tile
  *   "pool_last_layer" (1) last CLIP-text layer: out-projection + MLP on the EOS rows only
  *   "fuse_qkv_attn"   (0) branch rows: q/k/v projection and attention in one kernel (q, k, v never in HBM)
+ *   "graphs"          (0) hipGraph replay of the two halves of a position-step (before / after the one size read):
+ *                         0 off, 1 on, -1 = czc_generate with B <= 4 only.  Correct (replay == eager, tested) but
+ *                         measured no faster at B = 1: the step is bound by its ~250 dependent small kernels, not
+ *                         by the host launches, which already run ahead of the GPU
  *   "fold_ln"         (0) bf16 CLIP-text tower at >= 2048 packed rows: LayerNorm applied inside the GEMM epilogues
  *                         (out-proj / fc2 emit a bf16 copy of the residual stream + row statistics; q/k/v / fc1 run
  *                         on gain-folded weights and finish the normalisation), no LayerNorm pass over HBM */
@@ -210,6 +214,8 @@ int czc_profile_enable(czc_engine* e, int on);
 int czc_profile_reset(czc_engine* e);
 int czc_profile_get(czc_engine* e, const char* kind, double* total_ms, int64_t* launches, double* flops);
 int czc_sync(czc_engine* e);
+/* step-graph counters: graph launches, captures so far, graphs currently cached */
+int czc_graph_stats(czc_engine* e, int64_t* launches, int64_t* captures, int64_t* cached);
 /* counters of the last generate/step: rows pushed through the CLIP text tower etc. */
 int czc_stats(czc_engine* e, int64_t* clip_rows, int64_t* clip_seqs, int64_t* bert_rows, int64_t* steps);
 
@@ -233,6 +239,7 @@ int czc_bench_gemm(int precision, int M, int N, int K, int act, int out_mode, in
 /* Process-wide kernel A/B switches for tests and tools: "gemm256" 0..3, "wreg" 0|1|2, "skinny", "splitk",
  * "mfma_attention", "attention_image" 0|1|2 (2 = force), "qkv_attn"; "*_dbg" are timing ablations (results invalid). */
 int czc_test_set_option(const char* name, int value);
+int czc_option_epoch(void); /* number of czc_test_set_option calls so far (engines drop cached step graphs when it moves) */
 int czc_test_layernorm(int precision, int M, int H, const float* x, const float* gamma, const float* beta, float eps,
                        float* y);
 /* qkv [sum(len), 3*heads*64] packed sequences; causal 0/1; scale; out [sum(len), heads*64] */

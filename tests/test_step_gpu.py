@@ -828,3 +828,39 @@ def test_first_sweep_large_batch_kernel_families_agree():
         lib.czc_test_set_option(b"wreg", 2)
         lib.czc_test_set_option(b"attention_image", 1)
         su.engine.close()
+
+
+@pytest.mark.parametrize("prec", [F32, BF16])
+@pytest.mark.parametrize("name", ["tiny_shuffle", "tiny_senti_seq", "tiny_span"])
+def test_step_graphs_replay_equals_eager(name, prec):
+    """hipGraph replay of the two halves of a position-step (small, launch-bound batches: configs[1]).  The same
+    generate call with graphs off and on -- three times, so that the second call captures and the third replays
+    every key -- must give identical ids and cosines, and the replays must actually happen."""
+    meta, arr = load_case(name)
+    su = harness.build_synthetic(meta["tiny"], prec, meta["bseed"], meta["cseed"], meta["logit_scale"], meta["regular_only"],
+                                 lexicon=meta["gamma"] is not None)
+    try:
+        eng = su.engine
+        eng.set_image_embeds(arr["image_embeds"])
+        hp = Engine.hyper(meta["alpha"], meta["beta"], meta["temperature"], meta["gamma"], meta["style"] == "negative")
+        init = su.bert_tok.encode(meta["prompt"] + su.bert_tok.mask_token * meta["L"])
+        pos, nm, every = harness.order_positions(meta["order"], meta["L"], meta["I"], order_list=meta["order_list"])
+        eng.set_option("graphs", 0)
+        ids0, cos0 = eng.generate(meta["B"], init, meta["L"], SEED_LEN, meta["K"], pos, hp, n_mask=nm, snapshot_every=every)
+        assert eng.graph_stats()["launches"] == 0
+        eng.set_option("graphs", 1)
+        for rep in range(3):
+            ids, cos = eng.generate(meta["B"], init, meta["L"], SEED_LEN, meta["K"], pos, hp, n_mask=nm, snapshot_every=every)
+            np.testing.assert_array_equal(ids, ids0)
+            np.testing.assert_array_equal(cos, cos0)
+        gs = eng.graph_stats()
+        assert gs["captures"] > 0 and gs["launches"] >= 2 * len(pos), gs
+        if prec == F32:
+            np.testing.assert_array_equal(ids0, arr["snaps"])
+        # a setter that changes a pointer, or a kernel switch, drops the cache
+        lib = native.load()
+        lib.czc_test_set_option(b"splitk", 1)
+        eng.generate(meta["B"], init, meta["L"], SEED_LEN, meta["K"], pos, hp, n_mask=nm, snapshot_every=every)
+        assert eng.graph_stats()["cached"] < gs["cached"] or eng.graph_stats()["captures"] == gs["captures"]
+    finally:
+        su.engine.close()
