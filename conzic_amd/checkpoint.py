@@ -10,7 +10,7 @@ from __future__ import annotations
 import glob
 import json
 import os
-from typing import Dict, Tuple
+from typing import Dict, Optional, Tuple
 
 import numpy as np
 
@@ -76,9 +76,12 @@ def load_tokenizers(bert_dir: str, clip_dir: str) -> Tuple[WordPieceTokenizer, C
     return WordPieceTokenizer(bert_tokens), ClipBpeTokenizer(clip_vocab, merges)
 
 
-def engine_from_checkpoints(bert_dir: str, clip_dir: str, precision: int = native.PREC_BF16, device: int = 0):
+def engine_from_checkpoints(bert_dir: str, clip_dir: str, precision: Optional[int] = None, device: int = 0):
     """-> (engine, bert_cfg, clip_cfg, bert_tokenizer, clip_tokenizer).  `logit_scale` comes from the checkpoint
-    tensor of that name (config.json only holds its init value)."""
+    tensor of that name (config.json only holds its init value); precision None = chosen from it
+    (`runtime.choose_precision`: split-fp16 MFMA for the published checkpoints' x100, bf16 towers below x20).
+    Legacy key names of old BERT checkpoints (`LayerNorm.gamma/beta`) and tensors the path never reads (pooler,
+    next-sentence head) are handled by `Engine.load_state` (`engine.normalize_state_name`)."""
     with open(os.path.join(bert_dir, "config.json")) as f:
         bcfg = bert_cfg_from_json(json.load(f))
     with open(os.path.join(clip_dir, "config.json")) as f:
@@ -88,6 +91,9 @@ def engine_from_checkpoints(bert_dir: str, clip_dir: str, precision: int = nativ
         ccfg.logit_scale = float(np.asarray(cw["logit_scale"]).reshape(-1)[0])
     bt, ct = load_tokenizers(bert_dir, clip_dir)
     from .harness import special_ids
+    if precision is None:
+        from .runtime import choose_precision
+        precision = choose_precision(ccfg.logit_scale)
     eng = Engine(bcfg, ccfg, special_ids(bt), precision, device)
     eng.load_state(bw)
     eng.load_state(cw)

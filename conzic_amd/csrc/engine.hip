@@ -97,7 +97,7 @@ struct czc_engine {
   std::map<std::vector<int>, int> graph_seen;
   int64_t stat_graph_launches = 0, stat_graph_captures = 0;
 
-  bool prof = false;
+  int prof = 0;  // 0 off, 1 every kernel class, 2 only the CLIP-text linear layers (the roofline kernel family)
   std::map<std::string, ProfKind> pk;
   int64_t stat_clip_rows = 0, stat_clip_seqs = 0, stat_bert_rows = 0, stat_steps = 0;
 };
@@ -159,6 +159,7 @@ struct ProfScope {
   ProfKind* k = nullptr;
   ProfScope(czc_engine* e_, const char* kind, double flops) : e(e_) {
     if (!e->prof) return;
+    if (e->prof == 2 && strcmp(kind, "gemm_clip_text") != 0) return;
     k = &e->pk[kind];
     if (k->used + 2 > k->ev.size()) {
       for (int i = 0; i < 2; ++i) {
@@ -1119,7 +1120,7 @@ int czc_sync(czc_engine* e) {
 
 int czc_profile_enable(czc_engine* e, int on) {
   if (!e) return CZC_ERR_ARG;
-  e->prof = on != 0;
+  e->prof = on < 0 ? 0 : (on > 2 ? 1 : on);
   return CZC_OK;
 }
 

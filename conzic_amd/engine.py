@@ -264,8 +264,9 @@ class Engine:
         self._ck(self.lib.czc_set_option(self.h, name.encode(), int(value)), f"czc_set_option({name})")
 
     # ---- measurement ------------------------------------------------------------------------------
-    def profile(self, on: bool):
-        self._ck(self.lib.czc_profile_enable(self.h, 1 if on else 0), "czc_profile_enable")
+    def profile(self, on):
+        """False/0 off, True/1 every kernel class, 2 only the CLIP-text linear layers (cheap: the roofline family)."""
+        self._ck(self.lib.czc_profile_enable(self.h, int(on)), "czc_profile_enable")
 
     def profile_reset(self):
         self._ck(self.lib.czc_profile_reset(self.h), "czc_profile_reset")

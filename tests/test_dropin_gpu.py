@@ -117,6 +117,48 @@ def test_clip_wrapper_methods():
     assert abs(float(np.asarray(score).sum()) - 1.0) < 1e-5
 
 
+def test_checkpoint_with_legacy_bert_names_and_published_logit_scale(tmp_path, monkeypatch):
+    """The published `bert-base-uncased` safetensors still carries TF-style `LayerNorm.gamma` / `LayerNorm.beta` and the
+    pooler / next-sentence tensors, and the published CLIP checkpoints carry logit_scale = ln 100: such a directory
+    loads, the engine precision is chosen from the logit scale (split-fp16), and a step equals the in-memory engine's."""
+    from conzic_amd import checkpoint, harness, native, synth
+    from conzic_amd.engine import Engine
+    monkeypatch.delenv("CZC_PRECISION", raising=False)
+    su = harness.build_synthetic(True, native.PREC_SPLIT, logit_scale=4.6052)
+    bw, cw = synth.make_bert_weights(su.bert_cfg, 11), synth.make_clip_weights(su.clip_cfg, 12)
+    legacy = {}
+    for k, v in bw.items():
+        if k.endswith("LayerNorm.weight"):
+            k = k[:-len("weight")] + "gamma"
+        elif k.endswith("LayerNorm.bias"):
+            k = k[:-len("bias")] + "beta"
+        legacy[k] = v
+    H = su.bert_cfg.hidden
+    legacy["bert.pooler.dense.weight"] = np.zeros((H, H), np.float32)
+    legacy["bert.pooler.dense.bias"] = np.zeros(H, np.float32)
+    legacy["cls.seq_relationship.weight"] = np.zeros((2, H), np.float32)
+    legacy["cls.seq_relationship.bias"] = np.zeros(2, np.float32)
+    legacy["bert.embeddings.position_ids"] = np.arange(su.bert_cfg.max_pos, dtype=np.float32)[None]
+    assert any(k.endswith(".gamma") for k in legacy)
+    bdir, cdir = checkpoint.write_checkpoint_dirs(str(tmp_path), su.bert_cfg, legacy, su.clip_cfg, cw, su.sv)
+    eng, bcfg, ccfg, bt, ct = checkpoint.engine_from_checkpoints(bdir, cdir)   # precision from the checkpoint
+    try:
+        assert abs(ccfg.logit_scale - 4.6052) < 1e-6 and eng.precision == native.PREC_SPLIT
+        eng.set_token_mask(su.token_mask)
+        emb = np.random.default_rng(3).standard_normal((2, su.clip_cfg.proj)).astype(np.float32)
+        inp = np.array([bt.encode("Image of a" + bt.mask_token * 5)] * 2, dtype=np.int32)
+        hp = Engine.hyper(0.02, 2.0, 0.1)
+        outs = []
+        for e in (eng, su.engine):
+            e.set_image_embeds(emb)
+            outs.append(e.step(inp.copy(), 4, 12, hp))
+        np.testing.assert_array_equal(outs[0]["idxs"], outs[1]["idxs"])
+        np.testing.assert_array_equal(outs[0]["final_score"], outs[1]["final_score"])
+    finally:
+        eng.close()
+        su.engine.close()
+
+
 def test_engine_from_checkpoint_directories_matches_in_memory_engine(tmp_path):
     """Real-checkpoint route on synthetic weights laid out as Hugging Face directories:
     same step results as the engine fed from memory."""

@@ -230,3 +230,13 @@ def test_sentiwordnet_table_builder_with_stand_in_nltk():
     assert table[3, 3] == np.float32(-0.625) and table[4, 2] == 0.0 and not table[[0, 1, 7]].any()
     with pytest.raises(ImportError, match="nltk"):
         sentiment.build_sentiwordnet_tables(toks)
+
+
+def test_state_names_of_legacy_checkpoints_are_normalised():
+    from conzic_amd.engine import normalize_state_name as n
+    assert n("bert.embeddings.LayerNorm.gamma") == "bert.embeddings.LayerNorm.weight"
+    assert n("bert.encoder.layer.3.output.LayerNorm.beta") == "bert.encoder.layer.3.output.LayerNorm.bias"
+    assert n("cls.predictions.transform.LayerNorm.gamma") == "cls.predictions.transform.LayerNorm.weight"
+    assert n("bert.pooler.dense.weight") is None and n("cls.seq_relationship.bias") is None
+    assert n("bert.embeddings.position_ids") is None and n("cls.predictions.decoder.weight") is None
+    assert n("text_model.encoder.layers.0.mlp.fc1.weight") == "text_model.encoder.layers.0.mlp.fc1.weight"
