@@ -105,7 +105,7 @@ def main():
     ap.add_argument("--topk", type=int, default=200)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--order", default="sequential", choices=["sequential", "shuffle"])
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32", "split"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32", "split", "fp16"])
     ap.add_argument("--logit-scale", type=float, default=2.6592, help="CLIP logit_scale (HF init 2.6592; published checkpoint ln 100 = 4.6052)")
     ap.add_argument("--gamma", type=float, default=None, help="sentiment control weight (BASELINE configs[4]: 5.0)")
     ap.add_argument("--sentiment", default="positive", choices=["positive", "negative"])
@@ -136,8 +136,8 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    prec = {"bf16": native.PREC_BF16, "f32": native.PREC_F32, "split": native.PREC_SPLIT}[a.precision]
-    DT = {native.PREC_BF16: "bf16", native.PREC_F32: "f32",
+    prec = {"bf16": native.PREC_BF16, "f32": native.PREC_F32, "split": native.PREC_SPLIT, "fp16": native.PREC_FP16}[a.precision]
+    DT = {native.PREC_BF16: "bf16", native.PREC_F32: "f32", native.PREC_FP16: "fp16",
           native.PREC_SPLIT: "split-fp16 (fp16 hi+lo planes, 3 MFMA passes, fp32 accumulate)"}
     B, L, K, I = a.images, a.L, a.topk, a.iters
     lo = rank * B  # weak scaling: rank r polishes images [r*B, (r+1)*B)
@@ -264,6 +264,8 @@ def main():
             traffic, src = json.load(open(tp))["hbm_bytes_per_launch"], "profiles/r01_bench_gemm_traffic.json (rocprofv3 --pmc passes)"
         kern = {native.PREC_BF16: "CLIP-text linear layers: czc::gemm_wreg_kernel<bf16> (qkv, fc1; weights in registers) + "
                                   "czc::gemm256q_kernel<bf16> (out-proj, fc2; 256x256 LDS-DMA ring)",
+                native.PREC_FP16: "CLIP-text linear layers: czc::gemm_wreg_kernel<fp16> (qkv, fc1; weights in registers) + "
+                                  "czc::gemm256q_kernel<fp16> (out-proj, fc2; 256x256 LDS-DMA ring)",
                 native.PREC_SPLIT: "CLIP-text linear layers: czc::gemm_kernel<split_t> (three v_mfma_f32_32x32x16_f16 per product)",
                 native.PREC_F32: "CLIP-text linear layers: czc::gemm_kernel<float> (v_mfma_f32_32x32x2_f32)"}[prec_]
         return dict(bound="mfma", kernel=kern, achieved=round(ach, 1), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),

@@ -54,6 +54,7 @@ __device__ __forceinline__ long key_row(const Seg& g, int k) {
 // ------------------------------------------------------------------------------------------------
 constexpr int AT_MAXKT = 3;  // key tiles of 32 -> up to 96 keys
 
+template <typename HT>
 __global__ __launch_bounds__(256) void attention_mfma_kernel(const bf16_t* qkv, SegTable tab, int heads, int causal,
                                                              float scale, int KP, bf16_t* out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char at_lds[];
@@ -113,8 +114,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const bf16_t* qkv, 
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
           const uint4 kf = *(const uint4*)(kp + 16 * ks);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, kf),
-                                                        __builtin_bit_cast(bf16x8_t, qf[ks]), acc, 0, 0, 0);
+          acc = Half<HT>::mfma(kf, qf[ks], acc);
         }
         st[kt] = acc;
       }
@@ -147,10 +147,10 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const bf16_t* qkv, 
         }
 #pragma unroll
         for (int sstep = 0; sstep < 2; ++sstep) {
-          pf[kt][sstep].x = pack2_bf16(e[8 * sstep + 0], e[8 * sstep + 1]);
-          pf[kt][sstep].y = pack2_bf16(e[8 * sstep + 2], e[8 * sstep + 3]);
-          pf[kt][sstep].z = pack2_bf16(e[8 * sstep + 4], e[8 * sstep + 5]);
-          pf[kt][sstep].w = pack2_bf16(e[8 * sstep + 6], e[8 * sstep + 7]);
+          pf[kt][sstep].x = Half<HT>::pack2(e[8 * sstep + 0], e[8 * sstep + 1]);
+          pf[kt][sstep].y = Half<HT>::pack2(e[8 * sstep + 2], e[8 * sstep + 3]);
+          pf[kt][sstep].z = Half<HT>::pack2(e[8 * sstep + 4], e[8 * sstep + 5]);
+          pf[kt][sstep].w = Half<HT>::pack2(e[8 * sstep + 6], e[8 * sstep + 7]);
         }
       }
     }
@@ -173,8 +173,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const bf16_t* qkv, 
             const uint2 lo = *(const uint2*)(vrow + kt * 32 + 16 * sstep + 4 * half);
             const uint2 hi = *(const uint2*)(vrow + kt * 32 + 16 * sstep + 8 + 4 * half);
             const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
-            o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vf),
-                                                        __builtin_bit_cast(bf16x8_t, pf[kt][sstep]), o, 0, 0, 0);
+            o = Half<HT>::mfma(vf, pf[kt][sstep], o);
           }
         }
       }
@@ -183,8 +182,8 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const bf16_t* qkv, 
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
           uint2 w;
-          w.x = pack2_bf16(o[4 * qd] * inv, o[4 * qd + 1] * inv);
-          w.y = pack2_bf16(o[4 * qd + 2] * inv, o[4 * qd + 3] * inv);
+          w.x = Half<HT>::pack2(o[4 * qd] * inv, o[4 * qd + 1] * inv);
+          w.y = Half<HT>::pack2(o[4 * qd + 2] * inv, o[4 * qd + 3] * inv);
           *(uint2*)(op + 8 * qd) = w;
         }
       }
@@ -198,12 +197,6 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const bf16_t* qkv, 
 // probabilities are split into hi + lo before the PV product, V^T sits in LDS as two fp16 planes.  fp32-class
 // accuracy (the split engine's bar is 1e-4 on the fused score) at MFMA speed instead of the VALU kernel's.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned pack2_f16(float a, float b) {
-  typedef __attribute__((ext_vector_type(2))) _Float16 h2;
-  const h2 v = {(_Float16)a, (_Float16)b};
-  return __builtin_bit_cast(unsigned, v);
-}
-
 __global__ __launch_bounds__(256) void attention_mfma_split_kernel(const split_t* qkv, SegTable tab, int heads, int causal,
                                                                    float scale, int KP, split_t* out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char at_lds[];
@@ -366,6 +359,7 @@ __global__ __launch_bounds__(256) void attention_mfma_split_kernel(const split_t
 // ------------------------------------------------------------------------------------------------
 constexpr int AB_MAXT = 3;  // trunk key tiles (<= 96 trunk keys)
 
+template <typename HT>
 __global__ __launch_bounds__(256) void attention_branch_kernel(const bf16_t* qkv, SegTable tab, int B, int K, int G,
                                                                int heads, float scale, int KP, bf16_t* out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char at_lds[];
@@ -445,8 +439,7 @@ __global__ __launch_bounds__(256) void attention_branch_kernel(const bf16_t* qkv
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const uint4 kf = *(const uint4*)(kp + 16 * ks);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, kf),
-                                                      __builtin_bit_cast(bf16x8_t, qf[ks]), acc, 0, 0, 0);
+        acc = Half<HT>::mfma(kf, qf[ks], acc);
       }
       st[t] = acc;
     }
@@ -479,10 +472,10 @@ __global__ __launch_bounds__(256) void attention_branch_kernel(const bf16_t* qkv
       }
 #pragma unroll
       for (int sstep = 0; sstep < 2; ++sstep) {
-        pf[t][sstep].x = pack2_bf16(e[8 * sstep + 0], e[8 * sstep + 1]);
-        pf[t][sstep].y = pack2_bf16(e[8 * sstep + 2], e[8 * sstep + 3]);
-        pf[t][sstep].z = pack2_bf16(e[8 * sstep + 4], e[8 * sstep + 5]);
-        pf[t][sstep].w = pack2_bf16(e[8 * sstep + 6], e[8 * sstep + 7]);
+        pf[t][sstep].x = Half<HT>::pack2(e[8 * sstep + 0], e[8 * sstep + 1]);
+        pf[t][sstep].y = Half<HT>::pack2(e[8 * sstep + 2], e[8 * sstep + 3]);
+        pf[t][sstep].z = Half<HT>::pack2(e[8 * sstep + 4], e[8 * sstep + 5]);
+        pf[t][sstep].w = Half<HT>::pack2(e[8 * sstep + 6], e[8 * sstep + 7]);
       }
     }
   }
@@ -509,8 +502,7 @@ __global__ __launch_bounds__(256) void attention_branch_kernel(const bf16_t* qkv
           const uint2 lo = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr4_lds_t)(vp)));
           const uint2 hi = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr4_lds_t)(vp + 256)));
           const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
-          o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vf),
-                                                      __builtin_bit_cast(bf16x8_t, pf[t][sstep]), o, 0, 0, 0);
+          o = Half<HT>::mfma(vf, pf[t][sstep], o);
         }
       }
     }
@@ -519,8 +511,8 @@ __global__ __launch_bounds__(256) void attention_branch_kernel(const bf16_t* qkv
 #pragma unroll
       for (int qd = 0; qd < 4; ++qd) {
         uint2 w;
-        w.x = pack2_bf16(o[4 * qd] * inv, o[4 * qd + 1] * inv);
-        w.y = pack2_bf16(o[4 * qd + 2] * inv, o[4 * qd + 3] * inv);
+        w.x = Half<HT>::pack2(o[4 * qd] * inv, o[4 * qd + 1] * inv);
+        w.y = Half<HT>::pack2(o[4 * qd + 2] * inv, o[4 * qd + 3] * inv);
         *(uint2*)(op + 8 * qd) = w;
       }
     }
@@ -719,6 +711,7 @@ constexpr int A2_RING = 2;               // the next group streams in while this
 constexpr int A2_META = 4224;            // K + 1 segment offsets (K <= 1024), padded
 constexpr int A2_LDS = A2_RING * A2_STAGE + 2 * A2_TILE + A2_META;
 
+template <typename HT>
 __global__ __launch_bounds__(256) void attention_image_kernel(const bf16_t* qkv, SegTable tab, int B, int K, int G, int heads,
                                                               float scale, bf16_t* out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char at_lds[];
@@ -835,8 +828,7 @@ __global__ __launch_bounds__(256) void attention_image_kernel(const bf16_t* qkv,
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const uint4 kf = *(const uint4*)(kb + l31 * A2_ROWB + (((cq + 2 * ks) ^ (l31 & 15)) << 4));
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, kf),
-                                                      __builtin_bit_cast(bf16x8_t, qf[ks]), acc, 0, 0, 0);
+        acc = Half<HT>::mfma(kf, qf[ks], acc);
       }
       st[t] = acc;
     }
@@ -865,10 +857,10 @@ __global__ __launch_bounds__(256) void attention_image_kernel(const bf16_t* qkv,
       }
 #pragma unroll
       for (int sstep = 0; sstep < 2; ++sstep) {
-        pf[t][sstep].x = pack2_bf16(e[8 * sstep + 0], e[8 * sstep + 1]);
-        pf[t][sstep].y = pack2_bf16(e[8 * sstep + 2], e[8 * sstep + 3]);
-        pf[t][sstep].z = pack2_bf16(e[8 * sstep + 4], e[8 * sstep + 5]);
-        pf[t][sstep].w = pack2_bf16(e[8 * sstep + 6], e[8 * sstep + 7]);
+        pf[t][sstep].x = Half<HT>::pack2(e[8 * sstep + 0], e[8 * sstep + 1]);
+        pf[t][sstep].y = Half<HT>::pack2(e[8 * sstep + 2], e[8 * sstep + 3]);
+        pf[t][sstep].z = Half<HT>::pack2(e[8 * sstep + 4], e[8 * sstep + 5]);
+        pf[t][sstep].w = Half<HT>::pack2(e[8 * sstep + 6], e[8 * sstep + 7]);
       }
     }
     sum += __shfl_xor(sum, 32, 64);
@@ -898,8 +890,7 @@ __global__ __launch_bounds__(256) void attention_image_kernel(const bf16_t* qkv,
             const uint2 lo = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr4_lds_t)(vp)));
             const uint2 hi = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr4_lds_t)(vp + 256)));
             const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
-            o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vf), __builtin_bit_cast(bf16x8_t, pf[t][sstep]),
-                                                        o, 0, 0, 0);
+            o = Half<HT>::mfma(vf, pf[t][sstep], o);
           }
         }
       }
@@ -909,8 +900,8 @@ __global__ __launch_bounds__(256) void attention_image_kernel(const bf16_t* qkv,
       u32x2_t w[4];
 #pragma unroll
       for (int qd = 0; qd < 4; ++qd) {
-        w[qd].x = pack2_bf16(o[4 * qd] * inv, o[4 * qd + 1] * inv);
-        w[qd].y = pack2_bf16(o[4 * qd + 2] * inv, o[4 * qd + 3] * inv);
+        w[qd].x = Half<HT>::pack2(o[4 * qd] * inv, o[4 * qd + 1] * inv);
+        w[qd].y = Half<HT>::pack2(o[4 * qd + 2] * inv, o[4 * qd + 3] * inv);
       }
 #pragma unroll
       for (int qa = 0; qa < 2; ++qa) {
@@ -933,15 +924,15 @@ int launch_attention_trunks(const void* qkv, const SegTable& tab, int B, int max
   SegTable trunks = tab;
   trunks.n_seg = B;
   dim3 grid(B, cdiv(heads, wpb)), block(64 * wpb);
-  hipLaunchKernelGGL(attention_mfma_kernel, grid, block, (size_t)wpb * 64 * KPt * 2, st, (const bf16_t*)qkv, trunks, heads, 1,
+  hipLaunchKernelGGL(attention_mfma_kernel<bf16_t>, grid, block, (size_t)wpb * 64 * KPt * 2, st, (const bf16_t*)qkv, trunks, heads, 1,
                      scale, KPt, (bf16_t*)out);
   CZC_HIP_CHECK(hipGetLastError());
   return 0;
 }
 
-// trunks through the generic kernel (n_seg = B), branches packed G per wave
+// trunks through the generic kernel (n_seg = B), branches packed G per wave; f16: operands are IEEE fp16 (not bf16)
 int launch_attention_shared(const void* qkv, const SegTable& tab, int B, int K, int max_own, int max_keys, int heads,
-                            float scale, void* out, hipStream_t st) {
+                            float scale, void* out, hipStream_t st, int f16) {
   if (max_keys > 96 || max_own > 32 || max_own <= 0) return -1;  // caller falls back to the generic path
   const int G = 32 / max_own;
   const int KPt = ((max_keys + 31) & ~31) + 4;
@@ -950,8 +941,10 @@ int launch_attention_shared(const void* qkv, const SegTable& tab, int B, int K, 
     SegTable trunks = tab;
     trunks.n_seg = B;
     dim3 grid(B, cdiv(heads, wpb)), block(64 * wpb);
-    hipLaunchKernelGGL(attention_mfma_kernel, grid, block, (size_t)wpb * 64 * KPt * 2, st, (const bf16_t*)qkv, trunks,
-                       heads, 1, scale, KPt, (bf16_t*)out);
+    if (f16) hipLaunchKernelGGL(attention_mfma_kernel<f16_t>, grid, block, (size_t)wpb * 64 * KPt * 2, st, (const bf16_t*)qkv,
+                                trunks, heads, 1, scale, KPt, (bf16_t*)out);
+    else hipLaunchKernelGGL(attention_mfma_kernel<bf16_t>, grid, block, (size_t)wpb * 64 * KPt * 2, st, (const bf16_t*)qkv, trunks,
+                            heads, 1, scale, KPt, (bf16_t*)out);
   }
   // one work-group per (image, 4 heads) walking the image's groups in sequence: needs enough images to fill the
   // chip (a single image would leave 2 work-groups doing 40 groups each; the per-group kernel spreads those)
@@ -959,19 +952,24 @@ int launch_attention_shared(const void* qkv, const SegTable& tab, int B, int K, 
       (B * (heads / 4) >= 128 || g_use_attention_image == 2)) {
     static bool attr = false;
     if (!attr) {
-      CZC_HIP_CHECK(hipFuncSetAttribute((const void*)attention_image_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, A2_LDS));
+      CZC_HIP_CHECK(hipFuncSetAttribute((const void*)attention_image_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, A2_LDS));
+      CZC_HIP_CHECK(hipFuncSetAttribute((const void*)attention_image_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, A2_LDS));
       attr = true;
     }
-    hipLaunchKernelGGL(attention_image_kernel, dim3(B, heads / 4), dim3(256), A2_LDS, st, (const bf16_t*)qkv, tab, B, K, G, heads,
-                       scale, (bf16_t*)out);
+    if (f16) hipLaunchKernelGGL(attention_image_kernel<f16_t>, dim3(B, heads / 4), dim3(256), A2_LDS, st, (const bf16_t*)qkv, tab, B,
+                                K, G, heads, scale, (bf16_t*)out);
+    else hipLaunchKernelGGL(attention_image_kernel<bf16_t>, dim3(B, heads / 4), dim3(256), A2_LDS, st, (const bf16_t*)qkv, tab, B, K,
+                            G, heads, scale, (bf16_t*)out);
     CZC_HIP_CHECK(hipGetLastError());
     return 0;
   }
   const int KP = ((max_keys + 31) & ~31) + 32 + 1;  // key slots: trunk tiles + the own tile, padded to 1 (mod 4)
   const int gpi = cdiv(K, G);
   dim3 grid(B * gpi, cdiv(heads, wpb)), block(64 * wpb);
-  hipLaunchKernelGGL(attention_branch_kernel, grid, block, (size_t)wpb * 128 * KP, st, (const bf16_t*)qkv, tab, B, K,
-                     G, heads, scale, KP, (bf16_t*)out);
+  if (f16) hipLaunchKernelGGL(attention_branch_kernel<f16_t>, grid, block, (size_t)wpb * 128 * KP, st, (const bf16_t*)qkv, tab, B, K,
+                              G, heads, scale, KP, (bf16_t*)out);
+  else hipLaunchKernelGGL(attention_branch_kernel<bf16_t>, grid, block, (size_t)wpb * 128 * KP, st, (const bf16_t*)qkv, tab, B, K,
+                          G, heads, scale, KP, (bf16_t*)out);
   CZC_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -1088,13 +1086,15 @@ int launch_attention(int prec, const void* qkv, const SegTable& tab, int max_key
     snprintf(g_err, sizeof(g_err), "attention: %d keys per segment unsupported (1..96)", max_keys);
     return 1;
   }
-  if (prec == PREC_BF16 && g_use_mfma_attention) {
+  if (prec_is_half(prec) && (g_use_mfma_attention || prec == PREC_F16)) {  // fp16 has no VALU form: MFMA kernel always
     const int KP = ((max_keys + 31) & ~31) + 4;
     int wpb = heads >= 4 ? 4 : (heads >= 2 ? 2 : 1);
     const size_t shmem = (size_t)wpb * 64 * KP * 2;
     dim3 grid(tab.n_seg, cdiv(heads, wpb)), block(64 * wpb);
-    hipLaunchKernelGGL(attention_mfma_kernel, grid, block, shmem, st, (const bf16_t*)qkv, tab, heads, causal, scale, KP,
-                       (bf16_t*)out);
+    if (prec == PREC_F16) hipLaunchKernelGGL(attention_mfma_kernel<f16_t>, grid, block, shmem, st, (const bf16_t*)qkv, tab, heads,
+                                             causal, scale, KP, (bf16_t*)out);
+    else hipLaunchKernelGGL(attention_mfma_kernel<bf16_t>, grid, block, shmem, st, (const bf16_t*)qkv, tab, heads, causal, scale, KP,
+                            (bf16_t*)out);
     CZC_HIP_CHECK(hipGetLastError());
     return 0;
   }

@@ -27,7 +27,8 @@ __device__ __forceinline__ float blk_reduce(float v, float* red, int op) {  // o
 
 // cos[b,k] for all B*K candidates, one wave per candidate (the per-image kernel below used to walk its K
 // candidates with four waves: 13x off the HBM rate at B = 256, K = 200).  Same arithmetic, same order.
-__global__ __launch_bounds__(256) void cosine_kernel(const float* text_feat, const float* img_n, int B, int K, int D, float* cos_out) {
+__global__ __launch_bounds__(256) void cosine_kernel(const float* text_feat, const float* img_n, int B, int K, int D, float* cos_out,
+                                                     int* nonfinite) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= (long)B * K) return;
@@ -39,7 +40,11 @@ __global__ __launch_bounds__(256) void cosine_kernel(const float* text_feat, con
   float dot = 0.f;
   for (int c = lane; c < D; c += 64) dot += (t[c] / nrm) * img[c];
   dot = wave_sum(dot);
-  if (lane == 0) cos_out[row] = dot;
+  if (lane == 0) {
+    cos_out[row] = dot;
+    // a non-finite cosine means a tower overflowed (fp16 operands beyond 65504) or was fed NaN weights: reported, not hidden
+    if (nonfinite && !(fabsf(dot) <= 2.0f)) atomicOr(nonfinite, 1);
+  }
 }
 
 __global__ __launch_bounds__(CB_THREADS) void combine_kernel(CombineArgs a) {
@@ -112,7 +117,7 @@ int launch_combine(const CombineArgs& a, hipStream_t st) {
     return 1;
   }
   hipLaunchKernelGGL(cosine_kernel, dim3((unsigned)cdiv((long)a.B * a.K, 4)), dim3(256), 0, st, a.text_feat, a.img_n, a.B, a.K, a.D,
-                     a.clip_ref);
+                     a.clip_ref, a.nonfinite);
   hipLaunchKernelGGL(combine_kernel, dim3(a.B), dim3(CB_THREADS), 0, st, a);
   CZC_HIP_CHECK(hipGetLastError());
   return 0;

@@ -195,7 +195,7 @@ int need(czc_engine* e, const std::string& n, size_t numel, float** out) {
 // GEMM operand in engine precision (new allocation); frees nothing
 int to_act(czc_engine* e, int prec, const float* src, size_t numel, void** out) {
   void* p = nullptr;
-  E_HIP(hipMalloc(&p, numel * (prec == PREC_BF16 ? 2 : 4)));
+  E_HIP(hipMalloc(&p, numel * prec_bytes(prec)));
   E_CHECK(launch_convert(prec, src, p, (long)numel, e->st));
   *out = p;
   return 0;
@@ -204,7 +204,7 @@ int to_act(czc_engine* e, int prec, const float* src, size_t numel, void** out) 
 int build_layers(czc_engine* e, std::vector<LayerW>& L, int n_layers, int H, int I, bool bert_style,
                  const std::string& prefix) {
   const int prec = bert_style ? e->pb : e->pc;
-  const size_t es = prec == PREC_BF16 ? 2 : 4;
+  const size_t es = prec_bytes(prec);
   L.resize(n_layers);
   for (int n = 0; n < n_layers; ++n) {
     LayerW& l = L[n];
@@ -340,8 +340,8 @@ int clip_stack(czc_engine* e, const char* gk, std::vector<LayerW>& L, float* x, 
     else E_CHECK(gemm(e, P, gk, y, H, l.qkv_w, H, l.qkv_b, nullptr, 0, qkv, nullptr, 3 * H, M, 3 * H, H, ACT_NONE));
     { ProfScope ps(e, "attention", 0);
       int rc = -1;
-      if (plan_B > 0 && P == PREC_BF16 && g_use_mfma_attention && e->pack_branches)
-        rc = launch_attention_shared(qkv, tab, plan_B, plan_K, plan_max_own, max_keys, heads, scale, ctx, e->st);
+      if (plan_B > 0 && prec_is_half(P) && g_use_mfma_attention && e->pack_branches)
+        rc = launch_attention_shared(qkv, tab, plan_B, plan_K, plan_max_own, max_keys, heads, scale, ctx, e->st, P == PREC_F16);
       else if (plan_B > 0 && P == PREC_F16X3 && g_use_mfma_attention && e->pack_branches)
         rc = launch_attention_shared_split(qkv, tab, plan_B, plan_K, plan_max_own, max_keys, heads, scale, ctx, e->st);
       if (rc > 0) E_CHECK(rc);
@@ -468,6 +468,9 @@ int clip_plan(czc_engine* e, const int* cids, const int* clen, int B, int K, int
     E_CHECK(launch_scan(p.own_len, S, p.own_off, totals, e->st));
     E_CHECK(launch_prefix_finish(p.own_off, p.own_len, B, K, p.pre_off, p.eidx, totals + 6, e->st)); }
   E_HIP(hipMemcpyAsync(e->h_totals, totals, 32, hipMemcpyDeviceToHost, e->st));
+  int* flag;
+  E_CHECK(ensure(e, "s_nonfinite", 16, (void**)&flag));
+  E_HIP(hipMemcpyAsync(e->h_totals + 8, flag, 4, hipMemcpyDeviceToHost, e->st));  // the previous steps' cosine check
   return 0;
 }
 
@@ -506,6 +509,7 @@ int clip_tower(czc_engine* e, const int* cids, int B, int K, int share, int M, i
 int read_totals(czc_engine* e, int* M, int* max_len, int* max_branch, int* n_trunk) {
   const czc_config& c = e->cfg;
   *M = e->h_totals[0]; *max_len = e->h_totals[3]; *max_branch = e->h_totals[4]; *n_trunk = e->h_totals[6];
+  if (e->h_totals[8]) return fail(e, CZC_ERR_OVERFLOW, "non-finite CLIP cosine (fp16 operand overflow in a tower? use CZC_PREC_SPLIT)%s");
   if (e->h_totals[2]) return fail(e, CZC_ERR_OVERFLOW, "text bridge overflow (row text > CZC_BRIDGE_MAX_BYTES)%s");
   if (*max_len > c.clip_max_pos || *max_len > CZC_CLIP_MAX_LEN)
     return fail(e, CZC_ERR_ARG, "CLIP sequence longer than max_position_embeddings%s");
@@ -588,6 +592,7 @@ int step_phase_b(czc_engine* e, const StepArgs& a, int M, int max_len, int max_b
   ca.senti_raw = b.senti; ca.repeats = b.reps; ca.alpha = hp->alpha; ca.beta = hp->beta; ca.gamma = hp->gamma;
   ca.use_senti = hp->control; ca.B = a.B; ca.K = a.K; ca.D = c.clip_proj; ca.clip_score = cscore; ca.clip_ref = cref;
   ca.final_score = fin; ca.best = best; ca.best_cos = bcos; ca.inp = a.d_inp; ca.T = a.T; ca.gen_idx = a.gen_idx;
+  E_CHECK(ensure(e, "s_nonfinite", 16, (void**)&ca.nonfinite));
   { ProfScope ps(e, "combine", 0); E_CHECK(launch_combine(ca, e->st)); }
   return 0;
 }
@@ -690,7 +695,7 @@ int czc_create(const czc_config* cfg, int device_id, czc_engine** out) {
     return CZC_ERR_ARG;
   }
   if (cfg->precision != CZC_PREC_BF16 && cfg->precision != CZC_PREC_F32 && cfg->precision != CZC_PREC_ALL_BF16 &&
-      cfg->precision != CZC_PREC_SPLIT) {
+      cfg->precision != CZC_PREC_SPLIT && cfg->precision != CZC_PREC_FP16) {
     snprintf(czc::g_err, sizeof(czc::g_err), "czc_create: unknown precision");
     return CZC_ERR_ARG;
   }
@@ -709,11 +714,13 @@ int czc_create(const czc_config* cfg, int device_id, czc_engine** out) {
   // precision 0: CLIP towers on bf16 MFMA; BERT on split-fp16 MFMA (hi+lo planes, three fp16 passes,
   // ~22 mantissa bits: the tau=0.1 softmax amplifies logit error tenfold, and BERT is 1.4% of the
   // FLOPs); 1: everything on f32 MFMA; 2: everything bf16 (experiments); 3: every tower on split-fp16 MFMA
-  e->pc = cfg->precision == CZC_PREC_F32 ? PREC_F32 : (cfg->precision == CZC_PREC_SPLIT ? PREC_F16X3 : PREC_BF16);
+  // 4: CLIP towers on single-pass fp16 MFMA (the bf16 kernels on IEEE fp16 operands), BERT on split-fp16
+  e->pc = cfg->precision == CZC_PREC_F32 ? PREC_F32
+          : (cfg->precision == CZC_PREC_SPLIT ? PREC_F16X3 : (cfg->precision == CZC_PREC_FP16 ? PREC_F16 : PREC_BF16));
   e->pb = cfg->precision == CZC_PREC_ALL_BF16 ? PREC_BF16
                                               : (cfg->precision == CZC_PREC_F32 ? PREC_F32 : PREC_F16X3);
-  e->esz = e->pc == PREC_BF16 ? 2 : 4;
-  e->eb = e->pb == PREC_BF16 ? 2 : 4;
+  e->esz = prec_bytes(e->pc);
+  e->eb = prec_bytes(e->pb);
   if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&e->st) != hipSuccess ||
       hipHostMalloc((void**)&e->h_totals, 64) != hipSuccess) {
     snprintf(czc::g_err, sizeof(czc::g_err), "czc_create: stream/host allocation failed");
@@ -1030,6 +1037,7 @@ int czc_encode_text(czc_engine* e, const int32_t* clip_ids, const int32_t* clip_
   E_HIP(hipMemcpyAsync(cids, clip_ids, (size_t)n * CZC_CLIP_MAX_LEN * 4, hipMemcpyDefault, e->st));
   E_HIP(hipMemcpyAsync(clen, clip_len, (size_t)n * 4, hipMemcpyDefault, e->st));
   E_HIP(hipMemsetAsync(totals, 0, 32, e->st));
+  { int* flag; E_CHECK(ensure(e, "s_nonfinite", 16, (void**)&flag)); E_HIP(hipMemsetAsync(flag, 0, 16, e->st)); }
   float* feat;
   E_CHECK(clip_text_forward(e, cids, clen, n, 1, 0, totals, &feat));  // independent sequences: no sharing
   E_HIP(hipMemcpyAsync(out_embeds, feat, (size_t)n * e->cfg.clip_proj * 4, hipMemcpyDefault, e->st));
@@ -1044,6 +1052,7 @@ int czc_step(czc_engine* e, int32_t* inp, int B, int T, int gen_idx, int n_mask,
   e->err[0] = 0;
   e->graphs_now = e->use_graphs == 1;
   int* d_inp;
+  { int* flag; E_CHECK(ensure(e, "s_nonfinite", 16, (void**)&flag)); E_HIP(hipMemsetAsync(flag, 0, 16, e->st)); }
   E_CHECK(ensure(e, "g_inp", (size_t)B * T * 4, (void**)&d_inp));
   E_HIP(hipMemcpyAsync(d_inp, inp, (size_t)B * T * 4, hipMemcpyDefault, e->st));
   E_CHECK(step_device(e, d_inp, B, T, gen_idx, n_mask, dot_allowed, top_k, hp));
@@ -1064,7 +1073,9 @@ int czc_step(czc_engine* e, int32_t* inp, int B, int T, int gen_idx, int n_mask,
     E_CHECK(copy_out(e, out->logits, "b_logits", (size_t)B * e->cfg.bert_vocab * 4));
   }
   E_HIP(hipMemcpyAsync(inp, d_inp, (size_t)B * T * 4, hipMemcpyDefault, e->st));
+  E_HIP(hipMemcpyAsync(e->h_totals + 9, e->ws["s_nonfinite"].p, 4, hipMemcpyDeviceToHost, e->st));
   E_HIP(hipStreamSynchronize(e->st));
+  if (e->h_totals[9]) return fail(e, CZC_ERR_OVERFLOW, "non-finite CLIP cosine (fp16 operand overflow in a tower? use CZC_PREC_SPLIT)%s");
   return CZC_OK;
 }
 
@@ -1078,6 +1089,7 @@ int czc_generate(czc_engine* e, int B, int T, int L, int seed_len, const int32_t
   e->err[0] = 0;
   e->graphs_now = e->use_graphs == 1 || (e->use_graphs < 0 && B <= 4);  // launch-bound batches only
   int *d_inp, *d_row;
+  { int* flag; E_CHECK(ensure(e, "s_nonfinite", 16, (void**)&flag)); E_HIP(hipMemsetAsync(flag, 0, 16, e->st)); }
   E_CHECK(ensure(e, "g_inp", (size_t)B * T * 4, (void**)&d_inp));
   E_CHECK(ensure(e, "g_row", (size_t)T * 4, (void**)&d_row));
   E_HIP(hipMemcpyAsync(d_row, init_ids_host, (size_t)T * 4, hipMemcpyHostToDevice, e->st));
@@ -1096,7 +1108,9 @@ int czc_generate(czc_engine* e, int B, int T, int L, int seed_len, const int32_t
       ++snap;
     }
   }
+  E_HIP(hipMemcpyAsync(e->h_totals + 9, e->ws["s_nonfinite"].p, 4, hipMemcpyDeviceToHost, e->st));
   E_HIP(hipStreamSynchronize(e->st));
+  if (e->h_totals[9]) return fail(e, CZC_ERR_OVERFLOW, "non-finite CLIP cosine (fp16 operand overflow in a tower? use CZC_PREC_SPLIT)%s");
   return CZC_OK;
 }
 

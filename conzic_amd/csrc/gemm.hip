@@ -34,6 +34,12 @@ template <> struct Mma<bf16_t> {
                                                 0, 0);
   }
 };
+template <> struct Mma<f16_t> {
+  static constexpr int KPT = ROWB / 2;
+  __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x16_t& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+  }
+};
 template <> struct Mma<split_t> {
   static constexpr int KPT = ROWB / 4;  // 32 elements per 128-byte tile row (4 groups of 8 hi + 8 lo)
   __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x16_t& c) {
@@ -415,15 +421,17 @@ static int try_splitk(const GemmArgs& g, int tiles_m, int tiles_n, hipStream_t s
 
 int g_use_gemm256 = 3;  // 0: 128x128 only, 1: gemm256, 2: persistent wave-specialised gemm256p, 3: + 4-stage K ring (gemm256q)
 
-int launch_gemm(int prec, const GemmArgs& g, hipStream_t st) {
+int launch_gemm(int prec, const GemmArgs& g_in, hipStream_t st) {
+  GemmArgs g = g_in;
+  g.f16 = prec == PREC_F16;
   if (g.M <= 0) return 0;
-  const int kpt = prec == PREC_BF16 ? Mma<bf16_t>::KPT : Mma<float>::KPT;  // split_t: 32 like float
+  const int kpt = prec_is_half(prec) ? Mma<bf16_t>::KPT : Mma<float>::KPT;  // split_t: 32 like float
   if (g.K % kpt != 0 || g.N <= 0) {
     snprintf(g_err, sizeof(g_err), "gemm: K=%d must be a multiple of %d", g.K, kpt);
     return 1;
   }
-  if (prec == PREC_BF16 && gemm_wreg_eligible(g)) return launch_gemm_wreg(g, st);
-  if (prec == PREC_BF16 && g_use_gemm256 && gemm256_eligible(g)) return launch_gemm256(g, st);
+  if (prec_is_half(prec) && gemm_wreg_eligible(g)) return launch_gemm_wreg(g, st);
+  if (prec_is_half(prec) && g_use_gemm256 && gemm256_eligible(g)) return launch_gemm256(g, st);
   if (prec == PREC_F16X3 && gemm256s_eligible(g)) return launch_gemm256s(g, st);
   if (prec == PREC_F16X3 && launch_skinny(g, st)) {
     CZC_HIP_CHECK(hipGetLastError());
@@ -438,6 +446,7 @@ int launch_gemm(int prec, const GemmArgs& g, hipStream_t st) {
     return 0;
   }
   if (prec == PREC_BF16) launch_t<bf16_t>(g, tiles_m, tiles_n, vec, st);
+  else if (prec == PREC_F16) launch_t<f16_t>(g, tiles_m, tiles_n, vec, st);
   else if (prec == PREC_F16X3) launch_t<split_t>(g, tiles_m, tiles_n, vec, st);
   else launch_t<float>(g, tiles_m, tiles_n, vec, st);
   CZC_HIP_CHECK(hipGetLastError());

@@ -20,6 +20,8 @@
 //    consecutive inside one XCD's share, so an activation tile is fetched into one L2 only.
 //  * Epilogue as in gemm.hip: weights are the MFMA A operand, so each lane owns 4 consecutive output
 //    columns of one row per register quad -> 8-byte bf16 / 16-byte fp32 stores.
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace czc {
@@ -225,7 +227,7 @@ __device__ __forceinline__ float sum8_dpp(float v) {
 // STATS (fp32 path only): besides the fp32 result and its bf16 copy, every wave leaves the per-row (sum, sum of
 // squares) of its 64 result columns in g.row_stats[row][n/64][2] -- the LayerNorm statistics of the next layer in
 // eight fixed-order partials per 512-wide row, so the consumer GEMM can apply the LayerNorm in its epilogue.
-template <int ACT, bool OUT_F32, bool STATS = false>
+template <int ACT, bool OUT_F32, bool STATS = false, typename HT = bf16_t>
 __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x16_t (&acc)[4][2], unsigned char* patch, int m0,
                                               int n0, int wm, int wn, int lane) {
   const int half = lane >> 5;
@@ -249,7 +251,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x16_t (&acc)
             }
             v.x = act_fn<ACT>(v.x); v.y = act_fn<ACT>(v.y); v.z = act_fn<ACT>(v.z); v.w = act_fn<ACT>(v.w);
             const int slot = (cl >> 2) ^ (l31 & 15);
-            *(uint2*)(patch + l31 * 128 + slot * 8) = make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w));
+            *(uint2*)(patch + l31 * 128 + slot * 8) = make_uint2(Half<HT>::pack2(v.x, v.y), Half<HT>::pack2(v.z, v.w));
           }
         }
 #pragma unroll
@@ -304,7 +306,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x16_t (&acc)
                 pq[pass] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
               }
             }
-            pk[pass] = make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w));
+            pk[pass] = make_uint2(Half<HT>::pack2(v.x, v.y), Half<HT>::pack2(v.z, v.w));
           }
           if (oa && !(STATS && (g.ln_groups & 2))) {
             // bf16 copy in 16-byte stores (the epilogue is store-ISSUE bound): lanes rslot, rslot^1 hold adjacent
@@ -587,8 +589,9 @@ constexpr int QS = 4;                          // ring depth
 
 __device__ __forceinline__ int swzq(int row, int chunk) { return row * QROWB + ((chunk ^ ((row >> 2) & 3)) << 4); }
 
-template <int ACT, bool OUT_F32, bool STATS = false>
+template <int ACT, bool OUT_F32, bool STATS = false, bool F16 = false>
 __global__ __launch_bounds__(768) void gemm256q_kernel(GemmArgs g, int tiles_m, int tiles_n) {
+  using HT = std::conditional_t<F16, f16_t, bf16_t>;  // operand element type (common.h Half<>)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -691,8 +694,7 @@ __global__ __launch_bounds__(768) void gemm256q_kernel(GemmArgs g, int tiles_m, 
 #define CZC_RA(ks_, i_) (*(const uint4*)(sA + swzq(arow + 32 * (i_), 2 * (ks_) + half)))
 #define CZC_RB(ks_, j_) (*(const uint4*)(sB + swzq(brow + 32 * (j_), 2 * (ks_) + half)))
 #define CZC_MM(b_, a_, i_, j_)                                                                                  \
-  acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, b_), __builtin_bit_cast(bf16x8_t, a_), \
-                                                        acc[i_][j_], 0, 0, 0)
+  acc[i_][j_] = Half<HT>::mfma(b_, a_, acc[i_][j_])
       uint4 b0 = CZC_RB(0, 0), b1 = CZC_RB(0, 1), a0 = CZC_RA(0, 0), a1;
       a1 = CZC_RA(0, 1);
       CZC_MM(b0, a0, 0, 0); CZC_MM(b1, a0, 0, 1);
@@ -714,7 +716,7 @@ __global__ __launch_bounds__(768) void gemm256q_kernel(GemmArgs g, int tiles_m, 
 #undef CZC_RB
 #undef CZC_MM
     }
-    tile_epilogue<ACT, OUT_F32, STATS>(g, acc, smem + QS * QSTAGE + wave * 4096, m0, n0, wm, wn, lane);
+    tile_epilogue<ACT, OUT_F32, STATS, HT>(g, acc, smem + QS * QSTAGE + wave * 4096, m0, n0, wm, wn, lane);
   }
 }
 
@@ -1005,6 +1007,7 @@ int g_gemm256_min_m = 2048;
 int g_gemm_krot = 0;  // bit0: rotate K order per work-group (no gain measured); bits1-2: debug (skip MFMA / skip DMA)
 
 bool gemm256_eligible(const GemmArgs& g) {
+  if (g.f16 && (g_use_gemm256 != 3 || g.row_stats || g.N % 8 || g.ldc % 8)) return false;  // fp16 operands: ring kernel only
   return g.M >= g_gemm256_min_m && g.N % 4 == 0 && g.K % 64 == 0 && g.ldc % 4 == 0 && (!g.resid || g.ldr % 4 == 0) &&
          (g.act == ACT_NONE || g.act == ACT_QUICK_GELU) && (long)256 * g.lda * 2 < (1L << 31) &&
          (long)256 * g.ldw * 2 < (1L << 31);
@@ -1032,6 +1035,10 @@ int launch_gemm256(const GemmArgs& g, hipStream_t st) {
       CZC_ATTR((gemm256q_kernel<ACT_QUICK_GELU, false>));
       CZC_ATTR((gemm256q_kernel<ACT_QUICK_GELU, true>));
       CZC_ATTR((gemm256q_kernel<ACT_NONE, true, true>));
+      CZC_ATTR((gemm256q_kernel<ACT_NONE, false, false, true>));
+      CZC_ATTR((gemm256q_kernel<ACT_NONE, true, false, true>));
+      CZC_ATTR((gemm256q_kernel<ACT_QUICK_GELU, false, false, true>));
+      CZC_ATTR((gemm256q_kernel<ACT_QUICK_GELU, true, false, true>));
 #undef CZC_ATTR
     }
     const int tiles_m = cdiv(g.M, TM), tiles_n = cdiv(g.N, TN);
@@ -1049,9 +1056,14 @@ int launch_gemm256(const GemmArgs& g, hipStream_t st) {
         CZC_HIP_CHECK(hipGetLastError());
         return 0;
       }
-#define CZC_GOQ(A_, F_) hipLaunchKernelGGL((gemm256q_kernel<A_, F_>), gq, block, shp, st, g, tiles_m, tiles_n)
-      if (g.act == ACT_QUICK_GELU) { if (f32) CZC_GOQ(ACT_QUICK_GELU, true); else CZC_GOQ(ACT_QUICK_GELU, false); }
-      else { if (f32) CZC_GOQ(ACT_NONE, true); else CZC_GOQ(ACT_NONE, false); }
+#define CZC_GOQ(A_, F_, H_) hipLaunchKernelGGL((gemm256q_kernel<A_, F_, false, H_>), gq, block, shp, st, g, tiles_m, tiles_n)
+      if (g.f16) {
+        if (g.act == ACT_QUICK_GELU) { if (f32) CZC_GOQ(ACT_QUICK_GELU, true, true); else CZC_GOQ(ACT_QUICK_GELU, false, true); }
+        else { if (f32) CZC_GOQ(ACT_NONE, true, true); else CZC_GOQ(ACT_NONE, false, true); }
+      } else {
+        if (g.act == ACT_QUICK_GELU) { if (f32) CZC_GOQ(ACT_QUICK_GELU, true, false); else CZC_GOQ(ACT_QUICK_GELU, false, false); }
+        else { if (f32) CZC_GOQ(ACT_NONE, true, false); else CZC_GOQ(ACT_NONE, false, false); }
+      }
 #undef CZC_GOQ
       CZC_HIP_CHECK(hipGetLastError());
       return 0;

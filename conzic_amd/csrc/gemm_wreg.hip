@@ -67,9 +67,10 @@ __device__ __forceinline__ float wr_act(float v) {
   return v;
 }
 
-template <int ACT, bool DBG_NOLDS, bool ILV, bool LNF = false>
+template <int ACT, bool DBG_NOLDS, bool ILV, bool LNF = false, bool F16 = false>
 __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, int nsets, int nblk, int dbg) {
   static_assert(!LNF || ILV, "the folded-LayerNorm epilogue exists in the interleaved form only");
+  using HT = std::conditional_t<F16, f16_t, bf16_t>;  // operand element type: MFMA opcode + converter (common.h Half<>)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -170,10 +171,8 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, 
     for (int t = 0; t < 32; t += 2) {
       const u32x4_t a0 = DBG_NOLDS ? wreg[(t + 5) & 31] : *(const u32x4_t*)(sA + va[t & 7] + (t >> 3) * 256);
       const u32x4_t a1 = DBG_NOLDS ? wreg[(t + 6) & 31] : *(const u32x4_t*)(sA + va[(t + 1) & 7] + ((t + 1) >> 3) * 256);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wreg[t]), __builtin_bit_cast(bf16x8_t, a0),
-                                                     acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wreg[t + 1]),
-                                                     __builtin_bit_cast(bf16x8_t, a1), acc1, 0, 0, 0);
+      acc0 = Half<HT>::mfma(wreg[t], a0, acc0);
+      acc1 = Half<HT>::mfma(wreg[t + 1], a1, acc1);
     }
     if (DBG_NOLDS) return;
     // pin the stream: fragment reads run WR_AHEAD MFMAs ahead of their use (one wave must be able to
@@ -233,7 +232,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, 
                              acc0[4 * qd + 2] + acc1[4 * qd + 2] + b4.z, acc0[4 * qd + 3] + acc1[4 * qd + 3] + b4.w);
       v.x = wr_act<ACT>(v.x); v.y = wr_act<ACT>(v.y); v.z = wr_act<ACT>(v.z); v.w = wr_act<ACT>(v.w);
       const int slot = (2 * qd + half) ^ ((l31 >> 1) & 7);  // 8-byte slots of the 64-byte patch row
-      *(uint2*)(patch + l31 * 64 + slot * 8) = make_uint2(pk_bf16(v.x, v.y), pk_bf16(v.z, v.w));
+      *(uint2*)(patch + l31 * 64 + slot * 8) = make_uint2(Half<HT>::pack2(v.x, v.y), Half<HT>::pack2(v.z, v.w));
     }
     u32x4_t d[2];
 #pragma unroll
@@ -283,7 +282,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, 
     }
     v.x = wr_act<ACT>(v.x); v.y = wr_act<ACT>(v.y); v.z = wr_act<ACT>(v.z); v.w = wr_act<ACT>(v.w);
     const int slot = (2 * qd + half) ^ ((l31 >> 1) & 7);
-    *(uint2*)(patch + l31 * 64 + slot * 8) = make_uint2(pk_bf16(v.x, v.y), pk_bf16(v.z, v.w));
+    *(uint2*)(patch + l31 * 64 + slot * 8) = make_uint2(Half<HT>::pack2(v.x, v.y), Half<HT>::pack2(v.z, v.w));
   };
   auto epi_store = [&](int pass) {  // 16 patch rows -> one buffer store
     const int r = pass * 16 + rrow;
@@ -316,10 +315,8 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, 
 #pragma unroll
       for (int k = 0; k < 4; k += 2) {
         const int t = 4 * sgm + k;
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wreg[t]),
-                                                       __builtin_bit_cast(bf16x8_t, fr[sgm & 1][k]), acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wreg[t + 1]),
-                                                       __builtin_bit_cast(bf16x8_t, fr[sgm & 1][k + 1]), acc1, 0, 0, 0);
+        acc0 = Half<HT>::mfma(wreg[t], fr[sgm & 1][k], acc0);
+        acc1 = Half<HT>::mfma(wreg[t + 1], fr[sgm & 1][k + 1], acc1);
       }
       __builtin_amdgcn_sched_barrier(0);
       // descriptor arithmetic (a few dozen SALU) rides in the slots too: nothing but the wait and the barrier
@@ -417,6 +414,7 @@ int g_wreg_min_m = 2048;  // below this the 128x128 kernel wins (few blocks per 
 int g_wreg_dbg = 0;  // timing ablations only (results invalid): 1 no stores, 2 no MFMA, 4 no DMA refill, 8 no epilogue, 16 MFMA operands from registers only
 
 bool gemm_wreg_eligible(const GemmArgs& g) {
+  if (g.f16 && (g_use_wreg != 2 || g.ln_stats || (g_wreg_dbg & 16))) return false;  // fp16 operands: interleaved form only
   if (g.ln_stats && (g_use_wreg != 2 || !g.ln_s || g.ln_groups != 8 || (g_wreg_dbg & 16))) return false;
   return g_use_wreg && g.K == WR_K && g.M >= g_wreg_min_m && g.N % 8 == 0 && g.ldc % 8 == 0 && g.lda % 8 == 0 && g.ldw % 8 == 0 &&
          g.out_act && !g.out_f32 && !g.resid && (g.act == ACT_NONE || g.act == ACT_QUICK_GELU) &&
@@ -461,6 +459,20 @@ int launch_gemm_wreg(const GemmArgs& g, hipStream_t st) {
   } while (0)
     if (g.act == ACT_QUICK_GELU) CZC_WR_GOL(ACT_QUICK_GELU); else CZC_WR_GOL(ACT_NONE);
 #undef CZC_WR_GOL
+    CZC_HIP_CHECK(hipGetLastError());
+    return 0;
+  }
+  if (g.f16) {
+    dim3 gridh(n_cu);
+#define CZC_WR_GOH(A_)                                                                                                     \
+  do {                                                                                                                     \
+    CZC_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_wreg_kernel<A_, false, true, false, true>,                         \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, WR_LDS));                               \
+    hipLaunchKernelGGL((gemm_wreg_kernel<A_, false, true, false, true>), gridh, block, WR_LDS, st, g, ncg, nsets, nblk,   \
+                       g_wreg_dbg);                                                                                        \
+  } while (0)
+    if (g.act == ACT_QUICK_GELU) CZC_WR_GOH(ACT_QUICK_GELU); else CZC_WR_GOH(ACT_NONE);
+#undef CZC_WR_GOH
     CZC_HIP_CHECK(hipGetLastError());
     return 0;
   }

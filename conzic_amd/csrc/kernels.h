@@ -17,6 +17,7 @@ struct GemmArgs {
   void* out_act; float* out_f32; int ldc;
   int M, N, K;
   int act;
+  int f16 = 0;  // 2-byte operands are IEEE fp16 instead of bf16 (set by launch_gemm from the precision)
   // LayerNorm folded into the GEMMs around it (bf16 CLIP-text tower).
   // Producer side (fp32-output 256x256 kernel): per-row partial sums of the fp32 result over each 64-column
   // group, row_stats[m][N/64][2] = (sum, sum of squares); together with out_act (bf16 copy of the result)
@@ -111,7 +112,7 @@ extern int g_qkv_attn_dbg;  // per-image persistent branch attention (LDS-DMA ri
 // bf16 engine, shared-prefix plan (B trunk segments then B*K branch segments): returns -1 when the
 // shapes do not fit the packed-branch kernel (caller then uses launch_attention)
 int launch_attention_shared(const void* qkv, const SegTable& tab, int B, int K, int max_own, int max_keys, int heads,
-                            float scale, void* out, hipStream_t st);
+                            float scale, void* out, hipStream_t st, int f16 = 0);
 
 // the same for the split engine precision (qkv / out are split_t)
 int launch_attention_shared_split(const void* qkv, const SegTable& tab, int B, int K, int max_own, int max_keys, int heads,
@@ -176,6 +177,7 @@ struct CombineArgs {
   float* clip_score; float* clip_ref; float* final_score;  // [B,K] (non-null, engine scratch)
   int* best; float* best_cos;                                // [B]
   int* inp; int T; int gen_idx;                              // write-back target (may be null)
+  int* nonfinite = nullptr;                                  // set to 1 when a cosine is not finite (may be null)
 };
 int launch_combine(const CombineArgs& a, hipStream_t st);
 

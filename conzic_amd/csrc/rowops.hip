@@ -79,6 +79,9 @@ int launch_layernorm(int prec, const float* x, const int* row_idx, const float* 
   if (prec == PREC_BF16)
     hipLaunchKernelGGL(layernorm_kernel<bf16_t>, grid, block, 0, st, x, row_idx, gamma, beta, eps, M, H,
                        (bf16_t*)y_act, y_f32);
+  else if (prec == PREC_F16)
+    hipLaunchKernelGGL(layernorm_kernel<f16_t>, grid, block, 0, st, x, row_idx, gamma, beta, eps, M, H,
+                       (f16_t*)y_act, y_f32);
   else if (prec == PREC_F16X3)
     hipLaunchKernelGGL(layernorm_kernel<split_t>, grid, block, 0, st, x, row_idx, gamma, beta, eps, M, H,
                        (split_t*)y_act, y_f32);
@@ -133,6 +136,9 @@ int launch_bert_embed(int prec, const int* ids, int B, int T_, int H, const floa
   if (prec == PREC_BF16)
     hipLaunchKernelGGL(bert_embed_kernel<bf16_t>, grid, block, 0, st, ids, M, T_, H, word, pos, type0, gamma, beta, eps,
                        (bf16_t*)y_act, y_f32);
+  else if (prec == PREC_F16)
+    hipLaunchKernelGGL(bert_embed_kernel<f16_t>, grid, block, 0, st, ids, M, T_, H, word, pos, type0, gamma, beta, eps,
+                       (f16_t*)y_act, y_f32);
   else if (prec == PREC_F16X3)
     hipLaunchKernelGGL(bert_embed_kernel<split_t>, grid, block, 0, st, ids, M, T_, H, word, pos, type0, gamma, beta, eps,
                        (split_t*)y_act, y_f32);
@@ -199,6 +205,8 @@ int launch_im2col(int prec, const float* pixels, int B, int S, int p, void* out,
   dim3 grid((unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192)), block(256);
   if (prec == PREC_BF16)
     hipLaunchKernelGGL(im2col_kernel<bf16_t>, grid, block, 0, st, pixels, B, S, p, (bf16_t*)out);
+  else if (prec == PREC_F16)
+    hipLaunchKernelGGL(im2col_kernel<f16_t>, grid, block, 0, st, pixels, B, S, p, (f16_t*)out);
   else if (prec == PREC_F16X3)
     hipLaunchKernelGGL(im2col_kernel<split_t>, grid, block, 0, st, pixels, B, S, p, (split_t*)out);
   else
@@ -269,6 +277,8 @@ int launch_convert(int prec, const float* src, void* dst, long n, hipStream_t st
   dim3 grid((unsigned)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384)), block(256);
   if (prec == PREC_BF16)
     hipLaunchKernelGGL(convert_kernel<bf16_t>, grid, block, 0, st, src, (bf16_t*)dst, n);
+  else if (prec == PREC_F16)
+    hipLaunchKernelGGL(convert_kernel<f16_t>, grid, block, 0, st, src, (f16_t*)dst, n);
   else if (prec == PREC_F16X3)
     hipLaunchKernelGGL(convert_kernel<split_t>, grid, block, 0, st, src, (split_t*)dst, n);
   else
@@ -287,6 +297,7 @@ int launch_act_to_f32(int prec, const void* src, float* dst, long n, hipStream_t
   if (n <= 0) return 0;
   dim3 grid((unsigned)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384)), block(256);
   if (prec == PREC_BF16) hipLaunchKernelGGL(act_to_f32_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)src, dst, n);
+  else if (prec == PREC_F16) hipLaunchKernelGGL(act_to_f32_kernel<f16_t>, grid, block, 0, st, (const f16_t*)src, dst, n);
   else if (prec == PREC_F16X3) hipLaunchKernelGGL(act_to_f32_kernel<split_t>, grid, block, 0, st, (const split_t*)src, dst, n);
   else hipLaunchKernelGGL(act_to_f32_kernel<float>, grid, block, 0, st, (const float*)src, dst, n);
   CZC_HIP_CHECK(hipGetLastError());

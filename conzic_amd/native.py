@@ -17,6 +17,7 @@ PREC_BF16 = 0
 PREC_F32 = 1
 PREC_ALL_BF16 = 2
 PREC_SPLIT = 3
+PREC_FP16 = 4
 CLIP_MAX_LEN = 77
 
 

@@ -28,20 +28,26 @@ from .harness import order_positions
 # logit_scale.exp() ahead of softmax_K, so the fused score stays inside the 1e-3 budget only while that factor is
 # small (measured on the full-size goldens: in budget at 14.3 = HF init, far out at 100 = published checkpoint).
 BF16_MAX_LOGIT_SCALE_EXP = 20.0
+# single-pass fp16 towers (same speed as bf16, 11 significand bits): cosine error ~1.8e-4, fused score 5e-5 at x14.3 and
+# 2.3e-3 at x100 (measured on the full-size goldens, linear in the scale) -- in budget up to about x40
+FP16_MAX_LOGIT_SCALE_EXP = 40.0
 
 _PRECISIONS = {"bf16": native.PREC_BF16, "f32": native.PREC_F32, "fp32": native.PREC_F32,
-               "split": native.PREC_SPLIT, "split_fp16": native.PREC_SPLIT}
+               "split": native.PREC_SPLIT, "split_fp16": native.PREC_SPLIT, "fp16": native.PREC_FP16, "f16": native.PREC_FP16}
 
 
 def choose_precision(logit_scale: Optional[float]) -> int:
-    """Engine precision for a checkpoint: CZC_PRECISION (bf16 | split | f32) when set, else by the CLIP logit
+    """Engine precision for a checkpoint: CZC_PRECISION (bf16 | fp16 | split | f32) when set, else by the CLIP logit
     scale -- bf16 MFMA towers where exp(logit_scale) leaves their cosine error inside the 1e-3 fused-score
-    budget, split-fp16 MFMA (fp32-class) otherwise, which is the case for the published checkpoints."""
+    budget (<= x20), single-pass fp16 towers up to x40, split-fp16 MFMA (fp32-class) above, which is the case for the
+    published checkpoints (x100)."""
     p = os.environ.get("CZC_PRECISION", "auto").lower()
     if p != "auto":
         return _PRECISIONS[p]
-    if logit_scale is None or math.exp(float(logit_scale)) > BF16_MAX_LOGIT_SCALE_EXP:
+    if logit_scale is None or math.exp(float(logit_scale)) > FP16_MAX_LOGIT_SCALE_EXP:
         return native.PREC_SPLIT
+    if math.exp(float(logit_scale)) > BF16_MAX_LOGIT_SCALE_EXP:
+        return native.PREC_FP16
     return native.PREC_BF16
 
 

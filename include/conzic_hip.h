@@ -47,6 +47,12 @@ extern "C" {
                          /* published clip-vit-base-patch32), where a bf16 cosine error would be multiplied by   */
                          /* 100 ahead of softmax_K and leave the 1e-3 fused-score budget                          */
 
+#define CZC_PREC_FP16 4 /* CLIP towers on single-pass IEEE fp16 MFMA: the bf16 kernels with the fp16 opcode and converter */
+                        /* (same bytes, same speed), 11 significand bits instead of 8 -> ~8x smaller cosine error: inside  */
+                        /* the 1e-3 fused-score budget at the published logit scale (x100) where bf16 is out by 2-3x.  */
+                        /* BERT on split-fp16 as in CZC_PREC_BF16.  Operands are bounded (LayerNorm outputs, attention    */
+                        /* context, quick-GELU outputs); residual stream / accumulators / softmax / statistics stay fp32  */
+
 #define CZC_BRIDGE_MAX_BYTES 512 /* decoded caption text per candidate row */
 #define CZC_CLIP_MAX_LEN 77       /* clip/clip.py:71-72 (max_length = 77, truncation) */
 #define CZC_MAX_TOPK 1024

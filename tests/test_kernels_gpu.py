@@ -462,3 +462,37 @@ def test_split_fp16_mfma_attention(causal):
         finally:
             lib.czc_test_set_option(b"mfma_attention", 1)
         assert np.abs(out - out2).max() < 3e-5
+
+
+FP16 = 4  # internal precision code: f16_t storage, one fp16 MFMA pass (the bf16 kernels with the fp16 opcode)
+
+
+def _f16_round(a):
+    return np.ascontiguousarray(a).astype(np.float16).astype(np.float32)
+
+
+@pytest.mark.parametrize("M,N,K,act,mode", [(300, 200, 192, 0, "typed"), (3000, 512, 2048, 0, "resid"), (2100, 1536, 512, 0, "typed"),
+                                            (40000, 2048, 512, 1, "typed"), (40000, 512, 512, 0, "resid"), (129, 64, 3072, 2, "f32")])
+def test_fp16_gemm_kernel_families(M, N, K, act, mode):
+    """fp16 operands through the 128x128 kernel, the weight-stationary kernel and the 256x256 ring kernel: against an
+    fp64 reference on fp16-rounded operands (the kernels differ from bf16 only in the MFMA opcode and the converter)."""
+    rng = np.random.default_rng(M + N + K)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    R = rng.standard_normal((M, N)).astype(np.float32) if mode == "resid" else None
+    C = E.test_gemm(FP16, A, W, bias=bias, resid=R, act=act, typed_out=(mode == "typed"))
+    pre = (_f16_round(A).astype(np.float64) @ _f16_round(W).astype(np.float64).T + bias).astype(np.float32)
+    ref = _act(pre, act) + (R if R is not None else 0)
+    tol = 3e-4 * np.sqrt(K / 64) + (2 ** -10 * np.abs(ref).max() if mode == "typed" else 0)
+    assert np.abs(C - ref).max() < tol, np.abs(C - ref).max()
+
+
+@pytest.mark.parametrize("causal", [True, False])
+def test_fp16_attention(causal):
+    rng = np.random.default_rng(13)
+    heads = 8
+    lens = [15, 1, 7, 16, 20, 77, 50, 64, 65, 2]
+    qkv = _f16_round(rng.standard_normal((sum(lens), 3 * heads * 64)).astype(np.float32))
+    out = E.test_attention(FP16, qkv, lens, heads, causal, 0.125)
+    assert np.abs(out - _attn_ref(qkv, lens, heads, causal, 0.125)).max() < 2e-3

@@ -10,7 +10,7 @@ from goldutil import load_case
 
 pytestmark = pytest.mark.gpu
 
-BF16, F32, SPLIT = native.PREC_BF16, native.PREC_F32, native.PREC_SPLIT
+BF16, F32, SPLIT, FP16 = native.PREC_BF16, native.PREC_F32, native.PREC_SPLIT, native.PREC_FP16
 SEED_LEN = 4
 
 # fused-score tolerance of the north star ("within 1e-3 on the fused logits") at the BASELINE
@@ -21,6 +21,8 @@ def tol_final(prec, tiny):
         return 2e-5
     if prec == SPLIT:  # split-fp16 MFMA towers: fp32-class (22 mantissa bits), an order inside the 1e-3 bar
         return 1e-4
+    if prec == FP16:   # single-pass fp16 MFMA towers: ~8x below bf16 (measured 5e-5 on the full-size goldens at scale 14.3)
+        return 4e-3 if tiny else 1.5e-4
     return 2.5e-2 if tiny else 1e-3
 
 
@@ -120,11 +122,11 @@ def check_step(meta, arr, i, res, su, prec, next_inp):
             assert res["clip_len"][b * K + e_] == ln
             np.testing.assert_array_equal(res["clip_ids"][b * K + e_, :ln], arr["clip_ids"][i][b * K + g_, :ln])
         np.testing.assert_allclose(res["clip_ref"][b][ek], arr["clip_ref"][i][b][gk],
-                                   atol={F32: 5e-6, SPLIT: 1e-5}.get(prec, 4e-3))
+                                   atol={F32: 5e-6, SPLIT: 1e-5, FP16: 6e-4}.get(prec, 4e-3))
         if len(common) == K:
             np.testing.assert_allclose(res["clip_score"][b][ek], arr["clip_score"][i][b][gk],
                                        atol={F32: 2e-6, SPLIT: tol / 2}.get(prec, tol / 2),
-                                       rtol={F32: 1e-4, SPLIT: 2e-3}.get(prec, 5e-2))
+                                       rtol={F32: 1e-4, SPLIT: 2e-3}.get(prec, 5e-2 if meta["logit_scale"] < 4.0 else 0.2))
             np.testing.assert_allclose(res["final_score"][b][ek], gfin[b][gk], atol=tol, rtol=0)
             ERR_LOG.append((meta["name"], prec, float(np.abs(res["final_score"][b][ek] - gfin[b][gk]).max()),
                             float(np.abs(res["clip_ref"][b][ek] - arr["clip_ref"][i][b][gk]).max())))
@@ -298,6 +300,38 @@ def test_sentiment_table_keyed_by_word_and_pos(prec):
         su.engine.close()
 
 
+@pytest.mark.parametrize("name", [n for n in FULL if n != "full_scale100"])
+def test_step_parity_full_size_fp16(name):
+    """Single-pass fp16 MFMA CLIP towers (the bf16 kernels on IEEE fp16 operands, same speed): fused score within
+    1.5e-4 on the full-size goldens where bf16 is within 3.4e-4 of a 1e-3 bar."""
+    meta, arr = load_case(name)
+    teacher_forced(meta, arr, FP16, n_steps=10)
+
+
+def test_fp16_at_the_published_logit_scale_is_marginal():
+    """Why the product path picks split-fp16 and not plain fp16 at x100: on `full_scale100` the fp16 engine's worst fused
+    score error over the ten steps is 2.3e-3 (cosine error 1.8e-4 x 100 ahead of softmax_K) -- out of the 1e-3 bar by 2.3x
+    (bf16: by ~20x), and a peakier softmax than the goldens' would amplify it further.  Asserted as 'between split and 5e-3'."""
+    meta, arr = load_case("full_scale100")
+    su = setup_for(meta, FP16)
+    su.engine.set_image_embeds(arr["image_embeds"])
+    hp = Engine.hyper(meta["alpha"], meta["beta"], meta["temperature"])
+    worst = 0.0
+    for i in range(10):
+        inp = np.ascontiguousarray(arr["inp_before"][i], dtype=np.int32)
+        res = su.engine.step(inp, SEED_LEN + meta["positions"][i], meta["K"], hp, dot_allowed=(meta["positions"][i] == meta["L"] - 1))
+        if (res["idxs"] == arr["idxs"][i]).all():
+            worst = max(worst, float(np.abs(res["final_score"] - gold_final(meta, arr, i, su)).max()))
+    assert 1e-5 < worst < 5e-3, worst
+
+
+@pytest.mark.parametrize("name", [n for n in TINY if n != "tiny_scale100"])
+def test_step_parity_tiny_fp16(name):
+    meta, arr = load_case(name)
+    soft, n = teacher_forced(meta, arr, FP16)
+    assert soft <= n
+
+
 def test_precision_selected_from_logit_scale():
     """conzic_amd.runtime.choose_precision: bf16 towers only where exp(logit_scale) keeps them inside the
     budget; the published checkpoints' scale (100) gets the split-fp16 engine."""
@@ -306,6 +340,7 @@ def test_precision_selected_from_logit_scale():
     old = os.environ.pop("CZC_PRECISION", None)
     try:
         assert runtime.choose_precision(2.6592) == BF16
+        assert runtime.choose_precision(3.4) == FP16      # x30: bf16 out of budget, fp16 (8x smaller error) inside
         assert runtime.choose_precision(4.6052) == SPLIT
         assert runtime.choose_precision(None) == SPLIT
         os.environ["CZC_PRECISION"] = "f32"
