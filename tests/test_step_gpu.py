@@ -899,3 +899,37 @@ def test_step_graphs_replay_equals_eager(name, prec):
         assert eng.graph_stats()["cached"] < gs["cached"] or eng.graph_stats()["captures"] == gs["captures"]
     finally:
         su.engine.close()
+
+
+@pytest.mark.parametrize("B,L,K,filled", [(3, 7, 100, 7), (5, 9, 37, 4), (1, 25, 64, 25), (7, 10, 200, 0), (2, 15, 1024, 15),
+                                          (33, 6, 50, 6), (4, 12, 333, 12)])
+def test_odd_shapes_fast_engines_vs_f32_engine(B, L, K, filled):
+    """Ragged shapes the goldens do not have -- candidate counts that are no multiple of the attention packing factor
+    or of any tile size, K at CZC_MAX_TOPK, a 30-token BERT row (L = 25), a single image, an empty caption (first step of
+    the first sweep) -- through the bf16, fp16 and split engines, checked against the f32-MFMA engine (itself pinned to the
+    reference by the goldens) on one position-step: same candidates, fused scores within each precision's bar."""
+    rng = np.random.default_rng(B * 1000 + K)
+    emb = rng.standard_normal((B, 512)).astype(np.float32)
+    ref = None
+    for prec in (F32, BF16, FP16, SPLIT):
+        su = harness.build_synthetic(False, prec)
+        try:
+            if ref is None:
+                inp0 = np.array([su.bert_tok.encode("Image of a" + su.bert_tok.mask_token * L)] * B, dtype=np.int32)
+                regular = np.nonzero(su.token_mask[0] > 0)[0]
+                inp0[:, SEED_LEN:SEED_LEN + filled] = rng.choice(regular, size=(B, filled))
+            gen_idx = SEED_LEN + (min(filled, L) // 2 if filled else 0)
+            su.engine.set_image_embeds(emb)
+            res = su.engine.step(inp0.copy(), gen_idx, K, Engine.hyper(0.02, 2.0, 0.1), dot_allowed=False)
+            assert np.isfinite(res["final_score"]).all()
+            if prec == F32:
+                ref = res
+                continue
+            same = res["idxs"] == ref["idxs"]
+            assert same.mean() > 0.97, (prec, same.mean())  # a near-tie swap of two neighbours in the top-K list counts twice
+            np.testing.assert_array_equal(res["clip_len"].reshape(B, K)[same], ref["clip_len"].reshape(B, K)[same])
+            tol = {BF16: 1e-3 * max(1.0, 200.0 / K), FP16: 2e-4 * max(1.0, 200.0 / K), SPLIT: 2e-5}[prec]
+            err = np.abs(res["final_score"] - ref["final_score"])[same]
+            assert err.max() < tol, (prec, err.max())
+        finally:
+            su.engine.close()
