@@ -186,3 +186,23 @@ def test_engine_from_checkpoint_directories_matches_in_memory_engine(tmp_path):
     finally:
         eng.close()
         su.engine.close()
+
+
+@pytest.mark.parametrize("argv", [
+    ["--run_type", "caption", "--order", "sequential"],
+    ["--run_type", "caption", "--order", "span"],
+    ["--run_type", "controllable", "--control_type", "sentiment", "--sentiment_type", "negative", "--order", "shuffle"],
+    ["--run_type", "controllable", "--control_type", "pos", "--order", "sequential",
+     "--pos_type", '[["DET"], ["ADJ", "NOUN"], ["NOUN"], ["VERB"], ["ADP"]]'],
+])
+def test_demo_harness_runs_every_run_type(argv, caplog):
+    """conzic_amd.demo_cli in the role of demo.py (demo.py:105-153: set_seed once, models, token_mask, samples loop)
+    through every run type the reference's demo offers, on the tiny synthetic towers: runs to completion and logs a
+    final and a best caption per sample (gen_utils.py:326-333 / control_gen_utils.py tail)."""
+    from conzic_amd import demo_cli
+    caplog.set_level(logging.INFO)
+    demo_cli.main(["--synthetic", "--tiny", "--samples_num", "2", "--sentence_len", "5", "--candidate_k", "12",
+                   "--num_iterations", "2", "--batch_size", "2"] + argv)
+    text = "\n".join(r.getMessage() for r in caplog.records)
+    assert text.count("Sample ") == 2
+    assert "final caption" in text.lower() or "best caption" in text.lower()
