@@ -385,6 +385,10 @@ CASES = dict(
     full_shuffle_k512=dict(tiny=False, B=2, L=15, K=512, I=1, order="shuffle", image="synthetic"),
     # BASELINE configs[4] shape: sentiment control, gamma=5, L=12, K=200 (control_gen_utils.py:30-80)
     full_senti=dict(tiny=False, B=2, L=12, K=200, I=1, order="sequential", image="synthetic", gamma=5.0, style="positive"),
+    # POS control on full-size towers (control_gen_utils.py:136-195), the template demo.py:40-45 ships
+    full_pos=dict(tiny=False, B=2, L=10, K=200, I=1, order="sequential", image="synthetic", gamma=5.0,
+                  pos=[["DET"], ["ADJ", "NOUN"], ["NOUN"], ["VERB"], ["VERB"], ["ADV"], ["ADP"], ["DET", "NOUN"], ["NOUN"],
+                       ["NOUN", "."], [".", "NOUN"], [".", "NOUN"]]),
 )
 
 

@@ -107,7 +107,7 @@ def test_oracle_imageproc_matches_reference_processor(label, S):
     np.testing.assert_array_equal(preprocess(imgs, S), synth.pixels_from_u8(z["crops"]))
 
 
-@pytest.mark.parametrize("name,step", [("full_scale100", 6), ("full_senti", 7), ("full_shuffle_k512", 3)])
+@pytest.mark.parametrize("name,step", [("full_scale100", 6), ("full_senti", 7), ("full_shuffle_k512", 3), ("full_pos", 5)])
 def test_oracle_full_size_mid_trajectory_step(name, step):
     """The oracle on the full-size goldens added for the published logit scale (x100, clip/clip.py:95-98), the
     sentiment control path at configs[4] shape (gamma=5, L=12; control_gen_utils.py:53-63) and configs[3] shape
@@ -120,7 +120,7 @@ def test_oracle_full_size_mid_trajectory_step(name, step):
     emb = torch.from_numpy(arr["image_embeds"])
     o.update_token_mask(mask, meta["L"], pos)
     r = S.polish_step(o, inp, emb, mask, gen_idx, meta["K"], meta["temperature"], meta["alpha"], meta["beta"],
-                      gamma=meta["gamma"], ctl_signal=meta["style"])
+                      gamma=meta["gamma"], ctl_signal=meta["style"], pos_template=meta.get("pos"))
     np.testing.assert_array_equal(r["idxs"].numpy(), arr["idxs"][step])
     np.testing.assert_allclose(r["probs"].numpy(), arr["probs"][step], rtol=2e-4, atol=1e-7)
     np.testing.assert_allclose(r["clip_ref"].numpy(), arr["clip_ref"][step], atol=3e-6)

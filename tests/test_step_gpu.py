@@ -187,7 +187,7 @@ def teacher_forced(meta, arr, prec, n_steps=None):
 
 TINY = ["tiny_seq", "tiny_shuffle", "tiny_span", "tiny_random", "tiny_senti_seq", "tiny_senti_shuffle", "tiny_scale100",
         "tiny_pos_seq"]
-FULL = ["full_cfg1", "full_synth_b2", "full_regular", "full_scale100", "full_shuffle_k512", "full_senti"]
+FULL = ["full_cfg1", "full_synth_b2", "full_regular", "full_scale100", "full_shuffle_k512", "full_senti", "full_pos"]
 
 
 @pytest.mark.parametrize("name", TINY)
@@ -397,7 +397,7 @@ def test_generate_free_running_tiny_f32(name):
     assert texts == meta["texts"][:-1]
 
 
-@pytest.mark.parametrize("name", ["full_scale100", "full_senti", "full_shuffle_k512"])
+@pytest.mark.parametrize("name", ["full_scale100", "full_senti", "full_shuffle_k512", "full_pos"])
 def test_generate_free_running_full_size_split(name):
     """czc_generate on full-size towers in the split-fp16 precision reproduces the reference's trajectory
     id-for-id (published-checkpoint logit scale; sentiment control at configs[4] shape; K=512 shuffle at
@@ -406,7 +406,8 @@ def test_generate_free_running_full_size_split(name):
     su = setup_for(meta, SPLIT)
     eng = su.engine
     eng.set_image_embeds(arr["image_embeds"])
-    hp = Engine.hyper(meta["alpha"], meta["beta"], meta["temperature"], meta["gamma"], meta["style"] == "negative")
+    hp = Engine.hyper(meta["alpha"], meta["beta"], meta["temperature"], meta["gamma"], meta["style"] == "negative",
+                      control="pos" if meta.get("pos") else None)
     init = su.bert_tok.encode(meta["prompt"] + su.bert_tok.mask_token * meta["L"])
     pos, nm, every = harness.order_positions(meta["order"], meta["L"], meta["I"], order_list=meta["order_list"])
     assert pos == meta["positions"]
