@@ -210,8 +210,6 @@ int czc_test_set_option(const char* name, int value) {
   if (!strcmp(name, "gemm256_min_m")) { g_gemm256_min_m = value; return 0; }
   if (!strcmp(name, "mfma_attention")) { g_use_mfma_attention = value; return 0; }
   if (!strcmp(name, "attention_image")) { g_use_attention_image = value; return 0; }
-  if (!strcmp(name, "qkv_attn")) { g_use_qkv_attn = value; return 0; }
-  if (!strcmp(name, "qkv_attn_dbg")) { g_qkv_attn_dbg = value; return 0; }
   snprintf(czc::g_err, sizeof(czc::g_err), "unknown option %s", name);
   return CZC_ERR_ARG;
 }

@@ -917,19 +917,6 @@ __global__ __launch_bounds__(256) void attention_image_kernel(const bf16_t* qkv,
 
 int g_use_attention_image = 1;  // 0 off, 1 when the batch fills the chip, 2 always (tests)
 
-int launch_attention_trunks(const void* qkv, const SegTable& tab, int B, int max_keys, int heads, float scale, void* out,
-                            hipStream_t st) {
-  const int KPt = ((max_keys + 31) & ~31) + 4;
-  const int wpb = heads >= 4 ? 4 : (heads >= 2 ? 2 : 1);
-  SegTable trunks = tab;
-  trunks.n_seg = B;
-  dim3 grid(B, cdiv(heads, wpb)), block(64 * wpb);
-  hipLaunchKernelGGL(attention_mfma_kernel<bf16_t>, grid, block, (size_t)wpb * 64 * KPt * 2, st, (const bf16_t*)qkv, trunks, heads, 1,
-                     scale, KPt, (bf16_t*)out);
-  CZC_HIP_CHECK(hipGetLastError());
-  return 0;
-}
-
 // trunks through the generic kernel (n_seg = B), branches packed G per wave; f16: operands are IEEE fp16 (not bf16)
 int launch_attention_shared(const void* qkv, const SegTable& tab, int B, int K, int max_own, int max_keys, int heads,
                             float scale, void* out, hipStream_t st, int f16) {

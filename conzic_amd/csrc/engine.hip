@@ -82,8 +82,6 @@ struct czc_engine {
   int last_BT = 0;
   int share_prefix = 1;  // encode the candidates' common causal prefix once per image
   float* d_staged = nullptr; int staged_cap = 0, staged_n = 0;  // czc_preprocess_u8 output slots [cap][3][S][S]
-  int fuse_qkv_attn = 0;  // branch rows: q/k/v projection and attention in one kernel (qkv_attn.hip); same speed as the
-                          // two-kernel path on configs[2] today (0.78 vs 0.75 ms per layer), kept opt-in
   int pack_branches = 1; // pack several candidates' rows into one attention MFMA tile
   int pool_last_layer = 1; // last CLIP-text layer: out-proj + MLP on the EOS rows only
   int fold_ln = 0;         // bf16 CLIP-text tower: LayerNorm applied inside the GEMM epilogues (no LayerNorm pass over HBM);
@@ -301,7 +299,7 @@ int clip_stack(czc_engine* e, const char* gk, std::vector<LayerW>& L, float* x, 
   // a LayerNorm (q/k/v, fc1) read that copy with gain-folded weights and finish the LayerNorm in their epilogue.
   // Layer 0's LN1 (input = embeddings) and everything on pooled rows still run the LayerNorm kernel.
   const bool fold = P == PREC_BF16 && e->fold_ln && H == 512 && M >= 2048 && !L.empty() && L[0].qkv_wf &&
-                    g_use_wreg == 2 && g_use_gemm256 == 3 && !e->fuse_qkv_attn;
+                    g_use_wreg == 2 && g_use_gemm256 == 3;
   float* stats = nullptr;
   if (fold) E_CHECK(ensure(e, "cs_stats", (size_t)M * (H / 64) * 2 * 4, (void**)&stats));
   bool have_stats = false;
@@ -322,20 +320,10 @@ int clip_stack(czc_engine* e, const char* gk, std::vector<LayerW>& L, float* x, 
   };
   for (size_t n = 0; n < L.size(); ++n) {
     LayerW& l = L[n];
-    const bool fused = plan_B > 0 && plan_trunk_rows > 0 && P == PREC_BF16 && g_use_mfma_attention && e->pack_branches &&
-                       e->fuse_qkv_attn && qkv_attn_eligible(H, heads, max_keys, plan_max_own, plan_K);
     if (!(fold && have_stats)) {
       ProfScope ps(e, "rowops", 0);
       E_CHECK(launch_layernorm(P, x, nullptr, l.ln1_g, l.ln1_b, eps, M, H, y, nullptr, e->st));
     }
-    if (fused) {
-      // trunk rows (B*T of them) through the ordinary kernels; the B*K branches never write q,k,v to HBM
-      E_CHECK(gemm(e, P, gk, y, H, l.qkv_w, H, l.qkv_b, nullptr, 0, qkv, nullptr, 3 * H, plan_trunk_rows, 3 * H, H, ACT_NONE));
-      { ProfScope ps(e, "attention", 0);
-        E_CHECK(launch_attention_trunks(qkv, tab, plan_B, max_keys, heads, scale, ctx, e->st)); }
-      { ProfScope ps(e, gk, 2.0 * (M - plan_trunk_rows) * 3.0 * H * H);
-        E_CHECK(launch_qkv_attn(y, H, l.qkv_w, l.qkv_b, qkv, tab, plan_B, plan_K, plan_max_own, heads, scale, ctx, e->st)); }
-    } else {
     if (fold && have_stats) E_CHECK(lnf_gemm(l.qkv_wf, l.qkv_bf, l.qkv_sf, qkv, 3 * H, ACT_NONE));
     else E_CHECK(gemm(e, P, gk, y, H, l.qkv_w, H, l.qkv_b, nullptr, 0, qkv, nullptr, 3 * H, M, 3 * H, H, ACT_NONE));
     { ProfScope ps(e, "attention", 0);
@@ -346,7 +334,6 @@ int clip_stack(czc_engine* e, const char* gk, std::vector<LayerW>& L, float* x, 
         rc = launch_attention_shared_split(qkv, tab, plan_B, plan_K, plan_max_own, max_keys, heads, scale, ctx, e->st);
       if (rc > 0) E_CHECK(rc);
       if (rc < 0) E_CHECK(launch_attention(P, qkv, tab, max_keys, heads, causal, scale, ctx, e->st)); }
-    }
     if (pool_idx && n + 1 == L.size() && e->pool_last_layer) {
       void *ctx_e, *y_e, *h_e; float* x_e;
       E_CHECK(ensure(e, "cs_ctx_e", (size_t)n_pool * H * e->esz, &ctx_e));
@@ -657,7 +644,7 @@ int step_device(czc_engine* e, int* d_inp, int B, int T, int gen_idx, int n_mask
   auto fbits = [](float f) { int i; memcpy(&i, &f, 4); return i; };
   std::vector<int> key = {0, B, T, gen_idx, n_mask, dot_allowed, K, fbits(hp->alpha), fbits(hp->beta), fbits(hp->gamma),
                           fbits(hp->temperature), hp->control, hp->negative, e->share_prefix, e->pack_branches,
-                          e->pool_last_layer, e->fold_ln, e->fuse_qkv_attn, (int)(((uintptr_t)d_inp) >> 4)};
+                          e->pool_last_layer, e->fold_ln, (int)(((uintptr_t)d_inp) >> 4)};
   E_CHECK(run_phase(e, key, [&]() { return step_phase_a(e, a); }));
   if (n_mask > 0) { e->stat_bert_rows += B * T; e->last_BT = B * T; }
   E_HIP(hipStreamSynchronize(e->st));  // the one host round trip per step (the reference has one too, gen_utils.py:81)
@@ -1119,7 +1106,6 @@ int czc_set_option(czc_engine* e, const char* name, int value) {
   if (!strcmp(name, "share_prefix")) { e->share_prefix = value ? 1 : 0; return CZC_OK; }
   if (!strcmp(name, "pack_branches")) { e->pack_branches = value ? 1 : 0; return CZC_OK; }
   if (!strcmp(name, "pool_last_layer")) { e->pool_last_layer = value ? 1 : 0; return CZC_OK; }
-  if (!strcmp(name, "fuse_qkv_attn")) { e->fuse_qkv_attn = value ? 1 : 0; return CZC_OK; }
   if (!strcmp(name, "fold_ln")) { e->fold_ln = value ? 1 : 0; return CZC_OK; }
   if (!strcmp(name, "graphs")) { e->use_graphs = value; invalidate_graphs(e); return CZC_OK; }
   return fail(e, CZC_ERR_ARG, "unknown option %s", name);

@@ -100,15 +100,6 @@ int launch_attention(int prec, const void* qkv, const SegTable& tab, int max_key
                      void* out, hipStream_t st);
 extern int g_use_mfma_attention;
 extern int g_use_attention_image;
-// trunk segments only (the first B segments of a shared-prefix plan)
-int launch_attention_trunks(const void* qkv, const SegTable& tab, int B, int max_keys, int heads, float scale, void* out,
-                            hipStream_t st);
-// ---- qkv_attn.hip: fused q/k/v projection + branch attention (bf16, hidden 512, 8 heads) ----
-bool qkv_attn_eligible(int H, int heads, int max_keys, int max_own, int K);
-int launch_qkv_attn(const void* y, int ldy, const void* Wqkv, const float* bqkv, const void* qkv_trunk, const SegTable& tab, int B,
-                    int K, int max_own, int heads, float scale, void* ctx, hipStream_t st);
-extern int g_use_qkv_attn;
-extern int g_qkv_attn_dbg;  // per-image persistent branch attention (LDS-DMA ring) where the shapes allow
 // bf16 engine, shared-prefix plan (B trunk segments then B*K branch segments): returns -1 when the
 // shapes do not fit the packed-branch kernel (caller then uses launch_attention)
 int launch_attention_shared(const void* qkv, const SegTable& tab, int B, int K, int max_own, int max_keys, int heads,

@@ -203,7 +203,6 @@ int czc_generate(czc_engine* e, int B, int T, int L, int seed_len, const int32_t
  *                         times
  *   "pack_branches"   (1) attention of the branch rows with G candidates packed per 32-query MFMA tile
  *   "pool_last_layer" (1) last CLIP-text layer: out-projection + MLP on the EOS rows only
- *   "fuse_qkv_attn"   (0) branch rows: q/k/v projection and attention in one kernel (q, k, v never in HBM)
  *   "graphs"          (0) hipGraph replay of the two halves of a position-step (before / after the one size read):
  *                         0 off, 1 on, -1 = czc_generate with B <= 4 only.  Correct (replay == eager, tested) but
  *                         measured no faster at B = 1: the step is bound by its ~250 dependent small kernels, not
@@ -244,7 +243,7 @@ int czc_test_lnf_pair(int M, int K1, int N, const float* A, const float* Wo, con
  * (memory phase separate / interleaved into the MFMA stream) where eligible. */
 int czc_bench_gemm(int precision, int M, int N, int K, int act, int out_mode, int iters, int use256, double* ms_out);
 /* Process-wide kernel A/B switches for tests and tools: "gemm256" 0..3, "wreg" 0|1|2, "skinny", "splitk",
- * "mfma_attention", "attention_image" 0|1|2 (2 = force), "qkv_attn"; "*_dbg" are timing ablations (results invalid). */
+ * "mfma_attention", "attention_image" 0|1|2 (2 = force); "*_dbg" are timing ablations (results invalid). */
 int czc_test_set_option(const char* name, int value);
 int czc_option_epoch(void); /* number of czc_test_set_option calls so far (engines drop cached step graphs when it moves) */
 int czc_test_layernorm(int precision, int M, int H, const float* x, const float* gamma, const float* beta, float eps,

@@ -364,19 +364,6 @@ def test_step_parity_full_size_bf16_per_image_attention(name):
         lib.czc_test_set_option(b"attention_image", 1)
 
 
-@pytest.mark.parametrize("name", ["full_synth_b2", "full_regular"])
-def test_step_parity_full_size_bf16_fused_qkv_attention(name):
-    """Same bar (fused score within 1e-3 of the reference goldens) with the opt-in fused q/k/v projection +
-    branch attention kernel (qkv_attn.hip) serving the branch rows."""
-    meta, arr = load_case(name)
-    eng = setup_for(meta, BF16).engine
-    eng.set_option("fuse_qkv_attn", 1)
-    try:
-        teacher_forced(meta, arr, BF16, n_steps=10)
-    finally:
-        eng.set_option("fuse_qkv_attn", 0)
-
-
 @pytest.mark.parametrize("name", TINY)
 def test_generate_free_running_tiny_f32(name):
     """czc_generate (no host round trips) reproduces the reference trajectory id-for-id."""
@@ -551,32 +538,6 @@ def _packed_vs_per_segment(meta, arr):
         np.testing.assert_allclose(ra["final_score"], rb["final_score"], atol=2e-4)
 
 
-def test_fused_qkv_attention_matches_unfused():
-    """Branch rows through qkv_attn.hip (projection + attention in one kernel, q/k/v never in HBM) against the
-    two-kernel path on the same step: same bf16 roundings of q/k/v and the same attention arithmetic, so only the
-    30 trunk rows (a different GEMM kernel at M = 30) can differ, at fp32 summation-order level."""
-    meta, arr = load_case("full_synth_b2")
-    su = setup_for(meta, BF16)
-    eng = su.engine
-    eng.set_image_embeds(arr["image_embeds"])
-    hp = Engine.hyper(meta["alpha"], meta["beta"], meta["temperature"])
-    outs = []
-    for fuse in (1, 0):
-        eng.set_option("fuse_qkv_attn", fuse)
-        rows = []
-        for i in (0, 2, 5, arr["probs"].shape[0] - 1):
-            inp = np.ascontiguousarray(arr["inp_before"][i], dtype=np.int32)
-            rows.append(eng.step(inp, SEED_LEN + meta["positions"][i], meta["K"], hp,
-                                 dot_allowed=(meta["positions"][i] == meta["L"] - 1)))
-        outs.append(rows)
-    eng.set_option("fuse_qkv_attn", 0)
-    for ra, rb in zip(*outs):
-        np.testing.assert_array_equal(ra["clip_ids"], rb["clip_ids"])
-        np.testing.assert_allclose(ra["clip_ref"], rb["clip_ref"], atol=1e-3)
-        np.testing.assert_allclose(ra["final_score"], rb["final_score"], atol=2e-4)
-        assert np.isfinite(ra["final_score"]).all()
-
-
 @pytest.mark.parametrize("name,steps", [("full_synth_b2", (4, 7, 9)), ("full_shuffle_k512", (2, 9)), ("full_senti", (6, 11))])
 def test_folded_layernorm_matches_layernorm_kernel(name, steps):
     """bf16 engine: LayerNorm applied inside the GEMM epilogues (option fold_ln, applies above 2048 packed rows)
@@ -699,8 +660,8 @@ def test_minimal_shapes_k1_l1():
 
 def test_config3_shape_k512_l15_kernel_families_agree():
     """BASELINE configs[3] shape (K = 512 candidates, L = 15 -> T = 20, half-filled caption) on full-size towers:
-    the bf16 engine's three branch-attention routes (per-segment, per-(group,head), per-image persistent) and the
-    fused q/k/v + attention kernel agree with each other, and with the oracle within the 1e-3 bar."""
+    the bf16 engine's three branch-attention routes (per-segment, per-(group,head), per-image persistent) agree
+    with each other, and with the oracle within the 1e-3 bar."""
     from oracle import models as M, step as S, text as T
     su = harness.build_synthetic(False, BF16)
     lib = native.load()
@@ -720,10 +681,9 @@ def test_config3_shape_k512_l15_kernel_families_agree():
         hp = Engine.hyper(0.02, 2.0, 0.1)
         outs = {}
         for name, opts in (("per_image", dict(attention_image=2)), ("per_group", dict(attention_image=0)),
-                           ("per_segment", dict(attention_image=0, pack=0)), ("fused", dict(attention_image=2, fuse=1))):
+                           ("per_segment", dict(attention_image=0, pack=0))):
             assert lib.czc_test_set_option(b"attention_image", opts.get("attention_image", 1)) == 0
             su.engine.set_option("pack_branches", opts.get("pack", 1))
-            su.engine.set_option("fuse_qkv_attn", opts.get("fuse", 0))
             outs[name] = su.engine.step(inp.copy(), gen_idx, K, hp)
         tmask = torch.from_numpy(su.token_mask.copy())
         o.update_token_mask(tmask, L, 9)
@@ -786,7 +746,7 @@ def test_batch16_step_vs_oracle(prec):
 def test_large_batch_kernel_families_agree():
     """B = 64 images x K = 200 candidates (78 k packed CLIP rows, ~58 blocks per work-group of the weight-stationary
     GEMM, the per-image attention kernel selected by the engine itself): the exact-count vmcnt pipelines of
-    gemm_wreg / attention_image / qkv_attn against the kernels that do not rely on them, on the same step.
+    gemm_wreg / attention_image against the kernels that do not rely on them, on the same step.
     A mis-counted wait would show up here as a handful of wildly wrong rows, not as rounding noise."""
     su = harness.build_synthetic(False, BF16)
     lib = native.load()
@@ -804,11 +764,10 @@ def test_large_batch_kernel_families_agree():
         su.engine.set_image_embeds(rng.standard_normal((B, su.clip_cfg.proj)).astype(np.float32))
         hp = Engine.hyper(0.02, 2.0, 0.1)
         outs = {}
-        for name, wreg, att, fuse in (("default", 2, 1, 0), ("tiled_gemm", 0, 1, 0), ("per_group_attention", 2, 0, 0),
-                                      ("wreg_phase_separated", 1, 1, 0), ("fused_qkv_attention", 2, 1, 1)):
+        for name, wreg, att in (("default", 2, 1), ("tiled_gemm", 0, 1), ("per_group_attention", 2, 0),
+                                ("wreg_phase_separated", 1, 1)):
             assert lib.czc_test_set_option(b"wreg", wreg) == 0
             assert lib.czc_test_set_option(b"attention_image", att) == 0
-            su.engine.set_option("fuse_qkv_attn", fuse)
             outs[name] = su.engine.step(inp.copy(), gen_idx, K, hp)
         ref = outs["tiled_gemm"]
         for name, res in outs.items():
@@ -820,7 +779,7 @@ def test_large_batch_kernel_families_agree():
             np.testing.assert_allclose(res["final_score"], ref["final_score"], atol=1e-3, err_msg=name)
         # bit-reproducible from run to run
         again = su.engine.step(inp.copy(), gen_idx, K, hp)
-        np.testing.assert_array_equal(again["final_score"], outs["fused_qkv_attention"]["final_score"])
+        np.testing.assert_array_equal(again["final_score"], outs["wreg_phase_separated"]["final_score"])
     finally:
         lib.czc_test_set_option(b"wreg", 2)
         lib.czc_test_set_option(b"attention_image", 1)
