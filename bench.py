@@ -259,9 +259,11 @@ def main():
         # HBM bytes per launch come from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same
         # command (not measurable inside the run); only quoted for the workload and precision they were taken on
         traffic, src = None, None
-        tp = os.path.join(ROOT, "profiles", "r01_bench_gemm_traffic.json")
-        if prec_ == native.PREC_BF16 and os.path.exists(tp) and (B, L, K, I, a.order, a.gamma) == (256, 10, 200, 10, "sequential", None):
-            traffic, src = json.load(open(tp))["hbm_bytes_per_launch"], "profiles/r01_bench_gemm_traffic.json (rocprofv3 --pmc passes)"
+        tp = os.path.join(ROOT, "profiles", "r02_bench_gemm_traffic.json")
+        key = {native.PREC_BF16: "bf16", native.PREC_SPLIT: "split"}.get(prec_)
+        if key and os.path.exists(tp) and (B, L, K, I, a.order, a.gamma) == (256, 10, 200, 10, "sequential", None):
+            traffic = json.load(open(tp))[key]["hbm_bytes_per_launch"]
+            src = "profiles/r02_bench_gemm_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this workload)"
         kern = {native.PREC_BF16: "CLIP-text linear layers: czc::gemm_wreg_kernel<bf16> (qkv, fc1; weights in registers) + "
                                   "czc::gemm256q_kernel<bf16> (out-proj, fc2; 256x256 LDS-DMA ring)",
                 native.PREC_FP16: "CLIP-text linear layers: czc::gemm_wreg_kernel<fp16> (qkv, fc1; weights in registers) + "
