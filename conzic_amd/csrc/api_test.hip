@@ -136,7 +136,7 @@ int czc_bench_gemm(int precision, int M, int N, int K, int act, int out_mode, in
     g.ln_s = dB; g.ln_groups = 8; g.ln_eps = 1e-5f;
   }
   const int saved = g_use_gemm256, saved_wreg = g_use_wreg;
-  g_use_gemm256 = use256 >= 5 ? 3 : use256;  // 5: weight-stationary kernel where eligible
+  g_use_gemm256 = use256 >= 5 ? 3 : use256;  // 5: weight-stationary kernel where eligible; 4: loader-less 8-wave ring kernel
   g_use_wreg = use256 == 5 ? 1 : use256 == 6 ? 2 : 0;
   hipEvent_t e0, e1;
   T_HIP(hipEventCreate(&e0)); T_HIP(hipEventCreate(&e1));
@@ -206,6 +206,7 @@ int czc_test_set_option(const char* name, int value) {
   if (!strcmp(name, "gemm256s")) { g_use_gemm256s = value; return 0; }
   if (!strcmp(name, "wreg_dbg")) { g_wreg_dbg = value; return 0; }
   if (!strcmp(name, "lnf_dbg")) { g_lnf_dbg = value; return 0; }
+  if (!strcmp(name, "w_dbg")) { g_w_dbg = value; return 0; }
   if (!strcmp(name, "wreg_min_m")) { g_wreg_min_m = value; return 0; }
   if (!strcmp(name, "gemm256_min_m")) { g_gemm256_min_m = value; return 0; }
   if (!strcmp(name, "mfma_attention")) { g_use_mfma_attention = value; return 0; }

@@ -723,6 +723,138 @@ __global__ __launch_bounds__(768) void gemm256q_kernel(GemmArgs g, int tiles_m, 
 
 
 // ================================================================================================
+// gemm256w: the 4-deep ring of gemm256q WITHOUT loader waves.  Ablations of the loader-wave kernels
+// show that their inner loop cannot be software-pipelined at the 168-VGPR cap of a 12-wave work-group and tops out near
+// 1.0 PFLOP/s even with free operands.  Here the work-group is 8 waves with the full 256 registers each: every wave
+// multiplies AND lands its share of the next stages -- rows 32w .. 32w+31 of the A and of the W tile, two 1 KiB LDS-DMA
+// pieces each per stage -- three stages ahead, counted `vmcnt` for its own pieces at the top of a step, one barrier per
+// step.  The two waves of a SIMD (w, w+4) issue their pieces half a step apart (start / middle of the step), so one
+// of them always has MFMAs for the matrix pipe while the other sits in the vector-memory issue path.
+// ================================================================================================
+// DBG (timing ablations only, results are garbage): 1 no MFMA, 2 no MFMA + pieces of 8 rows x 128 B, 3 no DMA.
+template <int ACT, bool OUT_F32, bool F16 = false, int DBG = 0>
+__global__ __launch_bounds__(512) void gemm256w_kernel(GemmArgs g, int tiles_m, int tiles_n) {
+  using HT = std::conditional_t<F16, f16_t, bf16_t>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nk = g.K >> 5;  // 32-wide K steps
+  const int lda_b = g.lda * 2, ldw_b = g.ldw * 2;
+  const int my_tiles = tile_count(tiles_m, tiles_n, true);
+  const int total = my_tiles * nk;
+  const bool late = DBG == 8 ? false : wave >= 4;
+
+  // ---- DMA side: pieces ii = 0, 1 land tile rows wave*32 + ii*16 + (lane>>2); physical chunk lane&3 ----
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(
+      (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem);
+  const int rbase = wave * 32 + (lane >> 2);
+  const int cq = ((lane & 3) ^ ((lane >> 4) & 3)) << 4;
+  const int a0 = DBG == 2 ? (wave * 16 + (lane >> 3)) * lda_b + (lane & 7) * 16 : rbase * lda_b + cq;
+  const int w0 = DBG == 2 ? (wave * 16 + (lane >> 3)) * ldw_b + (lane & 7) * 16 : rbase * ldw_b + cq;
+  const int a16 = (DBG == 2 ? 8 : 16) * lda_b, w16 = (DBG == 2 ? 8 : 16) * ldw_b;
+  int cur_ti = -1;
+  u32x4_t rsA, rsW;
+  rsA.x = rsA.y = rsA.z = 0; rsA.w = 0x00020000u;
+  rsW = rsA;
+  auto issue = [&](int s) {
+    const int ti = s / nk, kt = s - ti * nk;
+    if (ti != cur_ti) {
+      cur_ti = ti;
+      int tm, tn;
+      tile_at(ti, tiles_m, tiles_n, true, tm, tn);
+      const int m0 = tm * TM, n0 = tn * TN;
+      const unsigned long long pa = (unsigned long long)g.A + (unsigned long long)m0 * lda_b;
+      const unsigned long long pw = (unsigned long long)g.W + (unsigned long long)n0 * ldw_b;
+      rsA.x = (unsigned)pa; rsA.y = (unsigned)(pa >> 32) & 0xffffu; rsA.z = (unsigned)(min(TM, g.M - m0) * lda_b);
+      rsW.x = (unsigned)pw; rsW.y = (unsigned)(pw >> 32) & 0xffffu; rsW.z = (unsigned)(min(TN, g.N - n0) * ldw_b);
+    }
+    const unsigned dstA = lds0 + (s & (QS - 1)) * QSTAGE + wave * (32 * QROWB);
+    const unsigned dstW = dstA + QA_BYTES;
+    const unsigned soA = DBG == 2 ? (kt >> 1) * 128 + (kt & 1) * 128 * lda_b : kt * QROWB;
+    const unsigned soW = DBG == 2 ? (kt >> 1) * 128 + (kt & 1) * 128 * ldw_b : kt * QROWB;
+    if (DBG == 3) return;
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %7, %9 offen lds\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %7, %9 offen lds\n\t"
+        "s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %5, %8, %10 offen lds\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %6, %8, %10 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(dstA), "s"(dstW), "v"(a0), "v"(a0 + a16), "v"(w0), "v"(w0 + w16), "s"(rsA), "s"(rsW), "s"(soA), "s"(soW)
+        : "memory", "scc");
+  };
+  for (int s = 0; s < QS - 1 && s < total; ++s) issue(s);
+
+  // ---- MFMA side: fragments run half a step ahead of the MFMAs, across the barrier ----
+  const int wm = wave >> 2, wn = wave & 3;
+  const int half = lane >> 5;
+  const int arow = wm * 128 + (lane & 31);
+  const int brow = wn * 64 + (lane & 31);
+#define CZC_RFRAG(st_, ks_, a_, b_)                                                                                      \
+  do {                                                                                                                   \
+    const unsigned char* sA_ = smem + ((st_) & (QS - 1)) * QSTAGE;                                                       \
+    const unsigned char* sB_ = sA_ + QA_BYTES;                                                                           \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) b_[j] = *(const uint4*)(sB_ + swzq(brow + 32 * j, 2 * (ks_) + half));  \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) a_[i] = *(const uint4*)(sA_ + swzq(arow + 32 * i, 2 * (ks_) + half));  \
+  } while (0)
+#define CZC_MMA8(a_, b_)                                                                                                 \
+  do {                                                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                        \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] = Half<HT>::mfma(b_[j], a_[i], acc[i][j]);                 \
+  } while (0)
+  uint4 ca[4], cb[2];  // k16 #0 of the step about to run, read during the step before
+  if (total > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (total == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();  // stage 0 published
+  asm volatile("" ::: "memory");
+  CZC_RFRAG(0, 0, ca, cb);
+  int step = 0;
+  for (int ti = 0; ti < my_tiles; ++ti) {
+    int tm, tn;
+    tile_at(ti, tiles_m, tiles_n, true, tm, tn);
+    const int m0 = tm * TM, n0 = tn * TN;
+    f32x16_t acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int kt = 0; kt < nk; ++kt, ++step) {
+      // own pieces of stage step+1 landed?  The only pieces issued after them are stage step+2's four (step+3 goes out
+      // below); epilogue traffic of a tile boundary in between only makes the count conservative.
+      if (step + 2 < total) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // publishes stage step+1; every wave has left stage step-1, whose slot is refilled now
+      asm volatile("" ::: "memory");
+      const bool refill = step + QS - 1 < total;
+      if (refill && !late) issue(step + QS - 1);
+      uint4 na[4], nb[2];
+      if (DBG != 1 && DBG != 2) CZC_RFRAG(step, 1, na, nb);
+      __builtin_amdgcn_sched_barrier(0);  // the reads stay ahead of the MFMAs that hide them
+      if (DBG == 9) __builtin_amdgcn_s_setprio(1);
+      if (DBG != 1 && DBG != 2) CZC_MMA8(ca, cb);
+      if (DBG == 9) __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (refill && late) issue(step + QS - 1);
+      if (DBG != 1 && DBG != 2) CZC_RFRAG(step + 1, 0, ca, cb);  // past the last stage: a stale slot, never multiplied
+      __builtin_amdgcn_sched_barrier(0);
+      if (DBG == 9) __builtin_amdgcn_s_setprio(1);
+      if (DBG != 1 && DBG != 2) CZC_MMA8(na, nb);
+      if (DBG == 9) __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    tile_epilogue<ACT, OUT_F32, false, HT>(g, acc, smem + QS * QSTAGE + wave * 4096, m0, n0, wm, wn, lane);
+  }
+#undef CZC_RFRAG
+#undef CZC_MMA8
+}
+
+// ================================================================================================
 // gemm256sq: gemm256q's 4-deep ring of 32 KiB stages for the SPLIT-fp16 precision.  A 64-byte tile row holds 16
 // elements ([8 hi | 8 lo] x 2 groups) = one k16 MFMA step, three fp16 passes per product: 24 MFMAs per stage and
 // wave on 12 ds_read_b128, loaders up to three stages ahead with counted vmcnt.  (gemm256s below, the two-stage
@@ -1007,7 +1139,7 @@ int g_gemm256_min_m = 2048;
 int g_gemm_krot = 0;  // bit0: rotate K order per work-group (no gain measured); bits1-2: debug (skip MFMA / skip DMA)
 
 bool gemm256_eligible(const GemmArgs& g) {
-  if (g.f16 && (g_use_gemm256 != 3 || g.row_stats || g.N % 8 || g.ldc % 8)) return false;  // fp16 operands: ring kernel only
+  if (g.f16 && (g_use_gemm256 < 3 || g.row_stats || g.N % 8 || g.ldc % 8)) return false;  // fp16 operands: ring kernels only
   return g.M >= g_gemm256_min_m && g.N % 4 == 0 && g.K % 64 == 0 && g.ldc % 4 == 0 && (!g.resid || g.ldr % 4 == 0) &&
          (g.act == ACT_NONE || g.act == ACT_QUICK_GELU) && (long)256 * g.lda * 2 < (1L << 31) &&
          (long)256 * g.ldw * 2 < (1L << 31);
@@ -1045,11 +1177,42 @@ int launch_gemm256(const GemmArgs& g, hipStream_t st) {
     const int nt = (g_gemm_krot & 32) ? tiles_m : tiles_m * tiles_n;  // work units: tiles, or M tiles for the M-major walk
     dim3 grid(nt < n_cu ? nt : n_cu), block(768);
     const bool f32 = g.out_f32 != nullptr || g.resid != nullptr;
-    if (g.row_stats && !(g_use_gemm256 == 3 && f32 && g.act == ACT_NONE && g.N % 64 == 0)) {
+    if (g.row_stats && !(g_use_gemm256 >= 3 && f32 && g.act == ACT_NONE && g.N % 64 == 0)) {
       snprintf(g_err, sizeof(g_err), "gemm256: row_stats needs the fp32-output ring kernel, no activation, N %% 64 == 0");
       return 1;
     }
-    if (g_use_gemm256 == 3) {
+    if (g_use_gemm256 == 4 && !g.row_stats && g_w_dbg && f32 && g.act == ACT_NONE && !g.f16) {
+      dim3 gq(tiles_m * tiles_n < n_cu ? tiles_m * tiles_n : n_cu), bw(512);
+#define CZC_GOWD(D_)                                                                                                     \
+  do {                                                                                                                   \
+    CZC_HIP_CHECK(hipFuncSetAttribute((const void*)gemm256w_kernel<ACT_NONE, true, false, D_>, hipFuncAttributeMaxDynamicSharedMemorySize, shp)); \
+    hipLaunchKernelGGL((gemm256w_kernel<ACT_NONE, true, false, D_>), gq, bw, shp, st, g, tiles_m, tiles_n);             \
+  } while (0)
+      if (g_w_dbg == 1) CZC_GOWD(1); else if (g_w_dbg == 2) CZC_GOWD(2); else if (g_w_dbg == 3) CZC_GOWD(3);
+      else if (g_w_dbg == 8) CZC_GOWD(8); else CZC_GOWD(9);
+#undef CZC_GOWD
+      CZC_HIP_CHECK(hipGetLastError());
+      return 0;
+    }
+    if (g_use_gemm256 == 4 && !g.row_stats) {
+      dim3 gq(tiles_m * tiles_n < n_cu ? tiles_m * tiles_n : n_cu), bw(512);
+#define CZC_GOW(A_, F_, H_)                                                                                              \
+  do {                                                                                                                   \
+    CZC_HIP_CHECK(hipFuncSetAttribute((const void*)gemm256w_kernel<A_, F_, H_>, hipFuncAttributeMaxDynamicSharedMemorySize, shp)); \
+    hipLaunchKernelGGL((gemm256w_kernel<A_, F_, H_>), gq, bw, shp, st, g, tiles_m, tiles_n);                            \
+  } while (0)
+      if (g.f16) {
+        if (g.act == ACT_QUICK_GELU) { if (f32) CZC_GOW(ACT_QUICK_GELU, true, true); else CZC_GOW(ACT_QUICK_GELU, false, true); }
+        else { if (f32) CZC_GOW(ACT_NONE, true, true); else CZC_GOW(ACT_NONE, false, true); }
+      } else {
+        if (g.act == ACT_QUICK_GELU) { if (f32) CZC_GOW(ACT_QUICK_GELU, true, false); else CZC_GOW(ACT_QUICK_GELU, false, false); }
+        else { if (f32) CZC_GOW(ACT_NONE, true, false); else CZC_GOW(ACT_NONE, false, false); }
+      }
+#undef CZC_GOW
+      CZC_HIP_CHECK(hipGetLastError());
+      return 0;
+    }
+    if (g_use_gemm256 >= 3) {
       dim3 gq(tiles_m * tiles_n < n_cu ? tiles_m * tiles_n : n_cu);
       if (g.row_stats) {
         hipLaunchKernelGGL((gemm256q_kernel<ACT_NONE, true, true>), gq, block, shp, st, g, tiles_m, tiles_n);
@@ -1092,6 +1255,7 @@ int launch_gemm256(const GemmArgs& g, hipStream_t st) {
   return 0;
 }
 
+int g_w_dbg = 0;  // timing ablations of gemm256w (test option w_dbg)
 int g_use_gemm256s = 1;  // 1: four-stage ring (gemm256sq), 2: two-stage form (gemm256s), 0: 128x128 kernel
 
 // split-fp16 operands; big-M layers only (BERT at a few thousand rows stays on the 128x128 + split-K path)

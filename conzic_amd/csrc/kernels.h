@@ -38,6 +38,7 @@ extern int g_use_gemm256;
 bool gemm256s_eligible(const GemmArgs& g);  // split-fp16 operands, same 256x256 persistent structure
 int launch_gemm256s(const GemmArgs& g, hipStream_t st);
 extern int g_use_gemm256s;
+extern int g_w_dbg;
 extern int g_gemm_krot;
 extern int g_use_skinny;
 extern int g_use_splitk;

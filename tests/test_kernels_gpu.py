@@ -234,7 +234,7 @@ def test_combine_first_argmax_on_ties():
     assert best[0] == 0 and np.allclose(fs, fs[0, 0])
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4])
 @pytest.mark.parametrize("M,N,K,act,resid", [(2048, 512, 512, 0, True), (3000, 1536, 512, 0, False),
                                              (5000, 2048, 512, 1, False), (2500, 512, 2048, 0, True),
                                              (2304, 320, 192, 1, True), (70000, 512, 512, 0, True)])

@@ -1,0 +1,24 @@
+"""Interleaved A/B of GEMM kernel variants on one shape (run-to-run noise on a box is several per cent: alternate the
+arms and compare medians).  usage: ab_gemm.py M N K act out_mode arm[,arm...] [rounds]; arm = use256[:w_dbg]"""
+import ctypes as C
+import statistics
+import sys
+
+sys.path.insert(0, __file__.rsplit('/', 2)[0])
+from conzic_amd import native  # noqa: E402
+
+lib = native.load()
+M, N, K, act, mode = (int(v) for v in sys.argv[1:6])
+arms = [tuple(int(x) for x in (a + ':0').split(':')[:2]) for a in sys.argv[6].split(',')]
+rounds = int(sys.argv[7]) if len(sys.argv) > 7 else 12
+t = {a: [] for a in arms}
+for r in range(rounds):
+    for a in (arms if r % 2 == 0 else arms[::-1]):
+        ms = C.c_double()
+        lib.czc_test_set_option(b'w_dbg', a[1])
+        native.check(lib.czc_bench_gemm(0, M, N, K, act, mode, 5, a[0], C.byref(ms)), None, "bench")
+        t[a].append(ms.value)
+for a in arms:
+    med = statistics.median(t[a])
+    print(f"M={M} N={N} K={K} use256={a[0]} w_dbg={a[1]}: median {med:.4f} ms  min {min(t[a]):.4f}  max {max(t[a]):.4f}  "
+          f"{2.0 * M * N * K / (med * 1e-3) / 1e12:.1f} TF/s", flush=True)

@@ -14,6 +14,8 @@ if len(sys.argv) > 3:
     lib.czc_test_set_option(b"wreg_dbg", int(sys.argv[3]))
 if os.environ.get('CZC_LNF_DBG'):
     lib.czc_test_set_option(b'lnf_dbg', int(os.environ['CZC_LNF_DBG']))
+if 'CZC_W_DBG' in os.environ:
+    lib.czc_test_set_option(b'w_dbg', int(os.environ['CZC_W_DBG']))
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 768000
 shapes = [("qkv", 1536, 512, 0, 0), ("out", 512, 512, 0, 1), ("fc1", 2048, 512, 1, 0), ("fc2", 512, 2048, 0, 1)]
 PREC = int(os.environ.get('CZC_GEMM_PREC', '0'))  # 0 bf16, 1 f32, 3 split-fp16 (use CZC_GEMM_VARIANTS=0)
