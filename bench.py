@@ -220,13 +220,14 @@ def main():
             # batch invariance: images 0-1 polished alone (B = 2) by the same engine must come out as they did inside
             # the batch of B (per-image work is independent: gen_utils.py:65-81 has no cross-image term).  The kernel
             # families the engine picks by row count for the big batch (per-image branch attention, weight-stationary
-            # and 256x256 GEMMs) are forced for the pair too: bf16 results depend on the fp32 summation order, and a
+            # 256x256 and full-row GEMMs) are forced for the pair too: bf16 results depend on the fp32 summation order, and a
             # near-tie winner that flips once changes the rest of that image's trajectory.  What can still differ:
             # split-K of the BERT layers (fp32-class).
             lib = native.load()
             lib.czc_test_set_option(b"attention_image", 2)
             lib.czc_test_set_option(b"wreg_min_m", 1)
             lib.czc_test_set_option(b"gemm256_min_m", 1)
+            lib.czc_test_set_option(b"rowln_min_m", 1)
             try:
                 eng.encode_images(pixels[:2])
                 ids2, cos2 = eng.generate(2, init, L, seed_len, K, pos, hp, n_mask=nm, snapshot_every=every)
@@ -234,6 +235,7 @@ def main():
                 lib.czc_test_set_option(b"attention_image", 1)
                 lib.czc_test_set_option(b"wreg_min_m", 2048)
                 lib.czc_test_set_option(b"gemm256_min_m", 2048)
+                lib.czc_test_set_option(b"rowln_min_m", 4096)
             same = (ids2 == ids[:, :2]).mean(axis=(0, 2))
             res["invariance"] = dict(images=2, batch=B, identical_token_frac=[round(float(x), 4) for x in same],
                                      final_ids_identical=[bool((ids2[-1, j] == ids[-1, j]).all()) for j in range(2)],
@@ -264,10 +266,14 @@ def main():
         if key and os.path.exists(tp) and (B, L, K, I, a.order, a.gamma) == (256, 10, 200, 10, "sequential", None):
             traffic = json.load(open(tp))[key]["hbm_bytes_per_launch"]
             src = "profiles/r02_bench_gemm_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this workload)"
-        kern = {native.PREC_BF16: "CLIP-text linear layers: czc::gemm_wreg_kernel<bf16> (qkv, fc1; weights in registers) + "
-                                  "czc::gemm256q_kernel<bf16> (out-proj, fc2; 256x256 LDS-DMA ring)",
-                native.PREC_FP16: "CLIP-text linear layers: czc::gemm_wreg_kernel<fp16> (qkv, fc1; weights in registers) + "
-                                  "czc::gemm256q_kernel<fp16> (out-proj, fc2; 256x256 LDS-DMA ring)",
+        fused = not any(kv.replace(" ", "") == "fuse_ln=0" for kv in a.opt)
+        half = ("CLIP-text linear layers: czc::gemm_wreg_kernel<%s> (qkv, fc1; weights in registers) + "
+                + ("czc::gemm_rowln_kernel<%s> (out-proj on full 512-wide rows; its launches also do the LayerNorm that follows -- "
+                   "without that fusion the same family measures frac 0.344 and 1.3 %% fewer captions/s, profiles/r02_fuse_ln_ab.json) + "
+                   "czc::gemm256q_kernel<%s> (fc2; 256x256 LDS-DMA ring)" if fused else
+                   "czc::gemm256q_kernel<%s> (out-proj, fc2; 256x256 LDS-DMA ring)"))
+        kern = {native.PREC_BF16: half % (("bf16",) * (3 if fused else 2)),
+                native.PREC_FP16: half % (("fp16",) * (3 if fused else 2)),
                 native.PREC_SPLIT: "CLIP-text linear layers: czc::gemm_kernel<split_t> (three v_mfma_f32_32x32x16_f16 per product)",
                 native.PREC_F32: "CLIP-text linear layers: czc::gemm_kernel<float> (v_mfma_f32_32x32x2_f32)"}[prec_]
         return dict(bound="mfma", kernel=kern, achieved=round(ach, 1), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),

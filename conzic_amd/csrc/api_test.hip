@@ -129,6 +129,10 @@ int czc_bench_gemm(int precision, int M, int N, int K, int act, int out_mode, in
     g.row_stats = (float*)pool.alloc((size_t)M * (N / 64) * 8); T_PTR(g.row_stats);
     g.ln_groups = g_lnf_dbg;  // timing ablations of the producer epilogue: 1 no statistics store, 2 no bf16 copy, 4 no statistics
   }
+  if (out_mode == 4 || out_mode == 5) {  // 4: full-row kernel with the LayerNorm in its epilogue; 5: the pair it replaces
+    g.out_act = pool.alloc((size_t)M * N * 2); T_PTR(g.out_act);
+    g.ln_gamma = dB; g.ln_beta = dB; g.ln_eps = 1e-5f; g.f16 = precision == PREC_F16;
+  }
   if (out_mode == 3) {
     std::vector<float> st((size_t)M * 16);
     for (size_t i = 0; i < st.size(); i += 2) { st[i] = 0.f; st[i + 1] = 64.f; }  // mean 0, variance 1
@@ -140,10 +144,20 @@ int czc_bench_gemm(int precision, int M, int N, int K, int act, int out_mode, in
   g_use_wreg = use256 == 5 ? 1 : use256 == 6 ? 2 : 0;
   hipEvent_t e0, e1;
   T_HIP(hipEventCreate(&e0)); T_HIP(hipEventCreate(&e1));
-  for (int i = 0; i < 2; ++i) T_CHECK(launch_gemm(precision, g, nullptr));
+  auto run = [&]() -> int {
+    if (out_mode == 4) return launch_gemm_rowln(g, nullptr);
+    if (out_mode == 5) {
+      GemmArgs p = g;
+      p.out_act = nullptr; p.ln_gamma = p.ln_beta = nullptr;
+      T_CHECK(launch_gemm(precision, p, nullptr));
+      return launch_layernorm(precision, g.out_f32, nullptr, g.ln_gamma, g.ln_beta, g.ln_eps, M, N, g.out_act, nullptr, nullptr);
+    }
+    return launch_gemm(precision, g, nullptr);
+  };
+  for (int i = 0; i < 2; ++i) T_CHECK(run());
   T_HIP(hipDeviceSynchronize());
   T_HIP(hipEventRecord(e0, nullptr));
-  for (int i = 0; i < iters; ++i) T_CHECK(launch_gemm(precision, g, nullptr));
+  for (int i = 0; i < iters; ++i) T_CHECK(run());
   T_HIP(hipEventRecord(e1, nullptr));
   T_HIP(hipEventSynchronize(e1));
   float ms = 0;
@@ -153,6 +167,34 @@ int czc_bench_gemm(int precision, int M, int N, int K, int act, int out_mode, in
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   *ms_out = ms / iters;
   return 0;
+}
+
+// Full-row GEMM with the LayerNorm in its epilogue (gemm_rowln_kernel; bf16 or fp16 operands, N = 512):
+//   x_out = resid + A[M,K].W[512,K]^T + bias;  y_out = LayerNorm(x_out; gamma, beta, eps) rounded to the operand type
+int czc_test_gemm_rowln(int precision, int M, int K, const float* A, const float* W, const float* bias, const float* resid,
+                        const float* gamma, const float* beta, float eps, float* x_out, float* y_out) {
+  const int H = 512;
+  if (precision != PREC_BF16 && precision != PREC_F16) { snprintf(czc::g_err, sizeof(czc::g_err), "gemm_rowln: bf16 / fp16 only"); return CZC_ERR_ARG; }
+  DevPool pool;
+  void* dA = up_act(pool, precision, A, (size_t)M * K); T_PTR(dA);
+  void* dW = up_act(pool, precision, W, (size_t)H * K); T_PTR(dW);
+  float* dB = bias ? (float*)pool.up(bias, (size_t)H * 4) : nullptr;
+  float* dx = (float*)pool.up(resid, (size_t)M * H * 4); T_PTR(dx);
+  float* dg = (float*)pool.up(gamma, (size_t)H * 4); T_PTR(dg);
+  float* dbt = (float*)pool.up(beta, (size_t)H * 4); T_PTR(dbt);
+  void* dy = pool.alloc((size_t)M * H * 2); T_PTR(dy);
+  GemmArgs g;
+  g.A = dA; g.lda = K; g.W = dW; g.ldw = K; g.bias = dB; g.resid = dx; g.ldr = H; g.out_act = dy; g.out_f32 = dx;
+  g.ldc = H; g.M = M; g.N = H; g.K = K; g.act = ACT_NONE; g.f16 = precision == PREC_F16;
+  g.ln_gamma = dg; g.ln_beta = dbt; g.ln_eps = eps;
+  const int saved = g_rowln_min_m;
+  g_rowln_min_m = 1;
+  const int rc = launch_gemm_rowln(g, nullptr);
+  g_rowln_min_m = saved;
+  T_CHECK(rc);
+  T_HIP(hipDeviceSynchronize());
+  T_HIP(hipMemcpy(x_out, dx, (size_t)M * H * 4, hipMemcpyDeviceToHost));
+  return down_act(pool, precision, dy, (size_t)M * H, y_out);
 }
 
 // Folded-LayerNorm GEMM pair on host data (bf16 engine kernels, hidden = K2 = 512):
@@ -207,6 +249,7 @@ int czc_test_set_option(const char* name, int value) {
   if (!strcmp(name, "wreg_dbg")) { g_wreg_dbg = value; return 0; }
   if (!strcmp(name, "lnf_dbg")) { g_lnf_dbg = value; return 0; }
   if (!strcmp(name, "w_dbg")) { g_w_dbg = value; return 0; }
+  if (!strcmp(name, "rowln_min_m")) { g_rowln_min_m = value; return 0; }
   if (!strcmp(name, "wreg_min_m")) { g_wreg_min_m = value; return 0; }
   if (!strcmp(name, "gemm256_min_m")) { g_gemm256_min_m = value; return 0; }
   if (!strcmp(name, "mfma_attention")) { g_use_mfma_attention = value; return 0; }

@@ -84,6 +84,9 @@ struct czc_engine {
   float* d_staged = nullptr; int staged_cap = 0, staged_n = 0;  // czc_preprocess_u8 output slots [cap][3][S][S]
   int pack_branches = 1; // pack several candidates' rows into one attention MFMA tile
   int pool_last_layer = 1; // last CLIP-text layer: out-proj + MLP on the EOS rows only
+  int fuse_ln = 1;         // bf16 / fp16 CLIP-text tower: 1 = out-proj as a full-row kernel with LN2 in its epilogue
+                           // (gemm_rowln_kernel; +1 % captions/s), 2 = fc2 -> next layer's LN1 as well (measured slower: the
+                           // K = 2048 GEMM pays more for 128-row tiles than the LayerNorm pass costs), 0 = off
   int fold_ln = 0;         // bf16 CLIP-text tower: LayerNorm applied inside the GEMM epilogues (no LayerNorm pass over HBM);
                            // measured slower than the LayerNorm kernel while out-proj / fc2 pay for the bf16 copy
 
@@ -300,6 +303,9 @@ int clip_stack(czc_engine* e, const char* gk, std::vector<LayerW>& L, float* x, 
   // Layer 0's LN1 (input = embeddings) and everything on pooled rows still run the LayerNorm kernel.
   const bool fold = P == PREC_BF16 && e->fold_ln && H == 512 && M >= 2048 && !L.empty() && L[0].qkv_wf &&
                     g_use_wreg == 2 && g_use_gemm256 == 3;
+  // LayerNorm fused into the producer: out-proj (fuse_ln >= 1) and fc2 (fuse_ln >= 2) run on full 512-wide rows and
+  // leave y = LN(x) beside the new fp32 x; the LayerNorm kernel then only runs where no such producer exists.
+  const bool rowln = !fold && prec_is_half(P) && e->fuse_ln && H == 512 && M >= g_rowln_min_m && I % 32 == 0;
   float* stats = nullptr;
   if (fold) E_CHECK(ensure(e, "cs_stats", (size_t)M * (H / 64) * 2 * 4, (void**)&stats));
   bool have_stats = false;
@@ -318,9 +324,20 @@ int clip_stack(czc_engine* e, const char* gk, std::vector<LayerW>& L, float* x, 
     g.row_stats = fold ? stats : nullptr;
     return gemm_ex(e, P, gk, g);
   };
+  auto resid_ln_gemm = [&](const void* A, int lda, const void* W, const float* b, int K, const float* gm,
+                           const float* bt) -> int {  // x += A.W^T + b; y = LN(x; gm, bt)
+    GemmArgs g;
+    g.A = A; g.lda = lda; g.W = W; g.ldw = K; g.bias = b; g.resid = x; g.ldr = H; g.out_act = y; g.out_f32 = x;
+    g.ldc = H; g.M = M; g.N = H; g.K = K; g.act = ACT_NONE; g.f16 = P == PREC_F16;
+    g.ln_gamma = gm; g.ln_beta = bt; g.ln_eps = eps;
+    ProfScope ps(e, gk, 2.0 * M * (double)H * K);
+    E_CHECK(launch_gemm_rowln(g, e->st));
+    return 0;
+  };
+  bool have_y = false;  // y already holds this layer's LN1 output (left by the previous layer's fc2)
   for (size_t n = 0; n < L.size(); ++n) {
     LayerW& l = L[n];
-    if (!(fold && have_stats)) {
+    if (!(fold && have_stats) && !have_y) {
       ProfScope ps(e, "rowops", 0);
       E_CHECK(launch_layernorm(P, x, nullptr, l.ln1_g, l.ln1_b, eps, M, H, y, nullptr, e->st));
     }
@@ -351,14 +368,17 @@ int clip_stack(czc_engine* e, const char* gk, std::vector<LayerW>& L, float* x, 
       *pooled = x_e;
       return 0;
     }
-    E_CHECK(resid_gemm(ctx, H, l.o_w, l.o_b, H));
+    if (rowln) E_CHECK(resid_ln_gemm(ctx, H, l.o_w, l.o_b, H, l.ln2_g, l.ln2_b));
+    else E_CHECK(resid_gemm(ctx, H, l.o_w, l.o_b, H));
     if (fold) {
       E_CHECK(lnf_gemm(l.fc1_wf, l.fc1_bf, l.fc1_sf, hbuf, I, ACT_QUICK_GELU));
     } else {
-      { ProfScope ps(e, "rowops", 0); E_CHECK(launch_layernorm(P, x, nullptr, l.ln2_g, l.ln2_b, eps, M, H, y, nullptr, e->st)); }
+      if (!rowln) { ProfScope ps(e, "rowops", 0); E_CHECK(launch_layernorm(P, x, nullptr, l.ln2_g, l.ln2_b, eps, M, H, y, nullptr, e->st)); }
       E_CHECK(gemm(e, P, gk, y, H, l.fc1_w, H, l.fc1_b, nullptr, 0, hbuf, nullptr, I, M, I, H, ACT_QUICK_GELU));
     }
-    E_CHECK(resid_gemm(hbuf, I, l.fc2_w, l.fc2_b, I));
+    have_y = rowln && e->fuse_ln >= 2 && n + 1 < L.size();
+    if (have_y) E_CHECK(resid_ln_gemm(hbuf, I, l.fc2_w, l.fc2_b, I, L[n + 1].ln1_g, L[n + 1].ln1_b));
+    else E_CHECK(resid_gemm(hbuf, I, l.fc2_w, l.fc2_b, I));
     have_stats = fold;
   }
   return 0;
@@ -644,7 +664,7 @@ int step_device(czc_engine* e, int* d_inp, int B, int T, int gen_idx, int n_mask
   auto fbits = [](float f) { int i; memcpy(&i, &f, 4); return i; };
   std::vector<int> key = {0, B, T, gen_idx, n_mask, dot_allowed, K, fbits(hp->alpha), fbits(hp->beta), fbits(hp->gamma),
                           fbits(hp->temperature), hp->control, hp->negative, e->share_prefix, e->pack_branches,
-                          e->pool_last_layer, e->fold_ln, (int)(((uintptr_t)d_inp) >> 4)};
+                          e->pool_last_layer, e->fold_ln, e->fuse_ln, (int)(((uintptr_t)d_inp) >> 4)};
   E_CHECK(run_phase(e, key, [&]() { return step_phase_a(e, a); }));
   if (n_mask > 0) { e->stat_bert_rows += B * T; e->last_BT = B * T; }
   E_HIP(hipStreamSynchronize(e->st));  // the one host round trip per step (the reference has one too, gen_utils.py:81)
@@ -1107,6 +1127,7 @@ int czc_set_option(czc_engine* e, const char* name, int value) {
   if (!strcmp(name, "pack_branches")) { e->pack_branches = value ? 1 : 0; return CZC_OK; }
   if (!strcmp(name, "pool_last_layer")) { e->pool_last_layer = value ? 1 : 0; return CZC_OK; }
   if (!strcmp(name, "fold_ln")) { e->fold_ln = value ? 1 : 0; return CZC_OK; }
+  if (!strcmp(name, "fuse_ln")) { e->fuse_ln = value; return CZC_OK; }  // 0 off, 1 out-proj -> LN2, 2 also fc2 -> next LN1
   if (!strcmp(name, "graphs")) { e->use_graphs = value; invalidate_graphs(e); return CZC_OK; }
   return fail(e, CZC_ERR_ARG, "unknown option %s", name);
 }

@@ -1133,10 +1133,296 @@ __global__ __launch_bounds__(768) void gemm256s_kernel(GemmArgs g, int tiles_m, 
   }
 }
 
+// ================================================================================================
+// gemm_rowln: x <- x + A.W^T + b over FULL 512-wide rows, with the LayerNorm that follows it in the pre-LN block
+// finished in the epilogue (HF:clip/modeling_clip.py:368-383: out-proj -> LN2 -> fc1, fc2 -> next layer's LN1).
+// A 128 x 512 tile per work-group: 8 waves, wave w owns columns 64w .. 64w+63 of all 128 rows (the per-wave 128 x 64
+// block of the 256 x 256 kernels), lands W rows 64w .. 64w+63 (which only it reads) and 16 of the 128 A rows.  Two
+// LDS rings -- A 4 x 8 KiB, W 3 x 32 KiB -- plus the eight 4 KiB epilogue patches fill the 160 KiB.  Per step a wave
+// issues A(step+3) then W(step+2) x 4, so `vmcnt(5)` at the top of a step says its W(step) pieces (and the older
+// A(step)) have landed.  The epilogue writes the fp32 row AND keeps it in the registers the accumulators leave, takes
+// the exact two-pass statistics of layernorm_kernel (mean, then centred squares) through two 512-byte exchanges in
+// the patches, and stores y = LN(x) in the activation type: the LayerNorm kernel and its 2 KiB-per-row read go away.
+// ================================================================================================
+constexpr int RL_TM = 128, RL_N = 512;
+constexpr int RL_AS = 4, RL_WS = 3;
+constexpr int RL_A_BYTES = RL_TM * QROWB;  // 8 KiB
+constexpr int RL_W_BYTES = RL_N * QROWB;   // 32 KiB
+constexpr int RL_W_BASE = RL_AS * RL_A_BYTES;
+constexpr int RL_PATCH = RL_W_BASE + RL_WS * RL_W_BYTES;
+constexpr int RL_LDS = RL_PATCH + 8 * 4096;  // 160 KiB
+
+template <bool F16>
+__global__ __launch_bounds__(512) void gemm_rowln_kernel(GemmArgs g, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, int tiles_m) {
+  using HT = std::conditional_t<F16, f16_t, bf16_t>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nk = g.K >> 5;
+  const int lda_b = g.lda * 2, ldw_b = g.ldw * 2;
+  const int my_tiles = (tiles_m - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int total = my_tiles * nk;
+  const bool late = wave >= 4;
+
+  // ---- DMA side ----
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(
+      (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem);
+  const int cq = ((lane & 3) ^ ((lane >> 4) & 3)) << 4;
+  const int a0 = (wave * 16 + (lane >> 2)) * lda_b + cq;
+  const int w0 = (wave * 64 + (lane >> 2)) * ldw_b + cq;
+  const int w16 = 16 * ldw_b;
+  u32x4_t rsA, rsW;
+  rsA.x = rsA.y = rsA.z = 0; rsA.w = 0x00020000u;
+  {
+    const unsigned long long pw = (unsigned long long)g.W;
+    rsW.x = (unsigned)pw; rsW.y = (unsigned)(pw >> 32) & 0xffffu; rsW.z = (unsigned)(RL_N * ldw_b); rsW.w = 0x00020000u;
+  }
+  int a_ti = -1;
+  auto issueA = [&](int s) {
+    const int ti = s / nk, kt = s - ti * nk;
+    if (ti != a_ti) {
+      a_ti = ti;
+      const int m0 = ((int)blockIdx.x + ti * (int)gridDim.x) * RL_TM;
+      const unsigned long long pa = (unsigned long long)g.A + (unsigned long long)m0 * lda_b;
+      rsA.x = (unsigned)pa; rsA.y = (unsigned)(pa >> 32) & 0xffffu; rsA.z = (unsigned)(min(RL_TM, g.M - m0) * lda_b);
+    }
+    const unsigned dst = lds0 + (s & (RL_AS - 1)) * RL_A_BYTES + wave * (16 * QROWB);
+    const unsigned so = kt * QROWB;
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(dst), "v"(a0), "s"(rsA), "s"(so)
+        : "memory", "scc");
+  };
+  auto issueW = [&](int s, int slot) {
+    const int kt = s % nk;
+    const unsigned dst = lds0 + RL_W_BASE + slot * RL_W_BYTES + wave * (64 * QROWB);
+    const unsigned so = kt * QROWB;
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %6, %7 offen lds\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %6, %7 offen lds\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %6, %7 offen lds\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %5, %6, %7 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(dst), "v"(w0), "v"(w0 + w16), "v"(w0 + 2 * w16), "v"(w0 + 3 * w16), "s"(rsW), "s"(so)
+        : "memory", "scc");
+  };
+  // virtual steps -3, -2, -1 of the steady-state order: A0 | A1 W0 | A2 W1
+  if (0 < total) issueA(0);
+  if (1 < total) issueA(1);
+  if (0 < total) issueW(0, 0);
+  if (2 < total) issueA(2);
+  if (1 < total) issueW(1, 1);
+
+  // ---- MFMA side ----
+  const int half = lane >> 5, l31 = lane & 31;
+  const int brow = wave * 64 + l31;
+  const int rrow = lane >> 3, rslot = lane & 7;
+  unsigned char* patch = smem + RL_PATCH + wave * 4096;
+  int step = 0, wslot = 0;  // wslot = step % 3
+  for (int ti = 0; ti < my_tiles; ++ti) {
+    const int m0 = ((int)blockIdx.x + ti * (int)gridDim.x) * RL_TM;
+    f32x16_t acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int kt = 0; kt < nk; ++kt, ++step) {
+      if (step + 2 < total) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else if (step + 1 < total) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // publishes A(step); every wave has left step-1, whose two slots are refilled now
+      asm volatile("" ::: "memory");
+      const int wnext = wslot == 0 ? 2 : wslot - 1;  // (step + 2) % 3
+      if (!late) {
+        if (step + 3 < total) issueA(step + 3);
+        if (step + 2 < total) issueW(step + 2, wnext);
+      }
+      const unsigned char* sA = smem + (step & (RL_AS - 1)) * RL_A_BYTES;
+      const unsigned char* sB = smem + RL_W_BASE + wslot * RL_W_BYTES;
+      uint4 b0[2], a0f[4], b1[2], a1f[4];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b0[j] = *(const uint4*)(sB + swzq(brow + 32 * j, half));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a0f[i] = *(const uint4*)(sA + swzq(l31 + 32 * i, half));
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b1[j] = *(const uint4*)(sB + swzq(brow + 32 * j, 2 + half));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a1f[i] = *(const uint4*)(sA + swzq(l31 + 32 * i, 2 + half));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = Half<HT>::mfma(b0[j], a0f[i], acc[i][j]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (late) {
+        if (step + 3 < total) issueA(step + 3);
+        if (step + 2 < total) issueW(step + 2, wnext);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = Half<HT>::mfma(b1[j], a1f[i], acc[i][j]);
+      wslot = wslot == 2 ? 0 : wslot + 1;
+    }
+
+    // ---- epilogue: x (fp32) out, exact LayerNorm statistics across the eight waves, y out ----
+    float4 vx[4][2][4];  // [i][j][pass]: row i*32 + pass*8 + rrow, columns wave*64 + j*32 + rslot*4 .. +3
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = wave * 64 + j * 32 + rslot * 4;
+        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g.bias) b4 = *(const float4*)(g.bias + col);
+        float4 r4[4];
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+          const int row = m0 + i * 32 + pass * 8 + rrow;
+          r4[pass] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (g.resid && row < g.M) r4[pass] = *(const float4*)(g.resid + (long)row * g.ldr + col);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int slot = (2 * q + half) ^ (l31 & 7);
+          *(float4*)(patch + l31 * 128 + slot * 16) =
+              make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+        }
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+          const int r = pass * 8 + rrow;
+          float4 v = *(const float4*)(patch + r * 128 + ((rslot ^ (r & 7)) << 4));
+          const int row = m0 + i * 32 + r;
+          v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+          v.x += r4[pass].x; v.y += r4[pass].y; v.z += r4[pass].z; v.w += r4[pass].w;
+          if (row < g.M && g.out_f32) *(float4*)(g.out_f32 + (long)row * g.ldc + col) = v;
+          vx[i][j][pass] = v;
+        }
+      }
+    }
+    // mean: this wave's 64-column partial per row -> its patch [0, 512); then every row group sums the eight partials
+    float mean[4][4], rstd[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        const float4 u = vx[i][0][pass], w = vx[i][1][pass];
+        const float s8 = sum8_dpp(((u.x + u.y) + (u.z + u.w)) + ((w.x + w.y) + (w.z + w.w)));
+        if (rslot == 0) *(float*)(patch + (i * 32 + pass * 8 + rrow) * 4) = s8;
+      }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        const float t = *(const float*)(smem + RL_PATCH + rslot * 4096 + (i * 32 + pass * 8 + rrow) * 4);
+        mean[i][pass] = sum8_dpp(t) / (float)RL_N;
+      }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        const float mu = mean[i][pass];
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const float4 u = vx[i][j][pass];
+          const float a = u.x - mu, b = u.y - mu, c = u.z - mu, d = u.w - mu;
+          q += (a * a + b * b) + (c * c + d * d);
+        }
+        const float q8 = sum8_dpp(q);
+        if (rslot == 0) *(float*)(patch + 512 + (i * 32 + pass * 8 + rrow) * 4) = q8;
+      }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        const float t = *(const float*)(smem + RL_PATCH + rslot * 4096 + 512 + (i * 32 + pass * 8 + rrow) * 4);
+        rstd[i][pass] = rsqrtf(sum8_dpp(t) / (float)RL_N + g.ln_eps);
+      }
+    HT* oa = (HT*)g.out_act;
+    const bool odd = rslot & 1;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = wave * 64 + j * 32 + rslot * 4;
+      const float4 gm = *(const float4*)(gamma + col);
+      const float4 bt = *(const float4*)(beta + col);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        uint2 pk[4];
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+          const float4 u = vx[i][j][pass];
+          const float mu = mean[i][pass], rs = rstd[i][pass];
+          pk[pass] = make_uint2(Half<HT>::pack2((u.x - mu) * rs * gm.x + bt.x, (u.y - mu) * rs * gm.y + bt.y),
+                                Half<HT>::pack2((u.z - mu) * rs * gm.z + bt.z, (u.w - mu) * rs * gm.w + bt.w));
+        }
+        // 16-byte stores: lanes rslot, rslot^1 hold adjacent 4-column pieces of the same rows; the even lane ends
+        // up with 8 columns of the first pass's row of a pair, the odd lane with 8 columns of the second's
+#pragma unroll
+        for (int pp = 0; pp < 4; pp += 2) {
+          const uint2 send = odd ? pk[pp] : pk[pp + 1];
+          uint2 recv;
+          recv.x = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send.x, 0xB1, 0xf, 0xf, true);
+          recv.y = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send.y, 0xB1, 0xf, 0xf, true);
+          const uint4 d = odd ? make_uint4(recv.x, recv.y, pk[pp + 1].x, pk[pp + 1].y)
+                              : make_uint4(pk[pp].x, pk[pp].y, recv.x, recv.y);
+          const int row = m0 + i * 32 + (pp + (odd ? 1 : 0)) * 8 + rrow;
+          const int c8 = wave * 64 + j * 32 + (rslot & 6) * 4;
+          if (row < g.M) *(uint4*)(oa + (long)row * RL_N + c8) = d;
+        }
+      }
+    }
+  }
+}
+
 }  // namespace
 
 int g_gemm256_min_m = 2048;
 int g_gemm_krot = 0;  // bit0: rotate K order per work-group (no gain measured); bits1-2: debug (skip MFMA / skip DMA)
+
+// x <- x + A.W^T + b with y = LayerNorm(x) from the same launch (gemm_rowln_kernel): N = 512 rows only.
+int g_rowln_min_m = 4096;
+bool gemm_rowln_eligible(const GemmArgs& g) {
+  return g.M >= g_rowln_min_m && g.N == RL_N && g.K % 32 == 0 && g.K >= 64 && g.ldc == RL_N && g.act == ACT_NONE && g.out_act &&
+         g.out_f32 && g.ln_gamma && g.ln_beta && !g.row_stats && g.lda % 8 == 0 && g.ldw % 8 == 0 &&
+         (!g.resid || g.ldr % 4 == 0) && (long)RL_TM * g.lda * 2 < (1L << 31) && (long)RL_N * g.ldw * 2 < (1L << 31);
+}
+int launch_gemm_rowln(const GemmArgs& g, hipStream_t st) {
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    CZC_HIP_CHECK(hipGetDevice(&dev));
+    CZC_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+    n_cu = prop.multiProcessorCount;
+    CZC_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_rowln_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, RL_LDS));
+    CZC_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_rowln_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, RL_LDS));
+  }
+  if (!gemm_rowln_eligible(g)) {
+    snprintf(g_err, sizeof(g_err), "gemm_rowln: shape not eligible (M=%d N=%d K=%d)", g.M, g.N, g.K);
+    return 1;
+  }
+  const int tiles_m = cdiv(g.M, RL_TM);
+  dim3 grid(tiles_m < n_cu ? tiles_m : n_cu), block(512);
+  if (g.f16) hipLaunchKernelGGL(gemm_rowln_kernel<true>, grid, block, RL_LDS, st, g, g.ln_gamma, g.ln_beta, tiles_m);
+  else hipLaunchKernelGGL(gemm_rowln_kernel<false>, grid, block, RL_LDS, st, g, g.ln_gamma, g.ln_beta, tiles_m);
+  CZC_HIP_CHECK(hipGetLastError());
+  return 0;
+}
 
 bool gemm256_eligible(const GemmArgs& g) {
   if (g.f16 && (g_use_gemm256 < 3 || g.row_stats || g.N % 8 || g.ldc % 8)) return false;  // fp16 operands: ring kernels only

@@ -30,6 +30,10 @@ struct GemmArgs {
   const float* ln_s = nullptr;      // [N]
   int ln_groups = 0;
   float ln_eps = 0.f;
+  // Full-row kernel (gemm_rowln, N = 512): out_f32 <- resid + A.W^T + bias and out_act <- LayerNorm(out_f32; ln_gamma,
+  // ln_beta, ln_eps) from one launch.
+  const float* ln_gamma = nullptr;
+  const float* ln_beta = nullptr;
 };
 int launch_gemm(int prec, const GemmArgs& g, hipStream_t st);
 bool gemm256_eligible(const GemmArgs& g);
@@ -39,6 +43,9 @@ bool gemm256s_eligible(const GemmArgs& g);  // split-fp16 operands, same 256x256
 int launch_gemm256s(const GemmArgs& g, hipStream_t st);
 extern int g_use_gemm256s;
 extern int g_w_dbg;
+bool gemm_rowln_eligible(const GemmArgs& g);  // gemm256.hip: 128 x 512 full-row kernel, LayerNorm in the epilogue
+int launch_gemm_rowln(const GemmArgs& g, hipStream_t st);
+extern int g_rowln_min_m;
 extern int g_gemm_krot;
 extern int g_use_skinny;
 extern int g_use_splitk;

@@ -308,6 +308,25 @@ def test_gemm(prec, A, W, bias=None, resid=None, act=0, typed_out=False):
     return Cm
 
 
+def test_gemm_rowln(prec, A, W, bias, resid, gamma, beta, eps):
+    """x = resid + A.W^T + bias and y = LayerNorm(x) from the full-row kernel (W has 512 rows)."""
+    lib = native.load()
+    A = np.ascontiguousarray(A, np.float32)
+    W = np.ascontiguousarray(W, np.float32)
+    M, K = A.shape
+    assert W.shape == (512, K)
+    b = None if bias is None else np.ascontiguousarray(bias, np.float32)
+    r = np.ascontiguousarray(resid, np.float32)
+    g = np.ascontiguousarray(gamma, np.float32)
+    bt = np.ascontiguousarray(beta, np.float32)
+    x = np.empty((M, 512), np.float32)
+    y = np.empty((M, 512), np.float32)
+    native.check(lib.czc_test_gemm_rowln(prec, M, K, A.ctypes.data, W.ctypes.data, _ptr(b), r.ctypes.data, g.ctypes.data,
+                                         bt.ctypes.data, C.c_float(eps), x.ctypes.data, y.ctypes.data), None,
+                 "czc_test_gemm_rowln")
+    return x, y
+
+
 def test_layernorm(prec, x, gamma, beta, eps):
     lib = native.load()
     x = np.ascontiguousarray(x, np.float32)

@@ -97,6 +97,7 @@ SIGNATURES = {
     "czc_stats": (_I, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "czc_test_gemm": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _I, _P]),
     "czc_test_lnf_pair": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, C.c_float, _P, _P, _I, _P, _P]),
+    "czc_test_gemm_rowln": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, C.c_float, _P, _P]),
     "czc_bench_gemm": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(C.c_double)]),
     "czc_test_set_option": (_I, [C.c_char_p, _I]),
     "czc_test_layernorm": (_I, [_I, _I, _I, _P, _P, _P, C.c_float, _P]),

@@ -207,6 +207,9 @@ int czc_generate(czc_engine* e, int B, int T, int L, int seed_len, const int32_t
  *                         0 off, 1 on, -1 = czc_generate with B <= 4 only.  Correct (replay == eager, tested) but
  *                         measured no faster at B = 1: the step is bound by its ~250 dependent small kernels, not
  *                         by the host launches, which already run ahead of the GPU
+ *   "fuse_ln"         (1) bf16 / fp16 CLIP-text tower at >= 4096 packed rows: the out-projection runs as a full-row
+ *                         kernel that also emits LN2 of its result (no LayerNorm pass for it); 2 = fc2 -> the next
+ *                         layer's LN1 as well (measured slower), 0 = off
  *   "fold_ln"         (0) bf16 CLIP-text tower at >= 2048 packed rows: LayerNorm applied inside the GEMM epilogues
  *                         (out-proj / fc2 emit a bf16 copy of the residual stream + row statistics; q/k/v / fc1 run
  *                         on gain-folded weights and finish the normalisation), no LayerNorm pass over HBM */
@@ -238,6 +241,10 @@ int czc_test_gemm(int precision, int M, int N, int K, const float* A, const floa
 int czc_test_lnf_pair(int M, int K1, int N, const float* A, const float* Wo, const float* bo, const float* resid,
                       const float* gamma, const float* beta, float eps, const float* W1, const float* b1, int act,
                       float* x_out, float* h_out);
+/* Full-row GEMM with the following LayerNorm in its epilogue (bf16 / fp16 operands, 512 columns, K % 32 == 0):
+ *   x_out[M,512] = resid + A[M,K] * W[512,K]^T + bias;  y_out = LayerNorm(x_out; gamma, beta, eps) in the operand type */
+int czc_test_gemm_rowln(int precision, int M, int K, const float* A, const float* W, const float* bias, const float* resid,
+                        const float* gamma, const float* beta, float eps, float* x_out, float* y_out);
 /* GEMM microbenchmark on device-resident data: ms per launch (tools/bench_gemm.py); use256: 0 128x128 kernel,
  * 1-3 the 256x256 LDS-DMA kernels (plain / persistent / persistent + K ring), 5-6 the weight-stationary kernel
  * (memory phase separate / interleaved into the MFMA stream) where eligible. */

@@ -407,6 +407,39 @@ def test_folded_layernorm_gemm_pair(M, K1, N, act, mean_shift):
     assert err.mean() < 4e-3 * (1.0 + abs(mean_shift))
 
 
+@pytest.mark.parametrize("prec", [0, 4])
+@pytest.mark.parametrize("M,K,mean_shift", [(128 * 3 + 37, 512, 0.0), (5000, 2048, 0.0), (70000, 512, 3.0), (1000, 64, 0.0),
+                                            (300, 96, 0.5), (41000, 2048, 0.0)])
+def test_full_row_gemm_with_layernorm_epilogue(prec, M, K, mean_shift):
+    """gemm_rowln_kernel: x = resid + A.W^T + b over full 512-wide rows and y = LayerNorm(x) from the same launch
+    (out-proj -> LN2, fc2 -> next LN1 of the pre-LN block, HF:clip/modeling_clip.py:368-383).  x against fp64 on the
+    rounded operands; y against the fp64 LayerNorm of the kernel's own x (isolates the statistics and the
+    normalisation) at the output type's rounding.  Ragged M, one and several tiles per work-group, the short-K
+    prologue paths (2 and 3 stages in total), a row mean far from zero."""
+    rng = np.random.default_rng(M + K)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((512, K)) * 0.03).astype(np.float32)
+    b = (rng.standard_normal(512) * 0.1).astype(np.float32)
+    resid = (rng.standard_normal((M, 512)) * 1.5 + mean_shift).astype(np.float32)
+    gamma = (1.0 + 0.3 * rng.standard_normal(512)).astype(np.float32)
+    beta = (0.2 * rng.standard_normal(512)).astype(np.float32)
+    x, y = E.test_gemm_rowln(prec, A, W, b, resid, gamma, beta, 1e-5)
+    dt = torch.bfloat16 if prec == 0 else torch.float16
+    rd = lambda a: torch.from_numpy(a).to(dt).to(torch.float64).numpy()
+    x_ref = resid.astype(np.float64) + rd(A) @ rd(W).T + b
+    assert np.abs(x - x_ref).max() < 2e-4 * np.sqrt(max(K, 512) / 512) * (1.0 + abs(mean_shift))
+    x64 = x.astype(np.float64)
+    mu = x64.mean(1, keepdims=True)
+    y_ref = (x64 - mu) / np.sqrt(x64.var(1, keepdims=True) + 1e-5) * gamma + beta
+    ulp = 2.0 ** -8 if prec == 0 else 2.0 ** -11
+    err = np.abs(y - y_ref)
+    assert (err <= ulp * np.abs(y_ref) + 2e-5 * (1.0 + abs(mean_shift))).all(), err.max()
+    # and the stand-alone LayerNorm kernel on the same x gives the same rounded rows (a few last-place flips at most)
+    y_k = E.test_layernorm(prec, x, gamma, beta, 1e-5) if prec == 0 else None
+    if y_k is not None:
+        assert (y_k != y).mean() < 2e-3 and np.abs(y_k - y).max() <= 2 * ulp * np.abs(y_ref).max()
+
+
 @pytest.mark.parametrize("M,N,K,act,mode", [(16384 + 37, 1536, 512, 0, "typed"), (20000, 2048, 512, 1, "typed"),
                                             (16500, 512, 2048, 0, "resid"), (16384, 512, 512, 0, "resid")])
 def test_split_fp16_gemm_256_tile_kernel(M, N, K, act, mode):

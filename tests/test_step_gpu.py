@@ -566,6 +566,46 @@ def test_folded_layernorm_matches_layernorm_kernel(name, steps):
         np.testing.assert_allclose(ra["final_score"], rb["final_score"], atol=1e-3)
 
 
+@pytest.mark.parametrize("prec", [BF16, FP16])
+@pytest.mark.parametrize("name,steps", [("full_synth_b2", (4, 7, 9)), ("full_shuffle_k512", (2, 9)), ("full_senti", (6, 11))])
+def test_fused_layernorm_matches_layernorm_kernel(name, steps, prec):
+    """CLIP-text path above 4096 packed rows: out-proj (default, fuse_ln = 1) and fc2 (fuse_ln = 2) as full-row kernels
+    that also emit the LayerNorm that follows them, against the same steps with the stand-alone LayerNorm kernel: the
+    same two-pass statistics on the same fp32 rows, so only last-place flips of the normalised rows remain.  With
+    both fused the LayerNorm kernel all but disappears from the profile (layer 0's LN1 and the pooled rows keep it)."""
+    lib = native.load()
+    meta, arr = load_case(name)
+    su = setup_for(meta, prec)
+    eng = su.engine
+    eng.set_image_embeds(arr["image_embeds"])
+    hp = Engine.hyper(meta["alpha"], meta["beta"], meta["temperature"], meta["gamma"], meta["style"] == "negative")
+    outs = []
+    try:
+        assert lib.czc_test_set_option(b"rowln_min_m", 256) == 0
+        for fuse in (2, 1, 0):
+            eng.set_option("fuse_ln", fuse)
+            eng.profile(1)
+            eng.profile_reset()
+            rows = []
+            for i in steps:
+                inp = np.ascontiguousarray(arr["inp_before"][i], dtype=np.int32)
+                rows.append(eng.step(inp, SEED_LEN + meta["positions"][i], meta["K"], hp,
+                                     dot_allowed=(meta["positions"][i] == meta["L"] - 1)))
+            outs.append((rows, eng.profile_get("rowops")))
+            eng.profile(0)
+    finally:
+        lib.czc_test_set_option(b"rowln_min_m", 4096)
+        eng.set_option("fuse_ln", 1)
+    for fused in outs[:2]:
+        for ra, rb in zip(fused[0], outs[2][0]):
+            np.testing.assert_array_equal(ra["clip_ids"], rb["clip_ids"])
+            assert np.isfinite(ra["final_score"]).all()
+            np.testing.assert_allclose(ra["clip_ref"], rb["clip_ref"], atol=1e-3 if prec == BF16 else 2e-4)
+            assert np.abs(ra["clip_ref"] - rb["clip_ref"]).mean() < (1e-4 if prec == BF16 else 6e-5)
+    n2, n1, n0 = (o[1]["launches"] for o in outs)
+    assert n2 < n1 - 9 * len(steps) and n1 < n0 - 9 * len(steps), (n2, n1, n0)
+
+
 @pytest.mark.parametrize("prec", [F32, BF16])
 def test_last_layer_pooling_is_exact(prec, one_gemm_family):
     """Running the last CLIP-text layer's out-projection/MLP on the EOS rows only is the same math."""
