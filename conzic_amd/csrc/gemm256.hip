@@ -530,7 +530,6 @@ __global__ __launch_bounds__(768) void gemm256p_kernel(GemmArgs g, int tiles_m, 
   const int half = lane >> 5;
   const int arow = wm * 128 + (lane & 31);
   const int brow = wn * 64 + (lane & 31);
-  bf16_t* oa = (bf16_t*)g.out_act;
   unsigned step = 0;
   const bool legacy = (g_krot_enable & 32) == 0;  // bit5 selects the (slower, measured) M-major walk
   const int my_tiles = tile_count(tiles_m, tiles_n, legacy);
