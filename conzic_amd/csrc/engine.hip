@@ -57,6 +57,8 @@ struct czc_engine {
   czc_config cfg;
   int dev = 0;
   hipStream_t st = nullptr;
+  bool shares_weights = false;  // czc_replicate: weights belong to the parent engine (which must outlive this one)
+  hipEvent_t prof_ref = nullptr;  // recorded by czc_profile_reset: time zero of czc_profile_intervals
   char err[512] = {0};
   bool finalized = false;
   size_t esz = 2;  // bytes per CLIP activation element
@@ -744,6 +746,8 @@ int czc_destroy(czc_engine* e) {
   (void)hipSetDevice(e->dev);
   (void)hipStreamSynchronize(e->st);
   invalidate_graphs(e);
+  if (e->shares_weights) { e->w.clear(); e->bert.clear(); e->ctext.clear(); e->cvis.clear();
+                           e->mlm_dense_w = e->decoder_w = e->tproj_w = e->vproj_w = e->patch_w = nullptr; }
   for (auto& kv : e->w) if (kv.second.p) (void)hipFree(kv.second.p);
   auto free_layers = [](std::vector<LayerW>& L) {
     for (auto& l : L) {
@@ -760,13 +764,42 @@ int czc_destroy(czc_engine* e) {
   (void)hipFree(e->d_mask); (void)hipFree(e->d_lex); (void)hipFree(e->d_lex_pos); (void)hipFree(e->d_lex_cls); (void)hipFree(e->d_img_n); (void)hipFree(e->d_staged);
   (void)hipFree(e->d_pos_tags); (void)hipFree(e->d_pos_masks);
   for (auto& kv : e->pk) for (hipEvent_t ev : kv.second.ev) (void)hipEventDestroy(ev);
+  if (e->prof_ref) (void)hipEventDestroy(e->prof_ref);
   if (e->h_totals) (void)hipHostFree(e->h_totals);
   (void)hipStreamDestroy(e->st);
   delete e;
   return CZC_OK;
 }
 
+// A second engine on the same GPU over the SAME resident weights: its own stream, workspace, image embeddings,
+// token mask / bridge / lexicon tables, options and profile.  Two (or three) of them driven from separate host
+// threads polish disjoint image sub-batches concurrently: one sub-batch's small BERT / top-K / LayerNorm / attention
+// launches and the tail rounds of its persistent GEMMs fill what the other's big launches leave idle.
+int czc_replicate(czc_engine* p, czc_engine** out) {
+  if (!p || !out) return CZC_ERR_ARG;
+  if (!p->finalized) return fail(p, CZC_ERR_STATE, "czc_replicate: czc_finalize_weights first%s");
+  czc_engine* e = new czc_engine();
+  e->cfg = p->cfg; e->dev = p->dev; e->finalized = true; e->shares_weights = true;
+  e->esz = p->esz; e->pb = p->pb; e->pc = p->pc; e->eb = p->eb;
+  e->w = p->w; e->bert = p->bert; e->ctext = p->ctext; e->cvis = p->cvis;
+  e->mlm_dense_w = p->mlm_dense_w; e->decoder_w = p->decoder_w; e->tproj_w = p->tproj_w; e->vproj_w = p->vproj_w;
+  e->patch_w = p->patch_w;
+  e->logit_scale_exp = p->logit_scale_exp;
+  e->share_prefix = p->share_prefix; e->pack_branches = p->pack_branches; e->pool_last_layer = p->pool_last_layer;
+  e->fuse_ln = p->fuse_ln; e->fold_ln = p->fold_ln; e->use_graphs = p->use_graphs;
+  memset(&e->bd, 0, sizeof(e->bd));
+  if (hipSetDevice(e->dev) != hipSuccess || hipStreamCreate(&e->st) != hipSuccess ||
+      hipHostMalloc((void**)&e->h_totals, 64) != hipSuccess) {
+    e->w.clear();
+    delete e;
+    return fail(p, CZC_ERR_HIP, "czc_replicate: stream/host allocation failed%s");
+  }
+  *out = e;
+  return CZC_OK;
+}
+
 int czc_load_tensor(czc_engine* e, const char* name, int dtype, int ndim, const int64_t* shape, const void* src) {
+  if (e && e->shares_weights) return fail(e, CZC_ERR_STATE, "czc_load_tensor: a replica shares its parent's weights%s");
   if (!e || !name || !src || ndim < 0 || ndim > 8) return CZC_ERR_ARG;
   if (dtype != 0) return fail(e, CZC_ERR_ARG, "czc_load_tensor(%s): only fp32 (dtype 0) is accepted", name);
   E_HIP(hipSetDevice(e->dev));
@@ -1148,6 +1181,8 @@ int czc_profile_enable(czc_engine* e, int on) {
 int czc_profile_reset(czc_engine* e) {
   if (!e) return CZC_ERR_ARG;
   (void)hipStreamSynchronize(e->st);
+  if (!e->prof_ref) (void)hipEventCreate(&e->prof_ref);
+  if (e->prof_ref) (void)hipEventRecord(e->prof_ref, e->st);
   for (auto& kv : e->pk) { kv.second.used = 0; kv.second.flops = 0; kv.second.launches = 0; }
   e->stat_clip_rows = e->stat_clip_seqs = e->stat_bert_rows = e->stat_steps = 0;
   return CZC_OK;
@@ -1172,6 +1207,31 @@ int czc_profile_get(czc_engine* e, const char* kind, double* total_ms, int64_t* 
   if (total_ms) *total_ms = ms;
   if (launches) *launches = n;
   if (flops) *flops = fl;
+  return CZC_OK;
+}
+
+// Start / end (ms) of every launch of kernel class `kind` since czc_profile_reset(e), on the clock whose zero is
+// czc_profile_reset(ref) (ref = e for one engine; the same ref for all engines that ran concurrently, so that the
+// host can take the union of their intervals: the time the GPU spent on that class with the launches overlapping).
+int czc_profile_intervals(czc_engine* e, czc_engine* ref, const char* kind, double* start_ms, double* end_ms, int cap,
+                          int* n_out) {
+  if (!e || !ref || !kind || !n_out || cap < 0 || (cap > 0 && (!start_ms || !end_ms))) return CZC_ERR_ARG;
+  if (!ref->prof_ref) return fail(e, CZC_ERR_STATE, "czc_profile_intervals: czc_profile_reset the reference engine first%s");
+  E_HIP(hipStreamSynchronize(e->st));
+  E_HIP(hipStreamSynchronize(ref->st));
+  int n = 0;
+  auto it = e->pk.find(kind);
+  if (it != e->pk.end()) {
+    ProfKind& k = it->second;
+    for (size_t i = 0; i + 1 < k.used; i += 2, ++n) {
+      if (n >= cap) continue;
+      float a = 0, b = 0;
+      E_HIP(hipEventElapsedTime(&a, ref->prof_ref, k.ev[i]));
+      E_HIP(hipEventElapsedTime(&b, ref->prof_ref, k.ev[i + 1]));
+      start_ms[n] = a; end_ms[n] = b;
+    }
+  }
+  *n_out = n;
   return CZC_OK;
 }
 

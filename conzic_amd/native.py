@@ -91,6 +91,8 @@ SIGNATURES = {
     "czc_profile_enable": (_I, [_P, _I]),
     "czc_profile_reset": (_I, [_P]),
     "czc_profile_get": (_I, [_P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    "czc_profile_intervals": (_I, [_P, _P, C.c_char_p, _P, _P, _I, C.POINTER(C.c_int)]),
+    "czc_replicate": (_I, [_P, C.POINTER(C.c_void_p)]),
     "czc_sync": (_I, [_P]),
     "czc_graph_stats": (_I, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "czc_option_epoch": (_I, []),

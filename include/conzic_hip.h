@@ -130,6 +130,13 @@ typedef struct czc_step_out {
 /* ---- lifecycle ---------------------------------------------------------------------- */
 int czc_create(const czc_config* cfg, int device_id, czc_engine** out_engine);
 int czc_destroy(czc_engine* e);
+/* A second engine on the same GPU that SHARES `parent`'s resident weights (no copy, no reload) and owns everything
+ * else: stream, workspace, image embeddings, token mask / bridge / lexicon / POS tables (set them on the replica
+ * as on the parent), options (copied at creation), profile.  Images are independent (gen_utils.py:64-81 has no
+ * cross-image term), so a host that drives parent and replica(s) from separate threads on disjoint sub-batches gets
+ * the same captions image for image while their kernels overlap on the GPU.  `parent` must be finalized and must
+ * outlive its replicas; czc_destroy(replica) frees only what the replica owns. */
+int czc_replicate(czc_engine* parent, czc_engine** out_engine);
 const char* czc_last_error(const czc_engine* e); /* e may be NULL: last create error */
 int czc_version(void);
 
@@ -222,6 +229,11 @@ int czc_set_option(czc_engine* e, const char* name, int value);
 int czc_profile_enable(czc_engine* e, int on);
 int czc_profile_reset(czc_engine* e);
 int czc_profile_get(czc_engine* e, const char* kind, double* total_ms, int64_t* launches, double* flops);
+/* Start / end (ms) of every launch of class `kind` since czc_profile_reset(e), on the clock whose zero is
+ * czc_profile_reset(ref) (ref == e for a single engine).  For engines that ran concurrently the host takes the union
+ * of their intervals = the time the GPU spent on that class.  Fills at most `cap` pairs; *n = number available. */
+int czc_profile_intervals(czc_engine* e, czc_engine* ref, const char* kind, double* start_ms, double* end_ms, int cap,
+                          int* n);
 int czc_sync(czc_engine* e);
 /* step-graph counters: graph launches, captures so far, graphs currently cached */
 int czc_graph_stats(czc_engine* e, int64_t* launches, int64_t* captures, int64_t* cached);

@@ -1,0 +1,110 @@
+"""Two image sub-batches on two HIP streams (czc_replicate + EngineGroup): same captions image for image.
+
+Images are independent units of the polishing loop (gen_utils.py:64-81: no cross-image term), so an engine plus a
+replica over the same weights, each driven from its own host thread on half of the images, must reproduce what one
+engine produces on all of them -- and therefore the reference's golden trajectories."""
+import numpy as np
+import pytest
+import torch
+
+from conzic_amd import harness, native, synth
+from conzic_amd.engine import Engine, EngineGroup, union_ms
+from goldutil import load_case
+
+pytestmark = pytest.mark.gpu
+SEED_LEN = 4
+BF16, F32, SPLIT = native.PREC_BF16, native.PREC_F32, native.PREC_SPLIT
+
+
+def _setup(meta, prec):
+    su = harness.build_synthetic(meta["tiny"], prec, meta["bseed"], meta["cseed"], meta["logit_scale"], meta["regular_only"],
+                                 lexicon=meta["gamma"] is not None)
+    if meta.get("pos"):
+        su.engine.set_pos(synth.make_pos_tags(len(su.sv.bert_tokens)), synth.pos_template_masks(meta["pos"]))
+    return su
+
+
+@pytest.mark.parametrize("name,prec", [("full_scale100", SPLIT), ("full_senti", SPLIT), ("full_pos", SPLIT), ("tiny_shuffle", F32)])
+def test_two_streams_reproduce_the_reference_trajectory(name, prec):
+    """One image per stream (min_images = 1): the golden snapshots of the imported reference come back id for id,
+    including the sentiment / POS tables that have to reach the replica (setter replay)."""
+    meta, arr = load_case(name)
+    su = _setup(meta, prec)
+    grp = EngineGroup(su.engine, streams=2, min_images=1)
+    try:
+        assert len(grp.parts(meta["B"])) == 2
+        grp.set_image_embeds(arr["image_embeds"])
+        hp = Engine.hyper(meta["alpha"], meta["beta"], meta["temperature"], meta["gamma"], meta["style"] == "negative",
+                          control="pos" if meta.get("pos") else None)
+        init = su.bert_tok.encode(meta["prompt"] + su.bert_tok.mask_token * meta["L"])
+        pos, nm, every = harness.order_positions(meta["order"], meta["L"], meta["I"], order_list=meta["order_list"],
+                                                 random_positions=meta["positions"] if meta["order"] == "random" else None)
+        assert pos == meta["positions"]
+        ids, cos = grp.generate(meta["B"], init, meta["L"], SEED_LEN, meta["K"], pos, hp, n_mask=nm, snapshot_every=every)
+        np.testing.assert_array_equal(ids, arr["snaps"])
+        np.testing.assert_allclose(cos, np.array(meta["scores"][:-1], dtype=np.float32), atol=2e-5)
+    finally:
+        grp.close()
+
+
+@pytest.mark.parametrize("prec", [BF16, SPLIT])
+def test_two_and_three_streams_match_one_engine(prec):
+    """B = 9 random images, full-size towers, two sweeps: one engine on all nine against two streams (5 + 4) and three
+    (3 + 3 + 3), pixels through czc_encode_images on every member.  The kernel families the engine picks by row count
+    are pinned (as bench.py does for its batch-invariance check), so bf16 comes out bit-identical; the split-fp16
+    engine agrees id for id with cosines to fp32 rounding."""
+    lib = native.load()
+    B, L, K, I = 9, 6, 64, 2
+    su = harness.build_synthetic(False, prec, logit_scale=2.6592 if prec == BF16 else 4.6052, regular_only=True)
+    pix = torch.from_numpy(synth.pixels_from_u8(synth.make_images_u8(B, su.clip_cfg.v_image))).to("cuda:0")
+    init = su.bert_tok.encode("Image of a" + su.bert_tok.mask_token * L)
+    pos, nm, every = harness.order_positions("sequential", L, I)
+    hp = Engine.hyper(0.02, 2.0, 0.1)
+    knobs = {b"attention_image": (2, 1), b"wreg_min_m": (1, 2048), b"gemm256_min_m": (1, 2048), b"rowln_min_m": (1, 4096)}
+    for k, (v, _) in knobs.items():
+        assert lib.czc_test_set_option(k, v) == 0
+    try:
+        su.engine.encode_images(pix)
+        ids0, cos0 = su.engine.generate(B, init, L, SEED_LEN, K, pos, hp, n_mask=nm, snapshot_every=every)
+        for streams in (2, 3):
+            grp = EngineGroup(su.engine, streams=streams, min_images=2)
+            assert [hi - lo for lo, hi in grp.parts(B)] == ([5, 4] if streams == 2 else [3, 3, 3])
+            emb = grp.encode_images(pix)
+            assert emb.shape == (B, su.clip_cfg.proj)
+            ids, cos = grp.generate(B, init, L, SEED_LEN, K, pos, hp, n_mask=nm, snapshot_every=every)
+            np.testing.assert_array_equal(ids, ids0)
+            if prec == BF16:
+                np.testing.assert_array_equal(cos, cos0)
+            else:  # the split-fp16 kernels have no row-count pins: fp32-level summation-order differences remain
+                np.testing.assert_allclose(cos, cos0, atol=2e-6)
+            grp.close(parent=False)
+    finally:
+        for k, (_, v) in knobs.items():
+            lib.czc_test_set_option(k, v)
+        su.engine.close()
+
+
+def test_group_profile_counts_overlapping_launches_once():
+    """profile_get of a group: launches and FLOPs add up over the members, busy_ms (union of the launch intervals on
+    one clock) is at most the sum of the durations and at least the longest member's."""
+    assert union_ms([np.array([[0.0, 1.0], [2.0, 3.0]]), np.array([[0.5, 2.5], [10.0, 11.0]])]) == 4.0
+    B, L, K = 64, 4, 100
+    su = harness.build_synthetic(False, BF16, regular_only=True)
+    grp = EngineGroup(su.engine, streams=2, min_images=8)
+    try:
+        pix = torch.from_numpy(synth.pixels_from_u8(synth.make_images_u8(B, su.clip_cfg.v_image))).to("cuda:0")
+        init = su.bert_tok.encode("Image of a" + su.bert_tok.mask_token * L)
+        pos, nm, every = harness.order_positions("sequential", L, 1)
+        hp = Engine.hyper(0.02, 2.0, 0.1)
+        grp.encode_images(pix)
+        grp.generate(B, init, L, SEED_LEN, K, pos, hp, n_mask=nm, snapshot_every=every)  # warm-up (workspace growth)
+        grp.profile_reset()
+        grp.profile(2)
+        grp.generate(B, init, L, SEED_LEN, K, pos, hp, n_mask=nm, snapshot_every=every)
+        grp.profile(0)
+        g = grp.profile_get("gemm_clip_text")
+        per = [e.profile_get("gemm_clip_text") for e in grp.engines]
+        assert g["launches"] == sum(p["launches"] for p in per) > 0
+        assert max(p["ms"] for p in per) * 0.5 < g["busy_ms"] <= g["ms"] * 1.001
+    finally:
+        grp.close()
