@@ -82,6 +82,11 @@ class Engine:
 
     # ---- lifecycle --------------------------------------------------------------------------
     def close(self):
+        g = getattr(self, "_group", None)  # runtime.py caches its EngineGroup here
+        if g is not None and g._pool is not None:
+            g._pool.shutdown(wait=True)
+            g._pool = None
+        self._group = None
         for r in getattr(self, "_replicas", []):
             r.close()  # replicas point at this engine's weights: they go first
         self._replicas = []

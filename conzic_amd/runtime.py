@@ -175,6 +175,25 @@ def clip_only_engine(clip, device: int = 0) -> Engine:
     return eng
 
 
+STREAMS_MIN_IMAGES = 32  # images per stream below which a batch is not split (smaller launches lose more than overlap gains)
+
+
+def _group_for(eng: Engine, batch_size: int):
+    """The engine itself, or its EngineGroup (engine + replicas on their own streams) when the batch is big enough
+    for CZC_STREAMS (default 2) sub-batches of at least STREAMS_MIN_IMAGES images."""
+    n = int(os.environ.get("CZC_STREAMS", "2"))
+    if n <= 1 or batch_size < 2 * STREAMS_MIN_IMAGES:
+        return eng
+    grp = getattr(eng, "_group", None)
+    if grp is None or grp.streams != n or grp.engines[0] is not eng or eng.h is None:
+        from .engine import EngineGroup
+        if grp is not None:
+            grp.close(parent=False)
+        grp = EngineGroup(eng, streams=n, min_images=STREAMS_MIN_IMAGES)
+        eng._group = grp
+    return grp
+
+
 def advance_order_rng(order: str, max_len: int, max_iters: int) -> None:
     """Consume from the process-global RNG streams exactly what one *_generation call would (gen_utils.py:110-111
     shuffle: one `random.shuffle`; :210 random: one `np.random.randint` per iteration).  A rank of an image-sharded
@@ -231,8 +250,17 @@ def run_generation(order: str, img_name, model, clip, tokenizer, image_instance,
         positions, n_mask, every = order_positions(order, max_len, iters, order_list=order_list)
     hp = Engine.hyper(alpha, beta, temperature, gamma, ctl_signal == "negative",
                       control="pos" if pos_template is not None else None)
-    ids, cos = eng.generate(batch_size, batch[0], max_len, seed_len, top_k, positions, hp, n_mask=n_mask,
-                            snapshot_every=every)
+    runner = _group_for(eng, batch_size)
+    if runner is not eng:
+        # two (CZC_STREAMS) contiguous image sub-batches on their own HIP streams over the same weights: the same
+        # captions image for image (images are independent, gen_utils.py:64-81), their kernels overlap on the GPU
+        from clip.clip import ImageEmbeds
+        emb = image_instance.embeds if isinstance(image_instance, ImageEmbeds) else clip.last_image_embeds()
+        runner.set_image_embeds(emb)
+    ids, cos = runner.generate(batch_size, batch[0], max_len, seed_len, top_k, positions, hp, n_mask=n_mask,
+                               snapshot_every=every)
+    if runner is not eng:
+        eng.set_image_embeds(emb)  # the first engine holds the whole batch again, as after a single-stream call
     # utils.update_token_mask mutates the caller's mask in place (utils.py:53-59): leave it as the
     # reference would after the last visited position
     if positions:

@@ -66,6 +66,36 @@ def test_generate_caption_dropin_matches_reference(name):
     assert mask[0, tok.vocab["."]] == (1.0 if last == meta["L"] - 1 else 0.0)
 
 
+def test_generate_caption_two_streams_same_captions(monkeypatch):
+    """batch_size = 64 through the reference-shaped generate_caption: above 2 x 32 images the runtime polishes two
+    sub-batches on two streams (CZC_STREAMS, default 2); captions, scores and the shuffle order drawn from the global
+    RNG are those of the one-stream run, and the second sample reuses the cached image embeddings on both streams."""
+    import utils
+    from conzic_amd import runtime
+    from gen_utils import generate_caption
+    meta, _ = load_case("tiny_shuffle")
+    meta = dict(meta, B=64)
+    logger = logging.getLogger("dropin-test")
+    names = [f"img{j}" for j in range(64)]
+    kw = dict(prompt=meta["prompt"], batch_size=64, max_len=meta["L"], top_k=meta["K"], temperature=meta["temperature"],
+              max_iter=2, alpha=meta["alpha"], beta=meta["beta"], generate_order="shuffle")
+    out = {}
+    for streams in ("1", "2"):
+        monkeypatch.setenv("CZC_STREAMS", streams)
+        lm, clip, tok, imgs, mask = _objects(meta)
+        utils.set_seed(meta["seed"])
+        res = [generate_caption(names, lm, clip, tok, imgs, mask.copy(), logger, **kw) for _ in range(2)]  # two samples
+        eng = runtime.get_engine(lm, clip, tok)
+        assert (getattr(eng, "_group", None) is not None) == (streams == "2")
+        if streams == "2":
+            assert eng._group.streams == 2 and [hi - lo for lo, hi in eng._group.parts(64)] == [32, 32]
+        out[streams] = res
+        runtime.evict()
+    for (t1, s1), (t2, s2) in zip(out["1"], out["2"]):
+        assert t1 == t2
+        np.testing.assert_allclose(np.array(s1), np.array(s2), atol=1e-6)
+
+
 def test_image_embeds_cached_across_samples():
     """North star: the ViT encode happens once per image.  The same image objects polished again (the samples_num
     loop of demo.py:83) and `ImageEmbeds` handed back in their place must not go through the vision tower again,
