@@ -248,7 +248,9 @@ def main():
             # near-tie winner that flips once changes the rest of that image's trajectory.  What can still differ:
             # split-K of the BERT layers (fp32-class).
             lib = native.load()
-            lib.czc_test_set_option(b"attention_image", 2)
+            # per-image persistent branch attention is what a sub-batch of >= 128 / (heads / 4) images runs (attention.hip)
+            sub_images = min(hi - lo for lo, hi in grp.parts(B))
+            lib.czc_test_set_option(b"attention_image", 2 if sub_images * (ccfg.heads // 4) >= 128 else 0)
             lib.czc_test_set_option(b"wreg_min_m", 1)
             lib.czc_test_set_option(b"gemm256_min_m", 1)
             lib.czc_test_set_option(b"rowln_min_m", 1)

@@ -1180,6 +1180,7 @@ int czc_profile_enable(czc_engine* e, int on) {
 
 int czc_profile_reset(czc_engine* e) {
   if (!e) return CZC_ERR_ARG;
+  (void)hipSetDevice(e->dev);  // the current device is per host thread (events are created on it)
   (void)hipStreamSynchronize(e->st);
   if (!e->prof_ref) (void)hipEventCreate(&e->prof_ref);
   if (e->prof_ref) (void)hipEventRecord(e->prof_ref, e->st);
@@ -1190,6 +1191,7 @@ int czc_profile_reset(czc_engine* e) {
 
 int czc_profile_get(czc_engine* e, const char* kind, double* total_ms, int64_t* launches, double* flops) {
   if (!e || !kind) return CZC_ERR_ARG;
+  E_HIP(hipSetDevice(e->dev));
   E_HIP(hipStreamSynchronize(e->st));
   double ms = 0;
   int64_t n = 0;
@@ -1217,6 +1219,8 @@ int czc_profile_intervals(czc_engine* e, czc_engine* ref, const char* kind, doub
                           int* n_out) {
   if (!e || !ref || !kind || !n_out || cap < 0 || (cap > 0 && (!start_ms || !end_ms))) return CZC_ERR_ARG;
   if (!ref->prof_ref) return fail(e, CZC_ERR_STATE, "czc_profile_intervals: czc_profile_reset the reference engine first%s");
+  if (ref->dev != e->dev) return fail(e, CZC_ERR_ARG, "czc_profile_intervals: engines on different devices%s");
+  E_HIP(hipSetDevice(e->dev));
   E_HIP(hipStreamSynchronize(e->st));
   E_HIP(hipStreamSynchronize(ref->st));
   int n = 0;
