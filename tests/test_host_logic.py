@@ -240,3 +240,20 @@ def test_state_names_of_legacy_checkpoints_are_normalised():
     assert n("bert.pooler.dense.weight") is None and n("cls.seq_relationship.bias") is None
     assert n("bert.embeddings.position_ids") is None and n("cls.predictions.decoder.weight") is None
     assert n("text_model.encoder.layers.0.mlp.fc1.weight") == "text_model.encoder.layers.0.mlp.fc1.weight"
+
+
+def test_engine_group_partition_and_interval_union():
+    """Host logic of the two-stream path: contiguous sub-batches of at least min_images images, never more parts than
+    engines; the busy time of overlapping launch intervals from several engines is counted once."""
+    from conzic_amd.engine import EngineGroup, union_ms
+    g = object.__new__(EngineGroup)
+    g.engines, g.min_images = [None, None], 32
+    assert g.parts(256) == [(0, 128), (128, 256)]
+    assert g.parts(65) == [(0, 33), (33, 65)]
+    assert g.parts(63) == [(0, 63)] and g.parts(1) == [(0, 1)]
+    g.engines = [None, None, None]
+    assert g.parts(256) == [(0, 86), (86, 171), (171, 256)]
+    assert g.parts(70) == [(0, 35), (35, 70)]
+    a = np.array([[0.0, 1.0], [2.0, 3.0]])
+    b = np.array([[0.5, 2.5], [10.0, 11.0]])
+    assert union_ms([a, b]) == 4.0 and union_ms([a]) == 2.0 and union_ms([np.zeros((0, 2))]) == 0.0
