@@ -117,6 +117,7 @@ def main():
     ap.add_argument("--streams", type=int, default=2,
                     help="concurrent image sub-batches per GPU, each on its own HIP stream over the same weights "
                          "(czc_replicate); 1 = one engine, one stream")
+    ap.add_argument("--min-images", type=int, default=32, help="images per stream below which a batch is not split")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=INT", help="engine option (czc_set_option), A/B runs")
     a = ap.parse_args()
 
@@ -186,7 +187,7 @@ def main():
         # the images are polished as `streams` contiguous sub-batches, each by its own engine replica (same weights, own
         # stream) driven from its own host thread: same captions image for image (tests/test_streams_gpu.py), and one
         # sub-batch's small launches and GEMM tail rounds overlap the other's big launches
-        grp = EngineGroup(eng, streams=a.streams, min_images=32)
+        grp = EngineGroup(eng, streams=a.streams, min_images=a.min_images)
         n_streams = len(grp.parts(B))
         t_setup = time.time() - t0
         init = su.bert_tok.encode("Image of a" + su.bert_tok.mask_token * L)
