@@ -95,6 +95,40 @@ def cpu_baseline(L, K):
                        f"({ts[0]:.2f}s + {ts[1]:.2f}s, image encode {t_img:.2f}s); caption = t1 + 9*t2 = {t_caption:.1f}s")
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this same command (rank r <-> GPU r, RCCL over
+    xGMI, rendezvous on 127.0.0.1), relay rank 0's JSON line, fail if any rank fails.  Never falls back to fewer GPUs."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    share = os.environ.get("CZC_SHARE_GPU") == "1"
+    if have < n and not share:
+        print(f"bench.py: --gpus {n} needs {n} visible GPUs, found {have} (no silent fallback to fewer GPUs; "
+              f"--share-gpu exists for single-device tests of the N-rank path only)", file=sys.stderr, flush=True)
+        return 2
+    if have < 1:
+        print("bench.py: no GPU visible (the engine has no CPU fallback)", file=sys.stderr, flush=True)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        if share and have < n:
+            env["CZC_DIST_BACKEND"] = "gloo"
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rcs = [p.wait() for p in procs]
+    bad = [(r, c) for r, c in enumerate(rcs) if c != 0]
+    if bad:
+        print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr, flush=True)
+        return 1
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -119,7 +153,14 @@ def main():
                          "(czc_replicate); 1 = one engine, one stream")
     ap.add_argument("--min-images", type=int, default=32, help="images per stream below which a batch is not split")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=INT", help="engine option (czc_set_option), A/B runs")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="TEST ONLY: allow --gpus N ranks on fewer than N devices (rank r -> device r %% count, gloo rendezvous: "
+                         "RCCL cannot put two ranks on one device).  Such a line says so in config.parallelism")
     a = ap.parse_args()
+    if a.share_gpu:
+        os.environ["CZC_SHARE_GPU"] = "1"
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(a.gpus))  # plain `python bench.py --gpus N`: this process becomes the launcher of N ranks
 
     import torch
     from conzic_amd import dist as czd
@@ -127,18 +168,25 @@ def main():
     from conzic_amd.engine import Engine, EngineGroup
 
     rank, world, local = czd.env_rank_world()
-    assert world == a.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {a.gpus}"
+    if world != a.gpus:
+        sys.exit(f"bench.py: WORLD_SIZE={world} but --gpus {a.gpus}: the launcher's rank count and --gpus must agree")
     assert torch.cuda.is_available(), "bench.py needs a GPU (the engine has no CPU fallback)"
-    local = local % torch.cuda.device_count()  # (single-GPU smoke runs of the N>1 path share device 0)
+    shared_gpu = torch.cuda.device_count() < world
+    if shared_gpu and os.environ.get("CZC_SHARE_GPU") != "1":
+        sys.exit(f"bench.py: {world} ranks but {torch.cuda.device_count()} visible GPUs (one rank per GPU; --share-gpu is for tests)")
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     backend = os.environ.get("CZC_DIST_BACKEND", "nccl")  # "nccl" == RCCL on ROCm
+    dist_world = None
     if world > 1:
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+        dist_world = dist.get_world_size()  # what the collective backend itself counts
+        assert dist_world == a.gpus, (dist_world, a.gpus)
 
     prec = {"bf16": native.PREC_BF16, "f32": native.PREC_F32, "split": native.PREC_SPLIT, "fp16": native.PREC_FP16}[a.precision]
     DT = {native.PREC_BF16: "bf16", native.PREC_F32: "f32", native.PREC_FP16: "fp16",
@@ -356,7 +404,10 @@ def main():
                                images_per_gpu=B, sentence_len=L, candidate_k=K, num_iterations=I, order=a.order,
                                gamma=a.gamma, sentiment=a.sentiment if a.gamma is not None else None,
                                logit_scale=a.logit_scale, parallelism=f"image-sharded x{world} (no per-step collective); {main_res['streams']} concurrent "
-                                           f"image sub-batches per GPU on separate HIP streams over one set of weights"),
+                                           f"image sub-batches per GPU on separate HIP streams over one set of weights"
+                                           + (f"; TEST RUN: {world} ranks share {torch.cuda.device_count()} device(s), {backend} rendezvous" if shared_gpu else "")),
+                   ranks=dict(world_size=world, backend=("rccl (torch 'nccl')" if backend == "nccl" else backend) if world > 1 else None,
+                              reported_by_backend=dist_world, devices_visible=torch.cuda.device_count(), shared_gpu=shared_gpu),
                    image_position_steps_per_s=round(value * L * I, 2),
                    algorithmic_tflop_per_caption=round(f_cap / 1e12, 3),
                    executed_tflop_per_caption=None if not gemm_fl else round(gemm_fl / B / 1e12, 3),

@@ -10,8 +10,7 @@
 
 using namespace czc;
 
-static int g_lnf_dbg = 0;
-static int g_option_epoch = 0;  // bumped by every czc_test_set_option: engines drop their cached step graphs
+static int g_bench_pad = 0;  // czc_bench_gemm: extra elements per row of A and W (row pitch vs L2 channel experiments)
 
 namespace {
 
@@ -108,40 +107,41 @@ int czc_bench_gemm(int precision, int M, int N, int K, int act, int out_mode, in
   for (auto& v : ha) v = rnd();
   for (auto& v : hw) v = rnd() * 0.05f;
   for (auto& v : hb) v = rnd();
-  void* dA = pool.alloc((size_t)M * K * es); T_PTR(dA);
+  const int pad = g_bench_pad;
+  const size_t Kp = (size_t)K + pad;
+  void* dA = pool.alloc((size_t)M * Kp * es); T_PTR(dA);
   float* tmp = (float*)pool.up(ha.data(), ha.size() * 4); T_PTR(tmp);
-  for (size_t off = 0; off < (size_t)M * K; off += ha.size()) {
-    const size_t n = std::min(ha.size(), (size_t)M * K - off);
+  for (size_t off = 0; off < (size_t)M * Kp; off += ha.size()) {
+    const size_t n = std::min(ha.size(), (size_t)M * Kp - off);
     T_CHECK(launch_convert(precision, tmp, (char*)dA + off * es, (long)n, nullptr));
   }
-  void* dW = up_act(pool, precision, hw.data(), hw.size()); T_PTR(dW);
+  void* dW = nullptr;
+  if (pad) {
+    std::vector<float> hwp((size_t)N * Kp);
+    for (auto& v : hwp) v = rnd() * 0.05f;
+    dW = up_act(pool, precision, hwp.data(), hwp.size());
+  } else {
+    dW = up_act(pool, precision, hw.data(), hw.size());
+  }
+  T_PTR(dW);
   float* dB = (float*)pool.up(hb.data(), hb.size() * 4); T_PTR(dB);
   void* dOa = nullptr; float* dOf = nullptr;
-  // out_mode: 0 activation-typed output; 1 fp32 output + fp32 residual (in place); 2 = 1 + bf16 copy + row statistics
-  // (LayerNorm-folding producer); 3 = 0 with the LayerNorm finished in the epilogue (LayerNorm-folding consumer)
-  if (out_mode == 0 || out_mode == 3) { dOa = pool.alloc((size_t)M * N * es); T_PTR(dOa); }
+  // out_mode: 0 activation-typed output; 1 fp32 output + fp32 residual (in place); 4 full-row kernel with the LayerNorm in
+  // its epilogue; 5 the GEMM + LayerNorm pair it replaces
+  if (out_mode == 0) { dOa = pool.alloc((size_t)M * N * es); T_PTR(dOa); }
   else { dOf = (float*)pool.alloc((size_t)M * N * 4); T_PTR(dOf); T_HIP(hipMemset(dOf, 0, (size_t)M * N * 4)); }
   GemmArgs g;
-  g.A = dA; g.lda = K; g.W = dW; g.ldw = K; g.bias = dB; g.resid = dOf; g.ldr = N; g.out_act = dOa; g.out_f32 = dOf;
+  g.A = dA; g.lda = (int)Kp; g.W = dW; g.ldw = (int)Kp; g.bias = dB; g.resid = dOf; g.ldr = N; g.out_act = dOa; g.out_f32 = dOf;
   g.ldc = N; g.M = M; g.N = N; g.K = K; g.act = act;
-  if (out_mode == 2) {
-    g.out_act = pool.alloc((size_t)M * N * 2); T_PTR(g.out_act);
-    g.row_stats = (float*)pool.alloc((size_t)M * (N / 64) * 8); T_PTR(g.row_stats);
-    g.ln_groups = g_lnf_dbg;  // timing ablations of the producer epilogue: 1 no statistics store, 2 no bf16 copy, 4 no statistics
-  }
   if (out_mode == 4 || out_mode == 5) {  // 4: full-row kernel with the LayerNorm in its epilogue; 5: the pair it replaces
     g.out_act = pool.alloc((size_t)M * N * 2); T_PTR(g.out_act);
     g.ln_gamma = dB; g.ln_beta = dB; g.ln_eps = 1e-5f; g.f16 = precision == PREC_F16;
   }
-  if (out_mode == 3) {
-    std::vector<float> st((size_t)M * 16);
-    for (size_t i = 0; i < st.size(); i += 2) { st[i] = 0.f; st[i + 1] = 64.f; }  // mean 0, variance 1
-    g.ln_stats = (const float*)pool.up(st.data(), st.size() * 4); T_PTR(g.ln_stats);
-    g.ln_s = dB; g.ln_groups = 8; g.ln_eps = 1e-5f;
-  }
   const int saved = g_use_gemm256, saved_wreg = g_use_wreg;
-  g_use_gemm256 = use256 >= 5 ? 3 : use256;  // 5: weight-stationary kernel where eligible; 4: loader-less 8-wave ring kernel
-  g_use_wreg = use256 == 5 ? 1 : use256 == 6 ? 2 : 0;
+  // use256: 0 128x128 kernel; 1 default choice of the ring kernels; 3 loader-wave ring kernel; 7 ping-pong ring kernel;
+  // 6 weight-stationary kernel where eligible (else the default ring kernel)
+  g_use_gemm256 = use256 == 7 ? 5 : use256 == 6 ? 1 : use256;
+  g_use_wreg = use256 == 6 ? 1 : 0;
   hipEvent_t e0, e1;
   T_HIP(hipEventCreate(&e0)); T_HIP(hipEventCreate(&e1));
   auto run = [&]() -> int {
@@ -197,57 +197,13 @@ int czc_test_gemm_rowln(int precision, int M, int K, const float* A, const float
   return down_act(pool, precision, dy, (size_t)M * H, y_out);
 }
 
-// Folded-LayerNorm GEMM pair on host data (bf16 engine kernels, hidden = K2 = 512):
-//   x_out = resid + A[M,K1].Wo[512,K1]^T + bo           (fp32-output 256x256 kernel: + bf16 copy + row statistics)
-//   h     = act(LN(x_out; gamma, beta, eps).W1[N,512]^T + b1)   (weight-stationary kernel, LayerNorm in its epilogue)
-// iters > 0 additionally times the consumer launch (ms_out, may be NULL).
-int czc_test_lnf_pair(int M, int K1, int N, const float* A, const float* Wo, const float* bo, const float* resid,
-                      const float* gamma, const float* beta, float eps, const float* W1, const float* b1, int act,
-                      float* x_out, float* h_out) {
-  const int H = 512;
-  DevPool pool;
-  void* dA = up_act(pool, PREC_BF16, A, (size_t)M * K1); T_PTR(dA);
-  void* dWo = up_act(pool, PREC_BF16, Wo, (size_t)H * K1); T_PTR(dWo);
-  float* dbo = (float*)pool.up(bo, (size_t)H * 4); T_PTR(dbo);
-  float* dx = (float*)pool.up(resid, (size_t)M * H * 4); T_PTR(dx);
-  float* dg = (float*)pool.up(gamma, (size_t)H * 4); T_PTR(dg);
-  float* dbt = (float*)pool.up(beta, (size_t)H * 4); T_PTR(dbt);
-  float* dW1 = (float*)pool.up(W1, (size_t)N * H * 4); T_PTR(dW1);
-  float* db1 = (float*)pool.up(b1, (size_t)N * 4); T_PTR(db1);
-  void* dW1f = pool.alloc((size_t)N * H * 2); T_PTR(dW1f);
-  float* ds = (float*)pool.alloc((size_t)N * 4); T_PTR(ds);
-  float* dbf = (float*)pool.alloc((size_t)N * 4); T_PTR(dbf);
-  void* dxb = pool.alloc((size_t)M * H * 2); T_PTR(dxb);
-  float* dst = (float*)pool.alloc((size_t)M * (H / 64) * 2 * 4); T_PTR(dst);
-  void* dh = pool.alloc((size_t)M * N * 2); T_PTR(dh);
-  T_CHECK(launch_fold_ln(dW1, db1, dg, dbt, N, H, dW1f, ds, dbf, nullptr));
-  GemmArgs p;
-  p.A = dA; p.lda = K1; p.W = dWo; p.ldw = K1; p.bias = dbo; p.resid = dx; p.ldr = H; p.out_act = dxb; p.out_f32 = dx;
-  p.ldc = H; p.M = M; p.N = H; p.K = K1; p.act = ACT_NONE; p.row_stats = dst;
-  if (!gemm256_eligible(p)) { snprintf(czc::g_err, sizeof(czc::g_err), "lnf_pair: producer shape not eligible"); return CZC_ERR_ARG; }
-  T_CHECK(launch_gemm256(p, nullptr));
-  GemmArgs c;
-  c.A = dxb; c.lda = H; c.W = dW1f; c.ldw = H; c.bias = dbf; c.resid = nullptr; c.ldr = 0; c.out_act = dh; c.out_f32 = nullptr;
-  c.ldc = N; c.M = M; c.N = N; c.K = H; c.act = act; c.ln_stats = dst; c.ln_s = ds; c.ln_groups = H / 64; c.ln_eps = eps;
-  if (!gemm_wreg_eligible(c)) { snprintf(czc::g_err, sizeof(czc::g_err), "lnf_pair: consumer shape not eligible"); return CZC_ERR_ARG; }
-  T_CHECK(launch_gemm_wreg(c, nullptr));
-  T_HIP(hipDeviceSynchronize());
-  T_HIP(hipMemcpy(x_out, dx, (size_t)M * H * 4, hipMemcpyDeviceToHost));
-  return down_act(pool, PREC_BF16, dh, (size_t)M * N, h_out);
-}
-
-int czc_option_epoch(void) { return g_option_epoch; }
-
 int czc_test_set_option(const char* name, int value) {
-  ++g_option_epoch;
   if (!strcmp(name, "gemm256")) { g_use_gemm256 = value; return 0; }
-  if (!strcmp(name, "gemm_krot")) { g_gemm_krot = value; return 0; }
   if (!strcmp(name, "skinny")) { g_use_skinny = value; return 0; }
   if (!strcmp(name, "splitk")) { g_use_splitk = value; return 0; }
   if (!strcmp(name, "wreg")) { g_use_wreg = value; return 0; }
   if (!strcmp(name, "gemm256s")) { g_use_gemm256s = value; return 0; }
-  if (!strcmp(name, "wreg_dbg")) { g_wreg_dbg = value; return 0; }
-  if (!strcmp(name, "lnf_dbg")) { g_lnf_dbg = value; return 0; }
+  if (!strcmp(name, "bench_pad")) { g_bench_pad = value; return 0; }
   if (!strcmp(name, "w_dbg")) { g_w_dbg = value; return 0; }
   if (!strcmp(name, "rowln_min_m")) { g_rowln_min_m = value; return 0; }
   if (!strcmp(name, "wreg_min_m")) { g_wreg_min_m = value; return 0; }

@@ -268,4 +268,58 @@ int launch_prefix_finish(const int* own_off, const int* own_len, int B, int K, i
   return 0;
 }
 
+// ---- screen-then-refine: segment plan of the second (split-fp16) pass ---------------------------------
+// One work-group per image.  count_off = exclusive scan of count (count_off[B] = R).  Trunk b keeps the prefix length
+// of the screening plan when the image has candidates to re-encode (else 0 rows); branch segments B + count_off[b] + i.
+__global__ __launch_bounds__(256) void refine_plan_kernel(const int* clen, const int* trunk_len, const int* list, const int* count,
+                                                          const int* count_off, int B, int K, int* own_len, int* pre_len, int* seg_src,
+                                                          int* seg_pos0, int* rlist, int* max_len_out) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int n = count[b], o = count_off[b];
+  const int pb = n > 0 ? trunk_len[b] : 0;
+  if (tid == 0) { own_len[b] = pb; pre_len[b] = 0; seg_src[b] = b * K; seg_pos0[b] = 0; }
+  int mx = 0, mxb = 0;
+  for (int i = tid; i < n; i += blockDim.x) {
+    const int flat = b * K + list[(long)b * K + i];
+    const int s = B + o + i;
+    const int len = clen[flat];
+    own_len[s] = len - pb;
+    pre_len[s] = pb;
+    seg_src[s] = flat;
+    seg_pos0[s] = pb;
+    rlist[o + i] = flat;
+    mx = max(mx, len);
+    mxb = max(mxb, len - pb);
+  }
+  if (mx) { atomicMax(max_len_out, mx); atomicMax(max_len_out + 1, mxb); }
+}
+
+int launch_refine_plan(const int* clip_len, const int* trunk_len, const int* list, const int* count, const int* count_off, int B, int K,
+                       int* own_len, int* pre_len, int* seg_src, int* seg_pos0, int* rlist, int* max_len_out, hipStream_t st) {
+  hipLaunchKernelGGL(refine_plan_kernel, dim3(B), dim3(256), 0, st, clip_len, trunk_len, list, count, count_off, B, K, own_len, pre_len,
+                     seg_src, seg_pos0, rlist, max_len_out);
+  CZC_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// after the scan of own_len over B + B*K segments: pre_off of branch r = own_off[its image's trunk]; eos_idx[r]
+__global__ void refine_finish_kernel(const int* own_off, const int* own_len, const int* count_off, int B, int K, int* pre_off,
+                                     int* eos_idx, const int* rlist) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B) pre_off[i] = 0;
+  if (i < count_off[B]) {
+    const int s = B + i;
+    pre_off[s] = own_off[rlist[i] / K];
+    eos_idx[i] = own_off[s] + own_len[s] - 1;
+  }
+}
+
+int launch_refine_finish(const int* own_off, const int* own_len, const int* count_off, int B, int K, int* pre_off, int* eos_idx,
+                         const int* rlist, hipStream_t st) {
+  hipLaunchKernelGGL(refine_finish_kernel, dim3(cdiv((long)B * K, 256)), dim3(256), 0, st, own_off, own_len, count_off, B, K, pre_off,
+                     eos_idx, rlist);
+  CZC_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
 }  // namespace czc

@@ -59,6 +59,27 @@ __global__ __launch_bounds__(CB_THREADS) void combine_kernel(CombineArgs a) {
   // cosines come from cosine_kernel through clip_ref (overwritten below with the reference's logits/scale form)
   for (int k = tid; k < K; k += CB_THREADS) s_cos[k] = a.clip_ref[(long)b * K + k];
   __syncthreads();
+  if (a.refine_kind) {
+    // screen-then-refine: candidates marked in refine_kind carry an exact (split-fp16) cosine in
+    // refine_cos; the others keep the screening (single-pass fp16) cosine minus the screening tower's mean error,
+    // estimated on the mass-stratified SAMPLE among the re-encoded candidates (kind 2, weight = strata it stands for)
+    float ds = 0.f, dw = 0.f;
+    for (int k = tid; k < K; k += CB_THREADS) {
+      const int kd = a.refine_kind[(long)b * K + k];
+      if ((kd & 3) == 2) {
+        const float w = (float)(kd >> 2);
+        ds += w * (s_cos[k] - a.refine_cos[(long)b * K + k]);
+        dw += w;
+      }
+    }
+    ds = blk_reduce(ds, red, 0);
+    dw = blk_reduce(dw, red, 0);
+    const float mu = dw > 0.f ? ds / dw : 0.f;
+    __syncthreads();
+    for (int k = tid; k < K; k += CB_THREADS)
+      s_cos[k] = a.refine_kind[(long)b * K + k] ? a.refine_cos[(long)b * K + k] : s_cos[k] - mu;
+    __syncthreads();
+  }
 
   // softmax over K of cos * scale
   float mx = -INFINITY;
@@ -111,13 +132,114 @@ __global__ __launch_bounds__(CB_THREADS) void combine_kernel(CombineArgs a) {
   }
 }
 
+// Screen-then-refine, selection.  After the screening pass (combine_kernel on the single-pass fp16 cosines) pick, per
+// image, the candidates whose cosine is re-encoded by the split-fp16 tower:
+//   kind 1: softmax_K mass above theta (their score error scales with beta * scale * p_k), plus the two best fused scores
+//           (the winner's cosine is what the caller gets back: gen_utils.py:80-81);
+//   kind 2: m_samples candidates of the rest, one per equal-MASS stratum in candidate order (where the cumulative
+//           softmax mass of the rest crosses (j + 1/2) / m of its total); kind = 2 | hits << 2 when one candidate
+//           covers several strata.  Their exact cosines give the mass-weighted mean error of the screening tower over
+//           the candidates that are NOT re-encoded, which the final combine removes.
+// list[b][0..count[b]) = the chosen candidate indices in ascending order.
+__global__ __launch_bounds__(CB_THREADS) void refine_select_kernel(const float* clip_score, const float* final_score, int K,
+                                                                   float theta, int m_samples, int* kind, int* list, int* count) {
+  __shared__ float s_p[CB_MAXK];
+  __shared__ float s_f[CB_MAXK];
+  __shared__ int s_kind[CB_MAXK];
+  __shared__ float red[8];
+  __shared__ int s_arg;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  for (int k = tid; k < K; k += CB_THREADS) {
+    s_p[k] = clip_score[(long)b * K + k];
+    s_f[k] = final_score[(long)b * K + k];
+    s_kind[k] = s_p[k] > theta ? 1 : 0;
+  }
+  __syncthreads();
+  for (int round = 0; round < 2; ++round) {  // first argmax of the fused score, then the runner-up
+    float bm = -INFINITY;
+    for (int k = tid; k < K; k += CB_THREADS) bm = fmaxf(bm, s_f[k]);
+    bm = blk_reduce(bm, red, 1);
+    if (tid == 0) s_arg = K;
+    __syncthreads();
+    for (int k = tid; k < K; k += CB_THREADS)
+      if (s_f[k] == bm) atomicMin(&s_arg, k);
+    __syncthreads();
+    if (tid == 0 && s_arg < K) { s_kind[s_arg] = 1; s_f[s_arg] = -INFINITY; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    float tot = 0.f;
+    for (int k = 0; k < K; ++k) if (!s_kind[k]) tot += s_p[k];
+    if (m_samples > 0 && tot > 0.f) {
+      float cum = 0.f;
+      int j = 0;
+      for (int k = 0; k < K && j < m_samples; ++k) {
+        if (s_kind[k]) continue;
+        cum += s_p[k];
+        int hits = 0;
+        while (j < m_samples && cum >= ((float)j + 0.5f) * tot / (float)m_samples) { ++hits; ++j; }
+        if (hits) s_kind[k] = 2 | (hits << 2);
+      }
+    }
+    int n = 0;
+    for (int k = 0; k < K; ++k) {
+      kind[(long)b * K + k] = s_kind[k];
+      if (s_kind[k]) list[(long)b * K + n++] = k;
+    }
+    count[b] = n;
+  }
+}
+
+int launch_refine_select(const float* clip_score, const float* final_score, int B, int K, float theta, int m_samples, int* kind,
+                         int* list, int* count, hipStream_t st) {
+  if (K > CB_MAXK) {
+    snprintf(g_err, sizeof(g_err), "refine_select: K=%d > %d", K, CB_MAXK);
+    return 1;
+  }
+  hipLaunchKernelGGL(refine_select_kernel, dim3(B), dim3(CB_THREADS), 0, st, clip_score, final_score, K, theta, m_samples, kind, list,
+                     count);
+  CZC_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// exact cosines of the re-encoded candidates: row r of text_feat belongs to flat candidate rlist[r] = b*K + k
+__global__ __launch_bounds__(256) void refine_cosine_kernel(const float* text_feat, const float* img_n, const int* rlist, const int* n_rows,
+                                                            int K, int D, float* cos_out, int* nonfinite) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= *n_rows) return;
+  const int flat = rlist[row];
+  const float* t = text_feat + row * D;
+  const float* img = img_n + (long)(flat / K) * D;
+  float nn = 0.f;
+  for (int c = lane; c < D; c += 64) nn += t[c] * t[c];
+  const float nrm = sqrtf(wave_sum(nn));
+  float dot = 0.f;
+  for (int c = lane; c < D; c += 64) dot += (t[c] / nrm) * img[c];
+  dot = wave_sum(dot);
+  if (lane == 0) {
+    cos_out[flat] = dot;
+    if (nonfinite && !(fabsf(dot) <= 2.0f)) atomicOr(nonfinite, 1);
+  }
+}
+
+int launch_refine_cosine(const float* text_feat, const float* img_n, const int* rlist, const int* n_rows_dev, int n_rows_max, int K, int D,
+                         float* cos_out, int* nonfinite, hipStream_t st) {
+  if (n_rows_max <= 0) return 0;
+  hipLaunchKernelGGL(refine_cosine_kernel, dim3((unsigned)cdiv(n_rows_max, 4)), dim3(256), 0, st, text_feat, img_n, rlist, n_rows_dev, K, D,
+                     cos_out, nonfinite);
+  CZC_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
 int launch_combine(const CombineArgs& a, hipStream_t st) {
   if (a.K > CB_MAXK) {
     snprintf(g_err, sizeof(g_err), "combine: K=%d > %d", a.K, CB_MAXK);
     return 1;
   }
-  hipLaunchKernelGGL(cosine_kernel, dim3((unsigned)cdiv((long)a.B * a.K, 4)), dim3(256), 0, st, a.text_feat, a.img_n, a.B, a.K, a.D,
-                     a.clip_ref, a.nonfinite);
+  if (a.text_feat)  // null: clip_ref already holds the cosines (second combine of the screen-then-refine engine)
+    hipLaunchKernelGGL(cosine_kernel, dim3((unsigned)cdiv((long)a.B * a.K, 4)), dim3(256), 0, st, a.text_feat, a.img_n, a.B, a.K, a.D,
+                       a.clip_ref, a.nonfinite);
   hipLaunchKernelGGL(combine_kernel, dim3(a.B), dim3(CB_THREADS), 0, st, a);
   CZC_HIP_CHECK(hipGetLastError());
   return 0;

@@ -173,7 +173,28 @@ __host__ __device__ inline size_t prec_bytes(int p) { return prec_is_half(p) ? 2
     }                                                                                            \
   } while (0)
 
-extern char g_err[512];
+extern thread_local char g_err[512];  // per host thread: two engines of an EngineGroup launch from two threads
+
+// One-time launch set-up of a kernel family (CU count, dynamic-LDS attributes), run by whichever host thread gets
+// there first behind a function-local static (C++11: initialised exactly once, other threads wait).
+struct LaunchInit { int n_cu = 0; int rc = 0; };
+template <typename F>
+inline LaunchInit launch_init(F attrs) {
+  LaunchInit li;
+  li.rc = [&]() -> int {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    CZC_HIP_CHECK(hipGetDevice(&dev));
+    CZC_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+    li.n_cu = prop.multiProcessorCount;
+    return attrs(li);
+  }();
+  return li;
+}
+inline int launch_init_failed(const char* what) {
+  snprintf(g_err, sizeof(g_err), "%s: one-time launch set-up failed (hipFuncSetAttribute / device query)", what);
+  return 2;
+}
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 

@@ -15,7 +15,7 @@
 #include "bridge_hash.h"
 
 namespace czc {
-char g_err[512] = {0};
+thread_local char g_err[512] = {0};
 }
 using namespace czc;
 
@@ -34,9 +34,6 @@ struct LayerW {
   void* fc1_w = nullptr; float* fc1_b = nullptr;
   void* fc2_w = nullptr; float* fc2_b = nullptr;
   float *ln2_g = nullptr, *ln2_b = nullptr;
-  // bf16 CLIP-text tower: LayerNorm folded into the q/k/v and fc1 weights (GemmArgs::ln_*, rowops.hip fold_ln_kernel)
-  void* qkv_wf = nullptr; float* qkv_sf = nullptr; float* qkv_bf = nullptr;
-  void* fc1_wf = nullptr; float* fc1_sf = nullptr; float* fc1_bf = nullptr;
 };
 
 struct Buf {
@@ -63,13 +60,20 @@ struct czc_engine {
   bool finalized = false;
   size_t esz = 2;  // bytes per CLIP activation element
   int pb = PREC_F32, pc = PREC_BF16;  // BERT / CLIP tower precisions
+  int pv = PREC_BF16;                 // CLIP vision tower precision (= pc, except split-fp16 in the screen-then-refine engine)
   size_t eb = 4;   // bytes per BERT activation element
+  // Screen-then-refine (CZC_PREC_REFINE): every candidate goes through the single-pass fp16 text tower; the candidates
+  // that carry the softmax_K mass (+ a mass-stratified sample of the rest) are re-encoded by the split-fp16 tower
+  // (ctext_x / tproj_wx) and the final scores are formed from the mixed cosines (combine.hip)
+  bool refine = false;
+  float refine_theta_x = 4.0f;  // mass threshold theta = refine_theta_x / (beta * exp(logit_scale)): 0.02 at beta 2, scale 100
+  int refine_samples = 12;      // strata of the sample among the candidates below the threshold
 
   std::map<std::string, Tensor> w;
-  std::vector<LayerW> bert, ctext, cvis;
+  std::vector<LayerW> bert, ctext, cvis, ctext_x;
   // extra processed weights
   void* mlm_dense_w = nullptr; void* decoder_w = nullptr; void* tproj_w = nullptr; void* vproj_w = nullptr;
-  void* patch_w = nullptr;
+  void* patch_w = nullptr; void* tproj_wx = nullptr;
 
   std::map<std::string, Buf> ws;
   float* d_mask = nullptr; int mask_vocab = 0;
@@ -89,20 +93,10 @@ struct czc_engine {
   int fuse_ln = 1;         // bf16 / fp16 CLIP-text tower: 1 = out-proj as a full-row kernel with LN2 in its epilogue
                            // (gemm_rowln_kernel; +1 % captions/s), 2 = fc2 -> next layer's LN1 as well (measured slower: the
                            // K = 2048 GEMM pays more for 128-row tiles than the LayerNorm pass costs), 0 = off
-  int fold_ln = 0;         // bf16 CLIP-text tower: LayerNorm applied inside the GEMM epilogues (no LayerNorm pass over HBM);
-                           // measured slower than the LayerNorm kernel while out-proj / fc2 pay for the bf16 copy
-
-  // hipGraph replay of the two halves of a position-step (before / after the one size read), small batches only
-  int use_graphs = 0;   // 0 off (default: measured no faster than eager launches), 1 on, -1 czc_generate with B <= 4
-  bool graphs_now = false, capturing = false, capture_broken = false;
-  int option_epoch = 0;
-  std::map<std::vector<int>, hipGraphExec_t> graphs;
-  std::map<std::vector<int>, int> graph_seen;
-  int64_t stat_graph_launches = 0, stat_graph_captures = 0;
-
   int prof = 0;  // 0 off, 1 every kernel class, 2 only the CLIP-text linear layers (the roofline kernel family)
   std::map<std::string, ProfKind> pk;
   int64_t stat_clip_rows = 0, stat_clip_seqs = 0, stat_bert_rows = 0, stat_steps = 0;
+  int64_t stat_refine_rows = 0, stat_refine_seqs = 0;
 };
 
 namespace {
@@ -131,20 +125,9 @@ int fail(czc_engine* e, int code, const char* fmt, const char* a = "") {
   return code;
 }
 
-void invalidate_graphs(czc_engine* e) {
-  for (auto& kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
-  e->graphs.clear();
-  e->graph_seen.clear();
-}
-
 int ensure(czc_engine* e, const char* name, size_t bytes, void** out) {
   Buf& b = e->ws[name];
   if (b.bytes < bytes) {
-    if (e->capturing) {  // no allocation inside a capture: give the capture up, the caller reruns the phase eagerly
-      e->capture_broken = true;
-      return fail(e, CZC_ERR_STATE, "workspace growth during graph capture%s");
-    }
-    invalidate_graphs(e);  // cached graphs hold the old pointers
     if (b.p) {
       E_HIP(hipStreamSynchronize(e->st));
       E_HIP(hipFree(b.p));
@@ -205,8 +188,7 @@ int to_act(czc_engine* e, int prec, const float* src, size_t numel, void** out) 
 }
 
 int build_layers(czc_engine* e, std::vector<LayerW>& L, int n_layers, int H, int I, bool bert_style,
-                 const std::string& prefix) {
-  const int prec = bert_style ? e->pb : e->pc;
+                 const std::string& prefix, int prec) {
   const size_t es = prec_bytes(prec);
   L.resize(n_layers);
   for (int n = 0; n < n_layers; ++n) {
@@ -246,23 +228,6 @@ int build_layers(czc_engine* e, std::vector<LayerW>& L, int n_layers, int H, int
     E_CHECK(need(e, fc2 + ".weight", (size_t)H * I, &t)); E_CHECK(to_act(e, prec, t, (size_t)H * I, &l.fc2_w));
     E_CHECK(need(e, fc2 + ".bias", H, &l.fc2_b));
     E_CHECK(need(e, ln2 + ".weight", H, &l.ln2_g)); E_CHECK(need(e, ln2 + ".bias", H, &l.ln2_b));
-    if (!bert_style && prec == PREC_BF16 && H == 512 && prefix.compare(0, 5, "text_") == 0) {
-      // pre-LN block: LN1 feeds q/k/v, LN2 feeds fc1 (HF:clip/modeling_clip.py:368-383)
-      float* fc1m;
-      E_CHECK(need(e, fc1 + ".weight", (size_t)I * H, &fc1m));
-      E_HIP(hipMalloc(&l.qkv_wf, (size_t)3 * H * H * 2));
-      E_HIP(hipMalloc((void**)&l.qkv_sf, (size_t)3 * H * 4));
-      E_HIP(hipMalloc((void**)&l.qkv_bf, (size_t)3 * H * 4));
-      E_HIP(hipMalloc(&l.fc1_wf, (size_t)I * H * 2));
-      E_HIP(hipMalloc((void**)&l.fc1_sf, (size_t)I * 4));
-      E_HIP(hipMalloc((void**)&l.fc1_bf, (size_t)I * 4));
-      const float* ws[3] = {qw, kw, vw};
-      const float* bs[3] = {qb, kb, vb};
-      for (int t3 = 0; t3 < 3; ++t3)
-        E_CHECK(launch_fold_ln(ws[t3], bs[t3], l.ln1_g, l.ln1_b, H, H, (char*)l.qkv_wf + (size_t)t3 * H * H * 2,
-                               l.qkv_sf + t3 * H, l.qkv_bf + t3 * H, e->st));
-      E_CHECK(launch_fold_ln(fc1m, l.fc1_b, l.ln2_g, l.ln2_b, I, H, l.fc1_wf, l.fc1_sf, l.fc1_bf, e->st));
-    }
   }
   return 0;
 }
@@ -288,43 +253,22 @@ int gemm_ex(czc_engine* e, int prec, const char* kind, const GemmArgs& g) {
 // `pool_idx` (optional): only these n_pool rows are needed after the stack (EOS rows of the CLIP text
 // tower).  The last layer then runs its out-projection and MLP on those rows only (K/V of every row
 // are still produced); the pooled residual rows are returned in *pooled (fp32 [n_pool, H]).
-int clip_stack(czc_engine* e, const char* gk, std::vector<LayerW>& L, float* x, int M, int H, int I, int heads,
+// P = precision of the layer weights in L (the engine's CLIP precision, or PREC_F16X3 for the refine pass).
+int clip_stack(czc_engine* e, int P, const char* gk, std::vector<LayerW>& L, float* x, int M, int H, int I, int heads,
                float eps, const SegTable& tab, int max_keys, int causal, int plan_B = 0, int plan_K = 0,
-               int plan_max_own = 0, const int* pool_idx = nullptr, int n_pool = 0, float** pooled = nullptr,
-               int plan_trunk_rows = 0) {
-  const int P = e->pc;
+               int plan_max_own = 0, const int* pool_idx = nullptr, int n_pool = 0, float** pooled = nullptr) {
+  const size_t esz = prec_bytes(P);
   void *y, *qkv, *ctx, *hbuf;
-  E_CHECK(ensure(e, "cs_y", (size_t)M * H * e->esz, &y));
-  E_CHECK(ensure(e, "cs_qkv", (size_t)M * 3 * H * e->esz, &qkv));
-  E_CHECK(ensure(e, "cs_ctx", (size_t)M * H * e->esz, &ctx));
-  E_CHECK(ensure(e, "cs_h", (size_t)M * I * e->esz, &hbuf));
+  E_CHECK(ensure(e, "cs_y", (size_t)M * H * esz, &y));
+  E_CHECK(ensure(e, "cs_qkv", (size_t)M * 3 * H * esz, &qkv));
+  E_CHECK(ensure(e, "cs_ctx", (size_t)M * H * esz, &ctx));
+  E_CHECK(ensure(e, "cs_h", (size_t)M * I * esz, &hbuf));
   const float scale = 1.0f / sqrtf(64.0f);
-  // LayerNorm folding (bf16 text tower, big batches): the fp32-output GEMMs (out-proj, fc2) also leave a bf16 copy
-  // of the new residual stream in `y` and its per-row statistics partials in `stats`; the K = 512 GEMMs that follow
-  // a LayerNorm (q/k/v, fc1) read that copy with gain-folded weights and finish the LayerNorm in their epilogue.
-  // Layer 0's LN1 (input = embeddings) and everything on pooled rows still run the LayerNorm kernel.
-  const bool fold = P == PREC_BF16 && e->fold_ln && H == 512 && M >= 2048 && !L.empty() && L[0].qkv_wf &&
-                    g_use_wreg == 2 && g_use_gemm256 == 3;
   // LayerNorm fused into the producer: out-proj (fuse_ln >= 1) and fc2 (fuse_ln >= 2) run on full 512-wide rows and
   // leave y = LN(x) beside the new fp32 x; the LayerNorm kernel then only runs where no such producer exists.
-  const bool rowln = !fold && prec_is_half(P) && e->fuse_ln && H == 512 && M >= g_rowln_min_m && I % 32 == 0;
-  float* stats = nullptr;
-  if (fold) E_CHECK(ensure(e, "cs_stats", (size_t)M * (H / 64) * 2 * 4, (void**)&stats));
-  bool have_stats = false;
-  auto lnf_gemm = [&](const void* Wf, const float* bf, const float* sf, void* out, int N, int act) -> int {
-    GemmArgs g;
-    g.A = y; g.lda = H; g.W = Wf; g.ldw = H; g.bias = bf; g.resid = nullptr; g.ldr = 0; g.out_act = out; g.out_f32 = nullptr;
-    g.ldc = N; g.M = M; g.N = N; g.K = H; g.act = act;
-    g.ln_stats = stats; g.ln_s = sf; g.ln_groups = H / 64; g.ln_eps = eps;
-    if (!gemm_wreg_eligible(g)) return fail(e, CZC_ERR_STATE, "folded LayerNorm GEMM not eligible%s");
-    return gemm_ex(e, P, gk, g);
-  };
-  auto resid_gemm = [&](const void* A, int lda, const void* W, const float* b, int K) -> int {  // x += A.W^T + b (+ copy, stats)
-    GemmArgs g;
-    g.A = A; g.lda = lda; g.W = W; g.ldw = K; g.bias = b; g.resid = x; g.ldr = H; g.out_act = fold ? y : nullptr; g.out_f32 = x;
-    g.ldc = H; g.M = M; g.N = H; g.K = K; g.act = ACT_NONE;
-    g.row_stats = fold ? stats : nullptr;
-    return gemm_ex(e, P, gk, g);
+  const bool rowln = prec_is_half(P) && e->fuse_ln && H == 512 && M >= g_rowln_min_m && I % 32 == 0;
+  auto resid_gemm = [&](const void* A, int lda, const void* W, const float* b, int K) -> int {  // x += A.W^T + b
+    return gemm(e, P, gk, A, lda, W, K, b, x, H, nullptr, x, H, M, H, K, ACT_NONE);
   };
   auto resid_ln_gemm = [&](const void* A, int lda, const void* W, const float* b, int K, const float* gm,
                            const float* bt) -> int {  // x += A.W^T + b; y = LN(x; gm, bt)
@@ -339,12 +283,11 @@ int clip_stack(czc_engine* e, const char* gk, std::vector<LayerW>& L, float* x, 
   bool have_y = false;  // y already holds this layer's LN1 output (left by the previous layer's fc2)
   for (size_t n = 0; n < L.size(); ++n) {
     LayerW& l = L[n];
-    if (!(fold && have_stats) && !have_y) {
+    if (!have_y) {
       ProfScope ps(e, "rowops", 0);
       E_CHECK(launch_layernorm(P, x, nullptr, l.ln1_g, l.ln1_b, eps, M, H, y, nullptr, e->st));
     }
-    if (fold && have_stats) E_CHECK(lnf_gemm(l.qkv_wf, l.qkv_bf, l.qkv_sf, qkv, 3 * H, ACT_NONE));
-    else E_CHECK(gemm(e, P, gk, y, H, l.qkv_w, H, l.qkv_b, nullptr, 0, qkv, nullptr, 3 * H, M, 3 * H, H, ACT_NONE));
+    E_CHECK(gemm(e, P, gk, y, H, l.qkv_w, H, l.qkv_b, nullptr, 0, qkv, nullptr, 3 * H, M, 3 * H, H, ACT_NONE));
     { ProfScope ps(e, "attention", 0);
       int rc = -1;
       if (plan_B > 0 && prec_is_half(P) && g_use_mfma_attention && e->pack_branches)
@@ -355,12 +298,12 @@ int clip_stack(czc_engine* e, const char* gk, std::vector<LayerW>& L, float* x, 
       if (rc < 0) E_CHECK(launch_attention(P, qkv, tab, max_keys, heads, causal, scale, ctx, e->st)); }
     if (pool_idx && n + 1 == L.size() && e->pool_last_layer) {
       void *ctx_e, *y_e, *h_e; float* x_e;
-      E_CHECK(ensure(e, "cs_ctx_e", (size_t)n_pool * H * e->esz, &ctx_e));
-      E_CHECK(ensure(e, "cs_y_e", (size_t)n_pool * H * e->esz, &y_e));
-      E_CHECK(ensure(e, "cs_h_e", (size_t)n_pool * I * e->esz, &h_e));
+      E_CHECK(ensure(e, "cs_ctx_e", (size_t)n_pool * H * esz, &ctx_e));
+      E_CHECK(ensure(e, "cs_y_e", (size_t)n_pool * H * esz, &y_e));
+      E_CHECK(ensure(e, "cs_h_e", (size_t)n_pool * I * esz, &h_e));
       E_CHECK(ensure(e, "cs_x_e", (size_t)n_pool * H * 4, (void**)&x_e));
       { ProfScope ps(e, "rowops", 0);
-        E_CHECK(launch_gather_rows_bytes(ctx, pool_idx, n_pool, H * (int)e->esz, ctx_e, e->st));
+        E_CHECK(launch_gather_rows_bytes(ctx, pool_idx, n_pool, H * (int)esz, ctx_e, e->st));
         E_CHECK(launch_gather_rows_f32(x, pool_idx, n_pool, H, x_e, e->st)); }
       E_CHECK(gemm(e, P, gk, ctx_e, H, l.o_w, H, l.o_b, x_e, H, nullptr, x_e, H, n_pool, H, H, ACT_NONE));
       { ProfScope ps(e, "rowops", 0);
@@ -371,17 +314,15 @@ int clip_stack(czc_engine* e, const char* gk, std::vector<LayerW>& L, float* x, 
       return 0;
     }
     if (rowln) E_CHECK(resid_ln_gemm(ctx, H, l.o_w, l.o_b, H, l.ln2_g, l.ln2_b));
-    else E_CHECK(resid_gemm(ctx, H, l.o_w, l.o_b, H));
-    if (fold) {
-      E_CHECK(lnf_gemm(l.fc1_wf, l.fc1_bf, l.fc1_sf, hbuf, I, ACT_QUICK_GELU));
-    } else {
-      if (!rowln) { ProfScope ps(e, "rowops", 0); E_CHECK(launch_layernorm(P, x, nullptr, l.ln2_g, l.ln2_b, eps, M, H, y, nullptr, e->st)); }
-      E_CHECK(gemm(e, P, gk, y, H, l.fc1_w, H, l.fc1_b, nullptr, 0, hbuf, nullptr, I, M, I, H, ACT_QUICK_GELU));
+    else {
+      E_CHECK(resid_gemm(ctx, H, l.o_w, l.o_b, H));
+      ProfScope ps(e, "rowops", 0);
+      E_CHECK(launch_layernorm(P, x, nullptr, l.ln2_g, l.ln2_b, eps, M, H, y, nullptr, e->st));
     }
+    E_CHECK(gemm(e, P, gk, y, H, l.fc1_w, H, l.fc1_b, nullptr, 0, hbuf, nullptr, I, M, I, H, ACT_QUICK_GELU));
     have_y = rowln && e->fuse_ln >= 2 && n + 1 < L.size();
     if (have_y) E_CHECK(resid_ln_gemm(hbuf, I, l.fc2_w, l.fc2_b, I, L[n + 1].ln1_g, L[n + 1].ln1_b));
     else E_CHECK(resid_gemm(hbuf, I, l.fc2_w, l.fc2_b, I));
-    have_stats = fold;
   }
   return 0;
 }
@@ -456,15 +397,17 @@ int mlm_head(czc_engine* e, int B, int T, int gen_idx, float** logits_out) {
 // clip_plan builds the segment table on the device and starts the read, clip_tower runs on the sizes it returned.
 struct PlanBufs { int *own_len, *pre_len, *src, *pos0, *own_off, *pre_off, *eidx; };
 
-int plan_bufs(czc_engine* e, int B, int K, PlanBufs* p) {
+// pfx "p": the plan of the screening / only pass; "r": the plan of the refine pass
+int plan_bufs(czc_engine* e, int B, int K, PlanBufs* p, const char* pfx = "p") {
   const int n_seq = B * K, S = B + n_seq;
-  E_CHECK(ensure(e, "p_own_len", (size_t)S * 4, (void**)&p->own_len));
-  E_CHECK(ensure(e, "p_pre_len", (size_t)S * 4, (void**)&p->pre_len));
-  E_CHECK(ensure(e, "p_src", (size_t)S * 4, (void**)&p->src));
-  E_CHECK(ensure(e, "p_pos0", (size_t)S * 4, (void**)&p->pos0));
-  E_CHECK(ensure(e, "p_own_off", (size_t)(S + 1) * 4, (void**)&p->own_off));
-  E_CHECK(ensure(e, "p_pre_off", (size_t)S * 4, (void**)&p->pre_off));
-  E_CHECK(ensure(e, "s_eidx", (size_t)n_seq * 4, (void**)&p->eidx));
+  const std::string q(pfx);
+  E_CHECK(ensure(e, (q + "_own_len").c_str(), (size_t)S * 4, (void**)&p->own_len));
+  E_CHECK(ensure(e, (q + "_pre_len").c_str(), (size_t)S * 4, (void**)&p->pre_len));
+  E_CHECK(ensure(e, (q + "_src").c_str(), (size_t)S * 4, (void**)&p->src));
+  E_CHECK(ensure(e, (q + "_pos0").c_str(), (size_t)S * 4, (void**)&p->pos0));
+  E_CHECK(ensure(e, (q + "_own_off").c_str(), (size_t)(S + 1) * 4, (void**)&p->own_off));
+  E_CHECK(ensure(e, (q + "_pre_off").c_str(), (size_t)S * 4, (void**)&p->pre_off));
+  E_CHECK(ensure(e, (q + "_eidx").c_str(), (size_t)n_seq * 4, (void**)&p->eidx));
   return 0;
 }
 
@@ -483,35 +426,44 @@ int clip_plan(czc_engine* e, const int* cids, const int* clen, int B, int K, int
   return 0;
 }
 
-int clip_tower(czc_engine* e, const int* cids, int B, int K, int share, int M, int max_len, int max_branch, int n_trunk,
-               float** feat_out) {
+// The text tower on a planned set of packed segments: n_seg segments (tab), M rows, n_pool sequences pooled at p.eidx.
+// P / L / tproj: the tower's precision and weights; plan_B > 0: regular B x K plan (packed-branch attention kernels).
+int clip_tower_on(czc_engine* e, int P, std::vector<LayerW>& L, const void* tproj, const char* gk, const int* cids,
+                  const PlanBufs& p, int n_seg, int n_pool, int M, int max_len, int plan_B, int plan_K, int max_branch,
+                  const char* feat_name, float** feat_out) {
   const czc_config& c = e->cfg;
-  const int P = e->pc;
   const int H = c.clip_hidden;
-  const int n_seq = B * K, S = B + n_seq;
-  PlanBufs p;
-  E_CHECK(plan_bufs(e, B, K, &p));
   float *x, *feat, *tok, *pos, *fg, *fb; void* pa;
   E_CHECK(ensure(e, "c_x", (size_t)M * H * 4, (void**)&x));
-  E_CHECK(ensure(e, "c_pa", (size_t)n_seq * H * e->esz, &pa));
-  E_CHECK(ensure(e, "c_feat", (size_t)n_seq * c.clip_proj * 4, (void**)&feat));
+  E_CHECK(ensure(e, "c_pa", (size_t)n_pool * H * prec_bytes(P), &pa));
+  E_CHECK(ensure(e, feat_name, (size_t)n_pool * c.clip_proj * 4, (void**)&feat));
   E_CHECK(need(e, "text_model.embeddings.token_embedding.weight", (size_t)c.clip_vocab * H, &tok));
   E_CHECK(need(e, "text_model.embeddings.position_embedding.weight", (size_t)c.clip_max_pos * H, &pos));
   E_CHECK(need(e, "text_model.final_layer_norm.weight", H, &fg));
   E_CHECK(need(e, "text_model.final_layer_norm.bias", H, &fb));
   { ProfScope ps(e, "rowops", 0);
-    E_CHECK(launch_clip_embed(cids, CZC_CLIP_MAX_LEN, p.src, p.pos0, p.own_off, p.own_len, S, max_len, H, tok, pos, x, e->st)); }
-  SegTable tab{p.pre_off, p.pre_len, p.own_off, p.own_len, S, 0};
+    E_CHECK(launch_clip_embed(cids, CZC_CLIP_MAX_LEN, p.src, p.pos0, p.own_off, p.own_len, n_seg, max_len, H, tok, pos, x, e->st)); }
+  SegTable tab{p.pre_off, p.pre_len, p.own_off, p.own_len, n_seg, 0};
   float* pooled = nullptr;
-  E_CHECK(clip_stack(e, "gemm_clip_text", e->ctext, x, M, H, c.clip_inter, c.clip_heads, c.clip_eps, tab, max_len, 1, B,
-                     K, max_branch, p.eidx, n_seq, &pooled, share ? n_trunk : 0));
+  E_CHECK(clip_stack(e, P, gk, L, x, M, H, c.clip_inter, c.clip_heads, c.clip_eps, tab, max_len, 1, plan_B,
+                     plan_K, max_branch, p.eidx, n_pool, &pooled));
   { ProfScope ps(e, "rowops", 0);
-    if (pooled) E_CHECK(launch_layernorm(P, pooled, nullptr, fg, fb, c.clip_eps, n_seq, H, pa, nullptr, e->st));
-    else E_CHECK(launch_layernorm(P, x, p.eidx, fg, fb, c.clip_eps, n_seq, H, pa, nullptr, e->st)); }
-  E_CHECK(gemm(e, P, "gemm_clip_text", pa, H, e->tproj_w, H, nullptr, nullptr, 0, nullptr, feat, c.clip_proj, n_seq,
-               c.clip_proj, H, ACT_NONE));
+    if (pooled) E_CHECK(launch_layernorm(P, pooled, nullptr, fg, fb, c.clip_eps, n_pool, H, pa, nullptr, e->st));
+    else E_CHECK(launch_layernorm(P, x, p.eidx, fg, fb, c.clip_eps, n_pool, H, pa, nullptr, e->st)); }
+  E_CHECK(gemm(e, P, gk, pa, H, tproj, H, nullptr, nullptr, 0, nullptr, feat, c.clip_proj, n_pool, c.clip_proj, H, ACT_NONE));
   *feat_out = feat;
   return 0;
+}
+
+// the engine's text tower on the regular B x K plan built by clip_plan; `exact`: the refine engine's split-fp16 weights
+int clip_tower(czc_engine* e, const int* cids, int B, int K, int share, int M, int max_len, int max_branch, int n_trunk,
+               float** feat_out, bool exact = false) {
+  (void)share; (void)n_trunk;
+  PlanBufs p;
+  E_CHECK(plan_bufs(e, B, K, &p));
+  const bool x = exact && e->refine;
+  return clip_tower_on(e, x ? (int)PREC_F16X3 : e->pc, x ? e->ctext_x : e->ctext, x ? e->tproj_wx : e->tproj_w, "gemm_clip_text",
+                       cids, p, B + B * K, B * K, M, max_len, B, K, max_branch, "c_feat", feat_out);
 }
 
 // sizes of the tower from the totals the plan read back (after the stream has been synchronised)
@@ -526,12 +478,12 @@ int read_totals(czc_engine* e, int* M, int* max_len, int* max_branch, int* n_tru
 }
 
 int clip_text_forward(czc_engine* e, const int* cids, const int* clen, int B, int K, int share, int* totals,
-                      float** feat_out) {
+                      float** feat_out, bool exact = false) {
   E_CHECK(clip_plan(e, cids, clen, B, K, share, totals));
   E_HIP(hipStreamSynchronize(e->st));  // the one host round trip per step (the reference has one too, gen_utils.py:81)
   int M, max_len, max_branch, n_trunk;
   E_CHECK(read_totals(e, &M, &max_len, &max_branch, &n_trunk));
-  E_CHECK(clip_tower(e, cids, B, K, share, M, max_len, max_branch, n_trunk, feat_out));
+  E_CHECK(clip_tower(e, cids, B, K, share, M, max_len, max_branch, n_trunk, feat_out, exact));
   e->stat_clip_rows += M;
   e->stat_clip_seqs += B * K;
   return 0;
@@ -602,50 +554,54 @@ int step_phase_b(czc_engine* e, const StepArgs& a, int M, int max_len, int max_b
   ca.use_senti = hp->control; ca.B = a.B; ca.K = a.K; ca.D = c.clip_proj; ca.clip_score = cscore; ca.clip_ref = cref;
   ca.final_score = fin; ca.best = best; ca.best_cos = bcos; ca.inp = a.d_inp; ca.T = a.T; ca.gen_idx = a.gen_idx;
   E_CHECK(ensure(e, "s_nonfinite", 16, (void**)&ca.nonfinite));
-  { ProfScope ps(e, "combine", 0); E_CHECK(launch_combine(ca, e->st)); }
-  return 0;
-}
-
-// Launch-bound small batches (configs[1]: one image is ~250 launches of 5-20 us kernels per step): each half of the
-// step is captured into a hipGraph the SECOND time its key is seen (the first pass runs eagerly and sizes the
-// workspace) and replayed afterwards.  Key = everything a kernel argument or a kernel choice depends on: shapes,
-// position, hyper-parameters, engine options, the process-wide kernel switches' epoch, and for the second half the
-// sizes the plan produced.  Any workspace growth or pointer-changing setter drops all graphs (ensure()).
-extern "C" int czc_option_epoch(void);
-
-template <typename F>
-int run_phase(czc_engine* e, std::vector<int> key, F fn) {
-  if (!e->graphs_now || e->prof) return fn();
-  if (e->option_epoch != czc_option_epoch()) { invalidate_graphs(e); e->option_epoch = czc_option_epoch(); }
-  auto it = e->graphs.find(key);
-  if (it != e->graphs.end()) {
-    E_HIP(hipGraphLaunch(it->second, e->st));
-    e->stat_graph_launches += 1;
+  if (!e->refine) {
+    ProfScope ps(e, "combine", 0);
+    E_CHECK(launch_combine(ca, e->st));
     return 0;
   }
-  if (e->graph_seen[key]++ == 0) return fn();
-  e->capturing = true;
-  e->capture_broken = false;
-  hipGraph_t g = nullptr;
-  int rc = 0;
-  if (hipStreamBeginCapture(e->st, hipStreamCaptureModeThreadLocal) != hipSuccess) { e->capturing = false; return fn(); }
-  rc = fn();
-  const hipError_t he = hipStreamEndCapture(e->st, &g);
-  e->capturing = false;
-  hipGraphExec_t ex = nullptr;
-  if (rc || he != hipSuccess || e->capture_broken || !g ||
-      hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) != hipSuccess) {
-    if (g) (void)hipGraphDestroy(g);
-    (void)hipGetLastError();
-    e->err[0] = 0;
-    e->graph_seen[key] = -1000000;  // do not try this key again
-    return fn();
+  // ---- screen-then-refine: scores from the screening cosines (no write-back), selection, second pass, final scores ----
+  int *kind, *list, *count, *count_off, *rtot, *rlist;
+  float* rcos;
+  E_CHECK(ensure(e, "r_kind", (size_t)n_seq * 4, (void**)&kind));
+  E_CHECK(ensure(e, "r_list", (size_t)n_seq * 4, (void**)&list));
+  E_CHECK(ensure(e, "r_count", (size_t)a.B * 4, (void**)&count));
+  E_CHECK(ensure(e, "r_count_off", (size_t)(a.B + 1) * 4, (void**)&count_off));
+  E_CHECK(ensure(e, "r_tot", 64, (void**)&rtot));
+  E_CHECK(ensure(e, "r_rlist", (size_t)n_seq * 4, (void**)&rlist));
+  E_CHECK(ensure(e, "r_cos", (size_t)n_seq * 4, (void**)&rcos));
+  PlanBufs sp, rp;
+  E_CHECK(plan_bufs(e, a.B, a.K, &sp));
+  E_CHECK(plan_bufs(e, a.B, a.K, &rp, "r"));
+  const int S = a.B + n_seq;
+  const float theta = e->refine_theta_x / fmaxf(hp->beta * e->logit_scale_exp, 1e-6f);
+  { ProfScope ps(e, "combine", 0);
+    ca.inp = nullptr;
+    E_CHECK(launch_combine(ca, e->st));
+    E_CHECK(launch_refine_select(cscore, fin, a.B, a.K, theta, e->refine_samples, kind, list, count, e->st)); }
+  { ProfScope ps(e, "bridge", 0);
+    E_HIP(hipMemsetAsync(rtot, 0, 64, e->st));
+    E_HIP(hipMemsetAsync(rp.own_len, 0, (size_t)S * 4, e->st));
+    E_CHECK(launch_scan(count, a.B, count_off, rtot + 8, e->st));  // rtot[8] = R
+    E_CHECK(launch_refine_plan(b.clen, sp.own_len, list, count, count_off, a.B, a.K, rp.own_len, rp.pre_len, rp.src, rp.pos0, rlist,
+                               rtot + 3, e->st));
+    E_CHECK(launch_scan(rp.own_len, S, rp.own_off, rtot, e->st));   // rtot[0] = rows of the refine pass
+    E_CHECK(launch_refine_finish(rp.own_off, rp.own_len, count_off, a.B, a.K, rp.pre_off, rp.eidx, rlist, e->st)); }
+  E_HIP(hipMemcpyAsync(e->h_totals + 16, rtot, 48, hipMemcpyDeviceToHost, e->st));
+  E_HIP(hipStreamSynchronize(e->st));  // second (and last) host round trip of the step: the sizes of the refine pass
+  const int M2 = e->h_totals[16], max_len2 = e->h_totals[19], R = e->h_totals[24];
+  if (R < 0 || R > n_seq || M2 < 0) return fail(e, CZC_ERR_STATE, "refine plan returned impossible sizes%s");
+  if (R > 0) {
+    float* feat2;
+    E_CHECK(clip_tower_on(e, PREC_F16X3, e->ctext_x, e->tproj_wx, "gemm_clip_refine", b.cids, rp, a.B + R, R, M2, max_len2, 0, 0, 0,
+                          "c_feat2", &feat2));
+    ProfScope ps(e, "combine", 0);
+    E_CHECK(launch_refine_cosine(feat2, e->d_img_n, rlist, count_off + a.B, R, a.K, c.clip_proj, rcos, ca.nonfinite, e->st));
   }
-  (void)hipGraphDestroy(g);
-  e->graphs[key] = ex;
-  e->stat_graph_captures += 1;
-  E_HIP(hipGraphLaunch(ex, e->st));
-  e->stat_graph_launches += 1;
+  { ProfScope ps(e, "combine", 0);
+    ca.text_feat = nullptr; ca.inp = a.d_inp; ca.refine_kind = kind; ca.refine_cos = rcos;
+    E_CHECK(launch_combine(ca, e->st)); }
+  e->stat_refine_rows += M2;
+  e->stat_refine_seqs += R;
   return 0;
 }
 
@@ -663,18 +619,12 @@ int step_device(czc_engine* e, int* d_inp, int B, int T, int gen_idx, int n_mask
   if (hp->control == 2 && !e->d_pos_tags) return fail(e, CZC_ERR_STATE, "POS path needs czc_set_pos%s");
   if (n_mask <= 0 && e->last_BT != B * T) return fail(e, CZC_ERR_STATE, "n_mask=0 needs a previous forward of the same shape%s");
   StepArgs a{d_inp, B, T, gen_idx, n_mask, dot_allowed, K, *hp};
-  auto fbits = [](float f) { int i; memcpy(&i, &f, 4); return i; };
-  std::vector<int> key = {0, B, T, gen_idx, n_mask, dot_allowed, K, fbits(hp->alpha), fbits(hp->beta), fbits(hp->gamma),
-                          fbits(hp->temperature), hp->control, hp->negative, e->share_prefix, e->pack_branches,
-                          e->pool_last_layer, e->fold_ln, e->fuse_ln, (int)(((uintptr_t)d_inp) >> 4)};
-  E_CHECK(run_phase(e, key, [&]() { return step_phase_a(e, a); }));
+  E_CHECK(step_phase_a(e, a));
   if (n_mask > 0) { e->stat_bert_rows += B * T; e->last_BT = B * T; }
   E_HIP(hipStreamSynchronize(e->st));  // the one host round trip per step (the reference has one too, gen_utils.py:81)
   int M, max_len, max_branch, n_trunk;
   E_CHECK(read_totals(e, &M, &max_len, &max_branch, &n_trunk));
-  key[0] = 1;
-  key.insert(key.end(), {M, max_len, max_branch, n_trunk});
-  E_CHECK(run_phase(e, key, [&]() { return step_phase_b(e, a, M, max_len, max_branch, n_trunk); }));
+  E_CHECK(step_phase_b(e, a, M, max_len, max_branch, n_trunk));
   e->stat_clip_rows += M;
   e->stat_clip_seqs += B * K;
   e->stat_steps += 1;
@@ -704,7 +654,7 @@ int czc_create(const czc_config* cfg, int device_id, czc_engine** out) {
     return CZC_ERR_ARG;
   }
   if (cfg->precision != CZC_PREC_BF16 && cfg->precision != CZC_PREC_F32 && cfg->precision != CZC_PREC_ALL_BF16 &&
-      cfg->precision != CZC_PREC_SPLIT && cfg->precision != CZC_PREC_FP16) {
+      cfg->precision != CZC_PREC_SPLIT && cfg->precision != CZC_PREC_FP16 && cfg->precision != CZC_PREC_REFINE) {
     snprintf(czc::g_err, sizeof(czc::g_err), "czc_create: unknown precision");
     return CZC_ERR_ARG;
   }
@@ -724,10 +674,14 @@ int czc_create(const czc_config* cfg, int device_id, czc_engine** out) {
   // ~22 mantissa bits: the tau=0.1 softmax amplifies logit error tenfold, and BERT is 1.4% of the
   // FLOPs); 1: everything on f32 MFMA; 2: everything bf16 (experiments); 3: every tower on split-fp16 MFMA
   // 4: CLIP towers on single-pass fp16 MFMA (the bf16 kernels on IEEE fp16 operands), BERT on split-fp16
+  // 5: screen-then-refine: CLIP-text screening pass on single-pass fp16, refine pass / vision tower / BERT on split-fp16
+  e->refine = cfg->precision == CZC_PREC_REFINE;
   e->pc = cfg->precision == CZC_PREC_F32 ? PREC_F32
-          : (cfg->precision == CZC_PREC_SPLIT ? PREC_F16X3 : (cfg->precision == CZC_PREC_FP16 ? PREC_F16 : PREC_BF16));
+          : (cfg->precision == CZC_PREC_SPLIT ? PREC_F16X3
+             : ((cfg->precision == CZC_PREC_FP16 || e->refine) ? PREC_F16 : PREC_BF16));
   e->pb = cfg->precision == CZC_PREC_ALL_BF16 ? PREC_BF16
                                               : (cfg->precision == CZC_PREC_F32 ? PREC_F32 : PREC_F16X3);
+  e->pv = e->refine ? (int)PREC_F16X3 : e->pc;
   e->esz = prec_bytes(e->pc);
   e->eb = prec_bytes(e->pb);
   if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&e->st) != hipSuccess ||
@@ -745,20 +699,17 @@ int czc_destroy(czc_engine* e) {
   if (!e) return CZC_OK;
   (void)hipSetDevice(e->dev);
   (void)hipStreamSynchronize(e->st);
-  invalidate_graphs(e);
-  if (e->shares_weights) { e->w.clear(); e->bert.clear(); e->ctext.clear(); e->cvis.clear();
-                           e->mlm_dense_w = e->decoder_w = e->tproj_w = e->vproj_w = e->patch_w = nullptr; }
+  if (e->shares_weights) { e->w.clear(); e->bert.clear(); e->ctext.clear(); e->cvis.clear(); e->ctext_x.clear();
+                           e->mlm_dense_w = e->decoder_w = e->tproj_w = e->vproj_w = e->patch_w = e->tproj_wx = nullptr; }
   for (auto& kv : e->w) if (kv.second.p) (void)hipFree(kv.second.p);
   auto free_layers = [](std::vector<LayerW>& L) {
     for (auto& l : L) {
       (void)hipFree(l.qkv_w); (void)hipFree(l.qkv_b); (void)hipFree(l.o_w); (void)hipFree(l.fc1_w); (void)hipFree(l.fc2_w);
-      (void)hipFree(l.qkv_wf); (void)hipFree(l.qkv_sf); (void)hipFree(l.qkv_bf);
-      (void)hipFree(l.fc1_wf); (void)hipFree(l.fc1_sf); (void)hipFree(l.fc1_bf);
     }
   };
-  free_layers(e->bert); free_layers(e->ctext); free_layers(e->cvis);
+  free_layers(e->bert); free_layers(e->ctext); free_layers(e->cvis); free_layers(e->ctext_x);
   (void)hipFree(e->mlm_dense_w); (void)hipFree(e->decoder_w); (void)hipFree(e->tproj_w); (void)hipFree(e->vproj_w);
-  (void)hipFree(e->patch_w);
+  (void)hipFree(e->patch_w); (void)hipFree(e->tproj_wx);
   for (auto& kv : e->ws) if (kv.second.p) (void)hipFree(kv.second.p);
   for (void* p : e->bridge_allocs) (void)hipFree(p);
   (void)hipFree(e->d_mask); (void)hipFree(e->d_lex); (void)hipFree(e->d_lex_pos); (void)hipFree(e->d_lex_cls); (void)hipFree(e->d_img_n); (void)hipFree(e->d_staged);
@@ -780,13 +731,14 @@ int czc_replicate(czc_engine* p, czc_engine** out) {
   if (!p->finalized) return fail(p, CZC_ERR_STATE, "czc_replicate: czc_finalize_weights first%s");
   czc_engine* e = new czc_engine();
   e->cfg = p->cfg; e->dev = p->dev; e->finalized = true; e->shares_weights = true;
-  e->esz = p->esz; e->pb = p->pb; e->pc = p->pc; e->eb = p->eb;
-  e->w = p->w; e->bert = p->bert; e->ctext = p->ctext; e->cvis = p->cvis;
+  e->esz = p->esz; e->pb = p->pb; e->pc = p->pc; e->pv = p->pv; e->eb = p->eb;
+  e->refine = p->refine; e->refine_theta_x = p->refine_theta_x; e->refine_samples = p->refine_samples;
+  e->w = p->w; e->bert = p->bert; e->ctext = p->ctext; e->cvis = p->cvis; e->ctext_x = p->ctext_x;
   e->mlm_dense_w = p->mlm_dense_w; e->decoder_w = p->decoder_w; e->tproj_w = p->tproj_w; e->vproj_w = p->vproj_w;
-  e->patch_w = p->patch_w;
+  e->patch_w = p->patch_w; e->tproj_wx = p->tproj_wx;
   e->logit_scale_exp = p->logit_scale_exp;
   e->share_prefix = p->share_prefix; e->pack_branches = p->pack_branches; e->pool_last_layer = p->pool_last_layer;
-  e->fuse_ln = p->fuse_ln; e->fold_ln = p->fold_ln; e->use_graphs = p->use_graphs;
+  e->fuse_ln = p->fuse_ln;
   memset(&e->bd, 0, sizeof(e->bd));
   if (hipSetDevice(e->dev) != hipSuccess || hipStreamCreate(&e->st) != hipSuccess ||
       hipHostMalloc((void**)&e->h_totals, 64) != hipSuccess) {
@@ -820,9 +772,11 @@ int czc_finalize_weights(czc_engine* e) {
   E_HIP(hipSetDevice(e->dev));
   const czc_config& c = e->cfg;
   const bool has_bert = c.bert_layers > 0 && c.bert_vocab > 0;
-  if (has_bert) E_CHECK(build_layers(e, e->bert, c.bert_layers, c.bert_hidden, c.bert_inter, true, "bert.encoder.layer."));
-  E_CHECK(build_layers(e, e->ctext, c.clip_layers, c.clip_hidden, c.clip_inter, false, "text_model.encoder.layers."));
-  E_CHECK(build_layers(e, e->cvis, c.vis_layers, c.vis_hidden, c.vis_inter, false, "vision_model.encoder.layers."));
+  if (has_bert) E_CHECK(build_layers(e, e->bert, c.bert_layers, c.bert_hidden, c.bert_inter, true, "bert.encoder.layer.", e->pb));
+  E_CHECK(build_layers(e, e->ctext, c.clip_layers, c.clip_hidden, c.clip_inter, false, "text_model.encoder.layers.", e->pc));
+  if (e->refine)
+    E_CHECK(build_layers(e, e->ctext_x, c.clip_layers, c.clip_hidden, c.clip_inter, false, "text_model.encoder.layers.", PREC_F16X3));
+  E_CHECK(build_layers(e, e->cvis, c.vis_layers, c.vis_hidden, c.vis_inter, false, "vision_model.encoder.layers.", e->pv));
   float* t;
   if (has_bert) {
     E_CHECK(need(e, "cls.predictions.transform.dense.weight", (size_t)c.bert_hidden * c.bert_hidden, &t));
@@ -837,11 +791,12 @@ int czc_finalize_weights(czc_engine* e) {
   }
   E_CHECK(need(e, "text_projection.weight", (size_t)c.clip_proj * c.clip_hidden, &t));
   E_CHECK(to_act(e, e->pc, t, (size_t)c.clip_proj * c.clip_hidden, &e->tproj_w));
+  if (e->refine) E_CHECK(to_act(e, PREC_F16X3, t, (size_t)c.clip_proj * c.clip_hidden, &e->tproj_wx));
   E_CHECK(need(e, "visual_projection.weight", (size_t)c.clip_proj * c.vis_hidden, &t));
-  E_CHECK(to_act(e, e->pc, t, (size_t)c.clip_proj * c.vis_hidden, &e->vproj_w));
+  E_CHECK(to_act(e, e->pv, t, (size_t)c.clip_proj * c.vis_hidden, &e->vproj_w));
   const size_t pk = (size_t)3 * c.vis_patch * c.vis_patch;
   E_CHECK(need(e, "vision_model.embeddings.patch_embedding.weight", (size_t)c.vis_hidden * pk, &t));
-  E_CHECK(to_act(e, e->pc, t, (size_t)c.vis_hidden * pk, &e->patch_w));
+  E_CHECK(to_act(e, e->pv, t, (size_t)c.vis_hidden * pk, &e->patch_w));
   const Tensor* ls = find(e, "logit_scale");
   if (!ls) return fail(e, CZC_ERR_STATE, "missing tensor %s", "logit_scale");
   float lsv = 0.f;
@@ -866,7 +821,7 @@ int czc_finalize_weights(czc_engine* e) {
 int czc_set_token_mask(czc_engine* e, const float* mask, int vocab) {
   if (!e || !mask || vocab != e->cfg.bert_vocab) return e ? fail(e, CZC_ERR_ARG, "token mask size != bert_vocab%s") : CZC_ERR_ARG;
   E_HIP(hipSetDevice(e->dev));
-  if (!e->d_mask) { invalidate_graphs(e); E_HIP(hipMalloc((void**)&e->d_mask, (size_t)vocab * 4)); }
+  if (!e->d_mask) { E_HIP(hipMalloc((void**)&e->d_mask, (size_t)vocab * 4)); }
   E_HIP(hipMemcpy(e->d_mask, mask, (size_t)vocab * 4, hipMemcpyDefault));
   e->mask_vocab = vocab;
   return CZC_OK;
@@ -875,13 +830,12 @@ int czc_set_token_mask(czc_engine* e, const float* mask, int vocab) {
 int czc_set_lexicon(czc_engine* e, const float* lex, int vocab) {
   if (!e || !lex || vocab != e->cfg.bert_vocab) return e ? fail(e, CZC_ERR_ARG, "lexicon size != bert_vocab%s") : CZC_ERR_ARG;
   E_HIP(hipSetDevice(e->dev));
-  if (!e->d_lex) { invalidate_graphs(e); E_HIP(hipMalloc((void**)&e->d_lex, (size_t)vocab * 4)); }
+  if (!e->d_lex) { E_HIP(hipMalloc((void**)&e->d_lex, (size_t)vocab * 4)); }
   E_HIP(hipMemcpy(e->d_lex, lex, (size_t)vocab * 4, hipMemcpyDefault));
   return CZC_OK;
 }
 
 int czc_set_lexicon_pos(czc_engine* e, const float* table, const uint8_t* class_of_token, int vocab) {
-  if (e) invalidate_graphs(e);  // kernel arguments of cached step graphs may point at what this call replaces
   if (!e) return CZC_ERR_ARG;
   E_HIP(hipSetDevice(e->dev));
   if (!table) {  // back to the per-token lexicon of czc_set_lexicon
@@ -900,7 +854,6 @@ int czc_set_lexicon_pos(czc_engine* e, const float* table, const uint8_t* class_
 }
 
 int czc_set_pos(czc_engine* e, const uint8_t* tag_of_token, int vocab, const uint16_t* template_masks, int n_template) {
-  if (e) invalidate_graphs(e);  // kernel arguments of cached step graphs may point at what this call replaces
   if (!e || !tag_of_token || !template_masks) return CZC_ERR_ARG;
   if (vocab != e->cfg.bert_vocab || n_template <= 0 || n_template > 32) return fail(e, CZC_ERR_ARG, "bad POS tables%s");
   E_HIP(hipSetDevice(e->dev));
@@ -956,7 +909,6 @@ static int build_bridge(czc_engine* e, const czc_bridge_tables* t, BridgeDev* bd
 }
 
 int czc_set_bridge(czc_engine* e, const czc_bridge_tables* t) {
-  if (e) invalidate_graphs(e);  // kernel arguments of cached step graphs may point at what this call replaces
   if (!e || !t) return CZC_ERR_ARG;
   if (t->bert_vocab != e->cfg.bert_vocab) return fail(e, CZC_ERR_ARG, "bridge bert_vocab != config%s");
   E_HIP(hipSetDevice(e->dev));
@@ -974,7 +926,7 @@ int czc_set_image_embeds(czc_engine* e, const float* embeds, int B) {
   float* raw;
   E_CHECK(ensure(e, "img_raw", (size_t)B * D * 4, (void**)&raw));
   E_HIP(hipMemcpyAsync(raw, embeds, (size_t)B * D * 4, hipMemcpyDefault, e->st));
-  if (e->img_B < B) { invalidate_graphs(e); if (e->d_img_n) (void)hipFree(e->d_img_n); e->d_img_n = nullptr; E_HIP(hipMalloc((void**)&e->d_img_n, (size_t)B * D * 4)); }
+  if (e->img_B < B) { if (e->d_img_n) (void)hipFree(e->d_img_n); e->d_img_n = nullptr; E_HIP(hipMalloc((void**)&e->d_img_n, (size_t)B * D * 4)); }
   E_CHECK(launch_l2_normalize(raw, B, D, e->d_img_n, e->st));
   e->img_B = B;
   E_HIP(hipStreamSynchronize(e->st));
@@ -986,15 +938,16 @@ int czc_encode_images(czc_engine* e, const float* pixels, int B, float* out_embe
   if (!e->finalized) return fail(e, CZC_ERR_STATE, "weights not finalized%s");
   E_HIP(hipSetDevice(e->dev));
   const czc_config& c = e->cfg;
-  const int P = e->pc, S = c.vis_image, p = c.vis_patch, G = S / p, NP = G * G, H = c.vis_hidden;
+  const int P = e->pv, S = c.vis_image, p = c.vis_patch, G = S / p, NP = G * G, H = c.vis_hidden;
+  const size_t vsz = prec_bytes(P);
   const int Kc = 3 * p * p, T = NP + 1, M = B * T;
   float *pix, *pe, *x, *emb; void *patches, *ca; int* idx;
   E_CHECK(ensure(e, "v_pix", (size_t)B * 3 * S * S * 4, (void**)&pix));
-  E_CHECK(ensure(e, "v_patches", (size_t)B * NP * Kc * e->esz, &patches));
+  E_CHECK(ensure(e, "v_patches", (size_t)B * NP * Kc * vsz, &patches));
   E_CHECK(ensure(e, "v_pe", (size_t)B * NP * H * 4, (void**)&pe));
   E_CHECK(ensure(e, "v_x", (size_t)M * H * 4, (void**)&x));
   E_CHECK(ensure(e, "v_idx", (size_t)B * 4, (void**)&idx));
-  E_CHECK(ensure(e, "v_ca", (size_t)B * H * e->esz, &ca));
+  E_CHECK(ensure(e, "v_ca", (size_t)B * H * vsz, &ca));
   E_CHECK(ensure(e, "img_raw", (size_t)B * c.clip_proj * 4, (void**)&emb));
   E_HIP(hipMemcpyAsync(pix, pixels, (size_t)B * 3 * S * S * 4, hipMemcpyDefault, e->st));
   float *cls, *pos, *g0, *b0, *g1, *b1;
@@ -1010,12 +963,12 @@ int czc_encode_images(czc_engine* e, const float* pixels, int B, float* out_embe
     E_CHECK(launch_vision_assemble(pe, B, NP, H, cls, pos, x, e->st));
     E_CHECK(launch_layernorm(P, x, nullptr, g0, b0, c.clip_eps, M, H, nullptr, x, e->st)); }
   SegTable vtab{nullptr, nullptr, nullptr, nullptr, B, T};
-  E_CHECK(clip_stack(e, "gemm_vision", e->cvis, x, M, H, c.vis_inter, c.vis_heads, c.clip_eps, vtab, T, 0));
+  E_CHECK(clip_stack(e, P, "gemm_vision", e->cvis, x, M, H, c.vis_inter, c.vis_heads, c.clip_eps, vtab, T, 0));
   { ProfScope ps(e, "rowops", 0);
     E_CHECK(launch_make_row_index(idx, B, T, 0, e->st));
     E_CHECK(launch_layernorm(P, x, idx, g1, b1, c.clip_eps, B, H, ca, nullptr, e->st)); }
   E_CHECK(gemm(e, P, "gemm_vision", ca, H, e->vproj_w, H, nullptr, nullptr, 0, nullptr, emb, c.clip_proj, B, c.clip_proj, H, ACT_NONE));
-  if (e->img_B < B) { invalidate_graphs(e); if (e->d_img_n) (void)hipFree(e->d_img_n); e->d_img_n = nullptr; E_HIP(hipMalloc((void**)&e->d_img_n, (size_t)B * c.clip_proj * 4)); }
+  if (e->img_B < B) { if (e->d_img_n) (void)hipFree(e->d_img_n); e->d_img_n = nullptr; E_HIP(hipMalloc((void**)&e->d_img_n, (size_t)B * c.clip_proj * 4)); }
   E_CHECK(launch_l2_normalize(emb, B, c.clip_proj, e->d_img_n, e->st));
   e->img_B = B;
   if (out_embeds) E_HIP(hipMemcpyAsync(out_embeds, emb, (size_t)B * c.clip_proj * 4, hipMemcpyDefault, e->st));
@@ -1079,7 +1032,7 @@ int czc_encode_text(czc_engine* e, const int32_t* clip_ids, const int32_t* clip_
   E_HIP(hipMemsetAsync(totals, 0, 32, e->st));
   { int* flag; E_CHECK(ensure(e, "s_nonfinite", 16, (void**)&flag)); E_HIP(hipMemsetAsync(flag, 0, 16, e->st)); }
   float* feat;
-  E_CHECK(clip_text_forward(e, cids, clen, n, 1, 0, totals, &feat));  // independent sequences: no sharing
+  E_CHECK(clip_text_forward(e, cids, clen, n, 1, 0, totals, &feat, true));  // independent sequences: no sharing; exact tower
   E_HIP(hipMemcpyAsync(out_embeds, feat, (size_t)n * e->cfg.clip_proj * 4, hipMemcpyDefault, e->st));
   E_HIP(hipStreamSynchronize(e->st));
   return CZC_OK;
@@ -1090,7 +1043,6 @@ int czc_step(czc_engine* e, int32_t* inp, int B, int T, int gen_idx, int n_mask,
   if (!e || !inp || !hp || B <= 0) return CZC_ERR_ARG;
   E_HIP(hipSetDevice(e->dev));
   e->err[0] = 0;
-  e->graphs_now = e->use_graphs == 1;
   int* d_inp;
   { int* flag; E_CHECK(ensure(e, "s_nonfinite", 16, (void**)&flag)); E_HIP(hipMemsetAsync(flag, 0, 16, e->st)); }
   E_CHECK(ensure(e, "g_inp", (size_t)B * T * 4, (void**)&d_inp));
@@ -1127,7 +1079,6 @@ int czc_generate(czc_engine* e, int B, int T, int L, int seed_len, const int32_t
   if (seed_len + L > T) return fail(e, CZC_ERR_ARG, "generate: seed_len + L > T%s");
   E_HIP(hipSetDevice(e->dev));
   e->err[0] = 0;
-  e->graphs_now = e->use_graphs == 1 || (e->use_graphs < 0 && B <= 4);  // launch-bound batches only
   int *d_inp, *d_row;
   { int* flag; E_CHECK(ensure(e, "s_nonfinite", 16, (void**)&flag)); E_HIP(hipMemsetAsync(flag, 0, 16, e->st)); }
   E_CHECK(ensure(e, "g_inp", (size_t)B * T * 4, (void**)&d_inp));
@@ -1159,9 +1110,9 @@ int czc_set_option(czc_engine* e, const char* name, int value) {
   if (!strcmp(name, "share_prefix")) { e->share_prefix = value ? 1 : 0; return CZC_OK; }
   if (!strcmp(name, "pack_branches")) { e->pack_branches = value ? 1 : 0; return CZC_OK; }
   if (!strcmp(name, "pool_last_layer")) { e->pool_last_layer = value ? 1 : 0; return CZC_OK; }
-  if (!strcmp(name, "fold_ln")) { e->fold_ln = value ? 1 : 0; return CZC_OK; }
   if (!strcmp(name, "fuse_ln")) { e->fuse_ln = value; return CZC_OK; }  // 0 off, 1 out-proj -> LN2, 2 also fc2 -> next LN1
-  if (!strcmp(name, "graphs")) { e->use_graphs = value; invalidate_graphs(e); return CZC_OK; }
+  if (!strcmp(name, "refine_samples")) { e->refine_samples = value < 0 ? 0 : value; return CZC_OK; }
+  if (!strcmp(name, "refine_theta_x1000")) { e->refine_theta_x = (float)value / 1000.f; return CZC_OK; }
   return fail(e, CZC_ERR_ARG, "unknown option %s", name);
 }
 
@@ -1236,14 +1187,6 @@ int czc_profile_intervals(czc_engine* e, czc_engine* ref, const char* kind, doub
     }
   }
   *n_out = n;
-  return CZC_OK;
-}
-
-int czc_graph_stats(czc_engine* e, int64_t* launches, int64_t* captures, int64_t* cached) {
-  if (!e) return CZC_ERR_ARG;
-  if (launches) *launches = e->stat_graph_launches;
-  if (captures) *captures = e->stat_graph_captures;
-  if (cached) *cached = (int64_t)e->graphs.size();
   return CZC_OK;
 }
 

@@ -419,7 +419,7 @@ static int try_splitk(const GemmArgs& g, int tiles_m, int tiles_n, hipStream_t s
   return ks;
 }
 
-int g_use_gemm256 = 3;  // 0: 128x128 only, 1: gemm256, 2: persistent wave-specialised gemm256p, 3: + 4-stage K ring (gemm256q)
+int g_use_gemm256 = 1;  // 0: 128x128 only; 1: the 256x256 ring kernels of gemm256.hip (see launch_gemm256); 3 / 5 pin one of them
 
 int launch_gemm(int prec, const GemmArgs& g_in, hipStream_t st) {
   GemmArgs g = g_in;

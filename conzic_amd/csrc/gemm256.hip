@@ -1,25 +1,27 @@
-// 256x256-tile bf16 MFMA GEMM with LDS-DMA staging, for the CLIP-text linear layers over the
-// B*K candidate captions (M = 10^5..10^6 rows, N in {512,1536,2048}, K in {512,2048}).
+// 256x256-tile MFMA GEMMs with LDS-DMA staging for the big-batch linear layers of the CLIP towers
+// (M = 10^4..10^6 rows of candidate captions / image patches), bf16 or fp16 operands, fp32 accumulate:
 //
-//   C[M,N] = A[M,K] . W[N,K]^T (+bias)(quick-GELU)(+fp32 residual)      bf16 operands, fp32 accumulate
+//   C[M,N] = A[M,K] . W[N,K]^T (+bias)(quick-GELU)(+fp32 residual)
 //
-// Structure (MI355X_MICROARCH / cdna_hip_programming guides):
-//  * 512 threads = 8 waves as 2(M) x 4(N); each wave owns 128x64 of C as 4x2 v_mfma_f32_32x32x16_bf16
-//    tiles (128 accumulator registers).  One work-group per CU (128 KiB LDS, two 64 KiB stages).
-//  * K step 64 (128-byte rows).  Global->LDS goes through `buffer_load_dwordx4 ... lds` (no VGPR
-//    round trip, no ds_write): every wave instruction lands 1 KiB = 8 tile rows.  The LDS image is
-//    lane-linear, so the bank-conflict swizzle (16-byte chunk ^ ((row>>1)&7)) is applied to the
-//    per-lane SOURCE address and again on the ds_read_b128 side (guide rule 21).
-//  * Buffer descriptors are rebased per tile with num_records = valid rows * pitch: rows past M / N
-//    read as zero from the hardware bounds check, so ragged edges need no clamping and a tile never
-//    needs more than 32-bit offsets even when the activation tensor exceeds 4 GiB.
-//  * One raw s_barrier per K step: wait for tile kt (vmcnt(0)), barrier (which also proves every
-//    wave left compute(kt-1), so that stage is free), issue the LDS-DMA of tile kt+1, then 24
-//    ds_read_b128 + 32 MFMA per wave while the DMA flies.
-//  * Work-group -> tile map is XCD-aware (block b runs on XCD b%8): the N tiles of one M tile are
-//    consecutive inside one XCD's share, so an activation tile is fetched into one L2 only.
-//  * Epilogue as in gemm.hip: weights are the MFMA A operand, so each lane owns 4 consecutive output
-//    columns of one row per register quad -> 8-byte bf16 / 16-byte fp32 stores.
+// Common structure (MI355X_MICROARCH / cdna_hip_programming guides):
+//  * persistent work-groups, one per CU (160 KiB LDS), walking 256x256 output tiles through an XCD-aware map
+//    (work-group b runs on XCD b%8: the N tiles of one M tile sit on neighbouring CUs of one XCD, so an activation
+//    tile is fetched into one L2 only);
+//  * a 4-deep LDS ring of 32-wide K steps (32 KiB per stage: 256 activation rows + 256 weight rows of 64 bytes),
+//    filled by `buffer_load_dwordx4 ... lds` (no VGPR round trip, 1 KiB = 16 tile rows per instruction) from inline
+//    asm with COUNTED s_waitcnt vmcnt; the LDS image is lane-linear, so the bank-conflict swizzle
+//    (16-byte chunk ^ ((row>>2)&3)) sits in the per-lane SOURCE address and again on the ds_read_b128 side;
+//  * buffer descriptors rebased per tile with num_records = valid rows * pitch: rows past M / N read as zero from the
+//    hardware bounds check, so ragged edges need no clamping and offsets stay 32-bit beyond 4 GiB tensors;
+//  * 8 MFMA waves as 2(M) x 4(N), each 128x64 of C = 4x2 v_mfma_f32_32x32x16 tiles (128 accumulator registers);
+//    weights are the MFMA A operand, so a lane owns 4 consecutive output columns of one row per register quad, and
+//    the accumulators leave through a wave-private 4 KiB LDS patch as full 128-byte lines.
+// Three kernels on that base:
+//   gemm256q  8 MFMA waves + 4 LOADER waves that only issue the LDS-DMA (activation-typed outputs: vision qkv / fc1)
+//   gemm256x  no loader waves: two wave groups one phase apart, one in MFMAs while the other is in memory
+//             instructions (fp32-residual outputs: out-proj / fc2 -- 5 % faster than gemm256q there, A/B in DESIGN.md)
+//   gemm256sq gemm256q for split-fp16 operands (three fp16 passes per product)
+// plus gemm_rowln: 128 x 512 full-row tiles with the following LayerNorm finished in the epilogue.
 #include <type_traits>
 
 #include "kernels.h"
@@ -28,177 +30,13 @@ namespace czc {
 
 namespace {
 
-constexpr int TM = 256, TN = 256, ROWB = 128;
-constexpr int A_BYTES = TM * ROWB;            // 32 KiB
-constexpr int STAGE = A_BYTES + TN * ROWB;    // 64 KiB
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-
-__device__ __forceinline__ int swz(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
+constexpr int TM = 256, TN = 256;
 
 template <int ACT>
 __device__ __forceinline__ float act_fn(float v) {
   // x*sigmoid(1.702x) with the raw v_exp_f32 (2^x) and v_rcp_f32: ~1 ulp each, output is bf16 anyway
   if (ACT == ACT_QUICK_GELU) return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930156f * v));
   return v;
-}
-
-template <int ACT>
-__global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g, int tiles_m, int tiles_n) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-  const int half = lane >> 5;
-
-  const int nwg = tiles_m * tiles_n;
-  int lin = blockIdx.x;
-  {
-    const int xcd = lin & 7, q = nwg >> 3, r = nwg & 7;
-    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    lin = base + (lin >> 3);
-  }
-  const int tm = lin / tiles_n, tn = lin - tm * tiles_n;
-  const int m0 = tm * TM, n0 = tn * TN;
-
-  const int lda_b = g.lda * 2, ldw_b = g.ldw * 2;
-  const int rows_a = min(TM, g.M - m0), rows_w = min(TN, g.N - n0);
-  // buffer descriptors as plain SGPR quads (they are asm operands below): base, base_hi|stride 0,
-  // num_records (bytes), flags (DATA_FORMAT=32 as make_buffer_rsrc would set)
-  const unsigned long long pa = (unsigned long long)g.A + (unsigned long long)m0 * lda_b;
-  const unsigned long long pw = (unsigned long long)g.W + (unsigned long long)n0 * ldw_b;
-  u32x4_t rsA, rsW;
-  rsA.x = (unsigned)pa; rsA.y = (unsigned)(pa >> 32) & 0xffffu; rsA.z = (unsigned)(rows_a * lda_b); rsA.w = 0x00020000u;
-  rsW.x = (unsigned)pw; rsW.y = (unsigned)(pw >> 32) & 0xffffu; rsW.z = (unsigned)(rows_w * ldw_b); rsW.w = 0x00020000u;
-  const unsigned lds0 = __builtin_amdgcn_readfirstlane(
-      (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem);
-
-  // staging: instruction ii of wave w lands tile rows w*32 + ii*8 + (lane>>3); lane's physical
-  // chunk is lane&7, so it fetches logical chunk (lane&7) ^ ((row>>1)&7) of that row.
-  // (named scalars, not arrays: indexed pointer/offset arrays ended up in scratch memory)
-#define CZC_VO(ii, ld) ((wave * 32 + (ii) * 8 + (lane >> 3)) * (ld) + (((lane & 7) ^ (((ii) * 4 + (lane >> 4)) & 7)) << 4))
-  const int voA0 = CZC_VO(0, lda_b), voA1 = CZC_VO(1, lda_b), voA2 = CZC_VO(2, lda_b), voA3 = CZC_VO(3, lda_b);
-  const int voW0 = CZC_VO(0, ldw_b), voW1 = CZC_VO(1, ldw_b), voW2 = CZC_VO(2, ldw_b), voW3 = CZC_VO(3, ldw_b);
-#undef CZC_VO
-
-  f32x16_t acc[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int nk = g.K >> 6;
-  const int arow = wm * 128 + (lane & 31);
-  const int brow = wn * 64 + (lane & 31);
-
-  // LDS-DMA issued from inline asm: hipcc would otherwise drain every DMA (vmcnt(0)) in front of the
-  // first ds_read of the compute phase, because it cannot prove the two stages disjoint.  M0 = LDS
-  // destination of lane 0 (saved/restored inside the statement; `s_nop 0` covers the M0 write ->
-  // LDS-DMA hazard).  Completion is counted by hand: s_waitcnt vmcnt(0) at the top of each K step.
-#define CZC_STAGE_TILE(KT)                                                                             \
-  {                                                                                                    \
-    const unsigned dstA = lds0 + ((KT) & 1) * STAGE + wave * (32 * ROWB);                              \
-    const unsigned dstW = dstA + A_BYTES;                                                              \
-    const unsigned so = (KT) * ROWB;                                                                   \
-    unsigned keep;                                                                                     \
-    asm volatile(                                                                                      \
-        "s_mov_b32 %0, m0\n\t"                                                                         \
-        "s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %11, %13 offen lds\n\t"                \
-        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %11, %13 offen lds\n\t"         \
-        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %5, %11, %13 offen lds\n\t"         \
-        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %6, %11, %13 offen lds\n\t"         \
-        "s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %7, %12, %13 offen lds\n\t"                \
-        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %8, %12, %13 offen lds\n\t"         \
-        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %9, %12, %13 offen lds\n\t"         \
-        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %10, %12, %13 offen lds\n\t"        \
-        "s_mov_b32 m0, %0"                                                                             \
-        : "=&s"(keep)                                                                                  \
-        : "s"(dstA), "s"(dstW), "v"(voA0), "v"(voA1), "v"(voA2), "v"(voA3), "v"(voW0), "v"(voW1),      \
-          "v"(voW2), "v"(voW3), "s"(rsA), "s"(rsW), "s"(so)                                            \
-        : "memory", "scc");                                                                            \
-  }
-
-  CZC_STAGE_TILE(0);
-  for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (kt + 1 < nk) CZC_STAGE_TILE(kt + 1);
-    const unsigned char* sA = smem + (kt & 1) * STAGE;
-    const unsigned char* sB = sA + A_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const int ch = 2 * ks + half;
-      uint4 a[4], b[2];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = *(const uint4*)(sA + swz(arow + 32 * i, ch));
-#pragma unroll
-      for (int j = 0; j < 2; ++j) b[j] = *(const uint4*)(sB + swz(brow + 32 * j, ch));
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, b[j]),
-                                                              __builtin_bit_cast(bf16x8_t, a[i]), acc[i][j], 0, 0, 0);
-    }
-  }
-#undef CZC_STAGE_TILE
-
-  // epilogue: lane owns output row (lane&31) of each 32-row block and 4 consecutive columns per quad
-  bf16_t* oa = (bf16_t*)g.out_act;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = m0 + wm * 128 + i * 32 + (lane & 31);
-    if (row < g.M) {
-      const long ro = (long)row * g.ldc;
-      const long rr = (long)row * g.ldr;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int col = n0 + wn * 64 + j * 32 + 8 * q + 4 * half;
-          if (col < g.N) {
-            float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
-            if (g.bias) {
-              const float4 b4 = *(const float4*)(g.bias + col);
-              v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
-            }
-            v.x = act_fn<ACT>(v.x); v.y = act_fn<ACT>(v.y); v.z = act_fn<ACT>(v.z); v.w = act_fn<ACT>(v.w);
-            if (g.resid) {
-              const float4 r4 = *(const float4*)(g.resid + rr + col);
-              v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
-            }
-            if (g.out_f32) *(float4*)(g.out_f32 + ro + col) = v;
-            if (oa) {
-              uint2 o;
-              o.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
-              o.y = (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
-              *(uint2*)(oa + ro + col) = o;
-            }
-          }
-        }
-      }
-    }
-  }
-}
-
-// ================================================================================================
-// gemm256p: persistent, wave-specialised variant.
-//   * 12 waves per work-group: waves 0-7 are MFMA waves (never issue a global load), waves 8-11 are
-//     LOADER waves that only issue the LDS-DMA of the next K step (16 x 1 KiB each) -- PMC on the
-//     plain kernel showed the 8 DMA issues per K step costing the MFMA waves about as many cycles as
-//     their 32 MFMAs, and 53 % of wave cycles parked in s_waitcnt/s_barrier.
-//   * one work-group per CU walks tiles wg, wg+grid, ...; the K-step sequence is continuous across
-//     tiles (stage = step & 1), so while the MFMA waves run a tile's epilogue the loaders already
-//     fetch the next tile's first K step: the pipeline prologue disappears behind the epilogue.
-//   * hand-off per K step: loader `s_waitcnt vmcnt(0)` -> one s_barrier shared by all 12 waves ->
-//     loaders issue step+1 into the stage the MFMA waves just left, MFMA waves compute step.
-// ================================================================================================
-__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
-  unsigned r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-  return r;
 }
 
 __device__ __forceinline__ void tile_of(int t, int tiles_m, int tiles_n, int& tm, int& tn) {
@@ -224,10 +62,7 @@ __device__ __forceinline__ float sum8_dpp(float v) {
   return v;
 }
 
-// STATS (fp32 path only): besides the fp32 result and its bf16 copy, every wave leaves the per-row (sum, sum of
-// squares) of its 64 result columns in g.row_stats[row][n/64][2] -- the LayerNorm statistics of the next layer in
-// eight fixed-order partials per 512-wide row, so the consumer GEMM can apply the LayerNorm in its epilogue.
-template <int ACT, bool OUT_F32, bool STATS = false, typename HT = bf16_t>
+template <int ACT, bool OUT_F32, typename HT = bf16_t>
 __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x16_t (&acc)[4][2], unsigned char* patch, int m0,
                                               int n0, int wm, int wn, int lane) {
   const int half = lane >> 5;
@@ -270,7 +105,6 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x16_t (&acc)
       // fp32 output (+bias, +fp32 residual, optional bf16 copy): 32 rows x 32 columns per pass
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        float ps[4] = {0.f, 0.f, 0.f, 0.f}, pq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int col = n0 + wn * 64 + j * 32 + rslot * 4;
@@ -301,14 +135,10 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x16_t (&acc)
             v.x += r4[pass].x; v.y += r4[pass].y; v.z += r4[pass].z; v.w += r4[pass].w;
             if (row < g.M && col < g.N) {
               if (g.out_f32) *(float4*)(g.out_f32 + (long)row * g.ldc + col) = v;
-              if (STATS) {
-                ps[pass] += (v.x + v.y) + (v.z + v.w);
-                pq[pass] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
-              }
             }
             pk[pass] = make_uint2(Half<HT>::pack2(v.x, v.y), Half<HT>::pack2(v.z, v.w));
           }
-          if (oa && !(STATS && (g.ln_groups & 2))) {
+          if (oa) {
             // bf16 copy in 16-byte stores (the epilogue is store-ISSUE bound): lanes rslot, rslot^1 hold adjacent
             // 4-column pieces of the same row; swapping one piece per pass pair leaves the even lane with 8
             // columns of the first pass's row and the odd lane with 8 columns of the second pass's row
@@ -326,20 +156,6 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x16_t (&acc)
               if (row < g.M && c8 < g.N) *(uint4*)(oa + (long)row * g.ldc + c8) = d;
             }
           }
-        }
-        if (STATS && !(g.ln_groups & 4)) {
-          // the 8 lanes of a row (rslot 0..7) hold 8 columns each: reduce, then lane rslot == pass keeps pass's
-          // row, so that one 8-byte store per lane covers the 32 rows of this block
-          float ks = 0.f, kq = 0.f;
-#pragma unroll
-          for (int pass = 0; pass < 4; ++pass) {
-            const float s8 = sum8_dpp(ps[pass]), q8 = sum8_dpp(pq[pass]);
-            if (rslot == pass) { ks = s8; kq = q8; }
-          }
-          const int row = m0 + wm * 128 + i * 32 + rslot * 8 + rrow;
-          const int grp = (n0 >> 6) + wn;
-          if (rslot < 4 && row < g.M && n0 + wn * 64 < g.N && !(g.ln_groups & 1))
-            *(float2*)(g.row_stats + ((long)row * (g.N >> 6) + grp) * 2) = make_float2(ks, kq);
         }
       }
     }
@@ -409,174 +225,23 @@ __device__ __forceinline__ void tile_epilogue_split(const GemmArgs& g, f32x16_t 
   }
 }
 
-// Visit order of a persistent work-group.  Default ("legacy"): virtual tiles wg, wg+grid, ... through
-// the XCD-aware map, i.e. the N tiles of an M tile run CONCURRENTLY on neighbouring CUs of one XCD.
-// Alternative (debug bit5): one work-group walks all N tiles of an M tile back to back (A from HBM
-// once, then L2) -- measured 9 % slower (0.684 vs 0.621 ms on the qkv shape), kept for A/B runs.
-__device__ __forceinline__ int tile_count(int tiles_m, int tiles_n, bool legacy) {
-  const int grid = gridDim.x, wg = blockIdx.x;
-  if (legacy) {
-    const int nt = tiles_m * tiles_n;
-    return wg < nt ? (nt - 1 - wg) / grid + 1 : 0;
-  }
-  return wg < tiles_m ? ((tiles_m - 1 - wg) / grid + 1) * tiles_n : 0;
+// Visit order of a persistent work-group: virtual tiles wg, wg+grid, ... through the XCD-aware map, i.e. the N tiles
+// of an M tile run CONCURRENTLY on neighbouring CUs of one XCD.  (One work-group walking all N tiles of an M tile back
+// to back -- A from HBM once, then L2 -- measured 9 % slower on the qkv shape, round 2.)
+__device__ __forceinline__ int tile_count(int tiles_m, int tiles_n) {
+  const int grid = gridDim.x, wg = blockIdx.x, nt = tiles_m * tiles_n;
+  return wg < nt ? (nt - 1 - wg) / grid + 1 : 0;
 }
-__device__ __forceinline__ void tile_at(int i, int tiles_m, int tiles_n, bool legacy, int& tm, int& tn) {
-  const int grid = gridDim.x, wg = blockIdx.x;
-  if (legacy) { tile_of(wg + i * grid, tiles_m, tiles_n, tm, tn); return; }
-  const int round = i / tiles_n;
-  tn = i - round * tiles_n;
-  tm = wg + round * grid;
-}
-
-template <int ACT, bool OUT_F32>
-__global__ __launch_bounds__(768) void gemm256p_kernel(GemmArgs g, int tiles_m, int tiles_n, int g_krot_enable) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nk = g.K >> 6;
-  const int lda_b = g.lda * 2, ldw_b = g.ldw * 2;
-
-  if (wave >= 8) {
-    // ------------------------------- loader waves -------------------------------------------
-    const int lw = wave - 8;
-    const unsigned lds0 = __builtin_amdgcn_readfirstlane(
-        (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem);
-    // instruction ii (0..7) lands tile rows lw*64 + ii*8 + (lane>>3); swizzle phase depends on ii&1
-    const int rbase = lw * 64 + (lane >> 3);
-    const int ce = ((lane & 7) ^ ((lane >> 4) & 7)) << 4;        // ii even: (row>>1)&7 = lane>>4
-    const int co = ((lane & 7) ^ (((lane >> 4) + 4) & 7)) << 4;  // ii odd : +4
-    const int a_e = rbase * lda_b + ce, a_o = (rbase + 8) * lda_b + co;
-    const int w_e = rbase * ldw_b + ce, w_o = (rbase + 8) * ldw_b + co;
-    const int a16 = 16 * lda_b, w16 = 16 * ldw_b;
-    unsigned step = 0;
-    bool first = true;
-    const int krot = (g_krot_enable & 1) ? (int)((blockIdx.x >> 3) % (unsigned)nk) : 0;
-    const bool dbg_no_dma = g_krot_enable & 4;
-    const bool legacy = (g_krot_enable & 32) == 0;  // bit5 selects the (slower, measured) M-major walk
-    const int my_tiles = tile_count(tiles_m, tiles_n, legacy);
-    for (int ti = 0; ti < my_tiles; ++ti) {
-      int tm, tn;
-      tile_at(ti, tiles_m, tiles_n, legacy, tm, tn);
-      const int m0 = tm * TM, n0 = tn * TN;
-      const unsigned long long pa = (unsigned long long)g.A + (unsigned long long)m0 * lda_b;
-      const unsigned long long pw = (unsigned long long)g.W + (unsigned long long)n0 * ldw_b;
-      u32x4_t rsA, rsW;
-      rsA.x = (unsigned)pa; rsA.y = (unsigned)(pa >> 32) & 0xffffu;
-      rsA.z = (unsigned)(min(TM, g.M - m0) * lda_b); rsA.w = 0x00020000u;
-      rsW.x = (unsigned)pw; rsW.y = (unsigned)(pw >> 32) & 0xffffu;
-      rsW.z = (unsigned)(min(TN, g.N - n0) * ldw_b); rsW.w = 0x00020000u;
-      if (g_krot_enable & 8) rsA.z = 0;   // debug: out-of-range descriptor -> zeros, no A traffic
-      if (g_krot_enable & 16) rsW.z = 0;  // debug: no W traffic
-      for (int kt = 0; kt < nk; ++kt, ++step) {
-        if (!first) {
-          // previous step's DMA has landed -> publish it; the same barrier proves the stage this
-          // step is written to has been left by every MFMA wave
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          __builtin_amdgcn_s_barrier();
-        }
-        first = false;
-        const unsigned dstA = lds0 + (step & 1) * STAGE + lw * (64 * ROWB);
-        const unsigned dstW = dstA + A_BYTES;
-        // K steps are visited in a per-work-group rotated order (a sum is order-free): work-groups
-        // that share a W tile would otherwise all request the same lines of it at the same moment
-        int kr = kt + krot;
-        if (kr >= nk) kr -= nk;
-        const unsigned so = kr * ROWB;
-        unsigned keep;
-        if (!dbg_no_dma) asm volatile(
-            "s_mov_b32 %0, m0\n\t"
-            "s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %11, %13 offen lds\n\t"
-            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %11, %13 offen lds\n\t"
-            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %5, %11, %13 offen lds\n\t"
-            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %6, %11, %13 offen lds\n\t"
-            "s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %7, %12, %13 offen lds\n\t"
-            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %8, %12, %13 offen lds\n\t"
-            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %9, %12, %13 offen lds\n\t"
-            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %10, %12, %13 offen lds\n\t"
-            "s_mov_b32 m0, %0"
-            : "=&s"(keep)
-            : "s"(dstA), "s"(dstW), "v"(a_e), "v"(a_o), "v"(a_e + a16), "v"(a_o + a16), "v"(w_e), "v"(w_o),
-              "v"(w_e + w16), "v"(w_o + w16), "s"(rsA), "s"(rsW), "s"(so)
-            : "memory", "scc");
-        if (!dbg_no_dma) asm volatile(
-            "s_mov_b32 %0, m0\n\t"
-            "s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %11, %13 offen lds\n\t"
-            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %11, %13 offen lds\n\t"
-            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %5, %11, %13 offen lds\n\t"
-            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %6, %11, %13 offen lds\n\t"
-            "s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %7, %12, %13 offen lds\n\t"
-            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %8, %12, %13 offen lds\n\t"
-            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %9, %12, %13 offen lds\n\t"
-            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %10, %12, %13 offen lds\n\t"
-            "s_mov_b32 m0, %0"
-            : "=&s"(keep)
-            : "s"(dstA + 32 * ROWB), "s"(dstW + 32 * ROWB), "v"(a_e + 2 * a16), "v"(a_o + 2 * a16), "v"(a_e + 3 * a16),
-              "v"(a_o + 3 * a16), "v"(w_e + 2 * w16), "v"(w_o + 2 * w16), "v"(w_e + 3 * w16), "v"(w_o + 3 * w16),
-              "s"(rsA), "s"(rsW), "s"(so)
-            : "memory", "scc");
-      }
-    }
-    if (!first) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();  // publishes the very last step
-    }
-    return;
-  }
-
-  // --------------------------------- MFMA waves ---------------------------------------------
-  const int wm = wave >> 2, wn = wave & 3;
-  const int half = lane >> 5;
-  const int arow = wm * 128 + (lane & 31);
-  const int brow = wn * 64 + (lane & 31);
-  unsigned step = 0;
-  const bool legacy = (g_krot_enable & 32) == 0;  // bit5 selects the (slower, measured) M-major walk
-  const int my_tiles = tile_count(tiles_m, tiles_n, legacy);
-  for (int ti = 0; ti < my_tiles; ++ti) {
-    int tm, tn;
-    tile_at(ti, tiles_m, tiles_n, legacy, tm, tn);
-    const int m0 = tm * TM, n0 = tn * TN;
-    f32x16_t acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    for (int kt = 0; kt < nk; ++kt, ++step) {
-      __builtin_amdgcn_s_barrier();  // step's tile is in LDS (loaders waited for it before arriving)
-      asm volatile("" ::: "memory");
-      const unsigned char* sA = smem + (step & 1) * STAGE;
-      const unsigned char* sB = sA + A_BYTES;
-      if (g_krot_enable & 2) continue;  // debug: fill-rate measurement without MFMA work
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const int ch = 2 * ks + half;
-        uint4 a[4], b[2];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = *(const uint4*)(sA + swz(arow + 32 * i, ch));
-#pragma unroll
-        for (int j = 0; j < 2; ++j) b[j] = *(const uint4*)(sB + swz(brow + 32 * j, ch));
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, b[j]),
-                                                                __builtin_bit_cast(bf16x8_t, a[i]), acc[i][j], 0, 0, 0);
-      }
-    }
-    // epilogue (no barrier inside: the loaders are already fetching the next tile's first K step)
-    tile_epilogue<ACT, OUT_F32>(g, acc, smem + 2 * STAGE + wave * 4096, m0, n0, wm, wn, lane);
-  }
+__device__ __forceinline__ void tile_at(int i, int tiles_m, int tiles_n, int& tm, int& tn) {
+  tile_of(blockIdx.x + i * gridDim.x, tiles_m, tiles_n, tm, tn);
 }
 
 // ================================================================================================
-// gemm256q: gemm256p with a 4-deep ring of 32-wide K steps (4 x 32 KiB stages) instead of two
-// 64-wide stages.  The loaders run up to three steps ahead and wait with a COUNTED vmcnt, so a
-// step costs max(DMA issue, DMA latency, MFMA) instead of issue + latency: in gemm256p the 16 DMA
-// issues of a step (~1000 cycles) and the landing of the last one are serialised in front of every
-// barrier.
+// gemm256q: 12 waves per work-group: waves 0-7 are MFMA waves (never issue a global load), waves 8-11 are LOADER
+// waves that only issue the LDS-DMA of later K steps (8 x 1 KiB each per step).  The K-step sequence is continuous
+// across tiles, so while the MFMA waves run a tile's epilogue the loaders already fetch the next tile's first steps.
+// The loaders run up to three steps ahead and wait with a COUNTED vmcnt, so a step costs max(DMA issue, DMA latency,
+// MFMA) instead of issue + latency; hand-off per K step = one s_barrier shared by all 12 waves.
 //   LDS rows are 64 bytes (32 bf16): 16-byte chunk c of row r sits at chunk c ^ ((r>>2)&3)
 //   (16 distinct rows of a ds_read_b128 lane group -> 16 distinct slots of the 256-byte bank row);
 //   one DMA instruction lands 16 rows.
@@ -588,7 +253,7 @@ constexpr int QS = 4;                          // ring depth
 
 __device__ __forceinline__ int swzq(int row, int chunk) { return row * QROWB + ((chunk ^ ((row >> 2) & 3)) << 4); }
 
-template <int ACT, bool OUT_F32, bool STATS = false, bool F16 = false>
+template <int ACT, bool OUT_F32, bool F16 = false>
 __global__ __launch_bounds__(768) void gemm256q_kernel(GemmArgs g, int tiles_m, int tiles_n) {
   using HT = std::conditional_t<F16, f16_t, bf16_t>;  // operand element type (common.h Half<>)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -597,7 +262,7 @@ __global__ __launch_bounds__(768) void gemm256q_kernel(GemmArgs g, int tiles_m, 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nk = g.K >> 5;  // 32-wide K steps
   const int lda_b = g.lda * 2, ldw_b = g.ldw * 2;
-  const int my_tiles = tile_count(tiles_m, tiles_n, true);
+  const int my_tiles = tile_count(tiles_m, tiles_n);
   const int total = my_tiles * nk;
 
   if (wave >= 8) {
@@ -619,7 +284,7 @@ __global__ __launch_bounds__(768) void gemm256q_kernel(GemmArgs g, int tiles_m, 
       if (ti != cur_ti) {
         cur_ti = ti;
         int tm, tn;
-        tile_at(ti, tiles_m, tiles_n, true, tm, tn);
+        tile_at(ti, tiles_m, tiles_n, tm, tn);
         const int m0 = tm * TM, n0 = tn * TN;
         const unsigned long long pa = (unsigned long long)g.A + (unsigned long long)m0 * lda_b;
         const unsigned long long pw = (unsigned long long)g.W + (unsigned long long)n0 * ldw_b;
@@ -671,7 +336,7 @@ __global__ __launch_bounds__(768) void gemm256q_kernel(GemmArgs g, int tiles_m, 
   int step = 0;
   for (int ti = 0; ti < my_tiles; ++ti) {
     int tm, tn;
-    tile_at(ti, tiles_m, tiles_n, true, tm, tn);
+    tile_at(ti, tiles_m, tiles_n, tm, tn);
     const int m0 = tm * TM, n0 = tn * TN;
     f32x16_t acc[4][2];
 #pragma unroll
@@ -715,43 +380,54 @@ __global__ __launch_bounds__(768) void gemm256q_kernel(GemmArgs g, int tiles_m, 
 #undef CZC_RB
 #undef CZC_MM
     }
-    tile_epilogue<ACT, OUT_F32, STATS, HT>(g, acc, smem + QS * QSTAGE + wave * 4096, m0, n0, wm, wn, lane);
+    tile_epilogue<ACT, OUT_F32, HT>(g, acc, smem + QS * QSTAGE + wave * 4096, m0, n0, wm, wn, lane);
   }
 }
 
 
 
 // ================================================================================================
-// gemm256w: the 4-deep ring of gemm256q WITHOUT loader waves.  Ablations of the loader-wave kernels
-// show that their inner loop cannot be software-pipelined at the 168-VGPR cap of a 12-wave work-group and tops out near
-// 1.0 PFLOP/s even with free operands.  Here the work-group is 8 waves with the full 256 registers each: every wave
-// multiplies AND lands its share of the next stages -- rows 32w .. 32w+31 of the A and of the W tile, two 1 KiB LDS-DMA
-// pieces each per stage -- three stages ahead, counted `vmcnt` for its own pieces at the top of a step, one barrier per
-// step.  The two waves of a SIMD (w, w+4) issue their pieces half a step apart (start / middle of the step), so one
-// of them always has MFMAs for the matrix pipe while the other sits in the vector-memory issue path.
+// gemm256x: the 4-deep ring of 32 KiB stages driven by two wave GROUPS that run one phase apart ("ping-pong").
+// Counters and ablations of the ring kernels above say the same thing twice: with every wave of a SIMD in
+// the same phase, the fragment reads + DMA issue of a stage and its MFMAs ADD instead of overlapping (0.70 + 0.68 ->
+// 0.95 ms on the fc2 shape).  Here the two waves of a SIMD (w and w+4) are never in the same phase:
+//
+//     group 0 (waves 0-3, tile rows 0-127)  :  L(s) | M(s) | L(s+1) | M(s+1) | ...
+//     group 1 (waves 4-7, tile rows 128-255):       | L(s) | M(s)   | L(s+1) | ...        ( | = s_barrier of all 8 waves )
+//
+//   L(s): issue this wave's four 1 KiB LDS-DMA pieces of a later stage, then read the stage's 12 MFMA fragments
+//         (48 VGPRs: both k16 halves of 4 activation + 2 weight fragments) -- everything that blocks on the CU's
+//         vector-memory / LDS paths;
+//   M(s): 16 x v_mfma_f32_32x32x16 on those registers, nothing else (s_setprio 1 .. 0 around them).
+// So in every barrier interval each SIMD has one wave that owns the matrix pipe and one that is in memory instructions.
+// Ring protocol: stage t lives in slot t % 4.  Group 0 issues stage s+2 in L(s), group 1 stage s+3 in its L(s) (one
+// interval later); both target slots whose last reader passed an lgkmcnt(0) at least one barrier earlier.  Stage s+1 is
+// published by the barrier that ends group 0's M(s) = group 1's L(s): every wave waits for ITS pieces of s+1 with a
+// counted vmcnt just before that barrier (4 resp. 8 younger pieces may stay in flight).  At a tile end group 0 waits
+// one interval for group 1's last M, then both groups run the epilogue together; the ring runs on across tiles.
 // ================================================================================================
-// DBG (timing ablations only, results are garbage): 1 no MFMA, 2 no MFMA + pieces of 8 rows x 128 B, 3 no DMA.
+// DBG (timing ablations only, results are garbage): 1 no MFMA, 2 no DMA, 4 no fragment reads, 8 no epilogue
 template <int ACT, bool OUT_F32, bool F16 = false, int DBG = 0>
-__global__ __launch_bounds__(512) void gemm256w_kernel(GemmArgs g, int tiles_m, int tiles_n) {
+__global__ __launch_bounds__(512) void gemm256x_kernel(GemmArgs g, int tiles_m, int tiles_n, int var) {
   using HT = std::conditional_t<F16, f16_t, bf16_t>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;
   const int nk = g.K >> 5;  // 32-wide K steps
   const int lda_b = g.lda * 2, ldw_b = g.ldw * 2;
-  const int my_tiles = tile_count(tiles_m, tiles_n, true);
+  const int my_tiles = tile_count(tiles_m, tiles_n);
   const int total = my_tiles * nk;
-  const bool late = DBG == 8 ? false : wave >= 4;
+  const bool prio = !(var & 1), dma_late = var & 2;
 
   // ---- DMA side: pieces ii = 0, 1 land tile rows wave*32 + ii*16 + (lane>>2); physical chunk lane&3 ----
   const unsigned lds0 = __builtin_amdgcn_readfirstlane(
       (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem);
   const int rbase = wave * 32 + (lane >> 2);
   const int cq = ((lane & 3) ^ ((lane >> 4) & 3)) << 4;
-  const int a0 = DBG == 2 ? (wave * 16 + (lane >> 3)) * lda_b + (lane & 7) * 16 : rbase * lda_b + cq;
-  const int w0 = DBG == 2 ? (wave * 16 + (lane >> 3)) * ldw_b + (lane & 7) * 16 : rbase * ldw_b + cq;
-  const int a16 = (DBG == 2 ? 8 : 16) * lda_b, w16 = (DBG == 2 ? 8 : 16) * ldw_b;
+  const int a0 = rbase * lda_b + cq, w0 = rbase * ldw_b + cq;
+  const int a16 = 16 * lda_b, w16 = 16 * ldw_b;
   int cur_ti = -1;
   u32x4_t rsA, rsW;
   rsA.x = rsA.y = rsA.z = 0; rsA.w = 0x00020000u;
@@ -761,7 +437,7 @@ __global__ __launch_bounds__(512) void gemm256w_kernel(GemmArgs g, int tiles_m, 
     if (ti != cur_ti) {
       cur_ti = ti;
       int tm, tn;
-      tile_at(ti, tiles_m, tiles_n, true, tm, tn);
+      tile_at(ti, tiles_m, tiles_n, tm, tn);
       const int m0 = tm * TM, n0 = tn * TN;
       const unsigned long long pa = (unsigned long long)g.A + (unsigned long long)m0 * lda_b;
       const unsigned long long pw = (unsigned long long)g.W + (unsigned long long)n0 * ldw_b;
@@ -770,51 +446,40 @@ __global__ __launch_bounds__(512) void gemm256w_kernel(GemmArgs g, int tiles_m, 
     }
     const unsigned dstA = lds0 + (s & (QS - 1)) * QSTAGE + wave * (32 * QROWB);
     const unsigned dstW = dstA + QA_BYTES;
-    const unsigned soA = DBG == 2 ? (kt >> 1) * 128 + (kt & 1) * 128 * lda_b : kt * QROWB;
-    const unsigned soW = DBG == 2 ? (kt >> 1) * 128 + (kt & 1) * 128 * ldw_b : kt * QROWB;
-    if (DBG == 3) return;
+    const unsigned so = kt * QROWB;
+    if (DBG & 2) return;
     unsigned keep;
     asm volatile(
         "s_mov_b32 %0, m0\n\t"
         "s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %7, %9 offen lds\n\t"
         "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %7, %9 offen lds\n\t"
-        "s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %5, %8, %10 offen lds\n\t"
-        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %6, %8, %10 offen lds\n\t"
+        "s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %5, %8, %9 offen lds\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %6, %8, %9 offen lds\n\t"
         "s_mov_b32 m0, %0"
         : "=&s"(keep)
-        : "s"(dstA), "s"(dstW), "v"(a0), "v"(a0 + a16), "v"(w0), "v"(w0 + w16), "s"(rsA), "s"(rsW), "s"(soA), "s"(soW)
+        : "s"(dstA), "s"(dstW), "v"(a0), "v"(a0 + a16), "v"(w0), "v"(w0 + w16), "s"(rsA), "s"(rsW), "s"(so)
         : "memory", "scc");
   };
-  for (int s = 0; s < QS - 1 && s < total; ++s) issue(s);
-
-  // ---- MFMA side: fragments run half a step ahead of the MFMAs, across the barrier ----
-  const int wm = wave >> 2, wn = wave & 3;
-  const int half = lane >> 5;
-  const int arow = wm * 128 + (lane & 31);
-  const int brow = wn * 64 + (lane & 31);
-#define CZC_RFRAG(st_, ks_, a_, b_)                                                                                      \
-  do {                                                                                                                   \
-    const unsigned char* sA_ = smem + ((st_) & (QS - 1)) * QSTAGE;                                                       \
-    const unsigned char* sB_ = sA_ + QA_BYTES;                                                                           \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j) b_[j] = *(const uint4*)(sB_ + swzq(brow + 32 * j, 2 * (ks_) + half));  \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) a_[i] = *(const uint4*)(sA_ + swzq(arow + 32 * i, 2 * (ks_) + half));  \
-  } while (0)
-#define CZC_MMA8(a_, b_)                                                                                                 \
-  do {                                                                                                                   \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                        \
-      _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] = Half<HT>::mfma(b_[j], a_[i], acc[i][j]);                 \
-  } while (0)
-  uint4 ca[4], cb[2];  // k16 #0 of the step about to run, read during the step before
-  if (total > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else if (total == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();  // stage 0 published
+  const int ahead = 2 + grp;  // group 0 issues stage s+2 in L(s), group 1 stage s+3 in its L(s)
+  for (int s = 0; s < ahead && s < total; ++s) issue(s);
+  {
+    const int later = (total < ahead ? total : ahead) - 1;  // stages issued behind stage 0
+    if (later >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();  // publishes stage 0
   asm volatile("" ::: "memory");
-  CZC_RFRAG(0, 0, ca, cb);
+
+  // ---- MFMA side ----
+  const int wn = wave & 3;
+  const int half = lane >> 5;
+  const int arow = grp * 128 + (lane & 31);
+  const int brow = wn * 64 + (lane & 31);
   int step = 0;
   for (int ti = 0; ti < my_tiles; ++ti) {
     int tm, tn;
-    tile_at(ti, tiles_m, tiles_n, true, tm, tn);
+    tile_at(ti, tiles_m, tiles_n, tm, tn);
     const int m0 = tm * TM, n0 = tn * TN;
     f32x16_t acc[4][2];
 #pragma unroll
@@ -823,41 +488,84 @@ __global__ __launch_bounds__(512) void gemm256w_kernel(GemmArgs g, int tiles_m, 
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    for (int kt = 0; kt < nk; ++kt, ++step) {
-      // own pieces of stage step+1 landed?  The only pieces issued after them are stage step+2's four (step+3 goes out
-      // below); epilogue traffic of a tile boundary in between only makes the count conservative.
-      if (step + 2 < total) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();  // publishes stage step+1; every wave has left stage step-1, whose slot is refilled now
+    if (grp) {  // group 1 runs one phase behind: this barrier pairs with the one that ends group 0's L of the tile's first stage
+      __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      const bool refill = step + QS - 1 < total;
-      if (refill && !late) issue(step + QS - 1);
-      uint4 na[4], nb[2];
-      if (DBG != 1 && DBG != 2) CZC_RFRAG(step, 1, na, nb);
-      __builtin_amdgcn_sched_barrier(0);  // the reads stay ahead of the MFMAs that hide them
-      if (DBG == 9) __builtin_amdgcn_s_setprio(1);
-      if (DBG != 1 && DBG != 2) CZC_MMA8(ca, cb);
-      if (DBG == 9) __builtin_amdgcn_s_setprio(0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (refill && late) issue(step + QS - 1);
-      if (DBG != 1 && DBG != 2) CZC_RFRAG(step + 1, 0, ca, cb);  // past the last stage: a stale slot, never multiplied
-      __builtin_amdgcn_sched_barrier(0);
-      if (DBG == 9) __builtin_amdgcn_s_setprio(1);
-      if (DBG != 1 && DBG != 2) CZC_MMA8(na, nb);
-      if (DBG == 9) __builtin_amdgcn_s_setprio(0);
-      __builtin_amdgcn_sched_barrier(0);
     }
-    tile_epilogue<ACT, OUT_F32, false, HT>(g, acc, smem + QS * QSTAGE + wave * 4096, m0, n0, wm, wn, lane);
+    for (int kt = 0; kt < nk; ++kt, ++step) {
+      // ------------------------------- L(step) -------------------------------
+      const unsigned char* sA = smem + (step & (QS - 1)) * QSTAGE;
+      const unsigned char* sB = sA + QA_BYTES;
+      if (!dma_late && step + ahead < total) issue(step + ahead);
+      uint4 fa[2][4], fb[2][2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if (DBG & 4) fb[ks][j] = make_uint4(lane, step, ks, j);
+          else fb[ks][j] = *(const uint4*)(sB + swzq(brow + 32 * j, 2 * ks + half));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (DBG & 4) fa[ks][i] = make_uint4(lane, step, ks, i);
+          else fa[ks][i] = *(const uint4*)(sA + swzq(arow + 32 * i, 2 * ks + half));
+        }
+      }
+      if (dma_late && step + ahead < total) issue(step + ahead);
+      if (grp) {  // stage step+1 is published by the barrier below: this wave's pieces of it must have landed
+        if (step + 3 < total) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (step + 2 < total) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      // ------------------------------- M(step) -------------------------------
+      if (prio) __builtin_amdgcn_s_setprio(1);
+      if (DBG & 1) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {  // keep the fragments (and their LDS reads) alive without the matrix work
+#pragma unroll
+          for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(__builtin_bit_cast(u32x4_t, fb[ks][j])));
+#pragma unroll
+          for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(__builtin_bit_cast(u32x4_t, fa[ks][i])));
+        }
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = Half<HT>::mfma(fb[ks][j], fa[ks][i], acc[i][j]);
+      }
+      if (prio) __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!grp) {
+        if (step + 2 < total) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+    if (!grp) {  // group 1's last M of this tile
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+    if (DBG & 8) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[i][j]));
+    } else {
+      tile_epilogue<ACT, OUT_F32, HT>(g, acc, smem + QS * QSTAGE + wave * 4096, m0, n0, grp, wn, lane);
+    }
   }
-#undef CZC_RFRAG
-#undef CZC_MMA8
 }
 
 // ================================================================================================
 // gemm256sq: gemm256q's 4-deep ring of 32 KiB stages for the SPLIT-fp16 precision.  A 64-byte tile row holds 16
 // elements ([8 hi | 8 lo] x 2 groups) = one k16 MFMA step, three fp16 passes per product: 24 MFMAs per stage and
-// wave on 12 ds_read_b128, loaders up to three stages ahead with counted vmcnt.  (gemm256s below, the two-stage
-// form, waits for every stage's DMA latency in front of its barrier: 0.37 of MFMA peak; kept for A/B.)
+// wave on 12 ds_read_b128, loaders up to three stages ahead with counted vmcnt.
 // ================================================================================================
 template <int ACT, bool OUT_F32>
 __global__ __launch_bounds__(768) void gemm256sq_kernel(GemmArgs g, int tiles_m, int tiles_n) {
@@ -867,7 +575,7 @@ __global__ __launch_bounds__(768) void gemm256sq_kernel(GemmArgs g, int tiles_m,
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nk = g.K >> 4;  // one k16 MFMA step per stage: a 64-byte row = two split_t groups = 16 elements
   const int lda_b = g.lda * 4, ldw_b = g.ldw * 4;
-  const int my_tiles = tile_count(tiles_m, tiles_n, true);
+  const int my_tiles = tile_count(tiles_m, tiles_n);
   const int total = my_tiles * nk;
 
   if (wave >= 8) {
@@ -889,7 +597,7 @@ __global__ __launch_bounds__(768) void gemm256sq_kernel(GemmArgs g, int tiles_m,
       if (ti != cur_ti) {
         cur_ti = ti;
         int tm, tn;
-        tile_at(ti, tiles_m, tiles_n, true, tm, tn);
+        tile_at(ti, tiles_m, tiles_n, tm, tn);
         const int m0 = tm * TM, n0 = tn * TN;
         const unsigned long long pa = (unsigned long long)g.A + (unsigned long long)m0 * lda_b;
         const unsigned long long pw = (unsigned long long)g.W + (unsigned long long)n0 * ldw_b;
@@ -941,7 +649,7 @@ __global__ __launch_bounds__(768) void gemm256sq_kernel(GemmArgs g, int tiles_m,
   int step = 0;
   for (int ti = 0; ti < my_tiles; ++ti) {
     int tm, tn;
-    tile_at(ti, tiles_m, tiles_n, true, tm, tn);
+    tile_at(ti, tiles_m, tiles_n, tm, tn);
     const int m0 = tm * TM, n0 = tn * TN;
     f32x16_t acc[4][2];
 #pragma unroll
@@ -985,152 +693,6 @@ __global__ __launch_bounds__(768) void gemm256sq_kernel(GemmArgs g, int tiles_m,
 
 
 
-
-// ================================================================================================
-// gemm256s: the persistent wave-specialised 256x256 kernel (gemm256p structure: 8 MFMA waves + 4 LDS-DMA loader
-// waves, two 64 KiB stages of 128-byte rows) for the SPLIT-fp16 engine precision.  A 128-byte tile row is 32
-// elements as four groups of [8 fp16 hi | 8 fp16 lo] (common.h split_t), so one stage feeds two k16 MFMA steps, and
-// every product is three v_mfma_f32_32x32x16_f16 passes (hi*hi + lo*hi + hi*lo): 48 MFMAs per stage and wave on
-// 24 ds_read_b128 -- three times the matrix work of the bf16 kernel on twice the bytes, which moves these layers
-// from the HBM / CU-ingest bound of the bf16 tower towards the MFMA bound.
-// ================================================================================================
-template <int ACT, bool OUT_F32>
-__global__ __launch_bounds__(768) void gemm256s_kernel(GemmArgs g, int tiles_m, int tiles_n) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nk = g.K >> 5;  // 32 elements (128 bytes of split_t) per stage
-  const int lda_b = g.lda * 4, ldw_b = g.ldw * 4;
-  const int my_tiles = tile_count(tiles_m, tiles_n, true);
-
-  if (wave >= 8) {
-    // ------------------------------- loader waves (as gemm256p) -----------------------------
-    const int lw = wave - 8;
-    const unsigned lds0 = __builtin_amdgcn_readfirstlane(
-        (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem);
-    const int rbase = lw * 64 + (lane >> 3);
-    const int ce = ((lane & 7) ^ ((lane >> 4) & 7)) << 4;
-    const int co = ((lane & 7) ^ (((lane >> 4) + 4) & 7)) << 4;
-    const int a_e = rbase * lda_b + ce, a_o = (rbase + 8) * lda_b + co;
-    const int w_e = rbase * ldw_b + ce, w_o = (rbase + 8) * ldw_b + co;
-    const int a16 = 16 * lda_b, w16 = 16 * ldw_b;
-    unsigned step = 0;
-    bool first = true;
-    for (int ti = 0; ti < my_tiles; ++ti) {
-      int tm, tn;
-      tile_at(ti, tiles_m, tiles_n, true, tm, tn);
-      const int m0 = tm * TM, n0 = tn * TN;
-      const unsigned long long pa = (unsigned long long)g.A + (unsigned long long)m0 * lda_b;
-      const unsigned long long pw = (unsigned long long)g.W + (unsigned long long)n0 * ldw_b;
-      u32x4_t rsA, rsW;
-      rsA.x = (unsigned)pa; rsA.y = (unsigned)(pa >> 32) & 0xffffu;
-      rsA.z = (unsigned)(min(TM, g.M - m0) * lda_b); rsA.w = 0x00020000u;
-      rsW.x = (unsigned)pw; rsW.y = (unsigned)(pw >> 32) & 0xffffu;
-      rsW.z = (unsigned)(min(TN, g.N - n0) * ldw_b); rsW.w = 0x00020000u;
-      for (int kt = 0; kt < nk; ++kt, ++step) {
-        if (!first) {
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          __builtin_amdgcn_s_barrier();
-        }
-        first = false;
-        const unsigned dstA = lds0 + (step & 1) * STAGE + lw * (64 * ROWB);
-        const unsigned dstW = dstA + A_BYTES;
-        const unsigned so = kt * ROWB;
-        unsigned keep;
-        asm volatile(
-            "s_mov_b32 %0, m0\n\t"
-            "s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %11, %13 offen lds\n\t"
-            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %11, %13 offen lds\n\t"
-            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %5, %11, %13 offen lds\n\t"
-            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %6, %11, %13 offen lds\n\t"
-            "s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %7, %12, %13 offen lds\n\t"
-            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %8, %12, %13 offen lds\n\t"
-            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %9, %12, %13 offen lds\n\t"
-            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %10, %12, %13 offen lds\n\t"
-            "s_mov_b32 m0, %0"
-            : "=&s"(keep)
-            : "s"(dstA), "s"(dstW), "v"(a_e), "v"(a_o), "v"(a_e + a16), "v"(a_o + a16), "v"(w_e), "v"(w_o),
-              "v"(w_e + w16), "v"(w_o + w16), "s"(rsA), "s"(rsW), "s"(so)
-            : "memory", "scc");
-        asm volatile(
-            "s_mov_b32 %0, m0\n\t"
-            "s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %11, %13 offen lds\n\t"
-            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %11, %13 offen lds\n\t"
-            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %5, %11, %13 offen lds\n\t"
-            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %6, %11, %13 offen lds\n\t"
-            "s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %7, %12, %13 offen lds\n\t"
-            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %8, %12, %13 offen lds\n\t"
-            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %9, %12, %13 offen lds\n\t"
-            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %10, %12, %13 offen lds\n\t"
-            "s_mov_b32 m0, %0"
-            : "=&s"(keep)
-            : "s"(dstA + 32 * ROWB), "s"(dstW + 32 * ROWB), "v"(a_e + 2 * a16), "v"(a_o + 2 * a16), "v"(a_e + 3 * a16),
-              "v"(a_o + 3 * a16), "v"(w_e + 2 * w16), "v"(w_o + 2 * w16), "v"(w_e + 3 * w16), "v"(w_o + 3 * w16),
-              "s"(rsA), "s"(rsW), "s"(so)
-            : "memory", "scc");
-      }
-    }
-    if (!first) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-    }
-    return;
-  }
-
-  // --------------------------------- MFMA waves ---------------------------------------------
-  const int wm = wave >> 2, wn = wave & 3;
-  const int half = lane >> 5;
-  const int arow = wm * 128 + (lane & 31);
-  const int brow = wn * 64 + (lane & 31);
-  unsigned step = 0;
-  for (int ti = 0; ti < my_tiles; ++ti) {
-    int tm, tn;
-    tile_at(ti, tiles_m, tiles_n, true, tm, tn);
-    const int m0 = tm * TM, n0 = tn * TN;
-    f32x16_t acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    for (int kt = 0; kt < nk; ++kt, ++step) {
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      const unsigned char* sA = smem + (step & 1) * STAGE;
-      const unsigned char* sB = sA + A_BYTES;
-#define CZC_F16(v_) __builtin_bit_cast(f16x8_t, v_)
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const int ch = 2 * (2 * s2 + half);  // chunk 2g = hi plane, 2g+1 = lo plane of k-group g = 2*s2 + half
-        uint4 bh[2], bl[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          bh[j] = *(const uint4*)(sB + swz(brow + 32 * j, ch));
-          bl[j] = *(const uint4*)(sB + swz(brow + 32 * j, ch + 1));
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const uint4 ah = *(const uint4*)(sA + swz(arow + 32 * i, ch));
-          const uint4 al = *(const uint4*)(sA + swz(arow + 32 * i, ch + 1));
-          // (a_hi + a_lo)(w_hi + w_lo) ~ a_hi w_hi + a_lo w_hi + a_hi w_lo   (lo*lo ~ 2^-22, dropped); small terms first,
-          // pass-major over the two column tiles so that consecutive MFMAs never share an accumulator
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(CZC_F16(bl[j]), CZC_F16(ah), acc[i][j], 0, 0, 0);
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(CZC_F16(bh[j]), CZC_F16(al), acc[i][j], 0, 0, 0);
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(CZC_F16(bh[j]), CZC_F16(ah), acc[i][j], 0, 0, 0);
-        }
-      }
-#undef CZC_F16
-    }
-    unsigned char* patch = smem + 2 * STAGE + wave * 4096;
-    if (OUT_F32) tile_epilogue<ACT, true>(g, acc, patch, m0, n0, wm, wn, lane);
-    else tile_epilogue_split<ACT>(g, acc, patch, m0, n0, wm, wn, lane);
-  }
-}
 
 // ================================================================================================
 // gemm_rowln: x <- x + A.W^T + b over FULL 512-wide rows, with the LayerNorm that follows it in the pre-LN block
@@ -1391,32 +953,28 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(GemmArgs g, const float
 }  // namespace
 
 int g_gemm256_min_m = 2048;
-int g_gemm_krot = 0;  // bit0: rotate K order per work-group (no gain measured); bits1-2: debug (skip MFMA / skip DMA)
+int g_w_dbg = 0;  // gemm256x A/B switches (test option w_dbg): bit0 no s_setprio, bit1 DMA after the fragment reads; bits 8.. timing ablations
 
 // x <- x + A.W^T + b with y = LayerNorm(x) from the same launch (gemm_rowln_kernel): N = 512 rows only.
 int g_rowln_min_m = 4096;
 bool gemm_rowln_eligible(const GemmArgs& g) {
   return g.M >= g_rowln_min_m && g.N == RL_N && g.K % 32 == 0 && g.K >= 64 && g.ldc == RL_N && g.act == ACT_NONE && g.out_act &&
-         g.out_f32 && g.ln_gamma && g.ln_beta && !g.row_stats && g.lda % 8 == 0 && g.ldw % 8 == 0 &&
+         g.out_f32 && g.ln_gamma && g.ln_beta && g.lda % 8 == 0 && g.ldw % 8 == 0 &&
          (!g.resid || g.ldr % 4 == 0) && (long)RL_TM * g.lda * 2 < (1L << 31) && (long)RL_N * g.ldw * 2 < (1L << 31);
 }
 int launch_gemm_rowln(const GemmArgs& g, hipStream_t st) {
-  static int n_cu = 0;
-  if (!n_cu) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    CZC_HIP_CHECK(hipGetDevice(&dev));
-    CZC_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-    n_cu = prop.multiProcessorCount;
+  static const LaunchInit init = launch_init([](LaunchInit&) -> int {
     CZC_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_rowln_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, RL_LDS));
     CZC_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_rowln_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, RL_LDS));
-  }
+    return 0;
+  });
+  if (init.rc) return launch_init_failed("gemm_rowln");
   if (!gemm_rowln_eligible(g)) {
     snprintf(g_err, sizeof(g_err), "gemm_rowln: shape not eligible (M=%d N=%d K=%d)", g.M, g.N, g.K);
     return 1;
   }
   const int tiles_m = cdiv(g.M, RL_TM);
-  dim3 grid(tiles_m < n_cu ? tiles_m : n_cu), block(512);
+  dim3 grid(tiles_m < init.n_cu ? tiles_m : init.n_cu), block(512);
   if (g.f16) hipLaunchKernelGGL(gemm_rowln_kernel<true>, grid, block, RL_LDS, st, g, g.ln_gamma, g.ln_beta, tiles_m);
   else hipLaunchKernelGGL(gemm_rowln_kernel<false>, grid, block, RL_LDS, st, g, g.ln_gamma, g.ln_beta, tiles_m);
   CZC_HIP_CHECK(hipGetLastError());
@@ -1424,167 +982,96 @@ int launch_gemm_rowln(const GemmArgs& g, hipStream_t st) {
 }
 
 bool gemm256_eligible(const GemmArgs& g) {
-  if (g.f16 && (g_use_gemm256 < 3 || g.row_stats || g.N % 8 || g.ldc % 8)) return false;  // fp16 operands: ring kernels only
-  return g.M >= g_gemm256_min_m && g.N % 4 == 0 && g.K % 64 == 0 && g.ldc % 4 == 0 && (!g.resid || g.ldr % 4 == 0) &&
-         (g.act == ACT_NONE || g.act == ACT_QUICK_GELU) && (long)256 * g.lda * 2 < (1L << 31) &&
+  return g.M >= g_gemm256_min_m && g.N % 8 == 0 && g.K % 64 == 0 && g.ldc % 8 == 0 && g.lda % 8 == 0 && g.ldw % 8 == 0 &&
+         (!g.resid || g.ldr % 4 == 0) && (g.act == ACT_NONE || g.act == ACT_QUICK_GELU) && (long)256 * g.lda * 2 < (1L << 31) &&
          (long)256 * g.ldw * 2 < (1L << 31);
 }
 
+// g_use_gemm256: 0 = 128x128 kernel only; 1 (default) = gemm256x where the output is fp32 (+ residual), gemm256q where
+// it is activation-typed; 3 / 5 pin gemm256q / gemm256x for every epilogue (A/B runs and kernel tests)
 int launch_gemm256(const GemmArgs& g, hipStream_t st) {
-  static bool attr_set = false;
-  static int n_cu = 0;
-  const int shmem = 2 * STAGE;
-  if (g_use_gemm256 >= 2 && g.N % 8 == 0 && g.ldc % 8 == 0 && g.K % 64 == 0) {
-    const int shp = shmem + 8 * 4096;  // + one 4 KiB epilogue patch per MFMA wave = the full 160 KiB
-    if (!n_cu) {
-      int dev = 0;
-      hipDeviceProp_t prop;
-      CZC_HIP_CHECK(hipGetDevice(&dev));
-      CZC_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-      n_cu = prop.multiProcessorCount;
+  constexpr int shp = QS * QSTAGE + 8 * 4096;  // ring + one 4 KiB epilogue patch per MFMA wave = the full 160 KiB
+  static const LaunchInit init = launch_init([](LaunchInit&) -> int {
 #define CZC_ATTR(K_) CZC_HIP_CHECK(hipFuncSetAttribute((const void*)K_, hipFuncAttributeMaxDynamicSharedMemorySize, shp))
-      CZC_ATTR((gemm256p_kernel<ACT_NONE, false>));
-      CZC_ATTR((gemm256p_kernel<ACT_NONE, true>));
-      CZC_ATTR((gemm256p_kernel<ACT_QUICK_GELU, false>));
-      CZC_ATTR((gemm256p_kernel<ACT_QUICK_GELU, true>));
-      CZC_ATTR((gemm256q_kernel<ACT_NONE, false>));
-      CZC_ATTR((gemm256q_kernel<ACT_NONE, true>));
-      CZC_ATTR((gemm256q_kernel<ACT_QUICK_GELU, false>));
-      CZC_ATTR((gemm256q_kernel<ACT_QUICK_GELU, true>));
-      CZC_ATTR((gemm256q_kernel<ACT_NONE, true, true>));
-      CZC_ATTR((gemm256q_kernel<ACT_NONE, false, false, true>));
-      CZC_ATTR((gemm256q_kernel<ACT_NONE, true, false, true>));
-      CZC_ATTR((gemm256q_kernel<ACT_QUICK_GELU, false, false, true>));
-      CZC_ATTR((gemm256q_kernel<ACT_QUICK_GELU, true, false, true>));
+#define CZC_ATTR4(K_) CZC_ATTR((K_<ACT_NONE, false, false>)); CZC_ATTR((K_<ACT_NONE, true, false>)); \
+                      CZC_ATTR((K_<ACT_QUICK_GELU, false, false>)); CZC_ATTR((K_<ACT_QUICK_GELU, true, false>)); \
+                      CZC_ATTR((K_<ACT_NONE, false, true>)); CZC_ATTR((K_<ACT_NONE, true, true>)); \
+                      CZC_ATTR((K_<ACT_QUICK_GELU, false, true>)); CZC_ATTR((K_<ACT_QUICK_GELU, true, true>))
+    CZC_ATTR4(gemm256q_kernel);
+    CZC_ATTR4(gemm256x_kernel);
+#undef CZC_ATTR4
 #undef CZC_ATTR
+    return 0;
+  });
+  if (init.rc) return launch_init_failed("gemm256");
+  const int n_cu = init.n_cu;
+  const int tiles_m = cdiv(g.M, TM), tiles_n = cdiv(g.N, TN);
+  const bool f32 = g.out_f32 != nullptr || g.resid != nullptr;
+  dim3 gq(tiles_m * tiles_n < n_cu ? tiles_m * tiles_n : n_cu);
+  const bool pp = g_use_gemm256 == 5 || (g_use_gemm256 != 3 && f32);
+#ifdef CZC_EXPERIMENTS
+  if (pp && (g_w_dbg >> 8) && f32 && g.act == ACT_NONE && !g.f16) {  // timing ablations of the ping-pong kernel
+#define CZC_GOXD(D_)                                                                                                     \
+  case D_:                                                                                                               \
+    CZC_HIP_CHECK(hipFuncSetAttribute((const void*)gemm256x_kernel<ACT_NONE, true, false, D_>, hipFuncAttributeMaxDynamicSharedMemorySize, shp)); \
+    hipLaunchKernelGGL((gemm256x_kernel<ACT_NONE, true, false, D_>), gq, dim3(512), shp, st, g, tiles_m, tiles_n, g_w_dbg & 255); \
+    break
+    switch (g_w_dbg >> 8) {
+      CZC_GOXD(1); CZC_GOXD(2); CZC_GOXD(3); CZC_GOXD(4); CZC_GOXD(5); CZC_GOXD(6); CZC_GOXD(8); CZC_GOXD(9); CZC_GOXD(10); CZC_GOXD(12); CZC_GOXD(14);
+      default: snprintf(g_err, sizeof(g_err), "gemm256x: ablation %d not built", g_w_dbg >> 8); return 1;
     }
-    const int tiles_m = cdiv(g.M, TM), tiles_n = cdiv(g.N, TN);
-    const int nt = (g_gemm_krot & 32) ? tiles_m : tiles_m * tiles_n;  // work units: tiles, or M tiles for the M-major walk
-    dim3 grid(nt < n_cu ? nt : n_cu), block(768);
-    const bool f32 = g.out_f32 != nullptr || g.resid != nullptr;
-    if (g.row_stats && !(g_use_gemm256 >= 3 && f32 && g.act == ACT_NONE && g.N % 64 == 0)) {
-      snprintf(g_err, sizeof(g_err), "gemm256: row_stats needs the fp32-output ring kernel, no activation, N %% 64 == 0");
-      return 1;
-    }
-    if (g_use_gemm256 == 4 && !g.row_stats && g_w_dbg && f32 && g.act == ACT_NONE && !g.f16) {
-      dim3 gq(tiles_m * tiles_n < n_cu ? tiles_m * tiles_n : n_cu), bw(512);
-#define CZC_GOWD(D_)                                                                                                     \
-  do {                                                                                                                   \
-    CZC_HIP_CHECK(hipFuncSetAttribute((const void*)gemm256w_kernel<ACT_NONE, true, false, D_>, hipFuncAttributeMaxDynamicSharedMemorySize, shp)); \
-    hipLaunchKernelGGL((gemm256w_kernel<ACT_NONE, true, false, D_>), gq, bw, shp, st, g, tiles_m, tiles_n);             \
-  } while (0)
-      if (g_w_dbg == 1) CZC_GOWD(1); else if (g_w_dbg == 2) CZC_GOWD(2); else if (g_w_dbg == 3) CZC_GOWD(3);
-      else if (g_w_dbg == 8) CZC_GOWD(8); else CZC_GOWD(9);
-#undef CZC_GOWD
-      CZC_HIP_CHECK(hipGetLastError());
-      return 0;
-    }
-    if (g_use_gemm256 == 4 && !g.row_stats) {
-      dim3 gq(tiles_m * tiles_n < n_cu ? tiles_m * tiles_n : n_cu), bw(512);
-#define CZC_GOW(A_, F_, H_)                                                                                              \
-  do {                                                                                                                   \
-    CZC_HIP_CHECK(hipFuncSetAttribute((const void*)gemm256w_kernel<A_, F_, H_>, hipFuncAttributeMaxDynamicSharedMemorySize, shp)); \
-    hipLaunchKernelGGL((gemm256w_kernel<A_, F_, H_>), gq, bw, shp, st, g, tiles_m, tiles_n);                            \
-  } while (0)
-      if (g.f16) {
-        if (g.act == ACT_QUICK_GELU) { if (f32) CZC_GOW(ACT_QUICK_GELU, true, true); else CZC_GOW(ACT_QUICK_GELU, false, true); }
-        else { if (f32) CZC_GOW(ACT_NONE, true, true); else CZC_GOW(ACT_NONE, false, true); }
-      } else {
-        if (g.act == ACT_QUICK_GELU) { if (f32) CZC_GOW(ACT_QUICK_GELU, true, false); else CZC_GOW(ACT_QUICK_GELU, false, false); }
-        else { if (f32) CZC_GOW(ACT_NONE, true, false); else CZC_GOW(ACT_NONE, false, false); }
-      }
-#undef CZC_GOW
-      CZC_HIP_CHECK(hipGetLastError());
-      return 0;
-    }
-    if (g_use_gemm256 >= 3) {
-      dim3 gq(tiles_m * tiles_n < n_cu ? tiles_m * tiles_n : n_cu);
-      if (g.row_stats) {
-        hipLaunchKernelGGL((gemm256q_kernel<ACT_NONE, true, true>), gq, block, shp, st, g, tiles_m, tiles_n);
-        CZC_HIP_CHECK(hipGetLastError());
-        return 0;
-      }
-#define CZC_GOQ(A_, F_, H_) hipLaunchKernelGGL((gemm256q_kernel<A_, F_, false, H_>), gq, block, shp, st, g, tiles_m, tiles_n)
-      if (g.f16) {
-        if (g.act == ACT_QUICK_GELU) { if (f32) CZC_GOQ(ACT_QUICK_GELU, true, true); else CZC_GOQ(ACT_QUICK_GELU, false, true); }
-        else { if (f32) CZC_GOQ(ACT_NONE, true, true); else CZC_GOQ(ACT_NONE, false, true); }
-      } else {
-        if (g.act == ACT_QUICK_GELU) { if (f32) CZC_GOQ(ACT_QUICK_GELU, true, false); else CZC_GOQ(ACT_QUICK_GELU, false, false); }
-        else { if (f32) CZC_GOQ(ACT_NONE, true, false); else CZC_GOQ(ACT_NONE, false, false); }
-      }
-#undef CZC_GOQ
-      CZC_HIP_CHECK(hipGetLastError());
-      return 0;
-    }
-#define CZC_GO(A_, F_) hipLaunchKernelGGL((gemm256p_kernel<A_, F_>), grid, block, shp, st, g, tiles_m, tiles_n, g_gemm_krot)
-    if (g.act == ACT_QUICK_GELU) { if (f32) CZC_GO(ACT_QUICK_GELU, true); else CZC_GO(ACT_QUICK_GELU, false); }
-    else { if (f32) CZC_GO(ACT_NONE, true); else CZC_GO(ACT_NONE, false); }
-#undef CZC_GO
+#undef CZC_GOXD
     CZC_HIP_CHECK(hipGetLastError());
     return 0;
   }
-  if (!attr_set) {
-    CZC_HIP_CHECK(hipFuncSetAttribute((const void*)gemm256_kernel<ACT_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      shmem));
-    CZC_HIP_CHECK(hipFuncSetAttribute((const void*)gemm256_kernel<ACT_QUICK_GELU>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, shmem));
-    attr_set = true;
-  }
-  const int tiles_m = cdiv(g.M, TM), tiles_n = cdiv(g.N, TN);
-  dim3 grid(tiles_m * tiles_n), block(512);
-  if (g.act == ACT_QUICK_GELU)
-    hipLaunchKernelGGL(gemm256_kernel<ACT_QUICK_GELU>, grid, block, shmem, st, g, tiles_m, tiles_n);
-  else
-    hipLaunchKernelGGL(gemm256_kernel<ACT_NONE>, grid, block, shmem, st, g, tiles_m, tiles_n);
+#endif
+#define CZC_GO(K_, A_, F_, H_, T_, ...) hipLaunchKernelGGL((K_<A_, F_, H_>), gq, dim3(T_), shp, st, g, tiles_m, tiles_n, ##__VA_ARGS__)
+#define CZC_DISPATCH(K_, T_, ...)                                                                                          \
+  do {                                                                                                                     \
+    if (g.f16) {                                                                                                           \
+      if (g.act == ACT_QUICK_GELU) { if (f32) CZC_GO(K_, ACT_QUICK_GELU, true, true, T_, ##__VA_ARGS__); else CZC_GO(K_, ACT_QUICK_GELU, false, true, T_, ##__VA_ARGS__); } \
+      else { if (f32) CZC_GO(K_, ACT_NONE, true, true, T_, ##__VA_ARGS__); else CZC_GO(K_, ACT_NONE, false, true, T_, ##__VA_ARGS__); }                               \
+    } else {                                                                                                               \
+      if (g.act == ACT_QUICK_GELU) { if (f32) CZC_GO(K_, ACT_QUICK_GELU, true, false, T_, ##__VA_ARGS__); else CZC_GO(K_, ACT_QUICK_GELU, false, false, T_, ##__VA_ARGS__); } \
+      else { if (f32) CZC_GO(K_, ACT_NONE, true, false, T_, ##__VA_ARGS__); else CZC_GO(K_, ACT_NONE, false, false, T_, ##__VA_ARGS__); }                             \
+    }                                                                                                                      \
+  } while (0)
+  if (pp) CZC_DISPATCH(gemm256x_kernel, 512, g_w_dbg & 255);
+  else CZC_DISPATCH(gemm256q_kernel, 768);
+#undef CZC_DISPATCH
+#undef CZC_GO
   CZC_HIP_CHECK(hipGetLastError());
   return 0;
 }
 
-int g_w_dbg = 0;  // timing ablations of gemm256w (test option w_dbg)
-int g_use_gemm256s = 1;  // 1: four-stage ring (gemm256sq), 2: two-stage form (gemm256s), 0: 128x128 kernel
+int g_use_gemm256s = 1;  // 0: split-fp16 layers stay on the 128x128 kernel
 
 // split-fp16 operands; big-M layers only (BERT at a few thousand rows stays on the 128x128 + split-K path)
 bool gemm256s_eligible(const GemmArgs& g) {
   return g_use_gemm256s && g.M >= 16384 && g.N % 8 == 0 && g.K % 32 == 0 && g.ldc % 8 == 0 && g.lda % 8 == 0 && g.ldw % 8 == 0 &&
-         (!g.resid || g.ldr % 4 == 0) && (g.act == ACT_NONE || g.act == ACT_QUICK_GELU) && !g.row_stats && !g.ln_stats &&
+         (!g.resid || g.ldr % 4 == 0) && (g.act == ACT_NONE || g.act == ACT_QUICK_GELU) &&
          !(g.out_act && g.out_f32) && (long)256 * g.lda * 4 < (1L << 31) && (long)256 * g.ldw * 4 < (1L << 31);
 }
 
 int launch_gemm256s(const GemmArgs& g, hipStream_t st) {
-  static int n_cu = 0;
-  const int shp = 2 * STAGE + 8 * 4096;
-  if (!n_cu) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    CZC_HIP_CHECK(hipGetDevice(&dev));
-    CZC_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-    n_cu = prop.multiProcessorCount;
+  constexpr int shp = QS * QSTAGE + 8 * 4096;
+  static const LaunchInit init = launch_init([](LaunchInit&) -> int {
 #define CZC_ATTR(K_) CZC_HIP_CHECK(hipFuncSetAttribute((const void*)K_, hipFuncAttributeMaxDynamicSharedMemorySize, shp))
-    CZC_ATTR((gemm256s_kernel<ACT_NONE, false>));
-    CZC_ATTR((gemm256s_kernel<ACT_NONE, true>));
-    CZC_ATTR((gemm256s_kernel<ACT_QUICK_GELU, false>));
-    CZC_ATTR((gemm256s_kernel<ACT_QUICK_GELU, true>));
     CZC_ATTR((gemm256sq_kernel<ACT_NONE, false>));
     CZC_ATTR((gemm256sq_kernel<ACT_NONE, true>));
     CZC_ATTR((gemm256sq_kernel<ACT_QUICK_GELU, false>));
     CZC_ATTR((gemm256sq_kernel<ACT_QUICK_GELU, true>));
 #undef CZC_ATTR
-  }
-  const int tiles_m = cdiv(g.M, TM), tiles_n = cdiv(g.N, TN);
-  dim3 grid(tiles_m * tiles_n < n_cu ? tiles_m * tiles_n : n_cu), block(768);
-  const bool f32 = g.out_f32 != nullptr || g.resid != nullptr;
-  if (g_use_gemm256s == 1 && g.K % 16 == 0) {
-#define CZC_GOSQ(A_, F_) hipLaunchKernelGGL((gemm256sq_kernel<A_, F_>), grid, block, shp, st, g, tiles_m, tiles_n)
-    if (g.act == ACT_QUICK_GELU) { if (f32) CZC_GOSQ(ACT_QUICK_GELU, true); else CZC_GOSQ(ACT_QUICK_GELU, false); }
-    else { if (f32) CZC_GOSQ(ACT_NONE, true); else CZC_GOSQ(ACT_NONE, false); }
-#undef CZC_GOSQ
-    CZC_HIP_CHECK(hipGetLastError());
     return 0;
-  }
-#define CZC_GOS(A_, F_) hipLaunchKernelGGL((gemm256s_kernel<A_, F_>), grid, block, shp, st, g, tiles_m, tiles_n)
-  if (g.act == ACT_QUICK_GELU) { if (f32) CZC_GOS(ACT_QUICK_GELU, true); else CZC_GOS(ACT_QUICK_GELU, false); }
-  else { if (f32) CZC_GOS(ACT_NONE, true); else CZC_GOS(ACT_NONE, false); }
-#undef CZC_GOS
+  });
+  if (init.rc) return launch_init_failed("gemm256s");
+  const int tiles_m = cdiv(g.M, TM), tiles_n = cdiv(g.N, TN);
+  dim3 grid(tiles_m * tiles_n < init.n_cu ? tiles_m * tiles_n : init.n_cu), block(768);
+  const bool f32 = g.out_f32 != nullptr || g.resid != nullptr;
+#define CZC_GOSQ(A_, F_) hipLaunchKernelGGL((gemm256sq_kernel<A_, F_>), grid, block, shp, st, g, tiles_m, tiles_n)
+  if (g.act == ACT_QUICK_GELU) { if (f32) CZC_GOSQ(ACT_QUICK_GELU, true); else CZC_GOSQ(ACT_QUICK_GELU, false); }
+  else { if (f32) CZC_GOSQ(ACT_NONE, true); else CZC_GOSQ(ACT_NONE, false); }
+#undef CZC_GOSQ
   CZC_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -16,9 +16,9 @@
 //     per flop -- half of the tiled kernel -- and there is no weight traffic in steady state.
 //   * every wave multiplies every block against its own columns: one ds_read_b128 + one
 //     v_mfma_f32_32x32x16_bf16 per k16 step (LDS read pipe 50 % busy), two accumulator chains.
-//   * the two waves of a SIMD (w, w+4) run half a block apart: one does MFMA(i) then epilogue(i),
-//     the other epilogue(i-1) then MFMA(i), so bias / quick-GELU / bf16 pack / store of 32x32
-//     outputs always has a partner's MFMAs to hide behind.
+//   * the memory work of a block (ring refill, epilogue of the previous block, its two stores) is issued one
+//     instruction at a time between groups of four MFMAs: a VMEM instruction blocks its wave until the CU's
+//     vector-memory path takes it, so a burst keeps the wave out of the matrix pipe for a whole block period.
 //   * one barrier per block.  Loads, LDS-DMA and stores retire in order on gfx9's vmcnt, and every
 //     VMEM instruction of the loop is issued from inline asm in a fixed number per block, so the
 //     wait for block i is an exact count (two blocks of DMA + three epilogues of stores stay in
@@ -41,19 +41,9 @@ constexpr int WR_BLK = 32;                     // rows per block
 constexpr int WR_STAGE = WR_BLK * WR_ROWB;     // 32 KiB
 constexpr int WR_D = 4;                        // ring depth
 constexpr int WR_PATCH = 2048;                 // per-wave epilogue patch (32 rows x 64 bytes)
-constexpr int WR_BIAS = 256;                   // per-wave bias slice (32 floats) + folded-LayerNorm column sums (32 floats)
+constexpr int WR_BIAS = 128;                   // per-wave bias slice (32 floats)
 constexpr int WR_LDS = WR_D * WR_STAGE + 8 * (WR_PATCH + WR_BIAS);
-// LayerNorm folded into the epilogue (LNF): the per-row statistics partials of a block (32 rows x 16 floats) ride
-// an LDS ring of their own, five deep: the statistics of block b are read during block b+1's MFMA stream while
-// the refill of block b+4 is already being issued, so the ring of four that serves the activation rows (whose
-// slot is free as soon as the block's MFMAs are done) would be overwritten one block too early.
-constexpr int WR_SD = 5;
-constexpr int WR_SSLOT = 32 * 16 * 4;          // 2 KiB
-constexpr int WR_LDS_LNF = WR_LDS + WR_SD * WR_SSLOT;
-static_assert(WR_LDS_LNF <= 160 * 1024, "LDS budget");
-constexpr int WR_STORES = 2;                   // buffer stores per wave per epilogue
-constexpr int WR_DMAS = 4;
-constexpr int WR_AHEAD = 4;                    // fragment reads in flight ahead of the MFMA that uses them                     // LDS-DMA instructions per wave per block
+static_assert(WR_LDS <= 160 * 1024, "LDS budget");
 
 __device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {
   unsigned r;
@@ -67,9 +57,8 @@ __device__ __forceinline__ float wr_act(float v) {
   return v;
 }
 
-template <int ACT, bool DBG_NOLDS, bool ILV, bool LNF = false, bool F16 = false>
-__global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, int nsets, int nblk, int dbg) {
-  static_assert(!LNF || ILV, "the folded-LayerNorm epilogue exists in the interleaved form only");
+template <int ACT, bool F16 = false>
+__global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, int nsets, int nblk) {
   using HT = std::conditional_t<F16, f16_t, bf16_t>;  // operand element type: MFMA opcode + converter (common.h Half<>)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63;
@@ -103,8 +92,6 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, 
   unsigned char* patch = smem + WR_D * WR_STAGE + wave * WR_PATCH;
   float* bias_s = (float*)(smem + WR_D * WR_STAGE + 8 * WR_PATCH + wave * WR_BIAS);
   if (lane < 32) bias_s[lane] = (g.bias && col0 + lane < g.N) ? g.bias[col0 + lane] : 0.f;
-  if (LNF && lane < 32) bias_s[32 + lane] = col0 + lane < g.N ? g.ln_s[col0 + lane] : 0.f;
-  unsigned char* stat_ring = smem + WR_LDS;  // LNF only
 
   // ---- DMA side: this wave lands rows wave*4 + ii (ii 0..3) of every block ----
   const unsigned lds0 = __builtin_amdgcn_readfirstlane(
@@ -116,23 +103,6 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, 
     const int r = wave * 4 + ii;
     voff[ii] = r * pitch + ((lane ^ (r & 15)) << 4);
   }
-  // LNF: one more DMA per wave and block -- its four rows' statistics partials (4 x 64 bytes = one dword per lane)
-  u32x4_t rsS;
-  rsS.w = 0x00020000u;
-  const int spitch = g.ln_groups * 8;  // bytes of partials per row (64 for the 512-wide residual stream)
-  auto stat_piece = [&](int j) {
-    const long row0 = (long)(b0 + j) * WR_BLK;
-    const unsigned long long ps = (unsigned long long)g.ln_stats + (unsigned long long)row0 * spitch;
-    rsS.x = (unsigned)ps; rsS.y = (unsigned)(ps >> 32) & 0xffffu;
-    rsS.z = (unsigned)(min((long)WR_BLK, (long)g.M - row0) * spitch);
-    const unsigned dst = lds0 + WR_LDS + (j % WR_SD) * WR_SSLOT + wave * 256;
-    const int vo = wave * 256 + lane * 4;
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dword %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "s"(dst), "v"(vo), "s"(rsS)
-                 : "memory");
-  };
   u32x4_t rsA;
   rsA.w = 0x00020000u;
   auto issue = [&](int j) {  // block j of this work-group -> ring slot j % WR_D
@@ -152,7 +122,6 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, 
         : "=&s"(keep)
         : "s"(dst), "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "s"(rsA)
         : "memory", "scc");
-    if (LNF) stat_piece(j);
   };
 
   // ---- MFMA side ----
@@ -163,32 +132,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, 
   for (int tl = 0; tl < 8; ++tl) va[tl] = l31 * WR_ROWB + ((((2 * tl + half) ^ (l31 & 15)) & 15) << 4);
   f32x16_t acc0, acc1;
 
-  auto mfma_block = [&](int slot) {
-    const unsigned char* sA = smem + slot * WR_STAGE;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-#pragma unroll
-    for (int t = 0; t < 32; t += 2) {
-      const u32x4_t a0 = DBG_NOLDS ? wreg[(t + 5) & 31] : *(const u32x4_t*)(sA + va[t & 7] + (t >> 3) * 256);
-      const u32x4_t a1 = DBG_NOLDS ? wreg[(t + 6) & 31] : *(const u32x4_t*)(sA + va[(t + 1) & 7] + ((t + 1) >> 3) * 256);
-      acc0 = Half<HT>::mfma(wreg[t], a0, acc0);
-      acc1 = Half<HT>::mfma(wreg[t + 1], a1, acc1);
-    }
-    if (DBG_NOLDS) return;
-    // pin the stream: fragment reads run WR_AHEAD MFMAs ahead of their use (one wave must be able to
-    // keep the matrix pipe fed alone while its SIMD partner is in an epilogue)
-#pragma unroll
-    for (int k = 0; k < WR_AHEAD; ++k) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-#pragma unroll
-    for (int k = 0; k < 32 - WR_AHEAD; ++k) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-    }
-#pragma unroll
-    for (int k = 0; k < WR_AHEAD; ++k) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-  };
-
-  // ---- interleaved form (ILV): the memory work of a block is spread through its MFMA stream ----
+  // ---- the memory work of a block is spread through its MFMA stream ----
   // A VMEM instruction blocks its wave until the CU's vector-memory path accepts it, and that path is
   // the busy resource here (HBM-bound output stream).  Issued in a burst, six VMEM per wave per block
   // keep the wave out of the matrix pipe for about a whole block period; issued one at a time between
@@ -220,66 +164,15 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, 
   const unsigned coff0 = ccol < g.N ? (unsigned)(rrow * cpitch + ccol * 2) : 0x7ffffff0u;
   const unsigned coff1 = ccol < g.N ? (unsigned)((16 + rrow) * cpitch + ccol * 2) : 0x7ffffff0u;
 
-  auto epilogue = [&](int j) {  // block j: acc0 + acc1 -> bias, activation, bf16, 64-byte row segments
-    const long row0 = (long)(b0 + j) * WR_BLK;
-    const unsigned long long pc = (unsigned long long)g.out_act + (unsigned long long)row0 * cpitch;
-    rsC.x = (unsigned)pc; rsC.y = (unsigned)(pc >> 32) & 0xffffu;
-    rsC.z = (unsigned)(min((long)WR_BLK, (long)g.M - row0) * cpitch);
-#pragma unroll
-    for (int qd = 0; qd < 4; ++qd) {
-      const float4 b4 = *(const float4*)(bias_s + 8 * qd + 4 * half);
-      float4 v = make_float4(acc0[4 * qd] + acc1[4 * qd] + b4.x, acc0[4 * qd + 1] + acc1[4 * qd + 1] + b4.y,
-                             acc0[4 * qd + 2] + acc1[4 * qd + 2] + b4.z, acc0[4 * qd + 3] + acc1[4 * qd + 3] + b4.w);
-      v.x = wr_act<ACT>(v.x); v.y = wr_act<ACT>(v.y); v.z = wr_act<ACT>(v.z); v.w = wr_act<ACT>(v.w);
-      const int slot = (2 * qd + half) ^ ((l31 >> 1) & 7);  // 8-byte slots of the 64-byte patch row
-      *(uint2*)(patch + l31 * 64 + slot * 8) = make_uint2(Half<HT>::pack2(v.x, v.y), Half<HT>::pack2(v.z, v.w));
-    }
-    u32x4_t d[2];
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-      const int r = pass * 16 + rrow;
-      const int x = (r >> 1) & 7;
-      const u32x4_t t4 = *(const u32x4_t*)(patch + r * 64 + ((rs ^ (x >> 1)) << 4));
-      const u32x4_t sw = {t4.z, t4.w, t4.x, t4.y};
-      d[pass] = (x & 1) ? sw : t4;
-    }
-    if (!(dbg & 1))
-    asm volatile("buffer_store_dwordx4 %0, %2, %4, 0 offen\n\tbuffer_store_dwordx4 %1, %3, %4, 0 offen"
-                 :
-                 : "v"(d[0]), "v"(d[1]), "v"(coff0), "v"(coff1), "s"(rsC)
-                 : "memory");
-  };
-
   auto store_rebase = [&](int j) {
     const long row0 = (long)(b0 + j) * WR_BLK;
     const unsigned long long pc = (unsigned long long)g.out_act + (unsigned long long)row0 * cpitch;
     rsC.x = (unsigned)pc; rsC.y = (unsigned)(pc >> 32) & 0xffffu;
     rsC.z = (unsigned)(min((long)WR_BLK, (long)g.M - row0) * cpitch);
   };
-  // LNF: this lane's row of the block whose epilogue is running: rstd and -mean*rstd
-  float ln_r = 1.f, ln_nm = 0.f;
-  auto ln_row = [&](int j) {
-    const float4* sp = (const float4*)(stat_ring + (j % WR_SD) * WR_SSLOT + l31 * 64);
-    const float4 p0 = sp[0], p1 = sp[1], p2 = sp[2], p3 = sp[3];  // (s,q) x 8 column groups, summed in group order
-    const float sm = ((p0.x + p0.z) + (p1.x + p1.z)) + ((p2.x + p2.z) + (p3.x + p3.z));
-    const float sq = ((p0.y + p0.w) + (p1.y + p1.w)) + ((p2.y + p2.w) + (p3.y + p3.w));
-    const float inv = 1.0f / (float)WR_K;
-    const float mean = sm * inv;
-    const float var = fmaxf(sq * inv - mean * mean, 0.f);
-    ln_r = __builtin_amdgcn_rsqf(var + g.ln_eps);
-    ln_r = ln_r * (1.5f - 0.5f * (var + g.ln_eps) * ln_r * ln_r);  // one Newton step: v_rsq_f32 is ~1 ulp, LN wants better
-    ln_nm = -mean * ln_r;
-  };
   auto epi_quad = [&](int qd) {  // accP quad qd -> bias, activation, bf16 -> patch
     const float4 b4 = *(const float4*)(bias_s + 8 * qd + 4 * half);
-    float4 v;
-    if (LNF) {
-      const float4 s4 = *(const float4*)(bias_s + 32 + 8 * qd + 4 * half);
-      v = make_float4(fmaf(ln_r, accP[4 * qd], fmaf(ln_nm, s4.x, b4.x)), fmaf(ln_r, accP[4 * qd + 1], fmaf(ln_nm, s4.y, b4.y)),
-                      fmaf(ln_r, accP[4 * qd + 2], fmaf(ln_nm, s4.z, b4.z)), fmaf(ln_r, accP[4 * qd + 3], fmaf(ln_nm, s4.w, b4.w)));
-    } else {
-      v = make_float4(accP[4 * qd] + b4.x, accP[4 * qd + 1] + b4.y, accP[4 * qd + 2] + b4.z, accP[4 * qd + 3] + b4.w);
-    }
+    float4 v = make_float4(accP[4 * qd] + b4.x, accP[4 * qd + 1] + b4.y, accP[4 * qd + 2] + b4.z, accP[4 * qd + 3] + b4.w);
     v.x = wr_act<ACT>(v.x); v.y = wr_act<ACT>(v.y); v.z = wr_act<ACT>(v.z); v.w = wr_act<ACT>(v.w);
     const int slot = (2 * qd + half) ^ ((l31 >> 1) & 7);
     *(uint2*)(patch + l31 * 64 + slot * 8) = make_uint2(Half<HT>::pack2(v.x, v.y), Half<HT>::pack2(v.z, v.w));
@@ -322,7 +215,6 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, 
       // descriptor arithmetic (a few dozen SALU) rides in the slots too: nothing but the wait and the barrier
       // stands between two blocks' MFMA streams
       if (sgm == 0 && refill) { dma_rebase(jd); dma_piece(0); }
-      if (LNF && sgm == 0 && prev) ln_row(js);
       if (sgm == 1 && prev) epi_quad(0);
       if (sgm == 2 && refill) dma_piece(1);
       if (sgm == 2 && prev) epi_quad(1);
@@ -330,7 +222,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, 
       if (sgm == 4 && refill) dma_piece(2);
       if (sgm == 4 && prev) { epi_quad(3); store_rebase(js); }
       if (sgm == 5 && prev) epi_store(0);
-      if (sgm == 6 && refill) { dma_piece(3); if (LNF) stat_piece(jd); }
+      if (sgm == 6 && refill) dma_piece(3);
       if (sgm == 7 && prev) epi_store(1);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -338,24 +230,13 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, 
 
   const int pro = nb < WR_D - 1 ? nb : WR_D - 1;
   for (int j = 0; j < pro; ++j) issue(j);
-  // waves w and w+4 share a SIMD: the second runs half a block behind  (dbg 32 / 64: other pairings, A/B only)
-  const bool late = (dbg & 32) ? (wave & 1) : (dbg & 64) ? ((wave >> 1) & 1) : ((wave >> 2) & 1);
-
-  if (ILV) {
+  {
     using T_ = std::true_type;
     using F_ = std::false_type;
     auto step = [&](int i, auto steady_c) {
       // block i landed?  VMEM issued after its last DMA piece: S1 of that block period, then two full periods
       // of 4 DMA + 2 stores (stores start with the second block) -- all in order on vmcnt.
       constexpr bool STEADY = decltype(steady_c)::value;
-      // LNF: one more DMA per block (the statistics piece, issued right after the block's last row piece):
-      // 5 per prologue block, 7 per steady period -> 10 / 15 instead of 8 / 13
-      if (LNF) {
-        if (STEADY) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
-        else if (i + 2 >= nb) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (i < 4) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
-      } else
       if (STEADY) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
       else if (i + 2 >= nb) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else if (i < 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -372,66 +253,36 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, 
     for (; i + WR_D - 1 < nb; ++i) step(i, T_());
     for (; i < nb; ++i) step(i, F_());
     store_rebase(nb - 1);
-    if (LNF) ln_row(nb - 1);
     epi_quad(0); epi_quad(1); epi_quad(2); epi_quad(3);
     epi_store(0); epi_store(1);
-    return;
   }
-  for (int i = 0; i < nb; ++i) {
-    // block i must have landed.  VMEM issued after its DMA: the DMA of blocks i+1, i+2 and (from
-    // the fourth block on) three epilogues of stores -- all in order on vmcnt.
-    if (i + 2 >= nb) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (i < 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
-    static_assert(2 * WR_DMAS == 8 && 2 * WR_DMAS + 3 * WR_STORES == 14, "wait counts above");
-    if (!(dbg & 256)) __builtin_amdgcn_s_barrier();  // publishes block i; every wave has left block i-1's slot
-    asm volatile("" ::: "memory");
-    // A VMEM instruction blocks its wave until the CU's single vector-memory path takes it (~50 clocks
-    // per KiB), so each wave keeps its memory phase (ring refill, epilogue, stores) away from its MFMA
-    // phase and opposite to its SIMD partner's: one wave of every SIMD always owns the matrix pipe.
-    const bool refill = i + WR_D - 1 < nb && !(dbg & 4);
-    if (!late) {
-      if (dbg & 128) __builtin_amdgcn_s_setprio(3);
-      if (!(dbg & 2)) mfma_block(i & (WR_D - 1));
-      if (dbg & 128) __builtin_amdgcn_s_setprio(0);
-      if (refill) issue(i + WR_D - 1);
-      if (!(dbg & 8)) epilogue(i);
-    } else {
-      if (refill) issue(i + WR_D - 1);
-      if (i > 0 && !(dbg & 8)) epilogue(i - 1);
-      if (dbg & 128) __builtin_amdgcn_s_setprio(3);
-      if (!(dbg & 2)) mfma_block(i & (WR_D - 1));
-      if (dbg & 128) __builtin_amdgcn_s_setprio(0);
-    }
-  }
-  if (late && !(dbg & 8)) epilogue(nb - 1);
 }
 
 }  // namespace
 
-int g_use_wreg = 2;  // 1: memory phase after/before the MFMA phase, 2: memory work interleaved into the MFMA stream
+int g_use_wreg = 1;        // 0: every K = 512 layer goes to the tiled kernels (tests pin kernel families with it)
 int g_wreg_min_m = 2048;  // below this the 128x128 kernel wins (few blocks per work-group); tests lower it to pin the kernel family
-int g_wreg_dbg = 0;  // timing ablations only (results invalid): 1 no stores, 2 no MFMA, 4 no DMA refill, 8 no epilogue, 16 MFMA operands from registers only
 
 bool gemm_wreg_eligible(const GemmArgs& g) {
-  if (g.f16 && (g_use_wreg != 2 || g.ln_stats || (g_wreg_dbg & 16))) return false;  // fp16 operands: interleaved form only
-  if (g.ln_stats && (g_use_wreg != 2 || !g.ln_s || g.ln_groups != 8 || (g_wreg_dbg & 16))) return false;
   return g_use_wreg && g.K == WR_K && g.M >= g_wreg_min_m && g.N % 8 == 0 && g.ldc % 8 == 0 && g.lda % 8 == 0 && g.ldw % 8 == 0 &&
          g.out_act && !g.out_f32 && !g.resid && (g.act == ACT_NONE || g.act == ACT_QUICK_GELU) &&
          (long)g.ldc * 2 * WR_BLK < (1L << 30) && (long)g.lda * 2 * WR_BLK < (1L << 30);
 }
 
 int launch_gemm_wreg(const GemmArgs& g, hipStream_t st) {
-  static int n_cu = 0;
-  if (!n_cu) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    CZC_HIP_CHECK(hipGetDevice(&dev));
-    CZC_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-    n_cu = prop.multiProcessorCount & ~7;
-    CZC_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_wreg_kernel<ACT_NONE, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, WR_LDS));
-    CZC_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_wreg_kernel<ACT_QUICK_GELU, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, WR_LDS));
-  }
+  // one-time set-up behind a function-local static: engines on two host threads launch concurrently (EngineGroup)
+  static const LaunchInit init = launch_init([](LaunchInit& li) -> int {
+    li.n_cu &= ~7;
+#define CZC_ATTR(K_) CZC_HIP_CHECK(hipFuncSetAttribute((const void*)K_, hipFuncAttributeMaxDynamicSharedMemorySize, WR_LDS))
+    CZC_ATTR((gemm_wreg_kernel<ACT_NONE, false>));
+    CZC_ATTR((gemm_wreg_kernel<ACT_QUICK_GELU, false>));
+    CZC_ATTR((gemm_wreg_kernel<ACT_NONE, true>));
+    CZC_ATTR((gemm_wreg_kernel<ACT_QUICK_GELU, true>));
+#undef CZC_ATTR
+    return 0;
+  });
+  if (init.rc) return launch_init_failed("gemm_wreg");
+  const int n_cu = init.n_cu;
   const int ncg = cdiv(g.N, 256);
   const int nblk = cdiv(g.M, WR_BLK);
   int nsets = n_cu / ncg;
@@ -441,44 +292,9 @@ int launch_gemm_wreg(const GemmArgs& g, hipStream_t st) {
   }
   if (nsets > nblk) nsets = nblk;
   dim3 grid(n_cu), block(512);
-#define CZC_WR_GO(A_, N_, I_)                                                                                      \
-  do {                                                                                                             \
-    CZC_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_wreg_kernel<A_, N_, I_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                      WR_LDS));                                                                    \
-    hipLaunchKernelGGL((gemm_wreg_kernel<A_, N_, I_>), grid, block, WR_LDS, st, g, ncg, nsets, nblk, g_wreg_dbg);     \
-  } while (0)
-  const bool ilv = g_use_wreg == 2;
-  if (g.ln_stats) {
-    dim3 gridl(n_cu);
-#define CZC_WR_GOL(A_)                                                                                                 \
-  do {                                                                                                                 \
-    CZC_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_wreg_kernel<A_, false, true, true>,                            \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, WR_LDS_LNF));                       \
-    hipLaunchKernelGGL((gemm_wreg_kernel<A_, false, true, true>), gridl, block, WR_LDS_LNF, st, g, ncg, nsets, nblk,  \
-                       g_wreg_dbg);                                                                                    \
-  } while (0)
-    if (g.act == ACT_QUICK_GELU) CZC_WR_GOL(ACT_QUICK_GELU); else CZC_WR_GOL(ACT_NONE);
-#undef CZC_WR_GOL
-    CZC_HIP_CHECK(hipGetLastError());
-    return 0;
-  }
-  if (g.f16) {
-    dim3 gridh(n_cu);
-#define CZC_WR_GOH(A_)                                                                                                     \
-  do {                                                                                                                     \
-    CZC_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_wreg_kernel<A_, false, true, false, true>,                         \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, WR_LDS));                               \
-    hipLaunchKernelGGL((gemm_wreg_kernel<A_, false, true, false, true>), gridh, block, WR_LDS, st, g, ncg, nsets, nblk,   \
-                       g_wreg_dbg);                                                                                        \
-  } while (0)
-    if (g.act == ACT_QUICK_GELU) CZC_WR_GOH(ACT_QUICK_GELU); else CZC_WR_GOH(ACT_NONE);
-#undef CZC_WR_GOH
-    CZC_HIP_CHECK(hipGetLastError());
-    return 0;
-  }
-  if (g_wreg_dbg & 16) CZC_WR_GO(ACT_NONE, true, false);
-  else if (g.act == ACT_QUICK_GELU) { if (ilv) CZC_WR_GO(ACT_QUICK_GELU, false, true); else CZC_WR_GO(ACT_QUICK_GELU, false, false); }
-  else { if (ilv) CZC_WR_GO(ACT_NONE, false, true); else CZC_WR_GO(ACT_NONE, false, false); }
+#define CZC_WR_GO(A_, H_) hipLaunchKernelGGL((gemm_wreg_kernel<A_, H_>), grid, block, WR_LDS, st, g, ncg, nsets, nblk)
+  if (g.f16) { if (g.act == ACT_QUICK_GELU) CZC_WR_GO(ACT_QUICK_GELU, true); else CZC_WR_GO(ACT_NONE, true); }
+  else { if (g.act == ACT_QUICK_GELU) CZC_WR_GO(ACT_QUICK_GELU, false); else CZC_WR_GO(ACT_NONE, false); }
 #undef CZC_WR_GO
   CZC_HIP_CHECK(hipGetLastError());
   return 0;

@@ -18,27 +18,16 @@ struct GemmArgs {
   int M, N, K;
   int act;
   int f16 = 0;  // 2-byte operands are IEEE fp16 instead of bf16 (set by launch_gemm from the precision)
-  // LayerNorm folded into the GEMMs around it (bf16 CLIP-text tower).
-  // Producer side (fp32-output 256x256 kernel): per-row partial sums of the fp32 result over each 64-column
-  // group, row_stats[m][N/64][2] = (sum, sum of squares); together with out_act (bf16 copy of the result)
-  // this is everything the next layer's LayerNorm needs, so the LayerNorm kernel and its HBM pass disappear.
-  float* row_stats = nullptr;
-  // Consumer side (weight-stationary K = 512 kernel): A holds the bf16 copy of the RAW residual stream, W the
-  // weights pre-multiplied by the LayerNorm gain, ln_s[n] = sum_k W'[n,k], bias the folded bias; the epilogue
-  // turns acc = x.W'^T into LN(x).W^T + b = rstd*(acc - mean*ln_s[n]) + bias'[n] with mean/rstd from ln_stats.
-  const float* ln_stats = nullptr;  // [M][ln_groups][2]
-  const float* ln_s = nullptr;      // [N]
-  int ln_groups = 0;
-  float ln_eps = 0.f;
   // Full-row kernel (gemm_rowln, N = 512): out_f32 <- resid + A.W^T + bias and out_act <- LayerNorm(out_f32; ln_gamma,
   // ln_beta, ln_eps) from one launch.
   const float* ln_gamma = nullptr;
   const float* ln_beta = nullptr;
+  float ln_eps = 0.f;
 };
 int launch_gemm(int prec, const GemmArgs& g, hipStream_t st);
 bool gemm256_eligible(const GemmArgs& g);
-int launch_gemm256(const GemmArgs& g, hipStream_t st);  // gemm256.hip: 256x256 LDS-DMA bf16 kernel
-extern int g_use_gemm256;
+int launch_gemm256(const GemmArgs& g, hipStream_t st);  // gemm256.hip: 256x256 LDS-DMA ring kernels (bf16 / fp16 operands)
+extern int g_use_gemm256;  // 0 off, 1 default (ping-pong kernel for fp32 outputs, loader-wave kernel otherwise), 3 / 5 pin one of them
 bool gemm256s_eligible(const GemmArgs& g);  // split-fp16 operands, same 256x256 persistent structure
 int launch_gemm256s(const GemmArgs& g, hipStream_t st);
 extern int g_use_gemm256s;
@@ -46,13 +35,11 @@ extern int g_w_dbg;
 bool gemm_rowln_eligible(const GemmArgs& g);  // gemm256.hip: 128 x 512 full-row kernel, LayerNorm in the epilogue
 int launch_gemm_rowln(const GemmArgs& g, hipStream_t st);
 extern int g_rowln_min_m;
-extern int g_gemm_krot;
 extern int g_use_skinny;
 extern int g_use_splitk;
 bool gemm_wreg_eligible(const GemmArgs& g);
 int launch_gemm_wreg(const GemmArgs& g, hipStream_t st);  // gemm_wreg.hip: weights in registers, K = 512
 extern int g_use_wreg;
-extern int g_wreg_dbg;
 extern int g_wreg_min_m, g_gemm256_min_m;  // row-count thresholds of the two big-batch GEMM families
 
 // ---- imageproc.hip ------------------------------------------------------------------------
@@ -79,9 +66,6 @@ int launch_im2col(int prec, const float* pixels, int B, int S, int p, void* out,
 int launch_vision_assemble(const float* patch_out, int B, int P, int H, const float* cls, const float* pos, float* x,
                            hipStream_t st);
 int launch_convert(int prec, const float* src, void* dst, long n, hipStream_t st);  // fp32 -> act type
-// bf16 weights with the preceding LayerNorm's gain folded in, their row sums and the folded bias (GemmArgs::ln_*)
-int launch_fold_ln(const float* W, const float* bias, const float* gamma, const float* beta, int N, int K, void* Wf, float* s,
-                   float* bf, hipStream_t st);
 int launch_act_to_f32(int prec, const void* src, float* dst, long n, hipStream_t st);  // act type -> fp32
 // gather rows: dst[m] = src[idx[m]]  (fp32 rows of width H)
 int launch_gather_rows_f32(const float* src, const int* idx, int M, int H, float* dst, hipStream_t st);
@@ -177,7 +161,22 @@ struct CombineArgs {
   int* best; float* best_cos;                                // [B]
   int* inp; int T; int gen_idx;                              // write-back target (may be null)
   int* nonfinite = nullptr;                                  // set to 1 when a cosine is not finite (may be null)
+  // screen-then-refine: candidates with refine_kind != 0 take their cosine from refine_cos (see combine.hip)
+  const int* refine_kind = nullptr;                          // [B,K]
+  const float* refine_cos = nullptr;                         // [B,K]
 };
+// text_feat == null: clip_ref already holds the cosines
 int launch_combine(const CombineArgs& a, hipStream_t st);
+// screen-then-refine engine (combine.hip): choose the candidates to re-encode / cosines of the re-encoded rows
+int launch_refine_select(const float* clip_score, const float* final_score, int B, int K, float theta, int m_samples, int* kind,
+                         int* list, int* count, hipStream_t st);
+int launch_refine_cosine(const float* text_feat, const float* img_n, const int* rlist, const int* n_rows_dev, int n_rows_max, int K, int D,
+                         float* cos_out, int* nonfinite, hipStream_t st);
+// segment plan of the refine pass (bridge.hip): B trunks (prefix lengths of the screening plan) + the chosen candidates
+// of every image as branches, compacted in image order; segments past B + R get length 0
+int launch_refine_plan(const int* clip_len, const int* trunk_len, const int* list, const int* count, const int* count_off, int B, int K,
+                       int* own_len, int* pre_len, int* seg_src, int* seg_pos0, int* rlist, int* max_len_out, hipStream_t st);
+int launch_refine_finish(const int* own_off, const int* own_len, const int* count_off, int B, int K, int* pre_off, int* eos_idx,
+                         const int* rlist, hipStream_t st);
 
 }  // namespace czc

@@ -243,35 +243,6 @@ __global__ void convert_kernel(const float* src, T* dst, long n) {
     Act<T>::st(dst, i, src[i]);
 }
 
-// LayerNorm folded into the linear layer that follows it (HF:clip/modeling_clip.py:368-383: LN -> q/k/v, LN -> fc1):
-//   LN(x) . W^T + b = rstd * (x . W'^T - mean * s) + b'   with  W'[n,k] = W[n,k] * gamma[k]  (stored bf16),
-//   s[n] = sum_k W'[n,k] over the STORED (bf16-rounded) values, so that the mean term cancels exactly what the
-//   MFMA accumulated, and b'[n] = b[n] + sum_k beta[k] * W[n,k] in fp32.  One wave per output row n.
-__global__ __launch_bounds__(256) void fold_ln_kernel(const float* W, const float* bias, const float* gamma, const float* beta,
-                                                      int N, int K, bf16_t* Wf, float* s, float* bf) {
-  const int lane = threadIdx.x & 63;
-  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (n >= N) return;
-  float ss = 0.f, sb = 0.f;
-  for (int k = lane; k < K; k += 64) {
-    const float w = W[(long)n * K + k];
-    const bf16_t q = f2bf(w * gamma[k]);
-    Wf[(long)n * K + k] = q;
-    ss += bf2f(q);
-    sb += beta[k] * w;
-  }
-  ss = wave_sum(ss);
-  sb = wave_sum(sb);
-  if (lane == 0) { s[n] = ss; bf[n] = (bias ? bias[n] : 0.f) + sb; }
-}
-
-int launch_fold_ln(const float* W, const float* bias, const float* gamma, const float* beta, int N, int K, void* Wf, float* s,
-                   float* bf, hipStream_t st) {
-  hipLaunchKernelGGL(fold_ln_kernel, dim3(cdiv(N, 4)), dim3(256), 0, st, W, bias, gamma, beta, N, K, (bf16_t*)Wf, s, bf);
-  CZC_HIP_CHECK(hipGetLastError());
-  return 0;
-}
-
 int launch_convert(int prec, const float* src, void* dst, long n, hipStream_t st) {
   if (n <= 0) return 0;
   dim3 grid((unsigned)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384)), block(256);

@@ -46,14 +46,18 @@ def broadcast_state(state: Optional[Dict[str, np.ndarray]], device, src: int = 0
     bdev = device if dist.get_backend() == "nccl" else torch.device("cpu")
     flat = torch.empty(total, dtype=torch.float32, device=bdev)
     if rank == src:
-        host = torch.empty(total, dtype=torch.float32)
+        # every tensor goes straight into its slice of the bucket (one H2D copy per tensor when the bucket is on the
+        # GPU, no second host-side image of the 0.5 GB tower); tensors already on the device are copied D2D
         o = 0
         for k, s, alias in items:
             if alias is None:
                 n = int(np.prod(s)) if len(s) else 1
-                host[o:o + n] = torch.from_numpy(np.ascontiguousarray(state[k], dtype=np.float32).reshape(-1))
+                v = state[k]
+                if hasattr(v, "detach"):
+                    flat[o:o + n].copy_(v.detach().reshape(-1).to(torch.float32), non_blocking=True)
+                else:
+                    flat[o:o + n].copy_(torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32).reshape(-1)))
                 o += n
-        flat.copy_(host)
     dist.broadcast(flat, src=src)
     if flat.device != torch.device(device):
         flat = flat.to(device)

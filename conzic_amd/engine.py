@@ -321,11 +321,6 @@ class Engine:
         self._ck(self.lib.czc_stats(self.h, C.byref(a), C.byref(b), C.byref(c_), C.byref(d)), "czc_stats")
         return dict(clip_rows=a.value, clip_seqs=b.value, bert_rows=c_.value, steps=d.value)
 
-    def graph_stats(self):
-        a, b, c_ = C.c_int64(), C.c_int64(), C.c_int64()
-        self._ck(self.lib.czc_graph_stats(self.h, C.byref(a), C.byref(b), C.byref(c_)), "czc_graph_stats")
-        return dict(launches=a.value, captures=b.value, cached=c_.value)
-
     def sync(self):
         self._ck(self.lib.czc_sync(self.h), "czc_sync")
 

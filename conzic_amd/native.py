@@ -18,6 +18,7 @@ PREC_F32 = 1
 PREC_ALL_BF16 = 2
 PREC_SPLIT = 3
 PREC_FP16 = 4
+PREC_REFINE = 5
 CLIP_MAX_LEN = 77
 
 
@@ -94,11 +95,8 @@ SIGNATURES = {
     "czc_profile_intervals": (_I, [_P, _P, C.c_char_p, _P, _P, _I, C.POINTER(C.c_int)]),
     "czc_replicate": (_I, [_P, C.POINTER(C.c_void_p)]),
     "czc_sync": (_I, [_P]),
-    "czc_graph_stats": (_I, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
-    "czc_option_epoch": (_I, []),
     "czc_stats": (_I, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "czc_test_gemm": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _I, _P]),
-    "czc_test_lnf_pair": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, C.c_float, _P, _P, _I, _P, _P]),
     "czc_test_gemm_rowln": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, C.c_float, _P, _P]),
     "czc_bench_gemm": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(C.c_double)]),
     "czc_test_set_option": (_I, [C.c_char_p, _I]),

@@ -55,6 +55,12 @@ extern "C" {
 
 #define CZC_BRIDGE_MAX_BYTES 512 /* decoded caption text per candidate row */
 #define CZC_CLIP_MAX_LEN 77       /* clip/clip.py:71-72 (max_length = 77, truncation) */
+#define CZC_PREC_REFINE 5 /* screen-then-refine, for checkpoints with a large logit scale (published CLIP: x100): all K candidates  */
+                         /* through the single-pass fp16 text tower (CZC_PREC_FP16 speed), then the candidates that carry the     */
+                         /* softmax_K mass (p_k > 4 / (beta * exp(logit_scale)), the two best fused scores, and a mass-stratified  */
+                         /* sample of the rest that measures the screening tower's mean error) are re-encoded by the split-fp16   */
+                         /* tower and the scores are formed from the mixed cosines: fused score inside 1e-3 (measured <= 5e-4 on   */
+                         /* the goldens) at about twice the CZC_PREC_SPLIT throughput.  Vision tower and BERT: split-fp16.          */
 #define CZC_MAX_TOPK 1024
 #define CZC_MAX_BERT_LEN 64
 
@@ -210,16 +216,9 @@ int czc_generate(czc_engine* e, int B, int T, int L, int seed_len, const int32_t
  *                         times
  *   "pack_branches"   (1) attention of the branch rows with G candidates packed per 32-query MFMA tile
  *   "pool_last_layer" (1) last CLIP-text layer: out-projection + MLP on the EOS rows only
- *   "graphs"          (0) hipGraph replay of the two halves of a position-step (before / after the one size read):
- *                         0 off, 1 on, -1 = czc_generate with B <= 4 only.  Correct (replay == eager, tested) but
- *                         measured no faster at B = 1: the step is bound by its ~250 dependent small kernels, not
- *                         by the host launches, which already run ahead of the GPU
  *   "fuse_ln"         (1) bf16 / fp16 CLIP-text tower at >= 4096 packed rows: the out-projection runs as a full-row
  *                         kernel that also emits LN2 of its result (no LayerNorm pass for it); 2 = fc2 -> the next
- *                         layer's LN1 as well (measured slower), 0 = off
- *   "fold_ln"         (0) bf16 CLIP-text tower at >= 2048 packed rows: LayerNorm applied inside the GEMM epilogues
- *                         (out-proj / fc2 emit a bf16 copy of the residual stream + row statistics; q/k/v / fc1 run
- *                         on gain-folded weights and finish the normalisation), no LayerNorm pass over HBM */
+ *                         layer's LN1 as well (measured slower), 0 = off */
 int czc_set_option(czc_engine* e, const char* name, int value);
 
 /* ---- measurement ------------------------------------------------------------------------- */
@@ -235,8 +234,6 @@ int czc_profile_get(czc_engine* e, const char* kind, double* total_ms, int64_t* 
 int czc_profile_intervals(czc_engine* e, czc_engine* ref, const char* kind, double* start_ms, double* end_ms, int cap,
                           int* n);
 int czc_sync(czc_engine* e);
-/* step-graph counters: graph launches, captures so far, graphs currently cached */
-int czc_graph_stats(czc_engine* e, int64_t* launches, int64_t* captures, int64_t* cached);
 /* counters of the last generate/step: rows pushed through the CLIP text tower etc. */
 int czc_stats(czc_engine* e, int64_t* clip_rows, int64_t* clip_seqs, int64_t* bert_rows, int64_t* steps);
 
@@ -246,25 +243,18 @@ int czc_stats(czc_engine* e, int64_t* clip_rows, int64_t* clip_seqs, int64_t* be
  * `precision`, resid must be NULL) instead of the fp32 one -- the path the tower-internal layers use. */
 int czc_test_gemm(int precision, int M, int N, int K, const float* A, const float* W, const float* bias,
                   const float* resid, int act, float* C);
-/* The folded-LayerNorm GEMM pair of the bf16 CLIP-text tower (hidden 512) on host data:
- *   x_out[M,512] = resid + A[M,K1] * Wo[512,K1]^T + bo;  h[M,N] = act(LN(x_out; gamma, beta, eps) * W1[N,512]^T + b1)
- * through the producer kernel (fp32 result + bf16 copy + per-row statistics) and the weight-stationary consumer
- * kernel that finishes the LayerNorm in its epilogue.  M >= 2048, K1 % 64 == 0, N % 8 == 0. */
-int czc_test_lnf_pair(int M, int K1, int N, const float* A, const float* Wo, const float* bo, const float* resid,
-                      const float* gamma, const float* beta, float eps, const float* W1, const float* b1, int act,
-                      float* x_out, float* h_out);
 /* Full-row GEMM with the following LayerNorm in its epilogue (bf16 / fp16 operands, 512 columns, K % 32 == 0):
  *   x_out[M,512] = resid + A[M,K] * W[512,K]^T + bias;  y_out = LayerNorm(x_out; gamma, beta, eps) in the operand type */
 int czc_test_gemm_rowln(int precision, int M, int K, const float* A, const float* W, const float* bias, const float* resid,
                         const float* gamma, const float* beta, float eps, float* x_out, float* y_out);
 /* GEMM microbenchmark on device-resident data: ms per launch (tools/bench_gemm.py); use256: 0 128x128 kernel,
- * 1-3 the 256x256 LDS-DMA kernels (plain / persistent / persistent + K ring), 5-6 the weight-stationary kernel
- * (memory phase separate / interleaved into the MFMA stream) where eligible. */
+ * 1 the default choice among the 256x256 LDS-DMA ring kernels, 3 the loader-wave ring kernel, 7 the ping-pong ring
+ * kernel, 6 the weight-stationary kernel where eligible. */
 int czc_bench_gemm(int precision, int M, int N, int K, int act, int out_mode, int iters, int use256, double* ms_out);
-/* Process-wide kernel A/B switches for tests and tools: "gemm256" 0..3, "wreg" 0|1|2, "skinny", "splitk",
- * "mfma_attention", "attention_image" 0|1|2 (2 = force); "*_dbg" are timing ablations (results invalid). */
+/* Process-wide kernel-family switches for tests and tools: "gemm256" 0|1|3|5, "wreg" 0|1, "gemm256s" 0|1, "skinny",
+ * "splitk", "mfma_attention", "attention_image" 0|1|2 (2 = force), the "*_min_m" row-count thresholds, "w_dbg"
+ * (ping-pong kernel A/B bits), "bench_pad" (row padding of czc_bench_gemm operands). */
 int czc_test_set_option(const char* name, int value);
-int czc_option_epoch(void); /* number of czc_test_set_option calls so far (engines drop cached step graphs when it moves) */
 int czc_test_layernorm(int precision, int M, int H, const float* x, const float* gamma, const float* beta, float eps,
                        float* y);
 /* qkv [sum(len), 3*heads*64] packed sequences; causal 0/1; scale; out [sum(len), heads*64] */

@@ -141,3 +141,33 @@ def test_run_cli_sharded_over_two_ranks_matches_single_process(tmp_path):
     for k in outs[1]:
         assert outs[1][k] == outs[2][k], k
         assert len(outs[1][k]) == 6
+
+
+def test_bench_gpus_2_spawns_two_ranks_on_a_shared_gpu():
+    """`python bench.py --gpus 2` without a launcher starts two ranks itself (a plain --gpus N run
+    must never report n_gpus 1).  On this one-GPU box the ranks share the device under the explicit test flag
+    (gloo rendezvous: RCCL cannot put two ranks on one device); on a node they are rank r <-> GPU r over RCCL."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--images", "64", "--steps", "1",
+                        "--warmup", "0", "--no-cpu-baseline", "--no-alt", "--no-invariance", "--share-gpu"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2
+    assert out["ranks"]["world_size"] == 2 and out["ranks"]["reported_by_backend"] == 2
+    assert out["ranks"]["shared_gpu"] is True and "TEST RUN" in out["config"]["parallelism"]
+    assert out["value"] > 0 and out["config"]["images_per_gpu"] == 64
+
+
+def test_bench_gpus_2_without_the_flag_fails_on_one_gpu():
+    import subprocess
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with fewer than 2 GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "CZC_SHARE_GPU")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode != 0 and "needs 2 visible GPUs" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

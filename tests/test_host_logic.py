@@ -257,3 +257,24 @@ def test_engine_group_partition_and_interval_union():
     a = np.array([[0.0, 1.0], [2.0, 3.0]])
     b = np.array([[0.5, 2.5], [10.0, 11.0]])
     assert union_ms([a, b]) == 4.0 and union_ms([a]) == 2.0 and union_ms([np.zeros((0, 2))]) == 0.0
+
+
+def test_bench_gpus_n_never_falls_back_to_fewer_gpus():
+    """`python bench.py --gpus 2` on a box with fewer than two GPUs (this container has none) must exit non-zero with
+    the reason and print no JSON line -- a --gpus 8 run can never come back as n_gpus 1 (missing #1).
+    A launcher whose rank count disagrees with --gpus is refused as well."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with fewer than 2 GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "CZC_SHARE_GPU")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert r.returncode != 0 and "needs 2 visible GPUs" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    env2 = dict(env, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=300, env=env2, cwd=root)
+    assert r.returncode != 0 and "WORLD_SIZE=4 but --gpus 2" in r.stderr

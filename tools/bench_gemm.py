@@ -8,22 +8,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from conzic_amd import native
 
 lib = native.load()
-if len(sys.argv) > 2:
-    lib.czc_test_set_option(b"gemm_krot", int(sys.argv[2]))
-if len(sys.argv) > 3:
-    lib.czc_test_set_option(b"wreg_dbg", int(sys.argv[3]))
-if os.environ.get('CZC_LNF_DBG'):
-    lib.czc_test_set_option(b'lnf_dbg', int(os.environ['CZC_LNF_DBG']))
 if 'CZC_W_DBG' in os.environ:
     lib.czc_test_set_option(b'w_dbg', int(os.environ['CZC_W_DBG']))
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 768000
 shapes = [("qkv", 1536, 512, 0, 0), ("out", 512, 512, 0, 1), ("fc1", 2048, 512, 1, 0), ("fc2", 512, 2048, 0, 1)]
 PREC = int(os.environ.get('CZC_GEMM_PREC', '0'))  # 0 bf16, 1 f32, 3 split-fp16 (use CZC_GEMM_VARIANTS=0)
-VARIANTS = tuple(int(v) for v in os.environ.get('CZC_GEMM_VARIANTS', '3,5,6').split(','))
-if len(sys.argv) > 4:
-    shapes.append(("fc1n", 2048, 512, 0, 0))  # fc1 shape without the activation (epilogue VALU share)
-if os.environ.get("CZC_GEMM_LNF"):  # LayerNorm-folding forms: producers (+ bf16 copy + row statistics), consumers
-    shapes += [("qkvL", 1536, 512, 0, 3), ("outL", 512, 512, 0, 2), ("fc1L", 2048, 512, 1, 3), ("fc2L", 512, 2048, 0, 2)]
+VARIANTS = tuple(int(v) for v in os.environ.get('CZC_GEMM_VARIANTS', '3,7,6').split(','))  # czc_bench_gemm use256 codes
 tot = {v: 0.0 for v in VARIANTS}
 fl = 0.0
 for name, N, K, act, mode in shapes:
