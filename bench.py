@@ -139,14 +139,15 @@ def main():
     ap.add_argument("--topk", type=int, default=200)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--order", default="sequential", choices=["sequential", "shuffle"])
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32", "split", "fp16"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32", "split", "fp16", "refine"])
     ap.add_argument("--logit-scale", type=float, default=2.6592, help="CLIP logit_scale (HF init 2.6592; published checkpoint ln 100 = 4.6052)")
     ap.add_argument("--gamma", type=float, default=None, help="sentiment control weight (BASELINE configs[4]: 5.0)")
     ap.add_argument("--sentiment", default="positive", choices=["positive", "negative"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event kernel timing (roofline)")
-    ap.add_argument("--no-alt", action="store_true", help="skip the second line (split-fp16 engine at the published logit scale)")
-    ap.add_argument("--alt-steps", type=int, default=1, help="timed steps of the split-fp16 / scale-100 leg")
+    ap.add_argument("--no-alt", action="store_true", help="skip the second leg (the engine the product path selects at the published logit scale)")
+    ap.add_argument("--alt-steps", type=int, default=None, help="timed steps of the scale-100 leg (default: --steps, same warm-up)")
+    ap.add_argument("--alt-split", action="store_true", help="also time the all-split-fp16 engine at the published logit scale (the round-2 product mode)")
     ap.add_argument("--no-invariance", action="store_true", help="skip the batch-invariance check after the timed loop")
     ap.add_argument("--streams", type=int, default=2,
                     help="concurrent image sub-batches per GPU, each on its own HIP stream over the same weights "
@@ -188,9 +189,13 @@ def main():
         dist_world = dist.get_world_size()  # what the collective backend itself counts
         assert dist_world == a.gpus, (dist_world, a.gpus)
 
-    prec = {"bf16": native.PREC_BF16, "f32": native.PREC_F32, "split": native.PREC_SPLIT, "fp16": native.PREC_FP16}[a.precision]
+    prec = {"bf16": native.PREC_BF16, "f32": native.PREC_F32, "split": native.PREC_SPLIT, "fp16": native.PREC_FP16,
+            "refine": native.PREC_REFINE}[a.precision]
     DT = {native.PREC_BF16: "bf16", native.PREC_F32: "f32", native.PREC_FP16: "fp16",
-          native.PREC_SPLIT: "split-fp16 (fp16 hi+lo planes, 3 MFMA passes, fp32 accumulate)"}
+          native.PREC_SPLIT: "split-fp16 (fp16 hi+lo planes, 3 MFMA passes, fp32 accumulate)",
+          native.PREC_REFINE: "fp16 screening pass + split-fp16 refine pass (fp32 accumulate)"}
+    if a.alt_steps is None:
+        a.alt_steps = a.steps
     B, L, K, I = a.images, a.L, a.topk, a.iters
     lo = rank * B  # weak scaling: rank r polishes images [r*B, (r+1)*B)
     u8 = synth.make_images_u8(B, first=lo)
@@ -264,10 +269,11 @@ def main():
             t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
-        kinds = ["gemm_clip_text", "gemm_bert", "gemm_vision", "attention", "rowops", "topk", "bridge", "combine"]
-        prof_timed = {"gemm_clip_text": grp.profile_get("gemm_clip_text")} if profile else {}
+        kinds = ["gemm_clip_text", "gemm_clip_refine", "gemm_bert", "gemm_vision", "attention", "rowops", "topk", "bridge", "combine"]
+        fam = ("gemm_clip_text", "gemm_clip_refine")  # the roofline family (the second only exists in the refine engine)
+        prof_timed = {k: grp.profile_get(k) for k in fam} if profile else {}
         stats = grp.stats()
-        prof, breakdown = prof_timed, {}
+        prof, breakdown, single_ms = prof_timed, {}, None
 
         def single_step():  # the same step on ONE engine and ONE stream (all B images in every launch)
             eng.encode_images(pixels)
@@ -281,16 +287,20 @@ def main():
                 # figures of the timed region are reported beside it
                 eng.profile_reset()
                 eng.profile(2)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
                 single_step()
+                eng.sync()
+                single_ms = (time.perf_counter() - t1) * 1e3
                 eng.profile(False)
-                prof = {"gemm_clip_text": eng.profile_get("gemm_clip_text")}
+                prof = {k: eng.profile_get(k) for k in fam}
             eng.profile_reset()
             eng.profile(1)
             single_step()
             eng.profile(False)
             breakdown = {k: eng.profile_get(k) for k in kinds}
         res = dict(dt=dt, prof=prof, prof_timed=prof_timed, breakdown=breakdown, stats=stats, setup_s=t_setup, invariance=None,
-                   streams=n_streams)
+                   streams=n_streams, single_ms=single_ms)
         if invariance and rank == 0 and B > 2:
             # batch invariance: images 0-1 polished alone (B = 2) by the same engine must come out as they did inside
             # the batch of B (per-image work is independent: gen_utils.py:65-81 has no cross-image term).  The kernel
@@ -324,19 +334,26 @@ def main():
 
     main_res = run_mode(prec, a.logit_scale, a.steps, a.warmup, not a.no_profile, opts=a.opt,
                         invariance=not a.no_invariance)
-    alt_res = None
+    alt_res = split_res = None
     if world == 1 and not a.no_alt and prec == native.PREC_BF16 and a.logit_scale < 4.0:
-        # the engine the product path selects for the published checkpoints (logit_scale = ln 100): split-fp16 MFMA
-        alt_res = run_mode(native.PREC_SPLIT, 4.6052, a.alt_steps, 1, not a.no_profile)
+        # the engine the product path selects for the published checkpoints (logit_scale = ln 100): screen-then-refine,
+        # same steps and warm-up as the headline leg
+        alt_res = run_mode(native.PREC_REFINE, 4.6052, a.alt_steps, a.warmup, not a.no_profile)
+        if a.alt_split:
+            split_res = run_mode(native.PREC_SPLIT, 4.6052, a.alt_steps, a.warmup, not a.no_profile)
 
     def roofline_of(res, prec_):
         prof = res["prof"]
         if not prof or not prof["gemm_clip_text"]["launches"]:
             return None
-        g = prof["gemm_clip_text"]
         passes = 3 if prec_ == native.PREC_SPLIT else 1  # split-fp16: every product is three fp16 MFMA passes
+        g = dict(prof["gemm_clip_text"])
+        g["flops"] *= passes
+        r = prof.get("gemm_clip_refine")
+        if r and r["launches"]:  # refine engine: the family is the screening GEMMs (1 pass) + the refine pass's (3 passes)
+            g = dict(ms=g["ms"] + r["ms"], launches=g["launches"] + r["launches"], flops=g["flops"] + 3 * r["flops"])
         peak = 157.3 if prec_ == native.PREC_F32 else PEAK_BF16_TFLOPS
-        ach = passes * g["flops"] / (g["ms"] * 1e-3) / 1e12
+        ach = g["flops"] / (g["ms"] * 1e-3) / 1e12
         # HBM bytes per launch come from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same
         # command (not measurable inside the run); only quoted for the workload and precision they were taken on
         traffic, src = None, None
@@ -355,17 +372,28 @@ def main():
                 native.PREC_FP16: half % (("fp16",) * (3 if fused else 2)),
                 native.PREC_SPLIT: "CLIP-text linear layers: czc::gemm256sq_kernel (split-fp16 operands, 256x256 LDS-DMA ring, three "
                                    "v_mfma_f32_32x32x16_f16 per product)",
-                native.PREC_F32: "CLIP-text linear layers: czc::gemm_kernel<float> (v_mfma_f32_32x32x2_f32)"}[prec_]
+                native.PREC_F32: "CLIP-text linear layers: czc::gemm_kernel<float> (v_mfma_f32_32x32x2_f32)"}
+        kern[native.PREC_REFINE] = ("screening pass: " + kern[native.PREC_FP16] + "; refine pass (the candidates that carry the "
+                                    "softmax_K mass): " + kern[native.PREC_SPLIT])
+        kern = kern[prec_]
         return dict(bound="mfma", kernel=kern, achieved=round(ach, 1), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
                     traffic=traffic, traffic_source=src, launches=g["launches"], avg_launch_ms=round(g["ms"] / g["launches"], 4),
-                    flops_per_launch=passes * g["flops"] / g["launches"], mfma_passes_per_product=passes,
+                    flops_per_launch=g["flops"] / g["launches"], mfma_passes_per_product=passes,
+                    refine_pass=None if not (r and r["launches"]) else dict(
+                        launches=r["launches"], ms=round(r["ms"], 1), mfma_tflop=round(3 * r["flops"] / 1e12, 2),
+                        share_of_family_time=round(r["ms"] / g["ms"], 3)),
                     **timed_region_of(res, passes, peak))
 
     def timed_region_of(res, passes, peak):
         """What the family's events say inside the timed region when it ran more than one stream."""
         if res["streams"] <= 1:
             return dict(measured_on="the timed region (one engine, one stream)")
-        t = res["prof_timed"]["gemm_clip_text"]
+        t = dict(res["prof_timed"]["gemm_clip_text"])
+        t["flops"] *= passes
+        r = res["prof_timed"].get("gemm_clip_refine")
+        if r and r["launches"]:
+            t = dict(ms=t["ms"] + r["ms"], launches=t["launches"] + r["launches"], flops=t["flops"] + 3 * r["flops"],
+                     busy_ms=t["busy_ms"] + r["busy_ms"])
         return dict(
             measured_on="one extra pass of the same step on ONE stream, run by bench.py right after the timed region: "
                         "HIP events on the engine's stream around every launch of the family",
@@ -373,7 +401,7 @@ def main():
                 streams=res["streams"], launches=t["launches"],
                 avg_launch_ms_contended=round(t["ms"] / max(t["launches"], 1), 4),
                 family_busy_union_ms=round(t["busy_ms"], 1),
-                frac_of_peak_over_union=round(passes * t["flops"] / (t["busy_ms"] * 1e-3) / 1e12 / peak, 4),
+                frac_of_peak_over_union=round(t["flops"] / (t["busy_ms"] * 1e-3) / 1e12 / peak, 4),
                 note="the timed region polishes the images as concurrent sub-batches on separate streams: a launch there "
                      "carries half the rows and its duration includes the time its kernel shared the GPU with the other "
                      "stream's kernels of every class (this is the duration rocprofv3 --stats of the default command "
@@ -416,16 +444,42 @@ def main():
                    kernel_ms_note="one extra untimed single-stream step with an event pair around every kernel class; the timed "
                                   "region only carries events around the roofline family",
                    clip_rows_per_step=st["clip_rows"] // max(1, a.steps), setup_s=round(main_res["setup_s"], 1),
+                   single_stream=None if main_res["single_ms"] is None else dict(
+                       ms_per_step=round(main_res["single_ms"], 2), value=round(B / main_res["single_ms"] * 1e3, 4),
+                       note="the same step on ONE engine / ONE stream, wall-clock around the pass `roofline` is measured on "
+                            "(same instrumentation as the timed region: events around the roofline family only): `roofline` "
+                            "and this step time come from one execution, `value` from the concurrent-sub-batch region"),
                    batch_invariance=main_res["invariance"])
+        if prec == native.PREC_REFINE:
+            out["refine"] = dict(candidate_seqs=st["clip_seqs"], re_encoded=st["refine_seqs"],
+                                 re_encoded_frac=round(st["refine_seqs"] / max(st["clip_seqs"], 1), 4),
+                                 rows=st["clip_rows"], re_encoded_rows=st["refine_rows"])
+
+        def alt_block(res, prec_, what):
+            av = B * a.alt_steps / res["dt"]
+            blk = dict(what=what, value=round(av, 4), unit="captions/s", dtype=DT[prec_], logit_scale=4.6052, steps=a.alt_steps,
+                       warmup=a.warmup, ms_per_step=round(res["dt"] / a.alt_steps * 1e3, 2), roofline=roofline_of(res, prec_),
+                       single_stream_ms_per_step=None if res["single_ms"] is None else round(res["single_ms"], 2),
+                       kernel_ms_one_step={k: round(v["ms"], 1) for k, v in res["breakdown"].items()})
+            rs = res["stats"]
+            if prec_ == native.PREC_REFINE:
+                blk["refine"] = dict(candidate_seqs=rs["clip_seqs"], re_encoded=rs["refine_seqs"],
+                                     re_encoded_frac=round(rs["refine_seqs"] / max(rs["clip_seqs"], 1), 4),
+                                     rows=rs["clip_rows"], re_encoded_rows=rs["refine_rows"])
+            return blk
+
         if alt_res is not None:
-            av = B * a.alt_steps / alt_res["dt"]
-            out["scale100_mode"] = dict(
-                what="same workload through the engine the product path selects for the published checkpoints "
-                     "(logit_scale = ln 100, clip/clip.py:95-98): every tower on split-fp16 MFMA, fp32-class parity "
-                     "(tests/test_step_gpu.py::test_step_parity_full_size_split)",
-                value=round(av, 4), unit="captions/s", dtype=DT[native.PREC_SPLIT], logit_scale=4.6052, steps=a.alt_steps,
-                warmup=1, ms_per_step=round(alt_res["dt"] / a.alt_steps * 1e3, 2), roofline=roofline_of(alt_res, native.PREC_SPLIT),
-                kernel_ms_one_step={k: round(v["ms"], 1) for k, v in alt_res["breakdown"].items()})
+            out["scale100_mode"] = alt_block(
+                alt_res, native.PREC_REFINE,
+                "same workload, same steps and warm-up, through the engine the product path selects for the published "
+                "checkpoints (logit_scale = ln 100, clip/clip.py:95-98; conzic_amd.runtime.choose_precision): screen-then-refine "
+                "-- all K candidates through the single-pass fp16 text tower, the candidates that carry the softmax_K mass "
+                "re-encoded by the split-fp16 tower; fused score within 1e-3 on all K candidates and reference trajectories "
+                "reproduced id for id (tests/test_step_gpu.py::test_step_parity_full_size_refine, "
+                "::test_generate_free_running_full_size_refine)")
+        if split_res is not None:
+            out["scale100_all_split"] = alt_block(split_res, native.PREC_SPLIT,
+                                                  "the same with every tower on split-fp16 MFMA (the round-2 product mode)")
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(L, K)
         else:

@@ -84,7 +84,7 @@ struct czc_engine {
   std::vector<void*> bridge_allocs;
   float* d_img_n = nullptr; int img_B = 0;
   float logit_scale_exp = 1.f;
-  int* h_totals = nullptr;  // pinned: [0]=rows [1]=max len [2]=overflow
+  int* h_totals = nullptr;  // pinned, 64 ints: [0..7] plan totals, [8],[9] non-finite flags, [16..27] refine-plan totals
   int last_BT = 0;
   int share_prefix = 1;  // encode the candidates' common causal prefix once per image
   float* d_staged = nullptr; int staged_cap = 0, staged_n = 0;  // czc_preprocess_u8 output slots [cap][3][S][S]
@@ -145,7 +145,7 @@ struct ProfScope {
   ProfKind* k = nullptr;
   ProfScope(czc_engine* e_, const char* kind, double flops) : e(e_) {
     if (!e->prof) return;
-    if (e->prof == 2 && strcmp(kind, "gemm_clip_text") != 0) return;
+    if (e->prof == 2 && strcmp(kind, "gemm_clip_text") != 0 && strcmp(kind, "gemm_clip_refine") != 0) return;
     k = &e->pk[kind];
     if (k->used + 2 > k->ev.size()) {
       for (int i = 0; i < 2; ++i) {
@@ -685,7 +685,7 @@ int czc_create(const czc_config* cfg, int device_id, czc_engine** out) {
   e->esz = prec_bytes(e->pc);
   e->eb = prec_bytes(e->pb);
   if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&e->st) != hipSuccess ||
-      hipHostMalloc((void**)&e->h_totals, 64) != hipSuccess) {
+      hipHostMalloc((void**)&e->h_totals, 256) != hipSuccess) {
     snprintf(czc::g_err, sizeof(czc::g_err), "czc_create: stream/host allocation failed");
     delete e;
     return CZC_ERR_HIP;
@@ -741,7 +741,7 @@ int czc_replicate(czc_engine* p, czc_engine** out) {
   e->fuse_ln = p->fuse_ln;
   memset(&e->bd, 0, sizeof(e->bd));
   if (hipSetDevice(e->dev) != hipSuccess || hipStreamCreate(&e->st) != hipSuccess ||
-      hipHostMalloc((void**)&e->h_totals, 64) != hipSuccess) {
+      hipHostMalloc((void**)&e->h_totals, 256) != hipSuccess) {
     e->w.clear();
     delete e;
     return fail(p, CZC_ERR_HIP, "czc_replicate: stream/host allocation failed%s");
@@ -1137,6 +1137,7 @@ int czc_profile_reset(czc_engine* e) {
   if (e->prof_ref) (void)hipEventRecord(e->prof_ref, e->st);
   for (auto& kv : e->pk) { kv.second.used = 0; kv.second.flops = 0; kv.second.launches = 0; }
   e->stat_clip_rows = e->stat_clip_seqs = e->stat_bert_rows = e->stat_steps = 0;
+  e->stat_refine_rows = e->stat_refine_seqs = 0;
   return CZC_OK;
 }
 
@@ -1196,6 +1197,13 @@ int czc_stats(czc_engine* e, int64_t* clip_rows, int64_t* clip_seqs, int64_t* be
   if (clip_seqs) *clip_seqs = e->stat_clip_seqs;
   if (bert_rows) *bert_rows = e->stat_bert_rows;
   if (steps) *steps = e->stat_steps;
+  return CZC_OK;
+}
+
+int czc_refine_stats(czc_engine* e, int64_t* refine_seqs, int64_t* refine_rows) {
+  if (!e) return CZC_ERR_ARG;
+  if (refine_seqs) *refine_seqs = e->stat_refine_seqs;
+  if (refine_rows) *refine_rows = e->stat_refine_rows;
   return CZC_OK;
 }
 

@@ -319,7 +319,10 @@ class Engine:
     def stats(self):
         a, b, c_, d = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
         self._ck(self.lib.czc_stats(self.h, C.byref(a), C.byref(b), C.byref(c_), C.byref(d)), "czc_stats")
-        return dict(clip_rows=a.value, clip_seqs=b.value, bert_rows=c_.value, steps=d.value)
+        rs, rr = C.c_int64(), C.c_int64()
+        self._ck(self.lib.czc_refine_stats(self.h, C.byref(rs), C.byref(rr)), "czc_refine_stats")
+        return dict(clip_rows=a.value, clip_seqs=b.value, bert_rows=c_.value, steps=d.value, refine_seqs=rs.value,
+                    refine_rows=rr.value)
 
     def sync(self):
         self._ck(self.lib.czc_sync(self.h), "czc_sync")

@@ -10,7 +10,8 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libconzic_hip.so")
+# CZC_LIB_PATH: a differently-built library for the kernel tools (`make EXPERIMENTS=1 LIB=...`: timing-ablation kernels)
+LIB_PATH = os.environ.get("CZC_LIB_PATH") or os.path.join(_HERE, "lib", "libconzic_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "conzic_hip.h")
 
 PREC_BF16 = 0
@@ -96,6 +97,7 @@ SIGNATURES = {
     "czc_replicate": (_I, [_P, C.POINTER(C.c_void_p)]),
     "czc_sync": (_I, [_P]),
     "czc_stats": (_I, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "czc_refine_stats": (_I, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "czc_test_gemm": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _I, _P]),
     "czc_test_gemm_rowln": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, C.c_float, _P, _P]),
     "czc_bench_gemm": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(C.c_double)]),

@@ -33,19 +33,24 @@ BF16_MAX_LOGIT_SCALE_EXP = 20.0
 FP16_MAX_LOGIT_SCALE_EXP = 40.0
 
 _PRECISIONS = {"bf16": native.PREC_BF16, "f32": native.PREC_F32, "fp32": native.PREC_F32,
-               "split": native.PREC_SPLIT, "split_fp16": native.PREC_SPLIT, "fp16": native.PREC_FP16, "f16": native.PREC_FP16}
+               "split": native.PREC_SPLIT, "split_fp16": native.PREC_SPLIT, "fp16": native.PREC_FP16, "f16": native.PREC_FP16,
+               "refine": native.PREC_REFINE}
 
 
 def choose_precision(logit_scale: Optional[float]) -> int:
-    """Engine precision for a checkpoint: CZC_PRECISION (bf16 | fp16 | split | f32) when set, else by the CLIP logit
-    scale -- bf16 MFMA towers where exp(logit_scale) leaves their cosine error inside the 1e-3 fused-score
-    budget (<= x20), single-pass fp16 towers up to x40, split-fp16 MFMA (fp32-class) above, which is the case for the
-    published checkpoints (x100)."""
+    """Engine precision for a checkpoint: CZC_PRECISION (bf16 | fp16 | refine | split | f32) when set, else by the CLIP
+    logit scale -- bf16 MFMA towers where exp(logit_scale) leaves their cosine error inside the 1e-3 fused-score
+    budget (<= x20), single-pass fp16 towers up to x40, and above that -- the published checkpoints, x100 -- the
+    screen-then-refine engine: every candidate through the single-pass fp16 text tower, the candidates that carry the
+    softmax_K mass re-encoded by the split-fp16 tower (fused score inside 1e-3 on all K candidates, trajectories
+    identical to the reference on the goldens, ~1.7x the all-split engine's throughput).  Unknown scale: all split-fp16."""
     p = os.environ.get("CZC_PRECISION", "auto").lower()
     if p != "auto":
         return _PRECISIONS[p]
-    if logit_scale is None or math.exp(float(logit_scale)) > FP16_MAX_LOGIT_SCALE_EXP:
+    if logit_scale is None:
         return native.PREC_SPLIT
+    if math.exp(float(logit_scale)) > FP16_MAX_LOGIT_SCALE_EXP:
+        return native.PREC_REFINE
     if math.exp(float(logit_scale)) > BF16_MAX_LOGIT_SCALE_EXP:
         return native.PREC_FP16
     return native.PREC_BF16

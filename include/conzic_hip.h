@@ -223,8 +223,8 @@ int czc_set_option(czc_engine* e, const char* name, int value);
 
 /* ---- measurement ------------------------------------------------------------------------- */
 /* HIP-event timing of kernel classes on the engine's own stream (bench.py roofline leg).  on: 0 off, 1 an event pair
- * around every kernel class (3 % slower at B = 256, 37 % at B = 1), 2 only around "gemm_clip_text" (the roofline family).
- * kind: "gemm_clip_text" | "gemm_bert" | "gemm_vision" | "attention" | "rowops" | "topk" | "bridge" | "combine" */
+ * around every kernel class (3 % slower at B = 256, 37 % at B = 1), 2 only around "gemm_clip_text" / "gemm_clip_refine" (the roofline family).
+ * kind: "gemm_clip_text" | "gemm_clip_refine" (second pass of CZC_PREC_REFINE) | "gemm_bert" | "gemm_vision" | "attention" | "rowops" | "topk" | "bridge" | "combine" */
 int czc_profile_enable(czc_engine* e, int on);
 int czc_profile_reset(czc_engine* e);
 int czc_profile_get(czc_engine* e, const char* kind, double* total_ms, int64_t* launches, double* flops);
@@ -236,6 +236,9 @@ int czc_profile_intervals(czc_engine* e, czc_engine* ref, const char* kind, doub
 int czc_sync(czc_engine* e);
 /* counters of the last generate/step: rows pushed through the CLIP text tower etc. */
 int czc_stats(czc_engine* e, int64_t* clip_rows, int64_t* clip_seqs, int64_t* bert_rows, int64_t* steps);
+/* CZC_PREC_REFINE engines: candidate sequences / packed rows re-encoded by the split-fp16 tower since czc_profile_reset
+ * (of the clip_seqs / clip_rows the screening pass saw); zero for the other precisions. */
+int czc_refine_stats(czc_engine* e, int64_t* refine_seqs, int64_t* refine_rows);
 
 /* ---- kernel-level parity hooks (tests only; host pointers, synchronous) -------------------- */
 /* C[M,N] = A[M,K] * W[N,K]^T (+bias) (+activation: 0 none, 1 quick_gelu, 2 gelu_erf) (+resid[M,N]).

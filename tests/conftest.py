@@ -44,3 +44,8 @@ def pytest_terminal_summary(terminalreporter):
     terminalreporter.write_line("golden parity, worst over image-steps (case, precision: |d final_score|, |d cosine|, n):")
     for (name, prec), (efin, ecos, n) in sorted(worst.items()):
         terminalreporter.write_line(f"  {name:22s} prec={prec}: {efin:.3e} {ecos:.3e} n={n}")
+    rlog = getattr(mod, "REFINE_LOG", None)
+    if rlog:
+        terminalreporter.write_line("screen-then-refine engine: candidate sequences re-encoded by the split-fp16 tower (case: seqs, rows):")
+        for name, seqs, rseqs, rows, rrows in rlog:
+            terminalreporter.write_line(f"  {name:22s} {rseqs}/{seqs} = {rseqs / max(seqs, 1):.3f}   rows {rrows}/{rows} = {rrows / max(rows, 1):.3f}")

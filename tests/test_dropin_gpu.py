@@ -150,11 +150,11 @@ def test_clip_wrapper_methods():
 def test_checkpoint_with_legacy_bert_names_and_published_logit_scale(tmp_path, monkeypatch):
     """The published `bert-base-uncased` safetensors still carries TF-style `LayerNorm.gamma` / `LayerNorm.beta` and the
     pooler / next-sentence tensors, and the published CLIP checkpoints carry logit_scale = ln 100: such a directory
-    loads, the engine precision is chosen from the logit scale (split-fp16), and a step equals the in-memory engine's."""
+    loads, the engine precision is chosen from the logit scale (screen-then-refine), and a step equals the in-memory engine's."""
     from conzic_amd import checkpoint, harness, native, synth
     from conzic_amd.engine import Engine
     monkeypatch.delenv("CZC_PRECISION", raising=False)
-    su = harness.build_synthetic(True, native.PREC_SPLIT, logit_scale=4.6052)
+    su = harness.build_synthetic(True, native.PREC_REFINE, logit_scale=4.6052)
     bw, cw = synth.make_bert_weights(su.bert_cfg, 11), synth.make_clip_weights(su.clip_cfg, 12)
     legacy = {}
     for k, v in bw.items():
@@ -173,7 +173,7 @@ def test_checkpoint_with_legacy_bert_names_and_published_logit_scale(tmp_path, m
     bdir, cdir = checkpoint.write_checkpoint_dirs(str(tmp_path), su.bert_cfg, legacy, su.clip_cfg, cw, su.sv)
     eng, bcfg, ccfg, bt, ct = checkpoint.engine_from_checkpoints(bdir, cdir)   # precision from the checkpoint
     try:
-        assert abs(ccfg.logit_scale - 4.6052) < 1e-6 and eng.precision == native.PREC_SPLIT
+        assert abs(ccfg.logit_scale - 4.6052) < 1e-6 and eng.precision == native.PREC_REFINE
         eng.set_token_mask(su.token_mask)
         emb = np.random.default_rng(3).standard_normal((2, su.clip_cfg.proj)).astype(np.float32)
         inp = np.array([bt.encode("Image of a" + bt.mask_token * 5)] * 2, dtype=np.int32)

@@ -11,6 +11,7 @@ from goldutil import load_case
 pytestmark = pytest.mark.gpu
 
 BF16, F32, SPLIT, FP16 = native.PREC_BF16, native.PREC_F32, native.PREC_SPLIT, native.PREC_FP16
+REFINE = native.PREC_REFINE
 SEED_LEN = 4
 
 # fused-score tolerance of the north star ("within 1e-3 on the fused logits") at the BASELINE
@@ -21,6 +22,8 @@ def tol_final(prec, tiny):
         return 2e-5
     if prec == SPLIT:  # split-fp16 MFMA towers: fp32-class (22 mantissa bits), an order inside the 1e-3 bar
         return 1e-4
+    if prec == REFINE:  # screen-then-refine: the north star's bar itself, at every logit scale (measured 3-5e-4 at x100)
+        return 1e-3
     if prec == FP16:   # single-pass fp16 MFMA towers: ~8x below bf16 (measured 5e-5 on the full-size goldens at scale 14.3)
         return 4e-3 if tiny else 1.5e-4
     return 2.5e-2 if tiny else 1e-3
@@ -122,7 +125,7 @@ def check_step(meta, arr, i, res, su, prec, next_inp):
             assert res["clip_len"][b * K + e_] == ln
             np.testing.assert_array_equal(res["clip_ids"][b * K + e_, :ln], arr["clip_ids"][i][b * K + g_, :ln])
         np.testing.assert_allclose(res["clip_ref"][b][ek], arr["clip_ref"][i][b][gk],
-                                   atol={F32: 5e-6, SPLIT: 1e-5, FP16: 6e-4}.get(prec, 4e-3))
+                                   atol={F32: 5e-6, SPLIT: 1e-5, FP16: 6e-4, REFINE: 6e-4}.get(prec, 4e-3))
         if len(common) == K:
             np.testing.assert_allclose(res["clip_score"][b][ek], arr["clip_score"][i][b][gk],
                                        atol={F32: 2e-6, SPLIT: tol / 2}.get(prec, tol / 2),
@@ -325,6 +328,74 @@ def test_fp16_at_the_published_logit_scale_is_marginal():
     assert 1e-5 < worst < 5e-3, worst
 
 
+REFINE_LOG = []  # (case, candidate sequences seen, re-encoded) per test, printed by conftest
+
+
+@pytest.mark.parametrize("name", FULL)
+def test_step_parity_full_size_refine(name):
+    """Screen-then-refine engine (CZC_PREC_REFINE; what the product path selects above x40, i.e. for the published
+    checkpoints): every full-size golden -- `full_scale100` is the case it exists for -- teacher-forced, fused score
+    inside the 1e-3 bar on ALL K candidates, winners identical wherever the reference's margin exceeds the bar, and
+    only a fraction of the candidates re-encoded by the split-fp16 tower."""
+    meta, arr = load_case(name)
+    su = setup_for(meta, REFINE)
+    su.engine.profile_reset()
+    soft, n = teacher_forced(meta, arr, REFINE, n_steps=None if meta["K"] <= 200 else 8)
+    assert soft <= 1
+    st = su.engine.stats()
+    REFINE_LOG.append((name, st["clip_seqs"], st["refine_seqs"], st["clip_rows"], st["refine_rows"]))
+    assert 0 < st["refine_seqs"] <= 0.35 * st["clip_seqs"], st
+
+
+@pytest.mark.parametrize("name", ["tiny_scale100", "tiny_seq", "tiny_senti_seq", "tiny_pos_seq", "tiny_span"])
+def test_step_parity_tiny_refine(name):
+    """K <= 16: (nearly) every candidate carries more softmax_K mass than the threshold, so the engine degenerates to the
+    split-fp16 one; span steps (n_mask = 0 re-use of the BERT forward) and the control paths go through the two-pass step."""
+    meta, arr = load_case(name)
+    soft, n = teacher_forced(meta, arr, REFINE)
+    assert soft <= max(1, n // 10)
+
+
+@pytest.mark.parametrize("name", ["full_scale100", "full_senti", "full_pos"])
+def test_generate_free_running_full_size_refine(name):
+    """czc_generate through the screen-then-refine engine reproduces the reference's trajectory id for id at the
+    published-checkpoint logit scale (and with the sentiment / POS control scores fused in)."""
+    meta, arr = load_case(name)
+    su = setup_for(meta, REFINE)
+    eng = su.engine
+    eng.set_image_embeds(arr["image_embeds"])
+    hp = Engine.hyper(meta["alpha"], meta["beta"], meta["temperature"], meta["gamma"], meta["style"] == "negative",
+                      control="pos" if meta.get("pos") else None)
+    init = su.bert_tok.encode(meta["prompt"] + su.bert_tok.mask_token * meta["L"])
+    pos, nm, every = harness.order_positions(meta["order"], meta["L"], meta["I"], order_list=meta["order_list"])
+    assert pos == meta["positions"]
+    ids, cos = eng.generate(meta["B"], init, meta["L"], SEED_LEN, meta["K"], pos, hp, n_mask=nm, snapshot_every=every)
+    np.testing.assert_array_equal(ids, arr["snaps"])
+    np.testing.assert_allclose(cos, np.array(meta["scores"][:-1], dtype=np.float32), atol=2e-5)  # the winner is always re-encoded
+
+
+def test_refine_engine_encode_text_and_images_are_exact():
+    """Outside the polishing step the refine engine answers with its exact towers: czc_encode_text through the split-fp16
+    text tower, czc_encode_images through the split-fp16 vision tower (compute_image_text_similarity_via_* callers)."""
+    from oracle import models as M
+    meta = dict(tiny=True, bseed=11, cseed=12, logit_scale=4.6052, regular_only=False, gamma=None)
+    su = setup_for(meta, REFINE)
+    ccfg = su.clip_cfg
+    rng = np.random.default_rng(1)
+    lens = np.array([2, 5, 77, 16, 9], np.int32)
+    ids = np.full((len(lens), 77), ccfg.eos_id, np.int32)
+    for r, L in enumerate(lens):
+        ids[r, 0] = ccfg.bos_id
+        ids[r, 1:L - 1] = rng.integers(0, ccfg.vocab - 2, size=L - 2)
+    out = su.engine.encode_text(ids, lens)
+    w = M.to_torch(synth.make_clip_weights(ccfg, 12))
+    ref = M.clip_text_embeds(w, ccfg, torch.from_numpy(ids.astype(np.int64)), torch.from_numpy(lens)).numpy()
+    assert np.abs(out - ref).max() < 5e-5 * max(1.0, np.abs(ref).max())
+    z = np.load(f"{harness.__file__.rsplit('/', 2)[0]}/tests/golden/vision_tiny.npz")
+    emb = su.engine.encode_images(synth.pixels_from_u8(synth.make_images_u8(3, ccfg.v_image)))
+    assert np.abs(emb - z["image_embeds"]).max() < 5e-5 * max(1.0, np.abs(z["image_embeds"]).max())
+
+
 @pytest.mark.parametrize("name", [n for n in TINY if n != "tiny_scale100"])
 def test_step_parity_tiny_fp16(name):
     meta, arr = load_case(name)
@@ -341,8 +412,10 @@ def test_precision_selected_from_logit_scale():
     try:
         assert runtime.choose_precision(2.6592) == BF16
         assert runtime.choose_precision(3.4) == FP16      # x30: bf16 out of budget, fp16 (8x smaller error) inside
-        assert runtime.choose_precision(4.6052) == SPLIT
+        assert runtime.choose_precision(4.6052) == REFINE  # published checkpoints: screen-then-refine
         assert runtime.choose_precision(None) == SPLIT
+        os.environ["CZC_PRECISION"] = "split"
+        assert runtime.choose_precision(4.6052) == SPLIT
         os.environ["CZC_PRECISION"] = "f32"
         assert runtime.choose_precision(4.6052) == F32
     finally:
