@@ -541,6 +541,7 @@ __global__ __launch_bounds__(256) void attention_branch_split_kernel(const split
   const int pre_off = tab.pre_off[s0], pre_len = tab.pre_len[s0];
   const int r0 = tab.own_off[s0];
   const int n_own = tab.own_off[s0 + Gc - 1] + tab.own_len[s0 + Gc - 1] - r0;  // <= 32 by construction
+  if (n_own <= 0) return;  // a group of empty slots (refine plan: images with fewer chosen candidates than the widest one)
   const int nkt_t = (pre_len + 31) >> 5;
   const int Hd = heads * 64;
   const long pitchb = 3L * Hd * 4;

@@ -269,19 +269,26 @@ int launch_prefix_finish(const int* own_off, const int* own_len, int B, int K, i
 }
 
 // ---- screen-then-refine: segment plan of the second (split-fp16) pass ---------------------------------
-// One work-group per image.  count_off = exclusive scan of count (count_off[B] = R).  Trunk b keeps the prefix length
-// of the screening plan when the image has candidates to re-encode (else 0 rows); branch segments B + count_off[b] + i.
+// One work-group per image.  count_off = exclusive scan of count (count_off[B] = R), *kr = max_b count[b].  The plan
+// keeps the REGULAR shape of the screening plan -- B trunks, then B x Kr branch slots, image b's chosen candidates in
+// slots b*Kr .. b*Kr + count[b] - 1 and the rest of its slots empty (own_len 0, pre-zeroed by the caller) -- so that the
+// packed-branch attention kernels serve it; pooled rows / rlist stay compact (row r = count_off[b] + i).  Trunk b keeps
+// the prefix length of the screening plan.
 __global__ __launch_bounds__(256) void refine_plan_kernel(const int* clen, const int* trunk_len, const int* list, const int* count,
-                                                          const int* count_off, int B, int K, int* own_len, int* pre_len, int* seg_src,
-                                                          int* seg_pos0, int* rlist, int* max_len_out) {
+                                                          const int* count_off, const int* kr, int B, int K, int* own_len, int* pre_len,
+                                                          int* seg_src, int* seg_pos0, int* rlist, int* max_len_out) {
   const int b = blockIdx.x, tid = threadIdx.x;
-  const int n = count[b], o = count_off[b];
+  const int n = count[b], o = count_off[b], Kr = *kr;
   const int pb = n > 0 ? trunk_len[b] : 0;
   if (tid == 0) { own_len[b] = pb; pre_len[b] = 0; seg_src[b] = b * K; seg_pos0[b] = 0; }
   int mx = 0, mxb = 0;
-  for (int i = tid; i < n; i += blockDim.x) {
+  for (int i = tid; i < Kr; i += blockDim.x) {
+    const int s = B + b * Kr + i;
+    if (i >= n) {  // empty slot: a zero-length segment of this image's trunk
+      pre_len[s] = pb; seg_src[s] = b * K; seg_pos0[s] = pb;
+      continue;
+    }
     const int flat = b * K + list[(long)b * K + i];
-    const int s = B + o + i;
     const int len = clen[flat];
     own_len[s] = len - pb;
     pre_len[s] = pb;
@@ -294,30 +301,34 @@ __global__ __launch_bounds__(256) void refine_plan_kernel(const int* clen, const
   if (mx) { atomicMax(max_len_out, mx); atomicMax(max_len_out + 1, mxb); }
 }
 
-int launch_refine_plan(const int* clip_len, const int* trunk_len, const int* list, const int* count, const int* count_off, int B, int K,
-                       int* own_len, int* pre_len, int* seg_src, int* seg_pos0, int* rlist, int* max_len_out, hipStream_t st) {
-  hipLaunchKernelGGL(refine_plan_kernel, dim3(B), dim3(256), 0, st, clip_len, trunk_len, list, count, count_off, B, K, own_len, pre_len,
-                     seg_src, seg_pos0, rlist, max_len_out);
+int launch_refine_plan(const int* clip_len, const int* trunk_len, const int* list, const int* count, const int* count_off,
+                       const int* kr_dev, int B, int K, int* own_len, int* pre_len, int* seg_src, int* seg_pos0, int* rlist,
+                       int* max_len_out, hipStream_t st) {
+  hipLaunchKernelGGL(refine_plan_kernel, dim3(B), dim3(256), 0, st, clip_len, trunk_len, list, count, count_off, kr_dev, B, K, own_len,
+                     pre_len, seg_src, seg_pos0, rlist, max_len_out);
   CZC_HIP_CHECK(hipGetLastError());
   return 0;
 }
 
-// after the scan of own_len over B + B*K segments: pre_off of branch r = own_off[its image's trunk]; eos_idx[r]
-__global__ void refine_finish_kernel(const int* own_off, const int* own_len, const int* count_off, int B, int K, int* pre_off,
-                                     int* eos_idx, const int* rlist) {
+// after the scan of own_len over B + B*K segment slots: pre_off of every branch slot = own_off[its image's trunk];
+// eos_idx[r] of the compact row r = count_off[b] + i
+__global__ void refine_finish_kernel(const int* own_off, const int* own_len, const int* count, const int* count_off, const int* kr,
+                                     int B, int* pre_off, int* eos_idx) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int Kr = *kr;
   if (i < B) pre_off[i] = 0;
-  if (i < count_off[B]) {
+  if (i < B * Kr) {
+    const int b = i / Kr, j = i - b * Kr;
     const int s = B + i;
-    pre_off[s] = own_off[rlist[i] / K];
-    eos_idx[i] = own_off[s] + own_len[s] - 1;
+    pre_off[s] = own_off[b];
+    if (j < count[b]) eos_idx[count_off[b] + j] = own_off[s] + own_len[s] - 1;
   }
 }
 
-int launch_refine_finish(const int* own_off, const int* own_len, const int* count_off, int B, int K, int* pre_off, int* eos_idx,
-                         const int* rlist, hipStream_t st) {
-  hipLaunchKernelGGL(refine_finish_kernel, dim3(cdiv((long)B * K, 256)), dim3(256), 0, st, own_off, own_len, count_off, B, K, pre_off,
-                     eos_idx, rlist);
+int launch_refine_finish(const int* own_off, const int* own_len, const int* count, const int* count_off, const int* kr_dev, int B, int K,
+                         int* pre_off, int* eos_idx, hipStream_t st) {
+  hipLaunchKernelGGL(refine_finish_kernel, dim3(cdiv((long)B * K, 256)), dim3(256), 0, st, own_off, own_len, count, count_off, kr_dev, B,
+                     pre_off, eos_idx);
   CZC_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -581,19 +581,20 @@ int step_phase_b(czc_engine* e, const StepArgs& a, int M, int max_len, int max_b
   { ProfScope ps(e, "bridge", 0);
     E_HIP(hipMemsetAsync(rtot, 0, 64, e->st));
     E_HIP(hipMemsetAsync(rp.own_len, 0, (size_t)S * 4, e->st));
-    E_CHECK(launch_scan(count, a.B, count_off, rtot + 8, e->st));  // rtot[8] = R
-    E_CHECK(launch_refine_plan(b.clen, sp.own_len, list, count, count_off, a.B, a.K, rp.own_len, rp.pre_len, rp.src, rp.pos0, rlist,
-                               rtot + 3, e->st));
+    E_CHECK(launch_scan(count, a.B, count_off, rtot + 8, e->st));  // rtot[8] = R, rtot[9] = Kr = largest per-image count
+    E_CHECK(launch_refine_plan(b.clen, sp.own_len, list, count, count_off, rtot + 9, a.B, a.K, rp.own_len, rp.pre_len, rp.src, rp.pos0,
+                               rlist, rtot + 3, e->st));
     E_CHECK(launch_scan(rp.own_len, S, rp.own_off, rtot, e->st));   // rtot[0] = rows of the refine pass
-    E_CHECK(launch_refine_finish(rp.own_off, rp.own_len, count_off, a.B, a.K, rp.pre_off, rp.eidx, rlist, e->st)); }
+    E_CHECK(launch_refine_finish(rp.own_off, rp.own_len, count, count_off, rtot + 9, a.B, a.K, rp.pre_off, rp.eidx, e->st)); }
   E_HIP(hipMemcpyAsync(e->h_totals + 16, rtot, 48, hipMemcpyDeviceToHost, e->st));
   E_HIP(hipStreamSynchronize(e->st));  // second (and last) host round trip of the step: the sizes of the refine pass
-  const int M2 = e->h_totals[16], max_len2 = e->h_totals[19], R = e->h_totals[24];
-  if (R < 0 || R > n_seq || M2 < 0) return fail(e, CZC_ERR_STATE, "refine plan returned impossible sizes%s");
+  const int M2 = e->h_totals[16], max_len2 = e->h_totals[19], max_branch2 = e->h_totals[20], R = e->h_totals[24], Kr = e->h_totals[25];
+  if (R < 0 || R > n_seq || M2 < 0 || Kr < 0 || Kr > a.K) return fail(e, CZC_ERR_STATE, "refine plan returned impossible sizes%s");
   if (R > 0) {
     float* feat2;
-    E_CHECK(clip_tower_on(e, PREC_F16X3, e->ctext_x, e->tproj_wx, "gemm_clip_refine", b.cids, rp, a.B + R, R, M2, max_len2, 0, 0, 0,
-                          "c_feat2", &feat2));
+    // regular B x Kr plan (empty slots have no rows): the packed-branch split attention serves it like the screening plan
+    E_CHECK(clip_tower_on(e, PREC_F16X3, e->ctext_x, e->tproj_wx, "gemm_clip_refine", b.cids, rp, a.B + a.B * Kr, R, M2, max_len2,
+                          a.B, Kr, max_branch2, "c_feat2", &feat2));
     ProfScope ps(e, "combine", 0);
     E_CHECK(launch_refine_cosine(feat2, e->d_img_n, rlist, count_off + a.B, R, a.K, c.clip_proj, rcos, ca.nonfinite, e->st));
   }

@@ -172,11 +172,13 @@ int launch_refine_select(const float* clip_score, const float* final_score, int 
                          int* list, int* count, hipStream_t st);
 int launch_refine_cosine(const float* text_feat, const float* img_n, const int* rlist, const int* n_rows_dev, int n_rows_max, int K, int D,
                          float* cos_out, int* nonfinite, hipStream_t st);
-// segment plan of the refine pass (bridge.hip): B trunks (prefix lengths of the screening plan) + the chosen candidates
-// of every image as branches, compacted in image order; segments past B + R get length 0
-int launch_refine_plan(const int* clip_len, const int* trunk_len, const int* list, const int* count, const int* count_off, int B, int K,
-                       int* own_len, int* pre_len, int* seg_src, int* seg_pos0, int* rlist, int* max_len_out, hipStream_t st);
-int launch_refine_finish(const int* own_off, const int* own_len, const int* count_off, int B, int K, int* pre_off, int* eos_idx,
-                         const int* rlist, hipStream_t st);
+// segment plan of the refine pass (bridge.hip): B trunks (prefix lengths of the screening plan) + B x Kr branch slots
+// (Kr = *kr_dev = the largest per-image count; an image's chosen candidates first, its other slots empty), i.e. the
+// regular shape the packed-branch attention kernels take; rlist / eos_idx are compact (row r = count_off[b] + i)
+int launch_refine_plan(const int* clip_len, const int* trunk_len, const int* list, const int* count, const int* count_off,
+                       const int* kr_dev, int B, int K, int* own_len, int* pre_len, int* seg_src, int* seg_pos0, int* rlist,
+                       int* max_len_out, hipStream_t st);
+int launch_refine_finish(const int* own_off, const int* own_len, const int* count, const int* count_off, const int* kr_dev, int B, int K,
+                         int* pre_off, int* eos_idx, hipStream_t st);
 
 }  // namespace czc

@@ -31,19 +31,26 @@ def pytest_collection_modifyitems(config, items):
 
 
 def pytest_terminal_summary(terminalreporter):
-    """Measured parity errors of the golden step tests (tests/test_step_gpu.py::ERR_LOG), worst per case and
-    engine precision, so that a GPU run leaves the numbers DESIGN.md quotes in its log."""
+    """Measured parity figures of the GPU tests (tests/test_step_gpu.py::ERR_LOG / DIVERGENCE_LOG / REFINE_LOG), so that a
+    GPU run leaves the numbers DESIGN.md quotes in its log."""
     mod = sys.modules.get("test_step_gpu")
-    log = getattr(mod, "ERR_LOG", None) if mod else None
-    if not log:
+    if not mod:
         return
-    worst = {}
-    for name, prec, efin, ecos in log:
-        w = worst.setdefault((name, prec), [0.0, 0.0, 0])
-        w[0], w[1], w[2] = max(w[0], efin), max(w[1], ecos), w[2] + 1
-    terminalreporter.write_line("golden parity, worst over image-steps (case, precision: |d final_score|, |d cosine|, n):")
-    for (name, prec), (efin, ecos, n) in sorted(worst.items()):
-        terminalreporter.write_line(f"  {name:22s} prec={prec}: {efin:.3e} {ecos:.3e} n={n}")
+    log = getattr(mod, "ERR_LOG", None)
+    if log:
+        worst = {}
+        for name, prec, efin, ecos in log:
+            w = worst.setdefault((name, prec), [0.0, 0.0, 0])
+            w[0], w[1], w[2] = max(w[0], efin), max(w[1], ecos), w[2] + 1
+        terminalreporter.write_line("golden parity, worst over image-steps (case, precision: |d final_score|, |d cosine|, n):")
+        for (name, prec), (efin, ecos, n) in sorted(worst.items()):
+            terminalreporter.write_line(f"  {name:22s} prec={prec}: {efin:.3e} {ecos:.3e} n={n}")
+    dlog = getattr(mod, "DIVERGENCE_LOG", None)
+    if dlog:
+        terminalreporter.write_line("free-running half-precision engines vs the reference trajectory (case, precision: identical tokens "
+                                    "while on the trajectory, images still on it at the end, reference top-2 margin at each first divergence):")
+        for name, prec, tot, same, alive, B, margins in dlog:
+            terminalreporter.write_line(f"  {name:22s} prec={prec}: {same}/{tot} tokens, {alive}/{B} images, margins {[f'{m:.1e}' for m in margins]}")
     rlog = getattr(mod, "REFINE_LOG", None)
     if rlog:
         terminalreporter.write_line("screen-then-refine engine: candidate sequences re-encoded by the split-fp16 tower (case: seqs, rows):")

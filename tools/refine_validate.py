@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Screen-then-refine engine against the all-split-fp16 engine (itself pinned to the reference within 8e-6)
+on MANY image-steps at the published logit scale: the goldens give ~20 image-steps per case, this gives B x P.
+
+    python tools/refine_validate.py [B] [positions] [samples,samples,...] [theta_x1000,...]  ->  one JSON line per setting
+
+Both engines see the same random image embeddings and the same sentences (later-sweep state: every position filled);
+the BERT tower is the same split-fp16 code in both, so the candidate lists are identical and the fused scores compare
+one to one.  Reports the worst and the 99.9th-percentile |d final_score| over all B*P*K candidates, winner agreement,
+and the share of candidates / rows the refine pass re-encodes."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from conzic_amd import harness, native  # noqa: E402
+from conzic_amd.engine import Engine  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+P = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+SAMPLES = [int(v) for v in (sys.argv[3] if len(sys.argv) > 3 else "12").split(",")]
+THETAS = [int(v) for v in (sys.argv[4] if len(sys.argv) > 4 else "4000").split(",")]
+L, K, SEED_LEN, SCALE = 10, 200, 4, 4.6052
+hp = Engine.hyper(0.02, 2.0, 0.1)
+rng = np.random.default_rng(2026)
+emb = rng.standard_normal((B, 512)).astype(np.float32)
+
+ref = harness.build_synthetic(False, native.PREC_SPLIT, logit_scale=SCALE, regular_only=True)
+inp0 = np.array([ref.bert_tok.encode("Image of a" + ref.bert_tok.mask_token * L)] * B, dtype=np.int32)
+regular = np.nonzero(ref.token_mask[0] > 0)[0]
+inp0[:, SEED_LEN:SEED_LEN + L] = rng.choice(regular, size=(B, L))
+ref.engine.set_image_embeds(emb)
+gold = []
+cur = inp0.copy()
+for p in range(P):
+    before = cur.copy()
+    r = ref.engine.step(cur, SEED_LEN + (p % L), K, hp, dot_allowed=(p % L == L - 1), want=("idxs", "final_score", "best", "clip_ref"))
+    gold.append((before, r))  # `cur` now carries the reference engine's winners: the next position's state
+ref.engine.close()
+
+su = harness.build_synthetic(False, native.PREC_REFINE, logit_scale=SCALE, regular_only=True)
+su.engine.set_image_embeds(emb)
+for th in THETAS:
+    for m in SAMPLES:
+        su.engine.set_option("refine_samples", m)
+        su.engine.set_option("refine_theta_x1000", th)
+        su.engine.profile_reset()
+        errs, agree, n, margins = [], 0, 0, []
+        for p, (before, r) in enumerate(gold):
+            res = su.engine.step(before.copy(), SEED_LEN + (p % L), K, hp, dot_allowed=(p % L == L - 1), want=("idxs", "final_score", "best"))
+            assert (res["idxs"] == r["idxs"]).all()
+            d = np.abs(res["final_score"] - r["final_score"])
+            errs.append(d.reshape(-1))
+            same = res["best"] == r["best"]
+            agree += int(same.sum())
+            n += B
+            srt = np.sort(r["final_score"], axis=1)[:, ::-1]
+            margins += [float(srt[b, 0] - srt[b, 1]) for b in range(B) if not same[b]]
+        e = np.concatenate(errs)
+        st = su.engine.stats()
+        print(json.dumps(dict(images=B, positions=P, K=K, logit_scale=SCALE, refine_samples=m, theta_x=th / 1000.0,
+                              max_abs_dfinal=float(e.max()), p999=float(np.quantile(e, 0.999)), mean=float(e.mean()),
+                              image_steps=n, winners_identical=agree, reference_margin_at_flips=margins,
+                              re_encoded_seq_frac=round(st["refine_seqs"] / max(st["clip_seqs"], 1), 4),
+                              re_encoded_row_frac=round(st["refine_rows"] / max(st["clip_rows"], 1), 4))), flush=True)
+su.engine.close()
+sys.stdout.flush()
+os._exit(0)
