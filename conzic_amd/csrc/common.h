@@ -45,9 +45,20 @@ __device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
 struct f16_t { unsigned short v; };
 typedef __attribute__((ext_vector_type(8))) _Float16 half8_t;
 
+// fp32 -> fp16 conversions must start from ONE fp32 value.  HIP compiles with -ffp-contract=fast: when v is the result of
+// a multiply or add that is still visible (o * inv, acc + bias, (x - mean) * rstd * g + b), the compiler may convert with a
+// single-rounding v_fma_mix*_f16 from the exact product in one place and with v_cvt_pk_f16_f32 from the fp32-rounded
+// value in another; at near-ties (about 1 value in 8000) the two differ by one fp16 ulp.  That broke the split
+// representation (the hi that feeds `v - hi` against the stored hi: hi + lo off by 2^-11 relative) and makes two kernels
+// that state the same arithmetic disagree in the last place.  pin() makes the fp32 value opaque first.
+__device__ __forceinline__ float pin(float v) {
+  asm("" : "+v"(v));
+  return v;
+}
+
 __device__ __forceinline__ uint32_t pack2_f16(float lo, float hi) {
   typedef __attribute__((ext_vector_type(2))) _Float16 h2;
-  const h2 v = {(_Float16)lo, (_Float16)hi};  // round-to-nearest-even (v_cvt_pk_f16_f32 / v_fma_mix*)
+  const h2 v = {(_Float16)pin(lo), (_Float16)pin(hi)};  // round-to-nearest-even of the fp32 values (v_cvt_pk_f16_f32)
   return __builtin_bit_cast(uint32_t, v);
 }
 
@@ -69,7 +80,7 @@ template <> struct Half<f16_t> {
   }
   __device__ static __forceinline__ uint32_t pack2(float lo, float hi) { return pack2_f16(lo, hi); }
   __device__ static __forceinline__ float to_f32(unsigned short r) { return (float)__builtin_bit_cast(_Float16, r); }
-  __device__ static __forceinline__ unsigned short from_f32(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }
+  __device__ static __forceinline__ unsigned short from_f32(float f) { return __builtin_bit_cast(unsigned short, (_Float16)pin(f)); }
 };
 
 // activation storage type per engine precision.  All accessors take (base pointer, ELEMENT index):
@@ -108,16 +119,6 @@ template <> struct Act<float> {
     *(float4*)(b + i) = make_float4(x, y, z, w);
   }
 };
-// Splitting v into fp16 hi + lo needs ONE fp32 value behind both parts.  HIP compiles with -ffp-contract=fast: when v is
-// the result of a multiply or add that is still visible (o * inv, acc + bias, x * sigmoid), the compiler derives the
-// hi that feeds `v - hi` with a single-rounding v_fma_mix*_f16 from the exact product, but the STORED hi with
-// v_cvt_pk_f16_f32 from the fp32-rounded one; at near-ties (about 1 value in 8000) the two differ by one fp16 ulp and
-// hi + lo is off by 2^-11 relative.  pin() makes the fp32 value opaque so that both conversions start from it.
-__device__ __forceinline__ float pin(float v) {
-  asm("" : "+v"(v));
-  return v;
-}
-
 template <> struct Act<split_t> {
   __device__ static __forceinline__ long off(long i) { return (i >> 3) * 32 + (i & 7) * 2; }
   __device__ static __forceinline__ float ld(const split_t* b, long i) {

@@ -68,7 +68,9 @@ __device__ __forceinline__ int swz(int row, int chunk) { return row * ROWB + ((c
 template <typename T, int ACT>
 __device__ __forceinline__ float apply_act(float v) {
   if (ACT == ACT_QUICK_GELU) {
-    if (sizeof(T) == 2) return v * __frcp_rn(1.0f + __expf(-1.702f * v));  // bf16 engine: fast path
+    // half-precision engines: the same raw v_exp_f32 / v_rcp_f32 form as the ring and weight-stationary kernels
+    // (gemm256.hip act_fn, gemm_wreg.hip wr_act) -- a layer must not change its last bits with the row count
+    if (sizeof(T) == 2) return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930156f * v));
     return v / (1.0f + expf(-1.702f * v));
   }
   if (ACT == ACT_GELU_ERF) return gelu_erf(v);

@@ -261,7 +261,10 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, 
 }  // namespace
 
 int g_use_wreg = 1;        // 0: every K = 512 layer goes to the tiled kernels (tests pin kernel families with it)
-int g_wreg_min_m = 2048;  // below this the 128x128 kernel wins (few blocks per work-group); tests lower it to pin the kernel family
+// Every eligible layer, whatever its row count: the kernel's two accumulator chains and raw-exp quick-GELU give other
+// last bits than the tiled kernels, so choosing by M would make an image's caption depend on its batch; measured at one
+// image (M ~ 1-3 k rows) it is also the faster kernel (4.21 vs 4.10 captions/s), at 8 images equal
+int g_wreg_min_m = 1;
 
 bool gemm_wreg_eligible(const GemmArgs& g) {
   return g_use_wreg && g.K == WR_K && g.M >= g_wreg_min_m && g.N % 8 == 0 && g.ldc % 8 == 0 && g.lda % 8 == 0 && g.ldw % 8 == 0 &&

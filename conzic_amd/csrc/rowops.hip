@@ -42,6 +42,53 @@ __device__ __forceinline__ void ln_row(float4 (&v)[NV], int H, int lane, const f
   }
 }
 
+// sum over the wave in the association order of gemm_rowln_kernel's epilogue (gemm256.hip): lane = 8*w + r sums its
+// neighbours r^1, r^2, r^4 first (the 64-column partial of "wave" w there), then w^1, w^2, w^4
+__device__ __forceinline__ float wave_sum_rowln_order(float v) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// H = 512 rows of the half-precision CLIP-text tower: the SAME arithmetic, operation for operation, as the LayerNorm
+// that gemm_rowln_kernel finishes in its epilogue (lane 8w + r holds columns 64w + 4r .. +3 and 64w + 32 + 4r .. +3;
+// exact two-pass statistics; identical reduction tree), so that a row normalised by this kernel (few packed rows:
+// the out-projection runs on the tiled GEMM) and by the full-row GEMM (many rows) come out bit-identical -- the
+// engine's results must not depend on the batch size through the choice between the two.
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm512_kernel(const float* x, const int* row_idx, const float* gamma,
+                                                           const float* beta, float eps, int M, T* y_act, float* y_f32) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const long src = row_idx ? row_idx[m] : m;
+  const float* xr = x + src * 512L;
+  const int c0 = (lane >> 3) * 64 + (lane & 7) * 4;
+  const float4 u = *(const float4*)(xr + c0), w = *(const float4*)(xr + c0 + 32);
+  const float mean = wave_sum_rowln_order(((u.x + u.y) + (u.z + u.w)) + ((w.x + w.y) + (w.z + w.w))) / 512.0f;
+  float q = 0.f;
+  {
+    const float a = u.x - mean, b = u.y - mean, c = u.z - mean, d = u.w - mean;
+    q += (a * a + b * b) + (c * c + d * d);
+  }
+  {
+    const float a = w.x - mean, b = w.y - mean, c = w.z - mean, d = w.w - mean;
+    q += (a * a + b * b) + (c * c + d * d);
+  }
+  const float rstd = rsqrtf(wave_sum_rowln_order(q) / 512.0f + eps);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int c = c0 + 32 * j;
+    const float4 v = j ? w : u;
+    const float4 gm = *(const float4*)(gamma + c);
+    const float4 bt = *(const float4*)(beta + c);
+    const float ox = (v.x - mean) * rstd * gm.x + bt.x, oy = (v.y - mean) * rstd * gm.y + bt.y;
+    const float oz = (v.z - mean) * rstd * gm.z + bt.z, ow = (v.w - mean) * rstd * gm.w + bt.w;
+    if (y_f32) *(float4*)(y_f32 + (long)m * 512 + c) = make_float4(ox, oy, oz, ow);
+    if (y_act) Act<T>::st4(y_act, (long)m * 512 + c, ox, oy, oz, ow);
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const int* row_idx, const float* gamma,
                                                         const float* beta, float eps, int M, int H, T* y_act,
@@ -76,7 +123,11 @@ int launch_layernorm(int prec, const float* x, const int* row_idx, const float* 
     return 1;
   }
   dim3 grid(cdiv(M, 4)), block(256);
-  if (prec == PREC_BF16)
+  if (H == 512 && prec == PREC_BF16)
+    hipLaunchKernelGGL(layernorm512_kernel<bf16_t>, grid, block, 0, st, x, row_idx, gamma, beta, eps, M, (bf16_t*)y_act, y_f32);
+  else if (H == 512 && prec == PREC_F16)
+    hipLaunchKernelGGL(layernorm512_kernel<f16_t>, grid, block, 0, st, x, row_idx, gamma, beta, eps, M, (f16_t*)y_act, y_f32);
+  else if (prec == PREC_BF16)
     hipLaunchKernelGGL(layernorm_kernel<bf16_t>, grid, block, 0, st, x, row_idx, gamma, beta, eps, M, H,
                        (bf16_t*)y_act, y_f32);
   else if (prec == PREC_F16)

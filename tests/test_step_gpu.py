@@ -1044,3 +1044,33 @@ def test_odd_shapes_fast_engines_vs_f32_engine(B, L, K, filled):
             assert err.max() < tol, (prec, err.max())
         finally:
             su.engine.close()
+
+
+@pytest.mark.parametrize("prec", [BF16, FP16])
+def test_caption_does_not_depend_on_the_batch(prec):
+    """Images are independent (gen_utils.py:64-81 has no cross-image term): an image polished alone and inside a batch of
+    eight must produce the SAME caption, token for token and cosine for cosine, with no kernel switches -- although the
+    batch takes the full-row / ring GEMMs and the per-image attention kernel never runs at this size while the single
+    image takes the tiled GEMM + LayerNorm kernel.  Free-running over two sweeps (a single near-tie flip would show)."""
+    su = harness.build_synthetic(False, prec, regular_only=True)
+    try:
+        B, L, K, I = 8, 6, 200, 2
+        rng = np.random.default_rng(404)
+        emb = rng.standard_normal((B, 512)).astype(np.float32)
+        hp = Engine.hyper(0.02, 2.0, 0.1)
+        init = su.bert_tok.encode("Image of a" + su.bert_tok.mask_token * L)
+        pos, nm, every = harness.order_positions("sequential", L, I)
+        su.engine.set_image_embeds(emb)
+        su.engine.profile_reset()
+        ids, cos = su.engine.generate(B, init, L, SEED_LEN, K, pos, hp, n_mask=nm, snapshot_every=every)
+        rows_batch = su.engine.stats()["clip_rows"] / len(pos)
+        for b in (0, 5):
+            su.engine.set_image_embeds(emb[b:b + 1])
+            su.engine.profile_reset()
+            ids1, cos1 = su.engine.generate(1, init, L, SEED_LEN, K, pos, hp, n_mask=nm, snapshot_every=every)
+            rows_one = su.engine.stats()["clip_rows"] / len(pos)
+            np.testing.assert_array_equal(ids1[:, 0], ids[:, b])
+            np.testing.assert_array_equal(cos1[:, 0], cos[:, b])
+        assert rows_batch > 4096 > 2048 > rows_one, (rows_batch, rows_one)  # the two runs really took different kernels
+    finally:
+        su.engine.close()
