@@ -62,7 +62,9 @@ __device__ __forceinline__ float sum8_dpp(float v) {
   return v;
 }
 
-template <int ACT, bool OUT_F32, typename HT = bf16_t>
+// EPI (A/B experiments of the fp32 path): bit 0 = request the residual rows of block n+1 before block n is processed
+// (two residual register sets), bit 1 = non-temporal residual loads and output stores
+template <int ACT, bool OUT_F32, typename HT = bf16_t, int EPI = 0>
 __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x16_t (&acc)[4][2], unsigned char* patch, int m0,
                                               int n0, int wm, int wn, int lane) {
   const int half = lane >> 5;
@@ -103,6 +105,25 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x16_t (&acc)
       }
     } else {
       // fp32 output (+bias, +fp32 residual, optional bf16 copy): 32 rows x 32 columns per pass
+      auto load_resid = [&](int i, int j, float4 (&r)[4]) {
+        const int col = n0 + wn * 64 + j * 32 + rslot * 4;
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+          const int row = m0 + wm * 128 + i * 32 + pass * 8 + rrow;
+          r[pass] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (g.resid && row < g.M && col < g.N) {
+            const float* p = g.resid + (long)row * g.ldr + col;
+            if (EPI & 2) {
+              const f32x4_t t = __builtin_nontemporal_load((const f32x4_t*)p);
+              r[pass] = make_float4(t[0], t[1], t[2], t[3]);
+            } else {
+              r[pass] = *(const float4*)p;
+            }
+          }
+        }
+      };
+      float4 rnext[4];
+      if (EPI & 1) load_resid(0, 0, rnext);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -112,11 +133,12 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x16_t (&acc)
           if (g.bias && col < g.N) b4 = *(const float4*)(g.bias + col);
           // residual rows first: four independent 16-byte loads in flight across the LDS round trip
           float4 r4[4];
+          if (EPI & 1) {
 #pragma unroll
-          for (int pass = 0; pass < 4; ++pass) {
-            const int row = m0 + wm * 128 + i * 32 + pass * 8 + rrow;
-            r4[pass] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (g.resid && row < g.M && col < g.N) r4[pass] = *(const float4*)(g.resid + (long)row * g.ldr + col);
+            for (int pass = 0; pass < 4; ++pass) r4[pass] = rnext[pass];
+            if (i * 2 + j + 1 < 8) load_resid((i * 2 + j + 1) >> 1, (i * 2 + j + 1) & 1, rnext);
+          } else {
+            load_resid(i, j, r4);
           }
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
@@ -134,7 +156,10 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x16_t (&acc)
             v.x = act_fn<ACT>(v.x); v.y = act_fn<ACT>(v.y); v.z = act_fn<ACT>(v.z); v.w = act_fn<ACT>(v.w);
             v.x += r4[pass].x; v.y += r4[pass].y; v.z += r4[pass].z; v.w += r4[pass].w;
             if (row < g.M && col < g.N) {
-              if (g.out_f32) *(float4*)(g.out_f32 + (long)row * g.ldc + col) = v;
+              if (g.out_f32) {
+                if (EPI & 2) __builtin_nontemporal_store(f32x4_t{v.x, v.y, v.z, v.w}, (f32x4_t*)(g.out_f32 + (long)row * g.ldc + col));
+                else *(float4*)(g.out_f32 + (long)row * g.ldc + col) = v;
+              }
             }
             pk[pass] = make_uint2(Half<HT>::pack2(v.x, v.y), Half<HT>::pack2(v.z, v.w));
           }
@@ -406,7 +431,8 @@ __global__ __launch_bounds__(768) void gemm256q_kernel(GemmArgs g, int tiles_m, 
 // counted vmcnt just before that barrier (4 resp. 8 younger pieces may stay in flight).  At a tile end group 0 waits
 // one interval for group 1's last M, then both groups run the epilogue together; the ring runs on across tiles.
 // ================================================================================================
-// DBG (timing ablations only, results are garbage): 1 no MFMA, 2 no DMA, 4 no fragment reads, 8 no epilogue
+// DBG (timing ablations only, results are garbage): 1 no MFMA, 2 no DMA, 4 no fragment reads, 8 no epilogue;
+// 16 / 32: epilogue A/B forms (tile_epilogue EPI bits 0 / 1; results stay correct)
 template <int ACT, bool OUT_F32, bool F16 = false, int DBG = 0>
 __global__ __launch_bounds__(512) void gemm256x_kernel(GemmArgs g, int tiles_m, int tiles_n, int var) {
   using HT = std::conditional_t<F16, f16_t, bf16_t>;
@@ -557,7 +583,7 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(GemmArgs g, int tiles_m, 
 #pragma unroll
         for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[i][j]));
     } else {
-      tile_epilogue<ACT, OUT_F32, HT>(g, acc, smem + QS * QSTAGE + wave * 4096, m0, n0, grp, wn, lane);
+      tile_epilogue<ACT, OUT_F32, HT, (DBG >> 4) & 3>(g, acc, smem + QS * QSTAGE + wave * 4096, m0, n0, grp, wn, lane);
     }
   }
 }
@@ -1018,6 +1044,7 @@ int launch_gemm256(const GemmArgs& g, hipStream_t st) {
     break
     switch (g_w_dbg >> 8) {
       CZC_GOXD(1); CZC_GOXD(2); CZC_GOXD(3); CZC_GOXD(4); CZC_GOXD(5); CZC_GOXD(6); CZC_GOXD(8); CZC_GOXD(9); CZC_GOXD(10); CZC_GOXD(12); CZC_GOXD(14);
+      CZC_GOXD(16); CZC_GOXD(32); CZC_GOXD(48); CZC_GOXD(13); CZC_GOXD(7);
       default: snprintf(g_err, sizeof(g_err), "gemm256x: ablation %d not built", g_w_dbg >> 8); return 1;
     }
 #undef CZC_GOXD

@@ -41,7 +41,7 @@ def main(d):
         gui = c.get("GRBM_GUI_ACTIVE", 0.0)
         busy = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
         out[fam] = dict(launches=launches[fam], mfma_tflop=round(fl / 1e12, 3),
-                        mfma_busy_share_of_simd_cycles=None if not gui else round(busy / (1024.0 * gui / 8.0), 4)  # GRBM_GUI_ACTIVE is summed over the 8 XCDs,
+                        mfma_busy_share_of_simd_cycles=None if not gui else round(busy / (1024.0 * gui / 8.0), 4),  # GRBM_GUI_ACTIVE is summed over the 8 XCDs
                         gui_active_cycles=gui)
     clip = sum(v["mfma_tflop"] for k, v in out.items() if k in ("gemm_rowln", "gemm256x", "gemm256q", "gemm_wreg", "gemm_128_bf16"))
     print(json.dumps(dict(per_family=out, total_mfma_tflop=round(tot / 1e12, 3), clip_half_precision_gemm_tflop=round(clip, 3),
