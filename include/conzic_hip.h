@@ -59,8 +59,9 @@ extern "C" {
                          /* through the single-pass fp16 text tower (CZC_PREC_FP16 speed), then the candidates that carry the     */
                          /* softmax_K mass (p_k > 4 / (beta * exp(logit_scale)), the two best fused scores, and a mass-stratified  */
                          /* sample of the rest that measures the screening tower's mean error) are re-encoded by the split-fp16   */
-                         /* tower and the scores are formed from the mixed cosines: fused score inside 1e-3 (measured <= 5e-4 on   */
-                         /* the goldens) at about twice the CZC_PREC_SPLIT throughput.  Vision tower and BERT: split-fp16.          */
+                         /* tower and the scores are formed from the mixed cosines: fused score inside 1e-3 (measured 6.3e-4 worst */
+                         /* on the goldens, 5.5e-4 over 256 k more candidates) at 1.8x the CZC_PREC_SPLIT throughput.  Vision tower */
+                         /* and BERT: split-fp16.  Options "refine_samples" (12) / "refine_theta_x1000" (4000) tune the selection.  */
 #define CZC_MAX_TOPK 1024
 #define CZC_MAX_BERT_LEN 64
 
@@ -218,7 +219,9 @@ int czc_generate(czc_engine* e, int B, int T, int L, int seed_len, const int32_t
  *   "pool_last_layer" (1) last CLIP-text layer: out-projection + MLP on the EOS rows only
  *   "fuse_ln"         (1) bf16 / fp16 CLIP-text tower at >= 4096 packed rows: the out-projection runs as a full-row
  *                         kernel that also emits LN2 of its result (no LayerNorm pass for it); 2 = fc2 -> the next
- *                         layer's LN1 as well (measured slower), 0 = off */
+ *                         layer's LN1 as well (measured slower), 0 = off
+ *   "refine_samples" (12), "refine_theta_x1000" (4000): CZC_PREC_REFINE selection -- strata of the mass-stratified sample
+ *                         and the softmax_K mass threshold theta = value / 1000 / (beta * exp(logit_scale)) */
 int czc_set_option(czc_engine* e, const char* name, int value);
 
 /* ---- measurement ------------------------------------------------------------------------- */
