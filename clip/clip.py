@@ -23,6 +23,26 @@ def _wrap(a: np.ndarray):
         return a
 
 
+def _fingerprint(im):
+    """Cheap content key of an image object for the one-entry embed cache: geometry, pixel type and a fixed subsample of
+    the pixels (257 values / 64 points).  None for objects it does not know (those are encoded on every call, like
+    the reference does, gen_utils.py:58)."""
+    try:
+        if isinstance(im, np.ndarray):
+            flat = im.reshape(-1)
+            step = max(1, flat.size // 257)
+            return ("nd", im.shape, str(im.dtype), flat[::step][:257].tobytes())
+        if hasattr(im, "getpixel") and hasattr(im, "size") and hasattr(im, "mode"):  # PIL.Image
+            w, h = im.size
+            if w <= 0 or h <= 0:
+                return None
+            pts = [((i * 37 + 11) % w, (i * 53 + 7) % h) for i in range(64)]
+            return ("pil", (w, h), im.mode, tuple(im.getpixel(p) for p in pts))
+    except Exception:
+        return None
+    return None
+
+
 class ImageEmbeds:
     """Image embeddings computed earlier (`CLIP.compute_image_representation_from_image_instance`), handed back in
     place of the images: the north star's "ViT image encode once per image, cached" across `samples_num` passes
@@ -110,19 +130,30 @@ class CLIP:
         # one-entry cache on the identity of the image objects: the same PIL image(s) polished again
         # (demo.py:83 loops samples_num times over one image) are encoded once
         imgs = image if isinstance(image, (list, tuple)) else [image]
-        key = tuple(id(im) for im in imgs)
+        # identity alone would serve stale embeddings to a caller that refills the same buffer / PIL object in place:
+        # the key also carries a content fingerprint (size, mode / dtype and a fixed pixel subsample); objects that
+        # cannot be fingerprinted are never cached
+        prints = [_fingerprint(im) for im in imgs]
+        key = None if any(fp is None for fp in prints) else tuple((id(im), fp) for im, fp in zip(imgs, prints))
         cached = getattr(self, "_img_cache", None)
+        if key is None:
+            self._img_cache = None
+            emb = self._encode_images_uncached(image)
+            self._last_embeds = np.ascontiguousarray(np.asarray(emb, dtype=np.float32))
+            return emb
         if cached is not None and cached[0] == key and all(a is b for a, b in zip(cached[1], imgs)):
             self._eng().set_image_embeds(cached[2])
+            self._last_embeds = cached[2]
             return _wrap(cached[2])
         emb = self._encode_images_uncached(image)
         self._img_cache = (key, list(imgs), np.ascontiguousarray(np.asarray(emb, dtype=np.float32)))
+        self._last_embeds = self._img_cache[2]
         return emb
 
     def last_image_embeds(self):
         """fp32 [B, proj] of the most recent image encode (to be handed back as `ImageEmbeds` on later samples)."""
-        cached = getattr(self, "_img_cache", None)
-        return None if cached is None else cached[2].copy()
+        last = getattr(self, "_last_embeds", None)
+        return None if last is None else last.copy()
 
     def _encode_images_uncached(self, image):
         if self.processor is not None:

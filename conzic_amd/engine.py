@@ -98,11 +98,13 @@ class Engine:
         """A second engine on the same GPU over the SAME weights (czc_replicate): own stream, workspace, image
         embeddings and tables.  Every setter call made on this engine so far is replayed on it, later ones are
         forwarded.  Closed with (before) its parent."""
-        if self._parent is not None:
-            return self._parent.replica()
+        parent = self._parent() if self._parent is not None else None
+        if parent is not None:
+            return parent.replica()
         r = object.__new__(Engine)
         r.lib, r.cfg, r.bert_cfg, r.clip_cfg, r.precision = self.lib, self.cfg, self.bert_cfg, self.clip_cfg, self.precision
-        r._keep, r._replay, r._replicas, r._parent = [], {}, [], self
+        import weakref
+        r._keep, r._replay, r._replicas, r._parent = [], {}, [], weakref.ref(self)  # no parent <-> replica cycle: both have __del__
         h = C.c_void_p()
         self._ck(self.lib.czc_replicate(self.h, C.byref(h)), "czc_replicate")
         r.h = h

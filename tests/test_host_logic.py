@@ -278,3 +278,20 @@ def test_bench_gpus_n_never_falls_back_to_fewer_gpus():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--no-cpu-baseline"],
                        capture_output=True, text=True, timeout=300, env=env2, cwd=root)
     assert r.returncode != 0 and "WORLD_SIZE=4 but --gpus 2" in r.stderr
+
+
+def test_image_cache_key_follows_the_pixels_not_only_the_object():
+    """The drop-in CLIP caches the last batch's embeddings per image OBJECT (demo.py:83 polishes one image samples_num
+    times); a caller that refills the same buffer in place must not get the old embeddings back."""
+    from PIL import Image
+    from clip.clip import _fingerprint
+    a = np.zeros((40, 30, 3), np.uint8)
+    k0 = _fingerprint(a)
+    a[:] = 7                       # same object, new pixels
+    assert _fingerprint(a) != k0
+    im = Image.new("RGB", (33, 21), (1, 2, 3))
+    k1 = _fingerprint(im)
+    assert k1 == _fingerprint(im)
+    im.paste((9, 9, 9), (0, 0, 33, 21))
+    assert _fingerprint(im) != k1
+    assert _fingerprint(object()) is None   # unknown objects are never cached
