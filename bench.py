@@ -342,11 +342,14 @@ def main():
         # HBM bytes per launch come from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same
         # command (not measurable inside the run); only quoted for the workload and precision they were taken on
         traffic, src = None, None
-        tp = os.path.join(ROOT, "profiles", "r02_bench_gemm_traffic.json")
-        key = {native.PREC_BF16: "bf16", native.PREC_SPLIT: "split"}.get(prec_)
+        tp = os.path.join(ROOT, "profiles", "r03_bench_gemm_traffic.json")
+        key = {native.PREC_BF16: "bf16", native.PREC_REFINE: "refine"}.get(prec_)
         if key and os.path.exists(tp) and (B, L, K, I, a.order, a.gamma) == (256, 10, 200, 10, "sequential", None):
-            traffic = json.load(open(tp))[key]["hbm_bytes_per_launch"]
-            src = "profiles/r02_bench_gemm_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this workload)"
+            tj = json.load(open(tp))
+            if key in tj:
+                traffic = tj[key]["hbm_bytes_per_launch"]
+                src = ("profiles/r03_bench_gemm_traffic.json (tools/probes/pmc_bench_traffic.sh: separate rocprofv3 --pmc FETCH_SIZE / "
+                       "WRITE_SIZE passes over one caption batch of this workload, gfx950 FETCH_SIZE x2 correction)")
         fused = not any(kv.replace(" ", "") == "fuse_ln=0" for kv in a.opt)
         half = ("CLIP-text linear layers: czc::gemm_wreg_kernel<%s> (qkv, fc1; weights in registers) + "
                 + ("czc::gemm_rowln_kernel<%s> (out-proj on full 512-wide rows; its launches also do the LayerNorm that follows -- "

@@ -3,14 +3,14 @@
 # usage: pmc_bench_traffic.sh ["bf16 2.6592" "split 4.6052" ...]   (default: both)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 export CZC_NORMAL_EXIT=1
-[ $# -eq 0 ] && set -- "bf16 2.6592" "split 4.6052"
+[ $# -eq 0 ] && set -- "bf16 2.6592" "refine 4.6052"
 NAMES=""
 for MODE in "$@"; do
   P=${MODE% *}; S=${MODE#* }
   NAMES="$NAMES $P"
   for C in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --kernel-trace --pmc $C --output-format csv -d gpurun_out/pmc_traffic -o ${P}_$C -- \
-      python bench.py --precision $P --logit-scale $S --steps 1 --warmup 0 --no-cpu-baseline --no-profile --no-alt --no-invariance \
+      python bench.py --streams 1 --precision $P --logit-scale $S --steps 1 --warmup 0 --no-cpu-baseline --no-profile --no-alt --no-invariance \
       > gpurun_out/pmc_traffic_${P}_$C.log 2>&1
   done
 done

@@ -8,12 +8,12 @@ import json
 import sys
 from collections import defaultdict
 
-FAMILIES = [("gemm_rowln", "gemm_rowln_kernel"), ("gemm256q", "gemm256q_kernel"), ("gemm256sq", "gemm256sq_kernel"),
+FAMILIES = [("gemm_rowln", "gemm_rowln_kernel"), ("gemm256x", "gemm256x_kernel"), ("gemm256q", "gemm256q_kernel"), ("gemm256sq", "gemm256sq_kernel"),
             ("gemm_wreg", "gemm_wreg_kernel"), ("gemm_split_128", "gemm_kernel<czc::split_t"),
             ("layernorm", "layernorm_kernel"), ("attention_image", "attention_image_kernel"),
             ("attention_branch_split", "attention_branch_split_kernel")]
-GEMM_TEXT = {"bf16": ("gemm_rowln", "gemm256q", "gemm_wreg"), "fp16": ("gemm_rowln", "gemm256q", "gemm_wreg"),
-             "split": ("gemm256sq",)}
+GEMM_TEXT = {"bf16": ("gemm_rowln", "gemm256x", "gemm256q", "gemm_wreg"), "fp16": ("gemm_rowln", "gemm256x", "gemm256q", "gemm_wreg"),
+             "refine": ("gemm_rowln", "gemm256x", "gemm256q", "gemm_wreg", "gemm256sq"), "split": ("gemm256sq",)}
 
 
 def family(name):
