@@ -354,8 +354,8 @@ def main():
         half = ("CLIP-text linear layers: czc::gemm_wreg_kernel<%s> (qkv, fc1; weights in registers) + "
                 + ("czc::gemm_rowln_kernel<%s> (out-proj on full 512-wide rows; its launches also do the LayerNorm that follows -- "
                    "without that fusion the same family measures frac 0.344 and 1.3 %% fewer captions/s, profiles/r02_fuse_ln_ab.json) + "
-                   "czc::gemm256q_kernel<%s> (fc2; 256x256 LDS-DMA ring)" if fused else
-                   "czc::gemm256q_kernel<%s> (out-proj, fc2; 256x256 LDS-DMA ring)"))
+                   "czc::gemm256x_kernel<%s> (fc2; 256x256 LDS-DMA ring, two wave groups one phase apart)" if fused else
+                   "czc::gemm256x_kernel<%s> (out-proj, fc2; 256x256 LDS-DMA ring, two wave groups one phase apart)"))
         kern = {native.PREC_BF16: half % (("bf16",) * (3 if fused else 2)),
                 native.PREC_FP16: half % (("fp16",) * (3 if fused else 2)),
                 native.PREC_SPLIT: "CLIP-text linear layers: czc::gemm256sq_kernel (split-fp16 operands, 256x256 LDS-DMA ring, three "

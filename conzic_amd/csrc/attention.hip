@@ -910,7 +910,7 @@ __global__ __launch_bounds__(256) void attention_image_kernel(const bf16_t* qkv,
         const u32x2_t sy = __builtin_amdgcn_permlane32_swap(w[qa].y, w[qa + 2].y, false, false);
         const u32x4_t d = {sx.x, sy.x, sx.y, sy.y};  // lower half-wave: quad qa, dims 0..7; upper: quad qa+2
         const unsigned co = (unsigned)(l31 * opitch + (h * 64 + dt * 32 + 8 * (qa + 2 * half)) * 2);
-        asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" : : "v"(d), "v"(co), "s"(rc) : "memory");
+        asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" : : "v"(d), "v"(co), "s"(rc) : "memory");
       }
     }
   }

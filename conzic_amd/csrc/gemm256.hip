@@ -187,6 +187,88 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x16_t (&acc)
 }
 
 
+// fp32-residual epilogue with every VMEM instruction in inline asm and COUNTED waits.  tile_epilogue's compiler-scheduled
+// form waits `vmcnt(0)` for each block's residual rows (the loads sit behind bounds branches, hipcc cannot count across
+// them), and vmcnt retires loads and stores in order: every block therefore also waits until the PREVIOUS block's stores
+// have reached memory -- eight load-latency + store-latency round trips per tile and wave, ~20 us of a 95 us fc2 tile.
+// Here the residual rows of block n+1 are requested before block n's stores are issued, so the wait for block n
+// (vmcnt = stores of n-1 + loads of n+1 still allowed in flight) never includes a store; rows / columns past the edge
+// are handled by the buffer descriptors (reads return 0, writes are dropped), so there are no branches.
+// Same arithmetic, same order (acc + bias, + residual) as tile_epilogue: bit-identical results.  NJ = 32-column blocks per wave.
+template <int NJ>
+__device__ __forceinline__ void tile_epilogue_f32_asm(const GemmArgs& g, f32x16_t (&acc)[4][NJ], unsigned char* patch, int m0, int n0,
+                                                      int wm, int wcol0, int lane) {
+  const int half = lane >> 5, l31 = lane & 31, rrow = lane >> 3, rslot = lane & 7;
+  const int rows = min(TM, g.M - m0);
+  auto desc = [&](const void* base, int ld, int n_rows) {
+    const unsigned long long pa = (unsigned long long)base + (unsigned long long)m0 * ld * 4;
+    u32x4_t r;
+    r.x = __builtin_amdgcn_readfirstlane((unsigned)pa);
+    r.y = __builtin_amdgcn_readfirstlane((unsigned)(pa >> 32) & 0xffffu);
+    r.z = __builtin_amdgcn_readfirstlane((unsigned)(n_rows * ld * 4));
+    r.w = 0x00020000u;
+    return r;
+  };
+  const u32x4_t rsR = desc(g.resid, g.ldr, rows), rsO = desc(g.out_f32, g.ldc, rows);
+  u32x4_t rsB;
+  {
+    const unsigned long long pb = (unsigned long long)g.bias;
+    rsB.x = __builtin_amdgcn_readfirstlane((unsigned)pb);
+    rsB.y = __builtin_amdgcn_readfirstlane((unsigned)(pb >> 32) & 0xffffu);
+    rsB.z = __builtin_amdgcn_readfirstlane((unsigned)(g.bias ? g.N * 4 : 0));  // no bias: every read returns 0
+    rsB.w = 0x00020000u;
+  }
+  asm volatile("s_nop 4" ::: "memory");  // descriptors fresh from v_readfirstlane -> buffer_* inside asm strings
+  constexpr int NB = 4 * NJ;
+  auto colof = [&](int blk) { return n0 + wcol0 + (blk % NJ) * 32 + rslot * 4; };
+  auto off = [&](int blk, int pass, int ld) -> unsigned {
+    const int col = colof(blk);
+    const int row = wm * 128 + (blk / NJ) * 32 + pass * 8 + rrow;
+    return col < g.N ? (unsigned)((row * ld + col) * 4) : 0x7ffffff0u;
+  };
+  f32x4_t bias4[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int col = colof(j);
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(bias4[j]) : "v"(col < g.N ? (unsigned)(col * 4) : 0x7ffffff0u), "s"(rsB) : "memory");
+  }
+  f32x4_t rr[2][4];
+  auto load_resid = [&](int blk, f32x4_t (&r)[4]) {
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass)
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(r[pass]) : "v"(off(blk, pass, g.ldr)), "s"(rsR) : "memory");
+  };
+  load_resid(0, rr[0]);
+#pragma unroll
+  for (int blk = 0; blk < NB; ++blk) {
+    const int i = blk / NJ, j = blk % NJ;
+    if (blk + 1 < NB) load_resid(blk + 1, rr[(blk + 1) & 1]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int slot = (2 * q + half) ^ (l31 & 7);
+      *(float4*)(patch + l31 * 128 + slot * 16) =
+          make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+    }
+    f32x4_t(&r)[4] = rr[blk & 1];
+    // residual rows of this block (and, first time round, the bias) have landed: younger = stores of block blk-1, loads of blk+1
+    if (blk == 0 || blk + 1 == NB)
+      asm volatile("s_waitcnt vmcnt(4)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(bias4[j]) : : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(8)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(bias4[j]) : : "memory");
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const int rw = pass * 8 + rrow;
+      const float4 t = *(const float4*)(patch + rw * 128 + ((rslot ^ (rw & 7)) << 4));
+      f32x4_t v;
+      v[0] = t.x + bias4[j][0]; v[1] = t.y + bias4[j][1]; v[2] = t.z + bias4[j][2]; v[3] = t.w + bias4[j][3];
+      v[0] += r[pass][0]; v[1] += r[pass][1]; v[2] += r[pass][2]; v[3] += r[pass][3];
+      // s_nop 1: a > 64-bit asm store must not be followed at once by a write of its data registers (hipcc pads its own
+      // stores, not an asm string: without it some lanes stored the next instruction's operands)
+      asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" : : "v"(v), "v"(off(blk, pass, g.ldc)), "s"(rsO) : "memory");
+    }
+  }
+}
+
 // Split-fp16 activation output (qkv / fc1 of the split engine): same 32x32 fp32 round trip through the patch as the
 // fp32 path, then lanes rslot / rslot^1 swap one 4-column piece per pass pair so that every lane holds the 8
 // consecutive columns of one split_t group (16 bytes of fp16 hi parts followed by 16 bytes of lo parts).
@@ -583,7 +665,14 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(GemmArgs g, int tiles_m, 
 #pragma unroll
         for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[i][j]));
     } else {
-      tile_epilogue<ACT, OUT_F32, HT, (DBG >> 4) & 3>(g, acc, smem + QS * QSTAGE + wave * 4096, m0, n0, grp, wn, lane);
+      if constexpr (OUT_F32 && ACT == ACT_NONE) {
+        if (!(var & 8) && g.resid && g.out_f32 && !g.out_act)
+          tile_epilogue_f32_asm<2>(g, acc, smem + QS * QSTAGE + wave * 4096, m0, n0, grp, wn * 64, lane);
+        else
+          tile_epilogue<ACT, OUT_F32, HT, (DBG >> 4) & 3>(g, acc, smem + QS * QSTAGE + wave * 4096, m0, n0, grp, wn, lane);
+      } else {
+        tile_epilogue<ACT, OUT_F32, HT, (DBG >> 4) & 3>(g, acc, smem + QS * QSTAGE + wave * 4096, m0, n0, grp, wn, lane);
+      }
     }
   }
 }
@@ -979,7 +1068,7 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(GemmArgs g, const float
 }  // namespace
 
 int g_gemm256_min_m = 2048;
-int g_w_dbg = 0;  // gemm256x A/B switches (test option w_dbg): bit0 no s_setprio, bit1 DMA after the fragment reads; bits 8.. timing ablations
+int g_w_dbg = 0;  // gemm256x A/B switches (test option w_dbg): bit0 no s_setprio, bit1 DMA after the fragment reads, bit3 compiler-scheduled fp32 epilogue instead of the asm-counted one; bits 8.. timing ablations
 
 // x <- x + A.W^T + b with y = LayerNorm(x) from the same launch (gemm_rowln_kernel): N = 512 rows only.
 int g_rowln_min_m = 4096;

@@ -183,7 +183,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, 
     const u32x4_t t4 = *(const u32x4_t*)(patch + r * 64 + ((rs ^ (x >> 1)) << 4));
     const u32x4_t sw = {t4.z, t4.w, t4.x, t4.y};
     const u32x4_t d = (x & 1) ? sw : t4;
-    asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" : : "v"(d), "v"(pass ? coff1 : coff0), "s"(rsC) : "memory");
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" : : "v"(d), "v"(pass ? coff1 : coff0), "s"(rsC) : "memory");
   };
   // block in ring slot `slot`: 8 groups of 4 MFMAs (fragments of group s+1 are read during group s), one
   // auxiliary step pinned after each group.  VMEM order per block: D0 D1 D2 S0 D3 S1.
