@@ -132,10 +132,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, int tiles_m, int 
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE_BYTES];
   // split-K launch (gridDim.y > 1): slice z multiplies k in [z*kchunk, (z+1)*kchunk) into its own fp32 slab
   // out_f32 + z*M*ldc (no bias / activation / residual: splitk_reduce_kernel adds them in a fixed order)
+  int kshift = 0;  // bytes the operand bases are moved into their rows (split-K): the descriptors still end where the rows end
   if (gridDim.y > 1) {
     const int z = blockIdx.y;
-    g.A = (const unsigned char*)g.A + (size_t)z * kchunk * sizeof(T);
-    g.W = (const unsigned char*)g.W + (size_t)z * kchunk * sizeof(T);
+    kshift = z * kchunk * (int)sizeof(T);
+    g.A = (const unsigned char*)g.A + (size_t)kshift;
+    g.W = (const unsigned char*)g.W + (size_t)kshift;
     g.out_f32 += (size_t)z * g.M * g.ldc;
     g.K = kchunk;
   }
@@ -159,9 +161,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, int tiles_m, int 
   // 32-bit and linear in the staging index (no per-row pointer arrays -> no scratch).
   const int lda_b = g.lda * (int)sizeof(T), ldw_b = g.ldw * (int)sizeof(T);
   const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)((const unsigned char*)g.A + (long)m0 * lda_b), (short)0,
-                                                     min(BM, g.M - m0) * lda_b, 0x00020000);
+                                                     min(BM, g.M - m0) * lda_b - kshift, 0x00020000);
   const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)((const unsigned char*)g.W + (long)n0 * ldw_b), (short)0,
-                                                     min(BN, g.N - n0) * ldw_b, 0x00020000);
+                                                     min(BN, g.N - n0) * ldw_b - kshift, 0x00020000);
   // staging map: thread t moves chunk (t&7) of rows (t>>3) + 32*i, i = 0..3, of both tiles
   const int sc = tid & 7, sr = tid >> 3;
   const int voA = sr * lda_b + sc * 16, voW = sr * ldw_b + sc * 16;
