@@ -938,12 +938,13 @@ int launch_attention_shared(const void* qkv, const SegTable& tab, int B, int K, 
   // chip (a single image would leave 2 work-groups doing 40 groups each; the per-group kernel spreads those)
   if (g_use_attention_image && heads % 4 == 0 && max_keys <= 32 && K <= 1024 &&
       (B * (heads / 4) >= 128 || g_use_attention_image == 2)) {
-    static bool attr = false;
-    if (!attr) {
+    // one-time set-up behind a function-local static (two engines launch from two host threads)
+    static const LaunchInit init = launch_init([](LaunchInit&) -> int {
       CZC_HIP_CHECK(hipFuncSetAttribute((const void*)attention_image_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, A2_LDS));
       CZC_HIP_CHECK(hipFuncSetAttribute((const void*)attention_image_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, A2_LDS));
-      attr = true;
-    }
+      return 0;
+    });
+    if (init.rc) return launch_init_failed("attention_image");
     if (f16) hipLaunchKernelGGL(attention_image_kernel<f16_t>, dim3(B, heads / 4), dim3(256), A2_LDS, st, (const bf16_t*)qkv, tab, B,
                                 K, G, heads, scale, (bf16_t*)out);
     else hipLaunchKernelGGL(attention_image_kernel<bf16_t>, dim3(B, heads / 4), dim3(256), A2_LDS, st, (const bf16_t*)qkv, tab, B, K,
