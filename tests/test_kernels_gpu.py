@@ -552,3 +552,33 @@ def test_weight_stationary_gemm_serves_every_row_count(act):
     C = E.test_gemm(BF16, A, W, bias=bias, act=act, typed_out=True)
     for m in (1, 31, 100, 2047):
         np.testing.assert_array_equal(E.test_gemm(BF16, A[:m], W, bias=bias, act=act, typed_out=True), C[:m])
+
+
+def test_kernel_families_agree_bitwise_on_random_shapes():
+    """Stress form of the three tests above: 24 random (M, N, K) with ragged edges, fp32-residual layer through the tiled
+    kernel, the loader-wave ring kernel and the ping-pong ring kernel (asm-counted epilogue), twice each: bit-identical
+    across kernels and across repetitions (a mis-counted wait or an unpadded hazard shows up as a few wrong lanes on some
+    launches, not as rounding noise)."""
+    lib = native.load()
+    rng = np.random.default_rng(20260929)
+    try:
+        assert lib.czc_test_set_option(b"gemm256_min_m", 1) == 0
+        for it in range(24):
+            M = int(rng.integers(1, 3000)) if it % 3 else int(rng.integers(3000, 40000))
+            N = int(rng.choice([512, 512, 1024, 320, 768, 256, 8 * int(rng.integers(1, 120))]))
+            K = 64 * int(rng.integers(1, 33))
+            A = rng.standard_normal((M, K)).astype(np.float32)
+            W = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
+            bias = rng.standard_normal(N).astype(np.float32) if it % 2 else None
+            R = rng.standard_normal((M, N)).astype(np.float32)
+            ref = None
+            for variant in (0, 3, 5, 5):
+                assert lib.czc_test_set_option(b"gemm256", variant) == 0
+                out = E.test_gemm(BF16, A, W, bias=bias, resid=R)
+                if ref is None:
+                    ref = out
+                else:
+                    np.testing.assert_array_equal(out, ref, err_msg=f"variant {variant} M={M} N={N} K={K}")
+    finally:
+        lib.czc_test_set_option(b"gemm256", 1)
+        lib.czc_test_set_option(b"gemm256_min_m", 2048)
