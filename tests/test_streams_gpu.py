@@ -13,7 +13,7 @@ from goldutil import load_case
 
 pytestmark = pytest.mark.gpu
 SEED_LEN = 4
-BF16, F32, SPLIT = native.PREC_BF16, native.PREC_F32, native.PREC_SPLIT
+BF16, F32, SPLIT, REFINE = native.PREC_BF16, native.PREC_F32, native.PREC_SPLIT, native.PREC_REFINE
 
 
 def _setup(meta, prec):
@@ -24,7 +24,8 @@ def _setup(meta, prec):
     return su
 
 
-@pytest.mark.parametrize("name,prec", [("full_scale100", SPLIT), ("full_senti", SPLIT), ("full_pos", SPLIT), ("tiny_shuffle", F32)])
+@pytest.mark.parametrize("name,prec", [("full_scale100", SPLIT), ("full_scale100", REFINE), ("full_senti", SPLIT), ("full_senti", REFINE),
+                                       ("full_pos", SPLIT), ("tiny_shuffle", F32)])
 def test_two_streams_reproduce_the_reference_trajectory(name, prec):
     """One image per stream (min_images = 1): the golden snapshots of the imported reference come back id for id,
     including the sentiment / POS tables that have to reach the replica (setter replay)."""
