@@ -369,9 +369,13 @@ __global__ __launch_bounds__(256) void attention_branch_kernel(const bf16_t* qkv
   int h = blockIdx.y * wpb + wave;
   const bool live = h < heads;
   if (!live) h = heads - 1;
-  const int gpi = (K + G - 1) / G;  // groups per image
-  const int b = blockIdx.x / gpi, k0 = (blockIdx.x - b * gpi) * G;
-  const int Gc = min(G, K - k0);
+  const int gpi = (K + G - 1) / G;  // groups per image the grid provides (G = the batch-wide packing factor)
+  const int b = blockIdx.x / gpi;
+  // this image's own packing factor: its arithmetic must not depend on the other images of the batch
+  const int Gb = tab.img_max ? 32 / max(1, tab.img_max[b]) : G;
+  const int k0 = (blockIdx.x - b * gpi) * Gb;
+  if (k0 >= K) return;  // Gb >= G: an image with short branches needs fewer groups than the grid provides
+  const int Gc = min(Gb, K - k0);
   const int s0 = B + b * K + k0;
   const int pre_off = tab.pre_off[s0], pre_len = tab.pre_len[s0];
   const int r0 = tab.own_off[s0];
@@ -535,8 +539,11 @@ __global__ __launch_bounds__(256) void attention_branch_split_kernel(const split
   const bool live = h < heads;
   if (!live) h = heads - 1;
   const int gpi = (K + G - 1) / G;
-  const int b = blockIdx.x / gpi, k0 = (blockIdx.x - b * gpi) * G;
-  const int Gc = min(G, K - k0);
+  const int b = blockIdx.x / gpi;
+  const int Gb = tab.img_max ? 32 / max(1, tab.img_max[b]) : G;  // per image, as in attention_branch_kernel
+  const int k0 = (blockIdx.x - b * gpi) * Gb;
+  if (k0 >= K) return;
+  const int Gc = min(Gb, K - k0);
   const int s0 = B + b * K + k0;
   const int pre_off = tab.pre_off[s0], pre_len = tab.pre_len[s0];
   const int r0 = tab.own_off[s0];
@@ -768,9 +775,10 @@ __global__ __launch_bounds__(256) void attention_image_kernel(const bf16_t* qkv,
     rs.w = 0x00020000u;
     return rs;
   };
-  const int ngroups = (K + G - 1) / G;
+  const int Gb = tab.img_max ? 32 / max(1, __builtin_amdgcn_readfirstlane(tab.img_max[b])) : G;  // this image's own packing factor
+  const int ngroups = (K + Gb - 1) / Gb;
   auto issue_group = [&](int gi) {
-    const int k0 = gi * G, Gc = min(G, K - k0);
+    const int k0 = gi * Gb, Gc = min(Gb, K - k0);
     const int r0 = __builtin_amdgcn_readfirstlane(meta[k0]);
     const int n_own = min(__builtin_amdgcn_readfirstlane(meta[k0 + Gc]) - r0, 32);
     const u32x4_t rs = rows_desc(r0, n_own);
@@ -802,7 +810,7 @@ __global__ __launch_bounds__(256) void attention_image_kernel(const bf16_t* qkv,
     asm volatile("" ::: "memory");
     if (gi + 1 < ngroups) issue_group(gi + 1);
 
-    const int k0 = gi * G, Gc = min(G, K - k0);
+    const int k0 = gi * Gb, Gc = min(Gb, K - k0);
     const int r0 = __builtin_amdgcn_readfirstlane(meta[k0]);
     const int n_own = min(__builtin_amdgcn_readfirstlane(meta[k0 + Gc]) - r0, 32);
     const unsigned char* Qs = ring + (gi & 1) * A2_STAGE;

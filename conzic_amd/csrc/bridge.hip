@@ -205,7 +205,7 @@ int launch_scan(const int* len, int n, int* off, int* totals, hipStream_t st) {
 // identical across the K candidates of an image, so that prefix is encoded once.
 __global__ __launch_bounds__(256) void prefix_plan_kernel(const int* cids, const int* clen, int B, int K, int share,
                                                           int* own_len, int* pre_len, int* seg_src, int* seg_pos0,
-                                                          int* max_len_out) {
+                                                          int* max_len_out, int* img_max) {
   __shared__ int s_p, s_max;
   const int b = blockIdx.x, tid = threadIdx.x;
   if (tid == 0) { s_p = 1 << 30; s_max = 0; }
@@ -230,6 +230,7 @@ __global__ __launch_bounds__(256) void prefix_plan_kernel(const int* cids, const
     own_len[b] = pb; pre_len[b] = 0; seg_src[b] = b * K; seg_pos0[b] = 0;
     atomicMax(max_len_out, s_max);
     atomicMax(max_len_out + 1, s_max - pb);  // longest branch (own rows of one candidate)
+    if (img_max) img_max[b] = s_max - pb;
   }
   for (int k = tid; k < K; k += blockDim.x) {
     const int s = B + b * K + k;
@@ -241,9 +242,9 @@ __global__ __launch_bounds__(256) void prefix_plan_kernel(const int* cids, const
 }
 
 int launch_prefix_plan(const int* clip_ids, const int* clip_len, int B, int K, int share, int* own_len, int* pre_len,
-                       int* seg_src, int* seg_pos0, int* max_len_out, hipStream_t st) {
+                       int* seg_src, int* seg_pos0, int* max_len_out, int* img_max, hipStream_t st) {
   hipLaunchKernelGGL(prefix_plan_kernel, dim3(B), dim3(256), 0, st, clip_ids, clip_len, B, K, share, own_len, pre_len,
-                     seg_src, seg_pos0, max_len_out);
+                     seg_src, seg_pos0, max_len_out, img_max);
   CZC_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -276,8 +277,11 @@ int launch_prefix_finish(const int* own_off, const int* own_len, int B, int K, i
 // the prefix length of the screening plan.
 __global__ __launch_bounds__(256) void refine_plan_kernel(const int* clen, const int* trunk_len, const int* list, const int* count,
                                                           const int* count_off, const int* kr, int B, int K, int* own_len, int* pre_len,
-                                                          int* seg_src, int* seg_pos0, int* rlist, int* max_len_out) {
+                                                          int* seg_src, int* seg_pos0, int* rlist, int* max_len_out, int* img_max) {
+  __shared__ int s_mxb;
   const int b = blockIdx.x, tid = threadIdx.x;
+  if (tid == 0) s_mxb = 0;
+  __syncthreads();
   const int n = count[b], o = count_off[b], Kr = *kr;
   const int pb = n > 0 ? trunk_len[b] : 0;
   if (tid == 0) { own_len[b] = pb; pre_len[b] = 0; seg_src[b] = b * K; seg_pos0[b] = 0; }
@@ -298,14 +302,16 @@ __global__ __launch_bounds__(256) void refine_plan_kernel(const int* clen, const
     mx = max(mx, len);
     mxb = max(mxb, len - pb);
   }
-  if (mx) { atomicMax(max_len_out, mx); atomicMax(max_len_out + 1, mxb); }
+  if (mx) { atomicMax(max_len_out, mx); atomicMax(max_len_out + 1, mxb); atomicMax(&s_mxb, mxb); }
+  __syncthreads();
+  if (tid == 0 && img_max) img_max[b] = s_mxb;
 }
 
 int launch_refine_plan(const int* clip_len, const int* trunk_len, const int* list, const int* count, const int* count_off,
                        const int* kr_dev, int B, int K, int* own_len, int* pre_len, int* seg_src, int* seg_pos0, int* rlist,
-                       int* max_len_out, hipStream_t st) {
+                       int* max_len_out, int* img_max, hipStream_t st) {
   hipLaunchKernelGGL(refine_plan_kernel, dim3(B), dim3(256), 0, st, clip_len, trunk_len, list, count, count_off, kr_dev, B, K, own_len,
-                     pre_len, seg_src, seg_pos0, rlist, max_len_out);
+                     pre_len, seg_src, seg_pos0, rlist, max_len_out, img_max);
   CZC_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -395,7 +395,7 @@ int mlm_head(czc_engine* e, int B, int T, int gen_idx, float** logits_out) {
 // (trunk segment) and every candidate only carries the rows from its first differing token on.
 // Two halves around the step's single host round trip (32 bytes of totals: rows, longest sequence, overflow):
 // clip_plan builds the segment table on the device and starts the read, clip_tower runs on the sizes it returned.
-struct PlanBufs { int *own_len, *pre_len, *src, *pos0, *own_off, *pre_off, *eidx; };
+struct PlanBufs { int *own_len, *pre_len, *src, *pos0, *own_off, *pre_off, *eidx, *img_max; };
 
 // pfx "p": the plan of the screening / only pass; "r": the plan of the refine pass
 int plan_bufs(czc_engine* e, int B, int K, PlanBufs* p, const char* pfx = "p") {
@@ -408,6 +408,7 @@ int plan_bufs(czc_engine* e, int B, int K, PlanBufs* p, const char* pfx = "p") {
   E_CHECK(ensure(e, (q + "_own_off").c_str(), (size_t)(S + 1) * 4, (void**)&p->own_off));
   E_CHECK(ensure(e, (q + "_pre_off").c_str(), (size_t)S * 4, (void**)&p->pre_off));
   E_CHECK(ensure(e, (q + "_eidx").c_str(), (size_t)n_seq * 4, (void**)&p->eidx));
+  E_CHECK(ensure(e, (q + "_img_max").c_str(), (size_t)B * 4, (void**)&p->img_max));
   return 0;
 }
 
@@ -416,7 +417,7 @@ int clip_plan(czc_engine* e, const int* cids, const int* clen, int B, int K, int
   E_CHECK(plan_bufs(e, B, K, &p));
   const int S = B + B * K;
   { ProfScope ps(e, "bridge", 0);
-    E_CHECK(launch_prefix_plan(cids, clen, B, K, share, p.own_len, p.pre_len, p.src, p.pos0, totals + 3, e->st));
+    E_CHECK(launch_prefix_plan(cids, clen, B, K, share, p.own_len, p.pre_len, p.src, p.pos0, totals + 3, p.img_max, e->st));
     E_CHECK(launch_scan(p.own_len, S, p.own_off, totals, e->st));
     E_CHECK(launch_prefix_finish(p.own_off, p.own_len, B, K, p.pre_off, p.eidx, totals + 6, e->st)); }
   E_HIP(hipMemcpyAsync(e->h_totals, totals, 32, hipMemcpyDeviceToHost, e->st));
@@ -443,7 +444,7 @@ int clip_tower_on(czc_engine* e, int P, std::vector<LayerW>& L, const void* tpro
   E_CHECK(need(e, "text_model.final_layer_norm.bias", H, &fb));
   { ProfScope ps(e, "rowops", 0);
     E_CHECK(launch_clip_embed(cids, CZC_CLIP_MAX_LEN, p.src, p.pos0, p.own_off, p.own_len, n_seg, max_len, H, tok, pos, x, e->st)); }
-  SegTable tab{p.pre_off, p.pre_len, p.own_off, p.own_len, n_seg, 0};
+  SegTable tab{p.pre_off, p.pre_len, p.own_off, p.own_len, n_seg, 0, plan_B > 0 ? p.img_max : nullptr};
   float* pooled = nullptr;
   E_CHECK(clip_stack(e, P, gk, L, x, M, H, c.clip_inter, c.clip_heads, c.clip_eps, tab, max_len, 1, plan_B,
                      plan_K, max_branch, p.eidx, n_pool, &pooled));
@@ -583,7 +584,7 @@ int step_phase_b(czc_engine* e, const StepArgs& a, int M, int max_len, int max_b
     E_HIP(hipMemsetAsync(rp.own_len, 0, (size_t)S * 4, e->st));
     E_CHECK(launch_scan(count, a.B, count_off, rtot + 8, e->st));  // rtot[8] = R, rtot[9] = Kr = largest per-image count
     E_CHECK(launch_refine_plan(b.clen, sp.own_len, list, count, count_off, rtot + 9, a.B, a.K, rp.own_len, rp.pre_len, rp.src, rp.pos0,
-                               rlist, rtot + 3, e->st));
+                               rlist, rtot + 3, rp.img_max, e->st));
     E_CHECK(launch_scan(rp.own_len, S, rp.own_off, rtot, e->st));   // rtot[0] = rows of the refine pass
     E_CHECK(launch_refine_finish(rp.own_off, rp.own_len, count, count_off, rtot + 9, a.B, a.K, rp.pre_off, rp.eidx, e->st)); }
   E_HIP(hipMemcpyAsync(e->h_totals + 16, rtot, 48, hipMemcpyDeviceToHost, e->st));

@@ -86,6 +86,10 @@ int launch_broadcast_rows_i32(const int* row, int T, int B, int* dst, hipStream_
 struct SegTable {
   const int* pre_off; const int* pre_len; const int* own_off; const int* own_len;
   int n_seg; int fixed_T;
+  // shared-prefix plans: longest branch (own rows of one candidate) of every image [B], or null.  The packed-branch
+  // kernels take their packing factor from it PER IMAGE (32 / img_max[b] candidates per 32-query tile), so that an
+  // image's attention arithmetic does not depend on which other images share its batch.
+  const int* img_max = nullptr;
 };
 // softmax(q k^T * scale [+causal]) v; qkv [M, 3*heads*64] act type; out [M, heads*64] (own rows only)
 int launch_attention(int prec, const void* qkv, const SegTable& tab, int max_keys, int heads, int causal, float scale,
@@ -139,7 +143,7 @@ int launch_scan(const int* len, int n, int* off, int* totals, hipStream_t st);
 //   trunk b: own_len p_b, src row b*K, pos0 0, pre_len 0;  branch (b,k): own_len len-p_b, src b*K+k, pos0 p_b, pre_len p_b
 // max_len_out (two device ints, pre-zeroed) receive max len and max branch own_len via atomicMax.
 int launch_prefix_plan(const int* clip_ids, const int* clip_len, int B, int K, int share, int* own_len, int* pre_len,
-                       int* seg_src, int* seg_pos0, int* max_len_out, hipStream_t st);
+                       int* seg_src, int* seg_pos0, int* max_len_out, int* img_max, hipStream_t st);  // img_max [B]: longest branch per image
 // after the scan of own_len: pre_off[trunk] = 0, pre_off[branch (b,k)] = own_off[b];
 // eos_idx[b*K+k] = own_off[B+b*K+k] + own_len[B+b*K+k] - 1
 int launch_prefix_finish(const int* own_off, const int* own_len, int B, int K, int* pre_off, int* eos_idx,
@@ -177,7 +181,7 @@ int launch_refine_cosine(const float* text_feat, const float* img_n, const int* 
 // regular shape the packed-branch attention kernels take; rlist / eos_idx are compact (row r = count_off[b] + i)
 int launch_refine_plan(const int* clip_len, const int* trunk_len, const int* list, const int* count, const int* count_off,
                        const int* kr_dev, int B, int K, int* own_len, int* pre_len, int* seg_src, int* seg_pos0, int* rlist,
-                       int* max_len_out, hipStream_t st);
+                       int* max_len_out, int* img_max, hipStream_t st);
 int launch_refine_finish(const int* own_off, const int* own_len, const int* count, const int* count_off, const int* kr_dev, int B, int K,
                          int* pre_off, int* eos_idx, hipStream_t st);
 

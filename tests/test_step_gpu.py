@@ -1074,3 +1074,40 @@ def test_caption_does_not_depend_on_the_batch(prec):
         assert rows_batch > 4096 > 2048 > rows_one, (rows_batch, rows_one)  # the two runs really took different kernels
     finally:
         su.engine.close()
+
+
+@pytest.mark.parametrize("prec", [BF16, SPLIT])
+def test_attention_packing_does_not_couple_the_images_of_a_batch(prec):
+    """With a real vocabulary words take different numbers of CLIP tokens, so the longest branch differs from image to
+    image.  The packed-branch attention takes its packing factor PER IMAGE (SegTable::img_max): an image with short
+    branches gets the same tiles -- the same fp32 association, the same bits -- whether or not a long-branch image rides
+    in the batch.  Image 1 of this batch carries multi-token ('irregular') words behind the polished position, images 0
+    and 2 one-token words; each is compared with itself polished alone."""
+    su = harness.build_synthetic(False, prec, logit_scale=2.6592 if prec == BF16 else 4.6052)
+    try:
+        sv = su.sv
+        B, L, K = 3, 8, 64
+        rng = np.random.default_rng(9)
+        regular = np.arange(sv.regular_lo, sv.regular_hi)
+        irregular = np.array([i for i, t in enumerate(sv.bert_tokens) if t.isalpha() and len(t) >= 6 and i < sv.regular_lo])
+        assert len(irregular) >= 20
+        inp = np.array([su.bert_tok.encode("Image of a" + su.bert_tok.mask_token * L)] * B, dtype=np.int32)
+        inp[:, SEED_LEN:SEED_LEN + L] = rng.choice(regular, size=(B, L))
+        inp[1, SEED_LEN + 5:SEED_LEN + 7] = rng.choice(irregular, size=2)  # two multi-token words: longer branches, still <= 32 rows
+        gen_idx = SEED_LEN + 2
+        emb = rng.standard_normal((B, su.clip_cfg.proj)).astype(np.float32)
+        hp = Engine.hyper(0.02, 2.0, 0.1)
+        su.engine.set_image_embeds(emb)
+        full = su.engine.step(inp.copy(), gen_idx, K, hp, want=("idxs", "clip_len", "clip_ref", "final_score", "best"))
+        lens = full["clip_len"].reshape(B, K)
+        assert lens[0].max() + 4 < lens[1].max() <= 30, (lens[0].max(), lens[1].max())  # really heterogeneous, still packable
+        for b in (0, 2):
+            su.engine.set_image_embeds(emb[b:b + 1])
+            one = su.engine.step(inp[b:b + 1].copy(), gen_idx, K, hp, want=("idxs", "clip_ref", "final_score", "best"))
+            np.testing.assert_array_equal(one["idxs"][0], full["idxs"][b])
+            np.testing.assert_array_equal(one["clip_ref"][0], full["clip_ref"][b])  # the whole CLIP side: bit for bit
+            # the fused score also carries alpha * BERT probabilities: BERT is fp32-class in every engine, and at one or two
+            # images (<= 32 rows) its GEMMs run on the K-split skinny kernel, another fp32 summation order (1e-6 relative)
+            np.testing.assert_allclose(one["final_score"][0], full["final_score"][b], rtol=0, atol=1e-6)
+    finally:
+        su.engine.close()
