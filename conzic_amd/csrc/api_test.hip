@@ -201,6 +201,7 @@ int czc_test_set_option(const char* name, int value) {
   if (!strcmp(name, "gemm256")) { g_use_gemm256 = value; return 0; }
   if (!strcmp(name, "skinny")) { g_use_skinny = value; return 0; }
   if (!strcmp(name, "splitk")) { g_use_splitk = value; return 0; }
+  if (!strcmp(name, "gemm_deep")) { g_gemm_deep = value; return 0; }
   if (!strcmp(name, "wreg")) { g_use_wreg = value; return 0; }
   if (!strcmp(name, "gemm256s")) { g_use_gemm256s = value; return 0; }
   if (!strcmp(name, "bench_pad")) { g_bench_pad = value; return 0; }

@@ -127,7 +127,11 @@ __device__ __forceinline__ void epilogue(const GemmArgs& g, f32x16_t (&acc)[2][2
   }
 }
 
-template <typename T, int ACT, bool VEC>
+// DEEP: operand requests run two K steps ahead (two register sets) instead of one -- for launches of at most one
+// work-group per CU (one or two images, the vision tower at small batches), which are chains of exposed L2 / HBM round
+// trips; with several work-groups per CU (BERT at hundreds of images) the vector-memory path is the bound and the extra
+// registers in flight cost 9 %, so the launcher picks by grid size.  Same summation order.
+template <typename T, int ACT, bool VEC, bool DEEP = false>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, int tiles_m, int tiles_n, int kchunk) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE_BYTES];
   // split-K launch (gridDim.y > 1): slice z multiplies k in [z*kchunk, (z+1)*kchunk) into its own fp32 slab
@@ -178,37 +182,44 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, int tiles_m, int 
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nk = g.K / Mma<T>::KPT;
-  u32x4_t ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3;
-#define CZC_LOAD_TILE(KT)                                                                     \
-  ra0 = __builtin_amdgcn_raw_buffer_load_b128(rsA, voA, (KT) * ROWB, 0);                       \
-  ra1 = __builtin_amdgcn_raw_buffer_load_b128(rsA, voA + 32 * lda_b, (KT) * ROWB, 0);          \
-  ra2 = __builtin_amdgcn_raw_buffer_load_b128(rsA, voA + 64 * lda_b, (KT) * ROWB, 0);          \
-  ra3 = __builtin_amdgcn_raw_buffer_load_b128(rsA, voA + 96 * lda_b, (KT) * ROWB, 0);          \
-  rw0 = __builtin_amdgcn_raw_buffer_load_b128(rsW, voW, (KT) * ROWB, 0);                       \
-  rw1 = __builtin_amdgcn_raw_buffer_load_b128(rsW, voW + 32 * ldw_b, (KT) * ROWB, 0);          \
-  rw2 = __builtin_amdgcn_raw_buffer_load_b128(rsW, voW + 64 * ldw_b, (KT) * ROWB, 0);          \
-  rw3 = __builtin_amdgcn_raw_buffer_load_b128(rsW, voW + 96 * ldw_b, (KT) * ROWB, 0);
-#define CZC_STORE_TILE(dst)                                   \
-  *(u32x4_t*)((dst) + soff) = ra0;                            \
-  *(u32x4_t*)((dst) + soff + 4096) = ra1;                     \
-  *(u32x4_t*)((dst) + soff + 8192) = ra2;                     \
-  *(u32x4_t*)((dst) + soff + 12288) = ra3;                    \
-  *(u32x4_t*)((dst) + TILE_BYTES + soff) = rw0;               \
-  *(u32x4_t*)((dst) + TILE_BYTES + soff + 4096) = rw1;        \
-  *(u32x4_t*)((dst) + TILE_BYTES + soff + 8192) = rw2;        \
-  *(u32x4_t*)((dst) + TILE_BYTES + soff + 12288) = rw3;
-  CZC_LOAD_TILE(0)
-  CZC_STORE_TILE(smem)
+  // requests past the last K step go to an empty descriptor: zeros, no memory traffic, never stored (so that no VMEM
+  // instruction sits behind a branch and hipcc keeps its counted vmcnt waits)
+  const auto rsNone = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, (short)0, 0, 0x00020000);
+  u32x4_t pa0, pa1, pa2, pa3, pw0, pw1, pw2, pw3, qa0, qa1, qa2, qa3, qw0, qw1, qw2, qw3;
+#define CZC_LOAD_TILE(S, KT)                                                                       \
+  {                                                                                                \
+    const auto ra_ = (KT) < nk ? rsA : rsNone;                                                     \
+    const auto rw_ = (KT) < nk ? rsW : rsNone;                                                     \
+    S##a0 = __builtin_amdgcn_raw_buffer_load_b128(ra_, voA, (KT) * ROWB, 0);                       \
+    S##a1 = __builtin_amdgcn_raw_buffer_load_b128(ra_, voA + 32 * lda_b, (KT) * ROWB, 0);          \
+    S##a2 = __builtin_amdgcn_raw_buffer_load_b128(ra_, voA + 64 * lda_b, (KT) * ROWB, 0);          \
+    S##a3 = __builtin_amdgcn_raw_buffer_load_b128(ra_, voA + 96 * lda_b, (KT) * ROWB, 0);          \
+    S##w0 = __builtin_amdgcn_raw_buffer_load_b128(rw_, voW, (KT) * ROWB, 0);                       \
+    S##w1 = __builtin_amdgcn_raw_buffer_load_b128(rw_, voW + 32 * ldw_b, (KT) * ROWB, 0);          \
+    S##w2 = __builtin_amdgcn_raw_buffer_load_b128(rw_, voW + 64 * ldw_b, (KT) * ROWB, 0);          \
+    S##w3 = __builtin_amdgcn_raw_buffer_load_b128(rw_, voW + 96 * ldw_b, (KT) * ROWB, 0);          \
+  }
+#define CZC_STORE_TILE(S, dst)                                   \
+  *(u32x4_t*)((dst) + soff) = S##a0;                             \
+  *(u32x4_t*)((dst) + soff + 4096) = S##a1;                      \
+  *(u32x4_t*)((dst) + soff + 8192) = S##a2;                      \
+  *(u32x4_t*)((dst) + soff + 12288) = S##a3;                     \
+  *(u32x4_t*)((dst) + TILE_BYTES + soff) = S##w0;                \
+  *(u32x4_t*)((dst) + TILE_BYTES + soff + 4096) = S##w1;         \
+  *(u32x4_t*)((dst) + TILE_BYTES + soff + 8192) = S##w2;         \
+  *(u32x4_t*)((dst) + TILE_BYTES + soff + 12288) = S##w3;
+  CZC_LOAD_TILE(p, 0)
+  if constexpr (DEEP) { CZC_LOAD_TILE(q, 1) }
+  CZC_STORE_TILE(p, smem)
   __syncthreads();
 
   const int arow = wm * 64 + (lane & 31);
   const int brow = wn * 64 + (lane & 31);
   const int half = lane >> 5;
 
-  for (int kt = 0; kt < nk; ++kt) {
+  auto compute = [&](int kt) {
     const unsigned char* sA = smem + (kt & 1) * STAGE_BYTES;
     const unsigned char* sB = sA + TILE_BYTES;
-    if (kt + 1 < nk) { CZC_LOAD_TILE(kt + 1) }
     if constexpr (sizeof(T) == 4 && !__is_same(T, float)) {
       // split_t: chunk 2g = hi plane, 2g+1 = lo plane of k-group g; MFMA step s takes group 2s+half.
       // (a_hi + a_lo)(w_hi + w_lo) ~ a_hi w_hi + a_lo w_hi + a_hi w_lo   (lo*lo ~ 2^-22, dropped)
@@ -234,37 +245,69 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, int tiles_m, int 
       }
     } else {
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const int ch = 2 * ks + half;
-      uint4 a[2], b[2];
+      for (int ks = 0; ks < 4; ++ks) {
+        const int ch = 2 * ks + half;
+        uint4 a[2], b[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        a[i] = *(const uint4*)(sA + swz(arow + 32 * i, ch));
-        b[i] = *(const uint4*)(sB + swz(brow + 32 * i, ch));
+        for (int i = 0; i < 2; ++i) {
+          a[i] = *(const uint4*)(sA + swz(arow + 32 * i, ch));
+          b[i] = *(const uint4*)(sB + swz(brow + 32 * i, ch));
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) Mma<T>::run(b[j], a[i], acc[i][j]);  // weight = A operand: D = C^T
       }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) Mma<T>::run(b[j], a[i], acc[i][j]);  // weight = A operand: D = C^T
     }
+  };
+
+  if constexpr (DEEP) {
+    for (int kt = 0; kt < nk; kt += 2) {
+      // even step: LDS buffer 0 holds step kt, set q holds step kt+1 (in flight), set p is free
+      CZC_LOAD_TILE(p, kt + 2)
+      __builtin_amdgcn_sched_barrier(0);  // the LDS stores of the older set stay BEHIND the MFMAs: hipcc would hoist them
+      compute(kt);                        // (and their vmcnt wait) in front, which gives the older set one period again
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + 1 < nk) { CZC_STORE_TILE(q, smem + STAGE_BYTES) }
+      __syncthreads();
+      if (kt + 1 >= nk) break;
+      // odd step: buffer 1 holds step kt+1, set p holds step kt+2 (in flight), set q is free
+      CZC_LOAD_TILE(q, kt + 3)
+      __builtin_amdgcn_sched_barrier(0);
+      compute(kt + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + 2 < nk) { CZC_STORE_TILE(p, smem) }
+      __syncthreads();
     }
-    if (kt + 1 < nk) {
-      unsigned char* dA = smem + ((kt + 1) & 1) * STAGE_BYTES;
-      CZC_STORE_TILE(dA)
+  } else {
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) { CZC_LOAD_TILE(p, kt + 1) }
+      compute(kt);
+      if (kt + 1 < nk) {
+        unsigned char* dA = smem + ((kt + 1) & 1) * STAGE_BYTES;
+        CZC_STORE_TILE(p, dA)
+      }
+      __syncthreads();
     }
-    __syncthreads();
   }
 #undef CZC_LOAD_TILE
 #undef CZC_STORE_TILE
   epilogue<T, ACT, VEC>(g, acc, m0, n0, wm, wn, lane);
 }
 
+int g_gemm_deep = 1;  // 0 never, 1 when the launch has at most one work-group per CU, 2 always (test option "gemm_deep")
+
 template <typename T>
 static void launch_t(const GemmArgs& g, int tiles_m, int tiles_n, bool vec, hipStream_t st, int ksplit = 1) {
   dim3 grid(tiles_m * tiles_n, ksplit), block(256);
   const int kchunk = g.K / ksplit;
-#define CZC_GEMM_LAUNCH(ACT_, VEC_) \
-  hipLaunchKernelGGL((gemm_kernel<T, ACT_, VEC_>), grid, block, 0, st, g, tiles_m, tiles_n, kchunk)
+  static const int n_cu = []() { int d = 0; hipDeviceProp_t pr; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 256; }();
+  const bool deep = g_gemm_deep == 2 || (g_gemm_deep == 1 && tiles_m * tiles_n * ksplit <= n_cu);  // at most one work-group per CU
+#define CZC_GEMM_LAUNCH(ACT_, VEC_)                                                                                        \
+  do {                                                                                                                     \
+    if (deep) hipLaunchKernelGGL((gemm_kernel<T, ACT_, VEC_, true>), grid, block, 0, st, g, tiles_m, tiles_n, kchunk);     \
+    else hipLaunchKernelGGL((gemm_kernel<T, ACT_, VEC_, false>), grid, block, 0, st, g, tiles_m, tiles_n, kchunk);        \
+  } while (0)
   if (vec) {
     if (g.act == ACT_QUICK_GELU) CZC_GEMM_LAUNCH(ACT_QUICK_GELU, true);
     else if (g.act == ACT_GELU_ERF) CZC_GEMM_LAUNCH(ACT_GELU_ERF, true);

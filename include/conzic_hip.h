@@ -258,7 +258,7 @@ int czc_test_gemm_rowln(int precision, int M, int K, const float* A, const float
  * kernel, 6 the weight-stationary kernel where eligible. */
 int czc_bench_gemm(int precision, int M, int N, int K, int act, int out_mode, int iters, int use256, double* ms_out);
 /* Process-wide kernel-family switches for tests and tools: "gemm256" 0|1|3|5, "wreg" 0|1, "gemm256s" 0|1, "skinny",
- * "splitk", "mfma_attention", "attention_image" 0|1|2 (2 = force), the "*_min_m" row-count thresholds, "w_dbg"
+ * "splitk", "gemm_deep" 0|1|2, "mfma_attention", "attention_image" 0|1|2 (2 = force), the "*_min_m" row-count thresholds, "w_dbg"
  * (ping-pong kernel A/B bits), "bench_pad" (row padding of czc_bench_gemm operands). */
 int czc_test_set_option(const char* name, int value);
 int czc_test_layernorm(int precision, int M, int H, const float* x, const float* gamma, const float* beta, float eps,

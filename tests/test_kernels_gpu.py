@@ -582,3 +582,29 @@ def test_kernel_families_agree_bitwise_on_random_shapes():
     finally:
         lib.czc_test_set_option(b"gemm256", 1)
         lib.czc_test_set_option(b"gemm256_min_m", 2048)
+
+
+@pytest.mark.parametrize("prec", [BF16, F32, F16X3])
+def test_tiled_gemm_prefetch_depth_does_not_change_results(prec):
+    """The 128 x 128 kernel requests its operands one K step ahead, or two for launches of at most one work-group per CU
+    (option gemm_deep): same summation order, bit-identical outputs -- odd and even step counts, a single step, ragged
+    edges, split-K slices."""
+    lib = native.load()
+    rng = np.random.default_rng(3 + prec)
+    try:
+        assert lib.czc_test_set_option(b"gemm256", 0) == 0 and lib.czc_test_set_option(b"wreg", 0) == 0
+        for (M, N, K, resid) in ((300, 200, 64, False), (129, 768, 192, True), (1400, 512, 2048, True), (77, 640, 320, False),
+                                 (3840, 768, 3072, True), (40, 512, 512, True)):
+            A = rng.standard_normal((M, K)).astype(np.float32)
+            W = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
+            bias = rng.standard_normal(N).astype(np.float32)
+            R = rng.standard_normal((M, N)).astype(np.float32) if resid else None
+            outs = []
+            for deep in (0, 2):
+                assert lib.czc_test_set_option(b"gemm_deep", deep) == 0
+                outs.append(E.test_gemm(prec, A, W, bias=bias, resid=R))
+            np.testing.assert_array_equal(outs[0], outs[1], err_msg=f"M={M} N={N} K={K}")
+    finally:
+        lib.czc_test_set_option(b"gemm_deep", 1)
+        lib.czc_test_set_option(b"gemm256", 1)
+        lib.czc_test_set_option(b"wreg", WREG_DEFAULT)
