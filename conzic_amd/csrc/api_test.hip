@@ -10,7 +10,8 @@
 
 using namespace czc;
 
-static int g_bench_pad = 0;  // czc_bench_gemm: extra elements per row of A and W (row pitch vs L2 channel experiments)
+static int g_bench_pad = 0;
+static int g_bridge_no_table = 0;  // czc_test_bridge: 1 = every chunk through the merge loop (option "bridge_no_table")  // czc_bench_gemm: extra elements per row of A and W (row pitch vs L2 channel experiments)
 
 namespace {
 
@@ -202,6 +203,7 @@ int czc_test_set_option(const char* name, int value) {
   if (!strcmp(name, "skinny")) { g_use_skinny = value; return 0; }
   if (!strcmp(name, "splitk")) { g_use_splitk = value; return 0; }
   if (!strcmp(name, "gemm_deep")) { g_gemm_deep = value; return 0; }
+  if (!strcmp(name, "bridge_no_table")) { g_bridge_no_table = value; return 0; }
   if (!strcmp(name, "wreg")) { g_use_wreg = value; return 0; }
   if (!strcmp(name, "gemm256s")) { g_use_gemm256s = value; return 0; }
   if (!strcmp(name, "bench_pad")) { g_bench_pad = value; return 0; }
@@ -296,6 +298,13 @@ int czc_test_bridge(const czc_bridge_tables* t, const czc_config* cfg, int n_row
   bd.hmask = (unsigned)(cap - 1);
   bd.bos_id = t->bos_id;
   bd.eos_id = t->eos_id;
+  if (!g_bridge_no_table) {  // the product's fast path: per-token ids tabulated on the device
+    int* tok_ids = (int*)pool.alloc((size_t)t->bert_vocab * BR_TOKMAX * 4); T_PTR(tok_ids);
+    uint8_t* tok_len = (uint8_t*)pool.alloc((size_t)t->bert_vocab); T_PTR(tok_len);
+    T_CHECK(launch_bridge_precompute(bd, tok_ids, tok_len, nullptr));
+    T_HIP(hipDeviceSynchronize());
+    bd.tok_bpe = tok_ids; bd.tok_bpe_len = tok_len;
+  }
   int* drows = (int*)pool.up(rows, (size_t)n_rows * T * 4); T_PTR(drows);
   int* dids = (int*)pool.alloc((size_t)n_rows * CZC_CLIP_MAX_LEN * 4); T_PTR(dids);
   int* dlen = (int*)pool.alloc((size_t)n_rows * 4); T_PTR(dlen);

@@ -23,6 +23,7 @@ constexpr int BR_THREADS = 64;
 constexpr int BR_MAXB = 512;   // == CZC_BRIDGE_MAX_BYTES
 constexpr int BR_MAXSYM = 64;  // longest pre-split chunk in bytes
 constexpr int BR_LEN = 77;
+constexpr int BR_MAXP = 64;    // pieces per row (== CZC_MAX_BERT_LEN)
 
 __device__ __forceinline__ bool merge_lookup(const BridgeDev& bd, int l, int r, unsigned& rank, int& out) {
   const unsigned long long key = ((unsigned long long)(unsigned)l << 32) | (unsigned)r;
@@ -48,6 +49,13 @@ __global__ __launch_bounds__(BR_THREADS) void bridge_kernel(BridgeDev bd, const 
   unsigned char* txt = br_lds + (size_t)threadIdx.x * BR_MAXB;
   unsigned char* cls = br_lds + (size_t)BR_THREADS * BR_MAXB + (size_t)threadIdx.x * BR_MAXB;
   int* sym = (int*)(br_lds + (size_t)2 * BR_THREADS * BR_MAXB) + threadIdx.x * BR_MAXSYM;
+  // piece list of the row (first byte, one past the last byte, token id): a pre-split chunk that is exactly one
+  // tabulated piece takes its CLIP ids from bd.tok_bpe instead of running the merge loop
+  unsigned char* pl_base = br_lds + (size_t)BR_THREADS * (2 * BR_MAXB + BR_MAXSYM * 4);
+  unsigned short* pl_beg = (unsigned short*)pl_base + threadIdx.x * BR_MAXP;
+  unsigned short* pl_end = (unsigned short*)pl_base + (BR_THREADS + threadIdx.x) * BR_MAXP;
+  int* pl_id = (int*)(pl_base + (size_t)BR_THREADS * BR_MAXP * 4) + threadIdx.x * BR_MAXP;
+  int np = 0;
 
   const long row = (long)blockIdx.x * BR_THREADS + threadIdx.x;
   if (row >= (long)B * K) return;
@@ -91,6 +99,7 @@ __global__ __launch_bounds__(BR_THREADS) void bridge_kernel(BridgeDev bd, const 
     } else if (!(fl & 6u)) {
       txt[n] = ' '; cls[n] = 3 | 4; ++n;
     }
+    if (np < BR_MAXP) { pl_beg[np] = (unsigned short)n; pl_end[np] = (unsigned short)(n + (int)(o1 - o0)); pl_id[np] = id; ++np; }
     for (unsigned o = o0; o < o1; ++o) {
       txt[n] = bd.piece_bytes[o];
       cls[n] = bd.piece_class[o];
@@ -103,7 +112,7 @@ __global__ __launch_bounds__(BR_THREADS) void bridge_kernel(BridgeDev bd, const 
   int* outp = clip_ids + row * BR_LEN;
   int nt = 0;  // text tokens emitted (cap 75)
   outp[0] = bd.bos_id;
-  int i = 0;
+  int i = 0, pp = 0;
   while (i < n && nt < BR_LEN - 2) {
     const int c = cls[i] & 3;
     if (c == 3) { ++i; continue; }
@@ -121,6 +130,18 @@ __global__ __launch_bounds__(BR_THREADS) void bridge_kernel(BridgeDev bd, const 
       if (c == 0) { while (j < n && (cls[j] & 3) == 0) ++j; }
       else if (c == 1) { while (j < n && !(cls[j] & 4)) ++j; }          // exactly one \p{N} character
       else { while (j < n && (cls[j] & 3) == 2) ++j; }
+    }
+    if (bd.tok_bpe_len && c == 0) {  // a run of letters that is exactly one tabulated piece: its ids are known
+      while (pp < np && pl_beg[pp] < i) ++pp;
+      if (pp < np && pl_beg[pp] == i && pl_end[pp] == j) {
+        const int id = pl_id[pp];
+        const int tl = bd.tok_bpe_len[id];
+        if (tl) {
+          for (int q = 0; q < tl && nt < BR_LEN - 2; ++q) outp[1 + nt++] = bd.tok_bpe[id * BR_TOKMAX + q];
+          i = j;
+          continue;
+        }
+      }
     }
     int m = j - i;
     if (m > BR_MAXSYM) { ovf = true; m = BR_MAXSYM; }
@@ -156,12 +177,50 @@ __global__ __launch_bounds__(BR_THREADS) void bridge_kernel(BridgeDev bd, const 
   if (ovf) atomicAdd(overflow, 1);
 }
 
+// One thread per BERT token: the byte-level BPE of the token standing alone as a word (the same symbol / merge rules as
+// above), tabulated when the piece is all letters (so that it is one pre-split chunk whenever spaces surround it) and
+// yields at most BR_TOKMAX ids.
+__global__ void bridge_precompute_kernel(BridgeDev bd, int* tok_ids, uint8_t* tok_len) {
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= bd.bert_vocab) return;
+  tok_len[id] = 0;
+  const unsigned o0 = bd.piece_off[id], o1 = bd.piece_off[id + 1];
+  int m = (int)(o1 - o0);
+  if (m <= 0 || m > BR_MAXSYM || (bd.piece_flags[id] & 1u)) return;
+  for (unsigned o = o0; o < o1; ++o)
+    if ((bd.piece_class[o] & 3) != 0) return;
+  int sym[BR_MAXSYM];
+  for (int q = 0; q < m; ++q) sym[q] = bd.byte_sym[bd.piece_bytes[o0 + q]];
+  sym[m - 1] = bd.byte_sym_eow[bd.piece_bytes[o0 + m - 1]];
+  while (m > 1) {
+    unsigned best = 0xFFFFFFFFu;
+    int bi = -1, bo = 0;
+    for (int q = 0; q + 1 < m; ++q) {
+      unsigned rk; int o;
+      if (merge_lookup(bd, sym[q], sym[q + 1], rk, o) && rk < best) { best = rk; bi = q; bo = o; }
+    }
+    if (bi < 0) break;
+    sym[bi] = bo;
+    for (int q = bi + 1; q + 1 < m; ++q) sym[q] = sym[q + 1];
+    --m;
+  }
+  if (m > BR_TOKMAX) return;
+  for (int q = 0; q < m; ++q) tok_ids[id * BR_TOKMAX + q] = sym[q];
+  tok_len[id] = (uint8_t)m;
+}
+
+int launch_bridge_precompute(const BridgeDev& bd, int* tok_ids, uint8_t* tok_len, hipStream_t st) {
+  hipLaunchKernelGGL(bridge_precompute_kernel, dim3(cdiv(bd.bert_vocab, 64)), dim3(64), 0, st, bd, tok_ids, tok_len);
+  CZC_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
 int launch_bridge(const BridgeDev& bd, const int* inp, int B, int T, int gen_idx, const int* cand, int K,
                   const float* lexicon, const float* lex_pos, const uint8_t* lex_cls, int negative, const PosDev& pos, int* clip_ids, int* clip_len, float* senti_raw,
                   float* repeats, int* overflow_flag, hipStream_t st) {
   const long rows = (long)B * K;
   if (rows <= 0) return 0;
-  const size_t shmem = (size_t)BR_THREADS * (2 * BR_MAXB + BR_MAXSYM * 4);
+  const size_t shmem = (size_t)BR_THREADS * (2 * BR_MAXB + BR_MAXSYM * 4 + BR_MAXP * 8);
   CZC_HIP_CHECK(hipFuncSetAttribute((const void*)bridge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
   hipLaunchKernelGGL(bridge_kernel, dim3(cdiv(rows, BR_THREADS)), dim3(BR_THREADS), shmem, st, bd, inp, B, T, gen_idx,
                      cand, K, lexicon, lex_pos, lex_cls, negative, pos, clip_ids, clip_len, senti_raw, repeats, overflow_flag);

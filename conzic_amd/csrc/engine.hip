@@ -907,6 +907,16 @@ static int build_bridge(czc_engine* e, const czc_bridge_tables* t, BridgeDev* bd
   bd->hmask = (unsigned)(cap - 1);
   bd->bos_id = t->bos_id;
   bd->eos_id = t->eos_id;
+  // ids of every all-letter token standing alone as a word, tabulated once by the same BPE code (bridge.hip)
+  bd->tok_bpe = nullptr; bd->tok_bpe_len = nullptr;
+  int* tok_ids = nullptr; uint8_t* tok_len = nullptr;
+  E_HIP(hipMalloc((void**)&tok_ids, (size_t)t->bert_vocab * BR_TOKMAX * 4 + 16));
+  e->bridge_allocs.push_back(tok_ids);
+  E_HIP(hipMalloc((void**)&tok_len, (size_t)t->bert_vocab + 16));
+  e->bridge_allocs.push_back(tok_len);
+  E_CHECK(launch_bridge_precompute(*bd, tok_ids, tok_len, e->st));
+  E_HIP(hipStreamSynchronize(e->st));
+  bd->tok_bpe = tok_ids; bd->tok_bpe_len = tok_len;
   return 0;
 }
 

@@ -123,7 +123,15 @@ struct BridgeDev {
   const unsigned long long* hvals;  // rank<<32 | out
   unsigned hmask;
   int bos_id, eos_id;
+  // per BERT token: the CLIP ids of the token standing alone as a word (all-letter pieces whose byte-level BPE yields at
+  // most BR_TOKMAX ids; tok_bpe_len 0 = not tabulated), filled once on the device by launch_bridge_precompute with the
+  // same BPE code the per-row kernel runs.  May be null (every chunk then takes the merge loop).
+  const int* tok_bpe = nullptr;
+  const uint8_t* tok_bpe_len = nullptr;
 };
+constexpr int BR_TOKMAX = 8;
+// fills tok_ids [bert_vocab * BR_TOKMAX] / tok_len [bert_vocab] (device buffers) from the uploaded tables of `bd`
+int launch_bridge_precompute(const BridgeDev& bd, int* tok_ids, uint8_t* tok_len, hipStream_t st);
 // rows: inp[b,:] with column gen_idx replaced by cand[b,k] (cand==null: rows are taken verbatim,
 // n_rows = B, K = 1).  Writes clip_ids [B*K,77], clip_len, and optionally senti/repeats.
 // Sentiment score of a row: sum of lexicon[id] over its non-special pieces, or -- when lex_pos [V][5] and

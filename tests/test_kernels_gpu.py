@@ -608,3 +608,30 @@ def test_tiled_gemm_prefetch_depth_does_not_change_results(prec):
         lib.czc_test_set_option(b"gemm_deep", 1)
         lib.czc_test_set_option(b"gemm256", 1)
         lib.czc_test_set_option(b"wreg", WREG_DEFAULT)
+
+
+@pytest.mark.parametrize("label", ["tiny", "full"])
+def test_bridge_token_table_equals_the_merge_loop(label):
+    """The text bridge takes the CLIP ids of a chunk that is exactly one all-letter BERT piece from a per-token table the
+    device fills once with the same BPE code; every other chunk ('##' continuations glued to a word, digits, punctuation,
+    contractions) runs the merge loop.  Random rows over the whole vocabulary, with and without the table: identical
+    ids and lengths, and the table really serves most words."""
+    lib = native.load()
+    sv = harness.cached_vocab(label == "tiny")
+    bt, ct = tokenizers_from_vocab(sv)
+    t = tables_from_tokenizers(bt, ct)
+    rng = np.random.default_rng(123)
+    V = len(sv.bert_tokens)
+    rows = rng.integers(0, V, size=(300, 16)).astype(np.int32)
+    rows[:, 0] = bt.vocab["[CLS]"]
+    rows[:100, 8] = bt.vocab["[MASK]"]            # specials in the middle are skipped
+    rows[100:200, 1:] = rng.integers(sv.regular_lo, sv.regular_hi, size=(100, 15))  # captions of whole words
+    try:
+        assert lib.czc_test_set_option(b"bridge_no_table", 1) == 0
+        ids0, ln0 = E.test_bridge(t, rows)
+        assert lib.czc_test_set_option(b"bridge_no_table", 0) == 0
+        ids1, ln1 = E.test_bridge(t, rows)
+    finally:
+        lib.czc_test_set_option(b"bridge_no_table", 0)
+    np.testing.assert_array_equal(ln0, ln1)
+    np.testing.assert_array_equal(ids0, ids1)
