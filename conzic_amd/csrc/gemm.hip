@@ -327,7 +327,7 @@ static void launch_t(const GemmArgs& g, int tiles_m, int tiles_n, bool vec, hipS
 // one row.  Partial sums meet in LDS; wave 0 applies bias / activation / residual and stores.
 typedef __attribute__((ext_vector_type(4))) float f32x4v_t;
 
-template <int ACT>
+template <int ACT, bool TWO>
 __global__ __launch_bounds__(256) void gemm_skinny_split_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float red[3][2][64][4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -338,11 +338,38 @@ __global__ __launch_bounds__(256) void gemm_skinny_split_kernel(GemmArgs g) {
   const int m_a = min(nl, g.M - 1), m_b = min(16 + nl, g.M - 1);
   const unsigned char* xa = (const unsigned char*)g.A + (long)m_a * g.lda * 4 + kb * 32;
   const unsigned char* xb = (const unsigned char*)g.A + (long)m_b * g.lda * 4 + kb * 32;
-  const bool two = g.M > 16;
+  constexpr bool two = TWO;
   f32x4v_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   const int steps = g.K >> 5;  // 32 k per MFMA step = 4 groups of (16 B hi + 16 B lo)
 #define CZC_F16(v_) __builtin_bit_cast(f16x8_t, v_)
-  for (int s2 = wave; s2 < steps; s2 += 4) {
+  // The kernel is a chain of L2 / HBM round trips (a wave owns steps wave, wave+4, ...: 6 of them at K = 768), so the
+  // operands of SK_U steps are requested together before their MFMAs run: one exposed latency per SK_U steps instead of
+  // one per step.  The MFMAs keep their order (same sums).
+  constexpr int SK_U = 6;
+  int s2 = wave;
+  for (; s2 + 4 * (SK_U - 1) < steps; s2 += 4 * SK_U) {
+    uint4 wh[SK_U], wl[SK_U], ah[SK_U], al[SK_U], bh[SK_U], bl[SK_U];
+#pragma unroll
+    for (int u = 0; u < SK_U; ++u) {
+      const long o = (long)(s2 + 4 * u) * 128;
+      wh[u] = *(const uint4*)(wp + o); wl[u] = *(const uint4*)(wp + o + 16);
+      ah[u] = *(const uint4*)(xa + o); al[u] = *(const uint4*)(xa + o + 16);
+      if (two) { bh[u] = *(const uint4*)(xb + o); bl[u] = *(const uint4*)(xb + o + 16); }
+    }
+    __builtin_amdgcn_sched_barrier(0);  // all requests first (hipcc would otherwise sink each load to its MFMA again)
+#pragma unroll
+    for (int u = 0; u < SK_U; ++u) {
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(CZC_F16(wl[u]), CZC_F16(ah[u]), acc0, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(CZC_F16(wh[u]), CZC_F16(al[u]), acc0, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(CZC_F16(wh[u]), CZC_F16(ah[u]), acc0, 0, 0, 0);
+      if (two) {
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(CZC_F16(wl[u]), CZC_F16(bh[u]), acc1, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(CZC_F16(wh[u]), CZC_F16(bl[u]), acc1, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(CZC_F16(wh[u]), CZC_F16(bh[u]), acc1, 0, 0, 0);
+      }
+    }
+  }
+  for (; s2 < steps; s2 += 4) {
     const long o = (long)s2 * 128;
     const uint4 wh = *(const uint4*)(wp + o), wl = *(const uint4*)(wp + o + 16);
     const uint4 ah = *(const uint4*)(xa + o), al = *(const uint4*)(xa + o + 16);
@@ -401,9 +428,12 @@ int g_use_skinny = 1;
 static bool launch_skinny(const GemmArgs& g, hipStream_t st) {
   if (!g_use_skinny || g.M > 32 || (g.K & 31) || (g.lda & 7) || (g.ldw & 7)) return false;
   dim3 grid(cdiv(g.N, 16)), block(256);
-  if (g.act == ACT_QUICK_GELU) hipLaunchKernelGGL(gemm_skinny_split_kernel<ACT_QUICK_GELU>, grid, block, 0, st, g);
-  else if (g.act == ACT_GELU_ERF) hipLaunchKernelGGL(gemm_skinny_split_kernel<ACT_GELU_ERF>, grid, block, 0, st, g);
-  else hipLaunchKernelGGL(gemm_skinny_split_kernel<ACT_NONE>, grid, block, 0, st, g);
+#define CZC_SK(A_) do { if (g.M > 16) hipLaunchKernelGGL((gemm_skinny_split_kernel<A_, true>), grid, block, 0, st, g); \
+                       else hipLaunchKernelGGL((gemm_skinny_split_kernel<A_, false>), grid, block, 0, st, g); } while (0)
+  if (g.act == ACT_QUICK_GELU) CZC_SK(ACT_QUICK_GELU);
+  else if (g.act == ACT_GELU_ERF) CZC_SK(ACT_GELU_ERF);
+  else CZC_SK(ACT_NONE);
+#undef CZC_SK
   return true;
 }
 
