@@ -127,7 +127,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs& g, f32x16_t (&acc)[2][2
   }
 }
 
-// DEEP: operand requests run two K steps ahead (two register sets) instead of one -- for launches of at most one
+// DEEP: operand requests run three K steps ahead (three rotating register sets) instead of one -- for launches of at most one
 // work-group per CU (one or two images, the vision tower at small batches), which are chains of exposed L2 / HBM round
 // trips; with several work-groups per CU (BERT at hundreds of images) the vector-memory path is the bound and the extra
 // registers in flight cost 9 %, so the launcher picks by grid size.  Same summation order.
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, int tiles_m, int 
   // requests past the last K step go to an empty descriptor: zeros, no memory traffic, never stored (so that no VMEM
   // instruction sits behind a branch and hipcc keeps its counted vmcnt waits)
   const auto rsNone = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, (short)0, 0, 0x00020000);
-  u32x4_t pa0, pa1, pa2, pa3, pw0, pw1, pw2, pw3, qa0, qa1, qa2, qa3, qw0, qw1, qw2, qw3;
+  u32x4_t pa0, pa1, pa2, pa3, pw0, pw1, pw2, pw3, qa0, qa1, qa2, qa3, qw0, qw1, qw2, qw3, ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3;
 #define CZC_LOAD_TILE(S, KT)                                                                       \
   {                                                                                                \
     const auto ra_ = (KT) < nk ? rsA : rsNone;                                                     \
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, int tiles_m, int 
   *(u32x4_t*)((dst) + TILE_BYTES + soff + 8192) = S##w2;         \
   *(u32x4_t*)((dst) + TILE_BYTES + soff + 12288) = S##w3;
   CZC_LOAD_TILE(p, 0)
-  if constexpr (DEEP) { CZC_LOAD_TILE(q, 1) }
+  if constexpr (DEEP) { CZC_LOAD_TILE(q, 1) CZC_LOAD_TILE(r, 2) }
   CZC_STORE_TILE(p, smem)
   __syncthreads();
 
@@ -262,23 +262,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, int tiles_m, int 
   };
 
   if constexpr (DEEP) {
-    for (int kt = 0; kt < nk; kt += 2) {
-      // even step: LDS buffer 0 holds step kt, set q holds step kt+1 (in flight), set p is free
-      CZC_LOAD_TILE(p, kt + 2)
-      __builtin_amdgcn_sched_barrier(0);  // the LDS stores of the older set stay BEHIND the MFMAs: hipcc would hoist them
-      compute(kt);                        // (and their vmcnt wait) in front, which gives the older set one period again
-      __builtin_amdgcn_sched_barrier(0);
-      if (kt + 1 < nk) { CZC_STORE_TILE(q, smem + STAGE_BYTES) }
-      __syncthreads();
-      if (kt + 1 >= nk) break;
-      // odd step: buffer 1 holds step kt+1, set p holds step kt+2 (in flight), set q is free
-      CZC_LOAD_TILE(q, kt + 3)
-      __builtin_amdgcn_sched_barrier(0);
-      compute(kt + 1);
-      __builtin_amdgcn_sched_barrier(0);
-      if (kt + 2 < nk) { CZC_STORE_TILE(p, smem) }
-      __syncthreads();
+    // three register sets rotate: at step t the LDS buffer t & 1 holds step t, two sets hold steps t+1 and t+2 (in
+    // flight), the third is free and requests step t+3; after the MFMAs step t+1 goes to the other LDS buffer
+#define CZC_DEEP_STEP(T_, FREE_, NEXT_)                                                                   \
+    {                                                                                                     \
+      CZC_LOAD_TILE(FREE_, (T_) + 3)                                                                      \
+      __builtin_amdgcn_sched_barrier(0); /* the LDS stores of the older set stay BEHIND the MFMAs: hipcc */ \
+      compute(T_);                       /* would hoist them (and their vmcnt wait) in front             */ \
+      __builtin_amdgcn_sched_barrier(0);                                                                  \
+      if ((T_) + 1 < nk) { CZC_STORE_TILE(NEXT_, smem + (((T_) + 1) & 1) * STAGE_BYTES) }                 \
+      __syncthreads();                                                                                    \
     }
+    for (int kt = 0; kt < nk; kt += 3) {
+      CZC_DEEP_STEP(kt, p, q)
+      if (kt + 1 >= nk) break;
+      CZC_DEEP_STEP(kt + 1, q, r)
+      if (kt + 2 >= nk) break;
+      CZC_DEEP_STEP(kt + 2, r, p)
+    }
+#undef CZC_DEEP_STEP
   } else {
     for (int kt = 0; kt < nk; ++kt) {
       if (kt + 1 < nk) { CZC_LOAD_TILE(p, kt + 1) }
