@@ -643,7 +643,7 @@ def one_gemm_family():
     lib.czc_test_set_option(b"wreg", 1)
 
 
-@pytest.mark.parametrize("prec", [F32, BF16])
+@pytest.mark.parametrize("prec", [F32, BF16, REFINE])
 @pytest.mark.parametrize("name", ["tiny_shuffle", "full_synth_b2"])
 def test_prefix_sharing_is_exact(prec, name, one_gemm_family):
     """Encoding the candidates' common causal prefix once (trunk + branches) must not change the
