@@ -295,3 +295,61 @@ def test_image_cache_key_follows_the_pixels_not_only_the_object():
     im.paste((9, 9, 9), (0, 0, 33, 21))
     assert _fingerprint(im) != k1
     assert _fingerprint(object()) is None   # unknown objects are never cached
+
+
+def test_visiting_orders_and_partitions_hold_their_invariants():
+    """Property tests (hypothesis) of the host-side schedule builders: every visiting order touches each position the
+    reference's number of times per sweep (gen_utils.py:64-65, :110-115, :160-166), span steps re-use the forward of the
+    step before them exactly when they are the second position of a pair, and the image partitions (ranks, streams) are
+    contiguous, disjoint and complete."""
+    from hypothesis import given, settings, strategies as st
+    from conzic_amd import dist as czd
+    from conzic_amd.engine import EngineGroup
+
+    @settings(max_examples=60, deadline=None)
+    @given(st.integers(1, 24), st.integers(1, 6), st.randoms(use_true_random=False))
+    def orders(L, iters, rnd):
+        lst = list(range(L))
+        rnd.shuffle(lst)
+        for order, kw in (("sequential", {}), ("shuffle", dict(order_list=lst)), ("span", {})):
+            pos, nm, every = harness.order_positions(order, L, iters, **kw)
+            assert every == L and len(pos) == len(nm) == L * iters
+            for it in range(iters):
+                sweep = pos[it * L:(it + 1) * L]
+                assert sorted(sweep) == list(range(L))
+                if order == "shuffle":
+                    assert sweep == lst
+            if order == "span":
+                for i, (p, n) in enumerate(zip(pos, nm)):
+                    assert n in (0, 1, 2)
+                    if n == 0:
+                        assert nm[i - 1] == 2 and pos[i - 1] == p - 1   # second position of a pair re-uses the forward
+                    if n == 2:
+                        assert nm[i + 1] == 0
+            else:
+                assert set(nm) == {1}
+    orders()
+
+    @settings(max_examples=80, deadline=None)
+    @given(st.integers(0, 5000), st.integers(1, 16))
+    def shards(n, world):
+        spans = [czd.shard_range(n, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        sizes = [hi - lo for lo, hi in spans]
+        assert max(sizes) - min(sizes) <= 1
+    shards()
+
+    class _E:  # EngineGroup.parts only needs len(engines) and min_images
+        pass
+
+    @settings(max_examples=80, deadline=None)
+    @given(st.integers(1, 600), st.integers(1, 4), st.integers(1, 64))
+    def parts(B, streams, min_images):
+        g = EngineGroup.__new__(EngineGroup)
+        g.engines, g.min_images = [_E()] * streams, min_images
+        p = g.parts(B)
+        assert p[0][0] == 0 and p[-1][1] == B and all(a[1] == b[0] for a, b in zip(p, p[1:]))
+        assert len(p) == 1 or all(hi - lo >= min_images for lo, hi in p)
+        assert 1 <= len(p) <= streams
+    parts()
