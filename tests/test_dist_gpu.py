@@ -171,3 +171,50 @@ def test_bench_gpus_2_without_the_flag_fails_on_one_gpu():
                        capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
     assert r.returncode != 0 and "needs 2 visible GPUs" in r.stderr
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def _rccl_single_rank(port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from conzic_amd import dist as czd
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)  # "nccl" is RCCL on ROCm
+    try:
+        rng = np.random.default_rng(5)
+        w = rng.standard_normal((33, 17)).astype(np.float32)
+        state = {"emb": w, "decoder_tied": w, "bias": rng.standard_normal(17).astype(np.float32),
+                 "scale": np.float32(2.5).reshape(()), "on_device": torch.arange(12, dtype=torch.float32, device=dev).view(3, 4)}
+        out = czd.broadcast_state(state, dev)
+        ok = all(v.device == dev and v.dtype == torch.float32 for v in out.values())
+        ok &= out["emb"].data_ptr() == out["decoder_tied"].data_ptr()  # tied tensors travel (and live) once
+        for k, v in state.items():
+            ref = v.cpu().numpy() if hasattr(v, "cpu") else np.asarray(v)
+            ok &= np.array_equal(out[k].cpu().numpy(), ref)
+        ids = rng.integers(0, 1000, size=(3, 4, 9)).astype(np.int32)
+        ok &= np.array_equal(czd.gather_ids(ids, 1), ids)
+        t = torch.tensor([1.25], dtype=torch.float64, device=dev)  # bench.py's max-over-ranks of the timed region
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.barrier(device_ids=[0])
+        torch.cuda.synchronize()
+        q.put((bool(ok), float(t.item()), dist.get_backend(), dist.get_world_size()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_backend_runs_the_start_up_broadcast_and_the_gather():
+    """The collectives of the N>1 path on the backend the GPU job uses (torch 'nccl' = RCCL): weights bucket broadcast
+    from device memory, id gather, max-reduce of the timing -- with the one rank this box has.  Multi-rank semantics
+    are covered by the gloo tests above; this one holds the device-side branches of conzic_amd/dist.py to RCCL itself."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_single_rank, args=(_free_port(), q))
+    p.start()
+    ok, t, backend, world = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert ok and t == 1.25 and backend == "nccl" and world == 1
