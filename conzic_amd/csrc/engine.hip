@@ -86,6 +86,8 @@ struct czc_engine {
   float logit_scale_exp = 1.f;
   int* h_totals = nullptr;  // pinned, 64 ints: [0..7] plan totals, [8],[9] non-finite flags, [16..27] refine-plan totals
   int last_BT = 0;
+  int bert_prune = 1;       // last BERT layer behind the attention on the one row per sequence the MLM head reads (n_mask == 1 steps)
+  int bert_pruned_idx = -1; // row the previous forward kept (-1: all rows of b_x are valid)
   int share_prefix = 1;  // encode the candidates' common causal prefix once per image
   float* d_staged = nullptr; int staged_cap = 0, staged_n = 0;  // czc_preprocess_u8 output slots [cap][3][S][S]
   int pack_branches = 1; // pack several candidates' rows into one attention MFMA tile
@@ -328,7 +330,10 @@ int clip_stack(czc_engine* e, int P, const char* gk, std::vector<LayerW>& L, flo
 }
 
 // ---- BERT encoder (post-LN) on [B*T] rows: leaves the final hidden state in ws "b_x" ----------
-int bert_forward(czc_engine* e, const int* d_inp, int B, int T) {
+// keep_idx >= 0: only row keep_idx of every sequence is read afterwards (the masked slot, gen_utils.py:69): the last layer
+// still forms q/k/v and the attention for all rows, then gathers that row and runs out-proj / LN / MLP / LN on B rows
+// instead of B*T; the result goes to ws "b_xg" [B,H].  Same kernels per row, so the row's values do not change.
+int bert_forward(czc_engine* e, const int* d_inp, int B, int T, int keep_idx = -1) {
   const czc_config& c = e->cfg;
   const int P = e->pb, M = B * T, H = c.bert_hidden, I = c.bert_inter;
   void *xa, *qkv, *ctx, *hbuf; float *x, *tmp;
@@ -347,12 +352,31 @@ int bert_forward(czc_engine* e, const int* d_inp, int B, int T) {
   { ProfScope ps(e, "rowops", 0);
     E_CHECK(launch_bert_embed(P, d_inp, B, T, H, word, pos, typ, g, b, c.bert_eps, xa, x, e->st)); }
   const float scale = 1.0f / sqrtf(64.0f);
+  e->bert_pruned_idx = -1;
   for (int n = 0; n < c.bert_layers; ++n) {
     LayerW& l = e->bert[n];
     E_CHECK(gemm(e, P, "gemm_bert", xa, H, l.qkv_w, H, l.qkv_b, nullptr, 0, qkv, nullptr, 3 * H, M, 3 * H, H, ACT_NONE));
     { ProfScope ps(e, "attention", 0);
       SegTable tab{nullptr, nullptr, nullptr, nullptr, B, T};
       E_CHECK(launch_attention(P, qkv, tab, T, c.bert_heads, 0, scale, ctx, e->st)); }
+    if (keep_idx >= 0 && n + 1 == c.bert_layers) {
+      int* idx; void* ctx_g; float* x_g;
+      E_CHECK(ensure(e, "b_pidx", (size_t)B * 4, (void**)&idx));
+      E_CHECK(ensure(e, "b_cg", (size_t)B * H * e->eb, &ctx_g));
+      E_CHECK(ensure(e, "b_xg", (size_t)B * H * 4, (void**)&x_g));
+      { ProfScope ps(e, "rowops", 0);
+        E_CHECK(launch_make_row_index(idx, B, T, keep_idx, e->st));
+        E_CHECK(launch_gather_rows_bytes(ctx, idx, B, H * (int)e->eb, ctx_g, e->st));
+        E_CHECK(launch_gather_rows_f32(x, idx, B, H, x_g, e->st)); }
+      // tmp / xa / hbuf: their first B rows are free here (xa fed this layer's q/k/v, hbuf the previous layer's fc2)
+      E_CHECK(gemm(e, P, "gemm_bert", ctx_g, H, l.o_w, H, l.o_b, x_g, H, nullptr, tmp, H, B, H, H, ACT_NONE));
+      { ProfScope ps(e, "rowops", 0); E_CHECK(launch_layernorm(P, tmp, nullptr, l.ln1_g, l.ln1_b, c.bert_eps, B, H, xa, x_g, e->st)); }
+      E_CHECK(gemm(e, P, "gemm_bert", xa, H, l.fc1_w, H, l.fc1_b, nullptr, 0, hbuf, nullptr, I, B, I, H, ACT_GELU_ERF));
+      E_CHECK(gemm(e, P, "gemm_bert", hbuf, I, l.fc2_w, I, l.fc2_b, x_g, H, nullptr, tmp, H, B, H, I, ACT_NONE));
+      { ProfScope ps(e, "rowops", 0); E_CHECK(launch_layernorm(P, tmp, nullptr, l.ln2_g, l.ln2_b, c.bert_eps, B, H, xa, x_g, e->st)); }
+      e->bert_pruned_idx = keep_idx;
+      break;
+    }
     E_CHECK(gemm(e, P, "gemm_bert", ctx, H, l.o_w, H, l.o_b, x, H, nullptr, tmp, H, M, H, H, ACT_NONE));
     { ProfScope ps(e, "rowops", 0); E_CHECK(launch_layernorm(P, tmp, nullptr, l.ln1_g, l.ln1_b, c.bert_eps, M, H, xa, x, e->st)); }
     E_CHECK(gemm(e, P, "gemm_bert", xa, H, l.fc1_w, H, l.fc1_b, nullptr, 0, hbuf, nullptr, I, M, I, H, ACT_GELU_ERF));
@@ -379,9 +403,15 @@ int mlm_head(czc_engine* e, int B, int T, int gen_idx, float** logits_out) {
   E_CHECK(need(e, "cls.predictions.transform.LayerNorm.weight", H, &g));
   E_CHECK(need(e, "cls.predictions.transform.LayerNorm.bias", H, &b));
   E_CHECK(need(e, "cls.predictions.bias", V, &bias));
+  if (e->bert_pruned_idx >= 0 && e->bert_pruned_idx != gen_idx)
+    return fail(e, CZC_ERR_STATE, "n_mask=0 re-use of a forward that kept one row only (it follows an n_mask >= 2 step, gen_utils.py:164-166)%s");
   { ProfScope ps(e, "rowops", 0);
-    E_CHECK(launch_make_row_index(idx, B, T, gen_idx, e->st));
-    E_CHECK(launch_gather_rows_f32(x, idx, B, H, gx, e->st));
+    if (e->bert_pruned_idx >= 0) {
+      gx = (float*)e->ws["b_xg"].p;  // the forward left exactly these rows
+    } else {
+      E_CHECK(launch_make_row_index(idx, B, T, gen_idx, e->st));
+      E_CHECK(launch_gather_rows_f32(x, idx, B, H, gx, e->st));
+    }
     E_CHECK(launch_convert(P, gx, ga, (long)B * H, e->st)); }
   E_CHECK(gemm(e, P, "gemm_bert", ga, H, e->mlm_dense_w, H, db, nullptr, 0, nullptr, t32, H, B, H, H, ACT_GELU_ERF));
   { ProfScope ps(e, "rowops", 0); E_CHECK(launch_layernorm(P, t32, nullptr, g, b, c.bert_eps, B, H, ta, nullptr, e->st)); }
@@ -515,7 +545,7 @@ int step_phase_a(czc_engine* e, const StepArgs& a) {
   const czc_hyper* hp = &a.hp;
   if (a.n_mask > 0) {
     E_CHECK(launch_mask_positions(a.d_inp, a.B, a.T, a.gen_idx, a.n_mask, c.mask_id, e->st));
-    E_CHECK(bert_forward(e, a.d_inp, a.B, a.T));
+    E_CHECK(bert_forward(e, a.d_inp, a.B, a.T, e->bert_prune && a.n_mask == 1 ? a.gen_idx : -1));
   }
   float* logits;
   E_CHECK(mlm_head(e, a.B, a.T, a.gen_idx, &logits));
@@ -740,7 +770,7 @@ int czc_replicate(czc_engine* p, czc_engine** out) {
   e->patch_w = p->patch_w; e->tproj_wx = p->tproj_wx;
   e->logit_scale_exp = p->logit_scale_exp;
   e->share_prefix = p->share_prefix; e->pack_branches = p->pack_branches; e->pool_last_layer = p->pool_last_layer;
-  e->fuse_ln = p->fuse_ln;
+  e->fuse_ln = p->fuse_ln; e->bert_prune = p->bert_prune;
   memset(&e->bd, 0, sizeof(e->bd));
   if (hipSetDevice(e->dev) != hipSuccess || hipStreamCreate(&e->st) != hipSuccess ||
       hipHostMalloc((void**)&e->h_totals, 256) != hipSuccess) {
@@ -1120,6 +1150,7 @@ int czc_generate(czc_engine* e, int B, int T, int L, int seed_len, const int32_t
 int czc_set_option(czc_engine* e, const char* name, int value) {
   if (!e || !name) return CZC_ERR_ARG;
   if (!strcmp(name, "share_prefix")) { e->share_prefix = value ? 1 : 0; return CZC_OK; }
+  if (!strcmp(name, "bert_prune")) { e->bert_prune = value ? 1 : 0; return CZC_OK; }
   if (!strcmp(name, "pack_branches")) { e->pack_branches = value ? 1 : 0; return CZC_OK; }
   if (!strcmp(name, "pool_last_layer")) { e->pool_last_layer = value ? 1 : 0; return CZC_OK; }
   if (!strcmp(name, "fuse_ln")) { e->fuse_ln = value; return CZC_OK; }  // 0 off, 1 out-proj -> LN2, 2 also fc2 -> next LN1

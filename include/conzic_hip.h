@@ -215,6 +215,8 @@ int czc_generate(czc_engine* e, int B, int T, int L, int seed_len, const int32_t
 /* Engine options (all are exact work reductions / kernel choices; results agree within the engine precision):
  *   "share_prefix"    (1) encode the causal prefix common to an image's K candidates once per step instead of K
  *                         times
+ *   "bert_prune"      (1) n_mask == 1 steps: the last BERT layer behind its attention (out-projection, LayerNorms, MLP) on the
+ *                         masked row of every sequence only -- the one row the MLM head reads (gen_utils.py:69)
  *   "pack_branches"   (1) attention of the branch rows with G candidates packed per 32-query MFMA tile
  *   "pool_last_layer" (1) last CLIP-text layer: out-projection + MLP on the EOS rows only
  *   "fuse_ln"         (1) bf16 / fp16 CLIP-text tower at >= 4096 packed rows: the out-projection runs as a full-row

@@ -677,6 +677,59 @@ def test_prefix_sharing_is_exact(prec, name, one_gemm_family):
             np.testing.assert_array_equal(ia, ib)
 
 
+@pytest.mark.parametrize("prec", [F32, BF16])
+@pytest.mark.parametrize("name", ["tiny_shuffle", "full_synth_b2", "full_senti"])
+def test_last_bert_layer_on_the_masked_row_only_is_exact(prec, name):
+    """The MLM head reads one row per sequence (gen_utils.py:69), so behind the last layer's attention only that row
+    goes through out-projection / LayerNorm / MLP / LayerNorm (option bert_prune, on by default for n_mask == 1 steps).
+    Same per-row arithmetic; the B-row GEMMs may take another K split than the B*T-row ones -> fp32 summation order."""
+    meta, arr = load_case(name)
+    su = setup_for(meta, prec)
+    eng = su.engine
+    eng.set_image_embeds(arr["image_embeds"])
+    hp = Engine.hyper(meta["alpha"], meta["beta"], meta["temperature"], meta["gamma"], meta["style"] == "negative")
+    outs = []
+    for prune in (1, 0):
+        eng.set_option("bert_prune", prune)
+        rows = []
+        for i in (0, 2, arr["probs"].shape[0] - 1):
+            if meta["reuse"][i]:
+                continue
+            inp = np.ascontiguousarray(arr["inp_before"][i], dtype=np.int32)
+            r = eng.step(inp, SEED_LEN + meta["positions"][i], meta["K"], hp, dot_allowed=(meta["positions"][i] == meta["L"] - 1),
+                         want=("logits", "probs", "idxs", "final_score", "best"))
+            rows.append((r, inp.copy()))
+        outs.append(rows)
+    eng.set_option("bert_prune", 1)
+    assert outs[0]
+    for (ra, ia), (rb, ib) in zip(*outs):
+        scale = float(np.abs(rb["logits"]).max())
+        assert float(np.abs(ra["logits"] - rb["logits"]).max()) <= 2e-6 * max(scale, 1.0) + 1e-6
+        np.testing.assert_array_equal(ra["idxs"], rb["idxs"])
+        np.testing.assert_allclose(ra["probs"], rb["probs"], rtol=2e-4, atol=1e-7)
+        np.testing.assert_array_equal(ia, ib)
+
+
+def test_reuse_of_a_one_row_forward_for_another_row_is_refused():
+    """n_mask = 0 re-uses the previous BERT forward for the second slot of a span (gen_utils.py:164-166) and follows an
+    n_mask = 2 step, which keeps every row.  After an n_mask = 1 step only the masked row exists: asking for another
+    row must fail loudly, the same row must still work."""
+    meta, arr = load_case("tiny_seq")
+    su = setup_for(meta, F32)
+    eng = su.engine
+    eng.set_image_embeds(arr["image_embeds"])
+    hp = Engine.hyper(meta["alpha"], meta["beta"], meta["temperature"])
+    inp = np.ascontiguousarray(arr["inp_before"][0], dtype=np.int32)
+    a = eng.step(inp.copy(), SEED_LEN + 1, meta["K"], hp, n_mask=1, want=("logits",))
+    b = eng.step(inp.copy(), SEED_LEN + 1, meta["K"], hp, n_mask=0, want=("logits",))
+    np.testing.assert_array_equal(a["logits"], b["logits"])
+    with pytest.raises(native.NativeError, match="kept one row"):
+        eng.step(inp.copy(), SEED_LEN + 2, meta["K"], hp, n_mask=0)
+    two = eng.step(inp.copy(), SEED_LEN + 1, meta["K"], hp, n_mask=2, want=("logits",))  # a span's first step keeps all rows
+    eng.step(inp.copy(), SEED_LEN + 2, meta["K"], hp, n_mask=0)
+    assert np.isfinite(two["logits"]).all()
+
+
 @pytest.mark.parametrize("kernel", ["per_group", "per_image"])
 @pytest.mark.parametrize("name", ["tiny_shuffle", "full_synth_b2"])
 def test_packed_branch_attention_matches_per_segment(name, kernel, one_gemm_family):
