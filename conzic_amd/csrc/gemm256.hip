@@ -195,7 +195,8 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x16_t (&acc)
 // (vmcnt = stores of n-1 + loads of n+1 still allowed in flight) never includes a store; rows / columns past the edge
 // are handled by the buffer descriptors (reads return 0, writes are dropped), so there are no branches.
 // Same arithmetic, same order (acc + bias, + residual) as tile_epilogue: bit-identical results.  NJ = 32-column blocks per wave.
-template <int NJ>
+// ABL (timing ablations, EXPERIMENTS build): 1 no residual loads, 2 no output stores
+template <int NJ, int ABL = 0>
 __device__ __forceinline__ void tile_epilogue_f32_asm(const GemmArgs& g, f32x16_t (&acc)[4][NJ], unsigned char* patch, int m0, int n0,
                                                       int wm, int wcol0, int lane) {
   const int half = lane >> 5, l31 = lane & 31, rrow = lane >> 3, rslot = lane & 7;
@@ -235,8 +236,10 @@ __device__ __forceinline__ void tile_epilogue_f32_asm(const GemmArgs& g, f32x16_
   f32x4_t rr[2][4];
   auto load_resid = [&](int blk, f32x4_t (&r)[4]) {
 #pragma unroll
-    for (int pass = 0; pass < 4; ++pass)
-      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(r[pass]) : "v"(off(blk, pass, g.ldr)), "s"(rsR) : "memory");
+    for (int pass = 0; pass < 4; ++pass) {
+      if (ABL & 1) asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0\n\tv_mov_b32 %2, 0\n\tv_mov_b32 %3, 0" : "=v"(r[pass][0]), "=v"(r[pass][1]), "=v"(r[pass][2]), "=v"(r[pass][3]));
+      else asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(r[pass]) : "v"(off(blk, pass, g.ldr)), "s"(rsR) : "memory");
+    }
   };
   load_resid(0, rr[0]);
 #pragma unroll
@@ -251,7 +254,11 @@ __device__ __forceinline__ void tile_epilogue_f32_asm(const GemmArgs& g, f32x16_
     }
     f32x4_t(&r)[4] = rr[blk & 1];
     // residual rows of this block (and, first time round, the bias) have landed: younger = stores of block blk-1, loads of blk+1
-    if (blk == 0 || blk + 1 == NB)
+    if (ABL) {  // the counts below assume four loads and four stores per block
+      if (blk == 0) asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(bias4[j]) : : "memory");
+      else if (ABL == 1) asm volatile("s_waitcnt vmcnt(8)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(bias4[j]) : : "memory");
+      else if (ABL == 2) asm volatile("s_waitcnt vmcnt(4)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(bias4[j]) : : "memory");
+    } else if (blk == 0 || blk + 1 == NB)
       asm volatile("s_waitcnt vmcnt(4)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(bias4[j]) : : "memory");
     else
       asm volatile("s_waitcnt vmcnt(8)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(bias4[j]) : : "memory");
@@ -264,7 +271,8 @@ __device__ __forceinline__ void tile_epilogue_f32_asm(const GemmArgs& g, f32x16_
       v[0] += r[pass][0]; v[1] += r[pass][1]; v[2] += r[pass][2]; v[3] += r[pass][3];
       // s_nop 1: a > 64-bit asm store must not be followed at once by a write of its data registers (hipcc pads its own
       // stores, not an asm string: without it some lanes stored the next instruction's operands)
-      asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" : : "v"(v), "v"(off(blk, pass, g.ldc)), "s"(rsO) : "memory");
+      if (ABL & 2) asm volatile("" : : "v"(v), "v"(off(blk, pass, g.ldc)));
+      else asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" : : "v"(v), "v"(off(blk, pass, g.ldc)), "s"(rsO) : "memory");
     }
   }
 }
@@ -514,7 +522,8 @@ __global__ __launch_bounds__(768) void gemm256q_kernel(GemmArgs g, int tiles_m, 
 // one interval for group 1's last M, then both groups run the epilogue together; the ring runs on across tiles.
 // ================================================================================================
 // DBG (timing ablations only, results are garbage): 1 no MFMA, 2 no DMA, 4 no fragment reads, 8 no epilogue;
-// 16 / 32: epilogue A/B forms (tile_epilogue EPI bits 0 / 1; results stay correct)
+// 16 / 32: epilogue A/B forms (tile_epilogue EPI bits 0 / 1; results stay correct); 64 / 128: asm epilogue without its
+// residual loads / without its stores
 template <int ACT, bool OUT_F32, bool F16 = false, int DBG = 0>
 __global__ __launch_bounds__(512) void gemm256x_kernel(GemmArgs g, int tiles_m, int tiles_n, int var) {
   using HT = std::conditional_t<F16, f16_t, bf16_t>;
@@ -667,7 +676,7 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(GemmArgs g, int tiles_m, 
     } else {
       if constexpr (OUT_F32 && ACT == ACT_NONE) {
         if (!(var & 8) && g.resid && g.out_f32 && !g.out_act)
-          tile_epilogue_f32_asm<2>(g, acc, smem + QS * QSTAGE + wave * 4096, m0, n0, grp, wn * 64, lane);
+          tile_epilogue_f32_asm<2, (DBG >> 6) & 3>(g, acc, smem + QS * QSTAGE + wave * 4096, m0, n0, grp, wn * 64, lane);
         else
           tile_epilogue<ACT, OUT_F32, HT, (DBG >> 4) & 3>(g, acc, smem + QS * QSTAGE + wave * 4096, m0, n0, grp, wn, lane);
       } else {
@@ -828,7 +837,8 @@ constexpr int RL_W_BASE = RL_AS * RL_A_BYTES;
 constexpr int RL_PATCH = RL_W_BASE + RL_WS * RL_W_BYTES;
 constexpr int RL_LDS = RL_PATCH + 8 * 4096;  // 160 KiB
 
-template <bool F16>
+// DBG (timing ablations, EXPERIMENTS build, results are garbage): 1 no MFMA, 2 no LDS-DMA, 4 no fragment reads, 8 no epilogue
+template <bool F16, int DBG = 0>
 __global__ __launch_bounds__(512) void gemm_rowln_kernel(GemmArgs g, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, int tiles_m) {
   using HT = std::conditional_t<F16, f16_t, bf16_t>;
@@ -866,6 +876,7 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(GemmArgs g, const float
     }
     const unsigned dst = lds0 + (s & (RL_AS - 1)) * RL_A_BYTES + wave * (16 * QROWB);
     const unsigned so = kt * QROWB;
+    if (DBG & 2) return;
     unsigned keep;
     asm volatile(
         "s_mov_b32 %0, m0\n\t"
@@ -879,6 +890,7 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(GemmArgs g, const float
     const int kt = s % nk;
     const unsigned dst = lds0 + RL_W_BASE + slot * RL_W_BYTES + wave * (64 * QROWB);
     const unsigned so = kt * QROWB;
+    if (DBG & 2) return;
     unsigned keep;
     asm volatile(
         "s_mov_b32 %0, m0\n\t"
@@ -927,6 +939,12 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(GemmArgs g, const float
       const unsigned char* sA = smem + (step & (RL_AS - 1)) * RL_A_BYTES;
       const unsigned char* sB = smem + RL_W_BASE + wslot * RL_W_BYTES;
       uint4 b0[2], a0f[4], b1[2], a1f[4];
+      if (DBG & 4) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { b0[j] = make_uint4(lane, step, j, 0); b1[j] = make_uint4(lane, step, j, 1); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { a0f[i] = make_uint4(lane, step, i, 2); a1f[i] = make_uint4(lane, step, i, 3); }
+      } else {
 #pragma unroll
       for (int j = 0; j < 2; ++j) b0[j] = *(const uint4*)(sB + swzq(brow + 32 * j, half));
 #pragma unroll
@@ -935,23 +953,45 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(GemmArgs g, const float
       for (int j = 0; j < 2; ++j) b1[j] = *(const uint4*)(sB + swzq(brow + 32 * j, 2 + half));
 #pragma unroll
       for (int i = 0; i < 4; ++i) a1f[i] = *(const uint4*)(sA + swzq(l31 + 32 * i, 2 + half));
+      }
       __builtin_amdgcn_sched_barrier(0);
+      if (DBG & 1) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(__builtin_bit_cast(u32x4_t, b0[j])));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(__builtin_bit_cast(u32x4_t, a0f[i])));
+      } else {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = Half<HT>::mfma(b0[j], a0f[i], acc[i][j]);
+      }
       __builtin_amdgcn_sched_barrier(0);
       if (late) {
         if (step + 3 < total) issueA(step + 3);
         if (step + 2 < total) issueW(step + 2, wnext);
       }
+      if (DBG & 1) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(__builtin_bit_cast(u32x4_t, b1[j])));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(__builtin_bit_cast(u32x4_t, a1f[i])));
+      } else {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = Half<HT>::mfma(b1[j], a1f[i], acc[i][j]);
+      }
       wslot = wslot == 2 ? 0 : wslot + 1;
     }
 
+    if (DBG & 8) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[i][j]));
+      continue;
+    }
     // ---- epilogue: x (fp32) out, exact LayerNorm statistics across the eight waves, y out ----
     float4 vx[4][2][4];  // [i][j][pass]: row i*32 + pass*8 + rrow, columns wave*64 + j*32 + rslot*4 .. +3
 #pragma unroll
@@ -1090,6 +1130,20 @@ int launch_gemm_rowln(const GemmArgs& g, hipStream_t st) {
   }
   const int tiles_m = cdiv(g.M, RL_TM);
   dim3 grid(tiles_m < init.n_cu ? tiles_m : init.n_cu), block(512);
+#ifdef CZC_EXPERIMENTS
+  if ((g_w_dbg >> 8) && !g.f16) {  // timing ablations (tools/ab_gemm.py, out_mode 4)
+#define CZC_RL_ABL(D_) case D_: \
+    CZC_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_rowln_kernel<false, D_>, hipFuncAttributeMaxDynamicSharedMemorySize, RL_LDS)); \
+    hipLaunchKernelGGL((gemm_rowln_kernel<false, D_>), grid, block, RL_LDS, st, g, g.ln_gamma, g.ln_beta, tiles_m); break;
+    switch (g_w_dbg >> 8) {
+      CZC_RL_ABL(1) CZC_RL_ABL(2) CZC_RL_ABL(3) CZC_RL_ABL(7) CZC_RL_ABL(8) CZC_RL_ABL(9) CZC_RL_ABL(10) CZC_RL_ABL(13) CZC_RL_ABL(15)
+      default: snprintf(g_err, sizeof(g_err), "gemm_rowln: ablation %d not built", g_w_dbg >> 8); return 1;
+    }
+#undef CZC_RL_ABL
+    CZC_HIP_CHECK(hipGetLastError());
+    return 0;
+  }
+#endif
   if (g.f16) hipLaunchKernelGGL(gemm_rowln_kernel<true>, grid, block, RL_LDS, st, g, g.ln_gamma, g.ln_beta, tiles_m);
   else hipLaunchKernelGGL(gemm_rowln_kernel<false>, grid, block, RL_LDS, st, g, g.ln_gamma, g.ln_beta, tiles_m);
   CZC_HIP_CHECK(hipGetLastError());
@@ -1134,6 +1188,7 @@ int launch_gemm256(const GemmArgs& g, hipStream_t st) {
     switch (g_w_dbg >> 8) {
       CZC_GOXD(1); CZC_GOXD(2); CZC_GOXD(3); CZC_GOXD(4); CZC_GOXD(5); CZC_GOXD(6); CZC_GOXD(8); CZC_GOXD(9); CZC_GOXD(10); CZC_GOXD(12); CZC_GOXD(14);
       CZC_GOXD(16); CZC_GOXD(32); CZC_GOXD(48); CZC_GOXD(13); CZC_GOXD(7);
+      CZC_GOXD(64); CZC_GOXD(128); CZC_GOXD(71); CZC_GOXD(135); CZC_GOXD(199);
       default: snprintf(g_err, sizeof(g_err), "gemm256x: ablation %d not built", g_w_dbg >> 8); return 1;
     }
 #undef CZC_GOXD
