@@ -837,7 +837,8 @@ constexpr int RL_W_BASE = RL_AS * RL_A_BYTES;
 constexpr int RL_PATCH = RL_W_BASE + RL_WS * RL_W_BYTES;
 constexpr int RL_LDS = RL_PATCH + 8 * 4096;  // 160 KiB
 
-// DBG (timing ablations, EXPERIMENTS build, results are garbage): 1 no MFMA, 2 no LDS-DMA, 4 no fragment reads, 8 no epilogue
+// DBG (timing ablations, EXPERIMENTS build, results are garbage): 1 no MFMA, 2 no LDS-DMA, 4 no fragment reads, 8 no epilogue,
+// 16 y not stored (-1 KB per row), 32 only the first 64 bytes of every x line stored, 64 only every other x line stored (-1 KB per row each)
 template <bool F16, int DBG = 0>
 __global__ __launch_bounds__(512) void gemm_rowln_kernel(GemmArgs g, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, int tiles_m) {
@@ -1021,7 +1022,9 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(GemmArgs g, const float
           const int row = m0 + i * 32 + r;
           v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
           v.x += r4[pass].x; v.y += r4[pass].y; v.z += r4[pass].z; v.w += r4[pass].w;
-          if (row < g.M && g.out_f32) *(float4*)(g.out_f32 + (long)row * g.ldc + col) = v;
+          if (DBG & 32) { if (row < g.M && g.out_f32 && rslot < 4) *(float4*)(g.out_f32 + (long)row * g.ldc + col) = v; }  // ablation: first 64 B of every x line
+          else if (DBG & 64) { if (row < g.M && g.out_f32 && j == 0) *(float4*)(g.out_f32 + (long)row * g.ldc + col) = v; }  // ablation: every other x line
+          else if (row < g.M && g.out_f32) *(float4*)(g.out_f32 + (long)row * g.ldc + col) = v;
           vx[i][j][pass] = v;
         }
       }
@@ -1098,7 +1101,8 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(GemmArgs g, const float
                               : make_uint4(pk[pp].x, pk[pp].y, recv.x, recv.y);
           const int row = m0 + i * 32 + (pp + (odd ? 1 : 0)) * 8 + rrow;
           const int c8 = wave * 64 + j * 32 + (rslot & 6) * 4;
-          if (row < g.M) *(uint4*)(oa + (long)row * RL_N + c8) = d;
+          if (DBG & 16) asm volatile("" ::"v"(d.x), "v"(d.y), "v"(d.z), "v"(d.w));  // ablation: y not stored
+          else if (row < g.M) *(uint4*)(oa + (long)row * RL_N + c8) = d;
         }
       }
     }
@@ -1136,7 +1140,7 @@ int launch_gemm_rowln(const GemmArgs& g, hipStream_t st) {
     CZC_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_rowln_kernel<false, D_>, hipFuncAttributeMaxDynamicSharedMemorySize, RL_LDS)); \
     hipLaunchKernelGGL((gemm_rowln_kernel<false, D_>), grid, block, RL_LDS, st, g, g.ln_gamma, g.ln_beta, tiles_m); break;
     switch (g_w_dbg >> 8) {
-      CZC_RL_ABL(1) CZC_RL_ABL(2) CZC_RL_ABL(3) CZC_RL_ABL(7) CZC_RL_ABL(8) CZC_RL_ABL(9) CZC_RL_ABL(10) CZC_RL_ABL(13) CZC_RL_ABL(15)
+      CZC_RL_ABL(1) CZC_RL_ABL(2) CZC_RL_ABL(3) CZC_RL_ABL(7) CZC_RL_ABL(8) CZC_RL_ABL(9) CZC_RL_ABL(10) CZC_RL_ABL(13) CZC_RL_ABL(15) CZC_RL_ABL(16) CZC_RL_ABL(32) CZC_RL_ABL(64)
       default: snprintf(g_err, sizeof(g_err), "gemm_rowln: ablation %d not built", g_w_dbg >> 8); return 1;
     }
 #undef CZC_RL_ABL
