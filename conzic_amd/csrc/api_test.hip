@@ -203,6 +203,7 @@ int czc_test_set_option(const char* name, int value) {
   if (!strcmp(name, "skinny")) { g_use_skinny = value; return 0; }
   if (!strcmp(name, "splitk")) { g_use_splitk = value; return 0; }
   if (!strcmp(name, "gemm_deep")) { g_gemm_deep = value; return 0; }
+  if (!strcmp(name, "gemm_small_tiles")) { g_gemm_small_tiles = value; return 0; }
   if (!strcmp(name, "bridge_no_table")) { g_bridge_no_table = value; return 0; }
   if (!strcmp(name, "wreg")) { g_use_wreg = value; return 0; }
   if (!strcmp(name, "gemm256s")) { g_use_gemm256s = value; return 0; }

@@ -23,8 +23,6 @@
 namespace czc {
 
 constexpr int BM = 128, BN = 128, ROWB = 128;  // ROWB: bytes of K per tile row
-constexpr int TILE_BYTES = BM * ROWB;           // 16 KiB (A) ; B identical
-constexpr int STAGE_BYTES = 2 * TILE_BYTES;     // A + B
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
@@ -79,22 +77,22 @@ __device__ __forceinline__ float apply_act(float v) {
 
 // VEC: N % 4 == 0 and ldc/ldr % 4 == 0 (every call of the polishing step except the 30522-wide
 // MLM decoder, which takes the scalar form).
-template <typename T, int ACT, bool VEC>
-__device__ __forceinline__ void epilogue(const GemmArgs& g, f32x16_t (&acc)[2][2], int m0, int n0, int wm, int wn,
+template <typename T, int ACT, bool VEC, int NB = 2>
+__device__ __forceinline__ void epilogue(const GemmArgs& g, f32x16_t (&acc)[NB][NB], int m0, int n0, int wm, int wn,
                                          int lane) {
   const int half = lane >> 5;
   T* oa = (T*)g.out_act;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = m0 + wm * 64 + i * 32 + (lane & 31);
+  for (int i = 0; i < NB; ++i) {
+    const int row = m0 + wm * (32 * NB) + i * 32 + (lane & 31);
     if (row >= g.M) continue;
     const long ro = (long)row * g.ldc;
     const long rr = (long)row * g.ldr;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NB; ++j) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int col = n0 + wn * 64 + j * 32 + 8 * q + 4 * half;
+        const int col = n0 + wn * (32 * NB) + j * 32 + 8 * q + 4 * half;
         if (VEC) {
           if (col >= g.N) continue;
           float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
@@ -131,9 +129,14 @@ __device__ __forceinline__ void epilogue(const GemmArgs& g, f32x16_t (&acc)[2][2
 // work-group per CU (one or two images, the vision tower at small batches), which are chains of exposed L2 / HBM round
 // trips; with several work-groups per CU (BERT at hundreds of images) the vector-memory path is the bound and the extra
 // registers in flight cost 9 %, so the launcher picks by grid size.  Same summation order.
-template <typename T, int ACT, bool VEC, bool DEEP = false>
+// TS: tile side, 128 or 64 (the same kernel with one 32x32 MFMA block per wave instead of 2x2): a launch that would put 128-wide
+// tiles on less than a quarter of the CUs (one image: 40 tiles for fc2) runs four times as many work-groups, each with a
+// quarter of the MFMA work per K step, on the same chain of operand round trips.  Same k order per output element.
+template <typename T, int ACT, bool VEC, bool DEEP = false, int TS = 128>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, int tiles_m, int tiles_n, int kchunk) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE_BYTES];
+  constexpr int NB = TS / 64;                // 32x32 MFMA blocks per wave and dimension
+  constexpr int TILE_B = TS * ROWB, STAGE_B = 2 * TILE_B;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE_B];
   // split-K launch (gridDim.y > 1): slice z multiplies k in [z*kchunk, (z+1)*kchunk) into its own fp32 slab
   // out_f32 + z*M*ldc (no bias / activation / residual: splitk_reduce_kernel adds them in a fixed order)
   int kshift = 0;  // bytes the operand bases are moved into their rows (split-K): the descriptors still end where the rows end
@@ -159,25 +162,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, int tiles_m, int 
     lin = base + (lin >> 3);
   }
   const int tm = lin / tiles_n, tn = lin - tm * tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
+  const int m0 = tm * TS, n0 = tn * TS;
 
   // Rebased buffer descriptors: rows past M / N read as zero (hardware bounds check), offsets are
   // 32-bit and linear in the staging index (no per-row pointer arrays -> no scratch).
   const int lda_b = g.lda * (int)sizeof(T), ldw_b = g.ldw * (int)sizeof(T);
   const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)((const unsigned char*)g.A + (long)m0 * lda_b), (short)0,
-                                                     min(BM, g.M - m0) * lda_b - kshift, 0x00020000);
+                                                     min(TS, g.M - m0) * lda_b - kshift, 0x00020000);
   const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)((const unsigned char*)g.W + (long)n0 * ldw_b), (short)0,
-                                                     min(BN, g.N - n0) * ldw_b - kshift, 0x00020000);
+                                                     min(TS, g.N - n0) * ldw_b - kshift, 0x00020000);
   // staging map: thread t moves chunk (t&7) of rows (t>>3) + 32*i, i = 0..3, of both tiles
   const int sc = tid & 7, sr = tid >> 3;
   const int voA = sr * lda_b + sc * 16, voW = sr * ldw_b + sc * 16;
   const int soff = swz(sr, sc);  // rows +32: same swizzle phase, +4096 bytes
 
-  f32x16_t acc[2][2];
+  f32x16_t acc[NB][NB];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NB; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NB; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -192,52 +195,56 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, int tiles_m, int 
     const auto rw_ = (KT) < nk ? rsW : rsNone;                                                     \
     S##a0 = __builtin_amdgcn_raw_buffer_load_b128(ra_, voA, (KT) * ROWB, 0);                       \
     S##a1 = __builtin_amdgcn_raw_buffer_load_b128(ra_, voA + 32 * lda_b, (KT) * ROWB, 0);          \
-    S##a2 = __builtin_amdgcn_raw_buffer_load_b128(ra_, voA + 64 * lda_b, (KT) * ROWB, 0);          \
-    S##a3 = __builtin_amdgcn_raw_buffer_load_b128(ra_, voA + 96 * lda_b, (KT) * ROWB, 0);          \
     S##w0 = __builtin_amdgcn_raw_buffer_load_b128(rw_, voW, (KT) * ROWB, 0);                       \
     S##w1 = __builtin_amdgcn_raw_buffer_load_b128(rw_, voW + 32 * ldw_b, (KT) * ROWB, 0);          \
-    S##w2 = __builtin_amdgcn_raw_buffer_load_b128(rw_, voW + 64 * ldw_b, (KT) * ROWB, 0);          \
-    S##w3 = __builtin_amdgcn_raw_buffer_load_b128(rw_, voW + 96 * ldw_b, (KT) * ROWB, 0);          \
+    if constexpr (TS == 128) {                                                                     \
+      S##a2 = __builtin_amdgcn_raw_buffer_load_b128(ra_, voA + 64 * lda_b, (KT) * ROWB, 0);        \
+      S##a3 = __builtin_amdgcn_raw_buffer_load_b128(ra_, voA + 96 * lda_b, (KT) * ROWB, 0);        \
+      S##w2 = __builtin_amdgcn_raw_buffer_load_b128(rw_, voW + 64 * ldw_b, (KT) * ROWB, 0);        \
+      S##w3 = __builtin_amdgcn_raw_buffer_load_b128(rw_, voW + 96 * ldw_b, (KT) * ROWB, 0);        \
+    }                                                                                              \
   }
 #define CZC_STORE_TILE(S, dst)                                   \
   *(u32x4_t*)((dst) + soff) = S##a0;                             \
   *(u32x4_t*)((dst) + soff + 4096) = S##a1;                      \
-  *(u32x4_t*)((dst) + soff + 8192) = S##a2;                      \
-  *(u32x4_t*)((dst) + soff + 12288) = S##a3;                     \
-  *(u32x4_t*)((dst) + TILE_BYTES + soff) = S##w0;                \
-  *(u32x4_t*)((dst) + TILE_BYTES + soff + 4096) = S##w1;         \
-  *(u32x4_t*)((dst) + TILE_BYTES + soff + 8192) = S##w2;         \
-  *(u32x4_t*)((dst) + TILE_BYTES + soff + 12288) = S##w3;
+  *(u32x4_t*)((dst) + TILE_B + soff) = S##w0;                    \
+  *(u32x4_t*)((dst) + TILE_B + soff + 4096) = S##w1;             \
+  if constexpr (TS == 128) {                                     \
+    *(u32x4_t*)((dst) + soff + 8192) = S##a2;                    \
+    *(u32x4_t*)((dst) + soff + 12288) = S##a3;                   \
+    *(u32x4_t*)((dst) + TILE_B + soff + 8192) = S##w2;           \
+    *(u32x4_t*)((dst) + TILE_B + soff + 12288) = S##w3;          \
+  }
   CZC_LOAD_TILE(p, 0)
   if constexpr (DEEP) { CZC_LOAD_TILE(q, 1) CZC_LOAD_TILE(r, 2) }
   CZC_STORE_TILE(p, smem)
   __syncthreads();
 
-  const int arow = wm * 64 + (lane & 31);
-  const int brow = wn * 64 + (lane & 31);
+  const int arow = wm * (32 * NB) + (lane & 31);
+  const int brow = wn * (32 * NB) + (lane & 31);
   const int half = lane >> 5;
 
   auto compute = [&](int kt) {
-    const unsigned char* sA = smem + (kt & 1) * STAGE_BYTES;
-    const unsigned char* sB = sA + TILE_BYTES;
+    const unsigned char* sA = smem + (kt & 1) * STAGE_B;
+    const unsigned char* sB = sA + TILE_B;
     if constexpr (sizeof(T) == 4 && !__is_same(T, float)) {
       // split_t: chunk 2g = hi plane, 2g+1 = lo plane of k-group g; MFMA step s takes group 2s+half.
       // (a_hi + a_lo)(w_hi + w_lo) ~ a_hi w_hi + a_lo w_hi + a_hi w_lo   (lo*lo ~ 2^-22, dropped)
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         const int ch = 2 * (2 * s2 + half);
-        uint4 ah[2], al[2], bh[2], bl[2];
+        uint4 ah[NB], al[NB], bh[NB], bl[NB];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NB; ++i) {
           ah[i] = *(const uint4*)(sA + swz(arow + 32 * i, ch));
           al[i] = *(const uint4*)(sA + swz(arow + 32 * i, ch + 1));
           bh[i] = *(const uint4*)(sB + swz(brow + 32 * i, ch));
           bl[i] = *(const uint4*)(sB + swz(brow + 32 * i, ch + 1));
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NB; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
+          for (int j = 0; j < NB; ++j) {
             Mma<T>::run(bl[j], ah[i], acc[i][j]);
             Mma<T>::run(bh[j], al[i], acc[i][j]);
             Mma<T>::run(bh[j], ah[i], acc[i][j]);
@@ -247,16 +254,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, int tiles_m, int 
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const int ch = 2 * ks + half;
-        uint4 a[2], b[2];
+        uint4 a[NB], b[NB];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NB; ++i) {
           a[i] = *(const uint4*)(sA + swz(arow + 32 * i, ch));
           b[i] = *(const uint4*)(sB + swz(brow + 32 * i, ch));
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NB; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) Mma<T>::run(b[j], a[i], acc[i][j]);  // weight = A operand: D = C^T
+          for (int j = 0; j < NB; ++j) Mma<T>::run(b[j], a[i], acc[i][j]);  // weight = A operand: D = C^T
       }
     }
   };
@@ -270,7 +277,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, int tiles_m, int 
       __builtin_amdgcn_sched_barrier(0); /* the LDS stores of the older set stay BEHIND the MFMAs: hipcc */ \
       compute(T_);                       /* would hoist them (and their vmcnt wait) in front             */ \
       __builtin_amdgcn_sched_barrier(0);                                                                  \
-      if ((T_) + 1 < nk) { CZC_STORE_TILE(NEXT_, smem + (((T_) + 1) & 1) * STAGE_BYTES) }                 \
+      if ((T_) + 1 < nk) { CZC_STORE_TILE(NEXT_, smem + (((T_) + 1) & 1) * STAGE_B) }                 \
       __syncthreads();                                                                                    \
     }
     for (int kt = 0; kt < nk; kt += 3) {
@@ -286,7 +293,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, int tiles_m, int 
       if (kt + 1 < nk) { CZC_LOAD_TILE(p, kt + 1) }
       compute(kt);
       if (kt + 1 < nk) {
-        unsigned char* dA = smem + ((kt + 1) & 1) * STAGE_BYTES;
+        unsigned char* dA = smem + ((kt + 1) & 1) * STAGE_B;
         CZC_STORE_TILE(p, dA)
       }
       __syncthreads();
@@ -294,20 +301,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, int tiles_m, int 
   }
 #undef CZC_LOAD_TILE
 #undef CZC_STORE_TILE
-  epilogue<T, ACT, VEC>(g, acc, m0, n0, wm, wn, lane);
+  epilogue<T, ACT, VEC, NB>(g, acc, m0, n0, wm, wn, lane);
 }
 
 int g_gemm_deep = 1;  // 0 never, 1 when the launch has at most one work-group per CU, 2 always (test option "gemm_deep")
 
+int g_gemm_small_tiles = 1;  // 64-wide tiles for launches of less than a quarter of the CUs (test option "gemm_small_tiles")
+
 template <typename T>
 static void launch_t(const GemmArgs& g, int tiles_m, int tiles_n, bool vec, hipStream_t st, int ksplit = 1) {
-  dim3 grid(tiles_m * tiles_n, ksplit), block(256);
   const int kchunk = g.K / ksplit;
   static const int n_cu = []() { int d = 0; hipDeviceProp_t pr; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 256; }();
   const bool deep = g_gemm_deep == 2 || (g_gemm_deep == 1 && tiles_m * tiles_n * ksplit <= n_cu);  // at most one work-group per CU
+  const bool small = g_gemm_small_tiles && deep && ksplit == 1 && tiles_m * tiles_n * 4 <= n_cu * g_gemm_small_tiles;
+  if (small) { tiles_m = cdiv(g.M, 64); tiles_n = cdiv(g.N, 64); }
+  dim3 grid(tiles_m * tiles_n, ksplit), block(256);
 #define CZC_GEMM_LAUNCH(ACT_, VEC_)                                                                                        \
   do {                                                                                                                     \
-    if (deep) hipLaunchKernelGGL((gemm_kernel<T, ACT_, VEC_, true>), grid, block, 0, st, g, tiles_m, tiles_n, kchunk);     \
+    if (small) hipLaunchKernelGGL((gemm_kernel<T, ACT_, VEC_, true, 64>), grid, block, 0, st, g, tiles_m, tiles_n, kchunk); \
+    else if (deep) hipLaunchKernelGGL((gemm_kernel<T, ACT_, VEC_, true>), grid, block, 0, st, g, tiles_m, tiles_n, kchunk); \
     else hipLaunchKernelGGL((gemm_kernel<T, ACT_, VEC_, false>), grid, block, 0, st, g, tiles_m, tiles_n, kchunk);        \
   } while (0)
   if (vec) {

@@ -37,7 +37,8 @@ int launch_gemm_rowln(const GemmArgs& g, hipStream_t st);
 extern int g_rowln_min_m;
 extern int g_use_skinny;
 extern int g_use_splitk;
-extern int g_gemm_deep;  // 128x128 kernel: two-deep operand prefetch 0 never / 1 for launches of <= one work-group per CU / 2 always
+extern int g_gemm_deep;
+extern int g_gemm_small_tiles;  // 128x128 kernel: two-deep operand prefetch 0 never / 1 for launches of <= one work-group per CU / 2 always
 bool gemm_wreg_eligible(const GemmArgs& g);
 int launch_gemm_wreg(const GemmArgs& g, hipStream_t st);  // gemm_wreg.hip: weights in registers, K = 512
 extern int g_use_wreg;

@@ -610,6 +610,35 @@ def test_tiled_gemm_prefetch_depth_does_not_change_results(prec):
         lib.czc_test_set_option(b"wreg", WREG_DEFAULT)
 
 
+@pytest.mark.parametrize("prec", [BF16, FP16, F32, F16X3])
+def test_tiled_gemm_small_tiles_do_not_change_results(prec):
+    """Launches that would put 128-wide tiles on less than a quarter of the CUs (one or two images) run the same kernel with
+    64-wide tiles (option gemm_small_tiles): four times the work-groups, the same k order per output element -- bit-identical
+    outputs, with and without residual / activation, ragged rows and columns, one K step and many."""
+    lib = native.load()
+    rng = np.random.default_rng(11 + prec)
+    try:
+        assert lib.czc_test_set_option(b"gemm256", 0) == 0 and lib.czc_test_set_option(b"wreg", 0) == 0
+        assert lib.czc_test_set_option(b"splitk", 0) == 0 and lib.czc_test_set_option(b"skinny", 0) == 0
+        for (M, N, K, resid, act) in ((1200, 512, 2048, True, 0), (1300, 512, 512, True, 0), (77, 640, 320, False, 1), (40, 512, 512, True, 0),
+                                      (333, 200, 64, False, 0), (1, 512, 128, True, 0), (700, 1024, 192, False, 1), (65, 64, 64, True, 0)):
+            A = rng.standard_normal((M, K)).astype(np.float32)
+            W = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
+            bias = rng.standard_normal(N).astype(np.float32)
+            R = rng.standard_normal((M, N)).astype(np.float32) if resid else None
+            outs = []
+            for small in (0, 1):
+                assert lib.czc_test_set_option(b"gemm_small_tiles", small) == 0
+                outs.append(E.test_gemm(prec, A, W, bias=bias, resid=R, act=act))
+            np.testing.assert_array_equal(outs[0], outs[1], err_msg=f"M={M} N={N} K={K}")
+    finally:
+        lib.czc_test_set_option(b"gemm_small_tiles", 1)
+        lib.czc_test_set_option(b"splitk", 1)
+        lib.czc_test_set_option(b"skinny", 1)
+        lib.czc_test_set_option(b"gemm256", 1)
+        lib.czc_test_set_option(b"wreg", WREG_DEFAULT)
+
+
 @pytest.mark.parametrize("label", ["tiny", "full"])
 def test_bridge_token_table_equals_the_merge_loop(label):
     """The text bridge takes the CLIP ids of a chunk that is exactly one all-letter BERT piece from a per-token table the
