@@ -306,7 +306,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, int tiles_m, int 
 
 int g_gemm_deep = 1;  // 0 never, 1 when the launch has at most one work-group per CU, 2 always (test option "gemm_deep")
 
-int g_gemm_small_tiles = 1;  // 64-wide tiles for launches of less than a quarter of the CUs (test option "gemm_small_tiles")
+// 64-wide tiles when the 128-wide tiles of a launch would number at most N/4 of the CUs (test option "gemm_small_tiles"; 0 never).
+// N = 1 is where one to sixteen images gain (+8..35 %); 2 adds +5 % at 32 images, 4 (= every launch of at most one 128-wide
+// tile per CU that is not split along K) +1.5 % at 128; 256 images unchanged (profiles/r03_small_tiles_ab.txt)
+int g_gemm_small_tiles = 4;
 
 template <typename T>
 static void launch_t(const GemmArgs& g, int tiles_m, int tiles_n, bool vec, hipStream_t st, int ksplit = 1) {

@@ -613,7 +613,7 @@ def test_tiled_gemm_prefetch_depth_does_not_change_results(prec):
 @pytest.mark.parametrize("prec", [BF16, FP16, F32, F16X3])
 def test_tiled_gemm_small_tiles_do_not_change_results(prec):
     """Launches that would put 128-wide tiles on less than a quarter of the CUs (one or two images) run the same kernel with
-    64-wide tiles (option gemm_small_tiles): four times the work-groups, the same k order per output element -- bit-identical
+    64-wide tiles (option gemm_small_tiles, default 4 = whenever the 128-wide tiles would not fill the CUs): four times the work-groups, the same k order per output element -- bit-identical
     outputs, with and without residual / activation, ragged rows and columns, one K step and many."""
     lib = native.load()
     rng = np.random.default_rng(11 + prec)
@@ -632,7 +632,7 @@ def test_tiled_gemm_small_tiles_do_not_change_results(prec):
                 outs.append(E.test_gemm(prec, A, W, bias=bias, resid=R, act=act))
             np.testing.assert_array_equal(outs[0], outs[1], err_msg=f"M={M} N={N} K={K}")
     finally:
-        lib.czc_test_set_option(b"gemm_small_tiles", 1)
+        lib.czc_test_set_option(b"gemm_small_tiles", 4)
         lib.czc_test_set_option(b"splitk", 1)
         lib.czc_test_set_option(b"skinny", 1)
         lib.czc_test_set_option(b"gemm256", 1)
