@@ -1111,11 +1111,11 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(GemmArgs g, const float
 
 }  // namespace
 
-int g_gemm256_min_m = 2048;
+int g_gemm256_min_m = 8192;  // below: the tiled kernel (64-wide tiles on small grids) is 1.6-2x faster at 2-5 k rows, equal at 9.6 k (tools/probes/mid_m_gemm.py)
 int g_w_dbg = 0;  // gemm256x A/B switches (test option w_dbg): bit0 no s_setprio, bit1 DMA after the fragment reads, bit3 compiler-scheduled fp32 epilogue instead of the asm-counted one; bits 8.. timing ablations
 
 // x <- x + A.W^T + b with y = LayerNorm(x) from the same launch (gemm_rowln_kernel): N = 512 rows only.
-int g_rowln_min_m = 4096;
+int g_rowln_min_m = 8192;  // below: tiled GEMM + LayerNorm pass (19 vs 27 us at 4.8 k rows, equal at 9.6 k; tools/probes/mid_m_rowln.py)
 bool gemm_rowln_eligible(const GemmArgs& g) {
   return g.M >= g_rowln_min_m && g.N == RL_N && g.K % 32 == 0 && g.K >= 64 && g.ldc == RL_N && g.act == ACT_NONE && g.out_act &&
          g.out_f32 && g.ln_gamma && g.ln_beta && g.lda % 8 == 0 && g.ldw % 8 == 0 &&

@@ -219,7 +219,7 @@ int czc_generate(czc_engine* e, int B, int T, int L, int seed_len, const int32_t
  *                         masked row of every sequence only -- the one row the MLM head reads (gen_utils.py:69)
  *   "pack_branches"   (1) attention of the branch rows with G candidates packed per 32-query MFMA tile
  *   "pool_last_layer" (1) last CLIP-text layer: out-projection + MLP on the EOS rows only
- *   "fuse_ln"         (1) bf16 / fp16 CLIP-text tower at >= 4096 packed rows: the out-projection runs as a full-row
+ *   "fuse_ln"         (1) bf16 / fp16 CLIP-text tower at >= 8192 packed rows: the out-projection runs as a full-row
  *                         kernel that also emits LN2 of its result (no LayerNorm pass for it); 2 = fc2 -> the next
  *                         layer's LN1 as well (measured slower), 0 = off
  *   "refine_samples" (12), "refine_theta_x1000" (4000): CZC_PREC_REFINE selection -- strata of the mass-stratified sample

@@ -581,7 +581,7 @@ def test_kernel_families_agree_bitwise_on_random_shapes():
                     np.testing.assert_array_equal(out, ref, err_msg=f"variant {variant} M={M} N={N} K={K}")
     finally:
         lib.czc_test_set_option(b"gemm256", 1)
-        lib.czc_test_set_option(b"gemm256_min_m", 2048)
+        lib.czc_test_set_option(b"gemm256_min_m", 8192)
 
 
 @pytest.mark.parametrize("prec", [BF16, F32, F16X3])

@@ -770,7 +770,7 @@ def _packed_vs_per_segment(meta, arr):
 @pytest.mark.parametrize("prec", [BF16, FP16])
 @pytest.mark.parametrize("name,steps", [("full_synth_b2", (4, 7, 9)), ("full_shuffle_k512", (2, 9)), ("full_senti", (6, 11))])
 def test_fused_layernorm_matches_layernorm_kernel(name, steps, prec):
-    """CLIP-text path above 4096 packed rows: out-proj (default, fuse_ln = 1) and fc2 (fuse_ln = 2) as full-row kernels
+    """CLIP-text path above 8192 packed rows: out-proj (default, fuse_ln = 1) and fc2 (fuse_ln = 2) as full-row kernels
     that also emit the LayerNorm that follows them, against the same steps with the stand-alone LayerNorm kernel: the
     same two-pass statistics on the same fp32 rows, so only last-place flips of the normalised rows remain.  With
     both fused the LayerNorm kernel all but disappears from the profile (layer 0's LN1 and the pooled rows keep it)."""
@@ -795,7 +795,7 @@ def test_fused_layernorm_matches_layernorm_kernel(name, steps, prec):
             outs.append((rows, eng.profile_get("rowops")))
             eng.profile(0)
     finally:
-        lib.czc_test_set_option(b"rowln_min_m", 4096)
+        lib.czc_test_set_option(b"rowln_min_m", 8192)
         eng.set_option("fuse_ln", 1)
     for fused in outs[:2]:
         for ra, rb in zip(fused[0], outs[2][0]):
@@ -1102,12 +1102,12 @@ def test_odd_shapes_fast_engines_vs_f32_engine(B, L, K, filled):
 @pytest.mark.parametrize("prec", [BF16, FP16])
 def test_caption_does_not_depend_on_the_batch(prec):
     """Images are independent (gen_utils.py:64-81 has no cross-image term): an image polished alone and inside a batch of
-    eight must produce the SAME caption, token for token and cosine for cosine, with no kernel switches -- although the
+    sixteen must produce the SAME caption, token for token and cosine for cosine, with no kernel switches -- although the
     batch takes the full-row / ring GEMMs and the per-image attention kernel never runs at this size while the single
     image takes the tiled GEMM + LayerNorm kernel.  Free-running over two sweeps (a single near-tie flip would show)."""
     su = harness.build_synthetic(False, prec, regular_only=True)
     try:
-        B, L, K, I = 8, 6, 200, 2
+        B, L, K, I = 16, 6, 200, 2
         rng = np.random.default_rng(404)
         emb = rng.standard_normal((B, 512)).astype(np.float32)
         hp = Engine.hyper(0.02, 2.0, 0.1)
@@ -1117,14 +1117,14 @@ def test_caption_does_not_depend_on_the_batch(prec):
         su.engine.profile_reset()
         ids, cos = su.engine.generate(B, init, L, SEED_LEN, K, pos, hp, n_mask=nm, snapshot_every=every)
         rows_batch = su.engine.stats()["clip_rows"] / len(pos)
-        for b in (0, 5):
+        for b in (0, 5, 11):
             su.engine.set_image_embeds(emb[b:b + 1])
             su.engine.profile_reset()
             ids1, cos1 = su.engine.generate(1, init, L, SEED_LEN, K, pos, hp, n_mask=nm, snapshot_every=every)
             rows_one = su.engine.stats()["clip_rows"] / len(pos)
             np.testing.assert_array_equal(ids1[:, 0], ids[:, b])
             np.testing.assert_array_equal(cos1[:, 0], cos[:, b])
-        assert rows_batch > 4096 > 2048 > rows_one, (rows_batch, rows_one)  # the two runs really took different kernels
+        assert rows_batch > 8192 > rows_one, (rows_batch, rows_one)  # the two runs really took different kernels
     finally:
         su.engine.close()
 
