@@ -311,12 +311,18 @@ int g_gemm_deep = 1;  // 0 never, 1 when the launch has at most one work-group p
 // tile per CU that is not split along K) +1.5 % at 128; 256 images unchanged (profiles/r03_small_tiles_ab.txt)
 int g_gemm_small_tiles = 4;
 
-template <typename T>
-static void launch_t(const GemmArgs& g, int tiles_m, int tiles_n, bool vec, hipStream_t st, int ksplit = 1) {
-  const int kchunk = g.K / ksplit;
+static int gemm_n_cu() {
   static const int n_cu = []() { int d = 0; hipDeviceProp_t pr; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 256; }();
-  const bool deep = g_gemm_deep == 2 || (g_gemm_deep == 1 && tiles_m * tiles_n * ksplit <= n_cu);  // at most one work-group per CU
-  const bool small = g_gemm_small_tiles && deep && ksplit == 1 && tiles_m * tiles_n * 4 <= n_cu * g_gemm_small_tiles;
+  return n_cu;
+}
+
+// split_small: a split-K launch whose K slices were sized for 64-wide tiles (try_splitk)
+template <typename T>
+static void launch_t(const GemmArgs& g, int tiles_m, int tiles_n, bool vec, hipStream_t st, int ksplit = 1, bool split_small = false) {
+  const int kchunk = g.K / ksplit;
+  const int n_cu = gemm_n_cu();
+  const bool deep = split_small || g_gemm_deep == 2 || (g_gemm_deep == 1 && tiles_m * tiles_n * ksplit <= n_cu);  // at most one work-group per CU
+  const bool small = split_small || (g_gemm_small_tiles && deep && ksplit == 1 && tiles_m * tiles_n * 4 <= n_cu * g_gemm_small_tiles);
   if (small) { tiles_m = cdiv(g.M, 64); tiles_n = cdiv(g.N, 64); }
   dim3 grid(tiles_m * tiles_n, ksplit), block(256);
 #define CZC_GEMM_LAUNCH(ACT_, VEC_)                                                                                        \
@@ -487,10 +493,24 @@ static int try_splitk(const GemmArgs& g, int tiles_m, int tiles_n, hipStream_t s
   *rc = 0;
   if (!g_use_splitk || g.out_act || !g.out_f32 || g.act != ACT_NONE || g.N % 4 || g.ldc % 4 || (g.resid && g.ldr % 4)) return 0;
   const int tiles = tiles_m * tiles_n;
-  if (tiles >= 384 || g.M < 256) return 0;
+  if (tiles >= 384) return 0;
+  // K = 768 (out-projection): the unsplit kernel on 64-wide tiles is faster at every row count (26 vs 39 us at 3840 rows,
+  // 14 vs 17 at 480; tools/probes/bert_gemm_forms.py); K = 3072 (fc2) gains from slices at every row count
+  if (g_gemm_small_tiles && g.K < 2048) return 0;
   int ks = 0;
-  for (int c = 4; c >= 2; --c)
-    if (g.K % (c * Mma<T>::KPT) == 0 && g.K / c >= 256 && tiles * c <= 1024) { ks = c; break; }
+  bool split_small = false;
+  if (g_gemm_small_tiles && tiles * 4 <= gemm_n_cu()) {
+    // few tiles (up to ~64 images): 64-wide tiles, and as many slices (up to 8, at least 256 of K each) as it takes to
+    // put a work-group on every CU
+    const int t64 = cdiv(g.M, 64) * cdiv(g.N, 64);
+    for (int c = 2; c <= 8; ++c)
+      if (g.K % (c * Mma<T>::KPT) == 0 && g.K / c >= 256) { ks = c; if (t64 * c >= gemm_n_cu()) break; }
+    split_small = ks != 0;
+  } else {
+    if (g.M < 256) return 0;
+    for (int c = 4; c >= 2; --c)
+      if (g.K % (c * Mma<T>::KPT) == 0 && g.K / c >= 256 && tiles * c <= 1024) { ks = c; break; }
+  }
   if (!ks) return 0;
   const size_t need = (size_t)ks * g.M * g.ldc * 4;
   float* ws = nullptr;
@@ -506,7 +526,7 @@ static int try_splitk(const GemmArgs& g, int tiles_m, int tiles_n, hipStream_t s
   }
   GemmArgs p = g;
   p.bias = nullptr; p.resid = nullptr; p.out_f32 = ws;
-  launch_t<T>(p, tiles_m, tiles_n, true, st, ks);
+  launch_t<T>(p, tiles_m, tiles_n, true, st, ks, split_small);
   const long n4 = (long)g.M * (g.N >> 2);
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv(n4, 256)), dim3(256), 0, st, ws, ks, (long)g.M * g.ldc,
                      g.bias, g.resid, g.ldr, g.out_f32, g.ldc, g.M, g.N);
