@@ -839,7 +839,10 @@ constexpr int RL_LDS = RL_PATCH + 8 * 4096;  // 160 KiB
 
 // DBG (timing ablations, EXPERIMENTS build, results are garbage): 1 no MFMA, 2 no LDS-DMA, 4 no fragment reads, 8 no epilogue,
 // 16 y not stored (-1 KB per row), 32 only the first 64 bytes of every x line stored, 64 only every other x line stored (-1 KB per row each)
-template <bool F16, int DBG = 0>
+// AE: the x phase of the epilogue with every VMEM instruction in inline asm and counted waits (below); false = the
+// compiler-scheduled form it replaces (test option w_dbg bit 3), which waits vmcnt(0) in front of every 32 x 32 block --
+// for the block's residual rows AND the previous block's stores: eight full memory round trips per tile.
+template <bool F16, int DBG = 0, bool AE = true>
 __global__ __launch_bounds__(512) void gemm_rowln_kernel(GemmArgs g, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, int tiles_m) {
   using HT = std::conditional_t<F16, f16_t, bf16_t>;
@@ -995,6 +998,76 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(GemmArgs g, const float
     }
     // ---- epilogue: x (fp32) out, exact LayerNorm statistics across the eight waves, y out ----
     float4 vx[4][2][4];  // [i][j][pass]: row i*32 + pass*8 + rrow, columns wave*64 + j*32 + rslot*4 .. +3
+    f32x4_t gmv[2], btv[2];  // AE: gamma / beta of this lane's columns, requested behind block 6 (they land under block 7 and the statistics)
+    if constexpr (AE) {
+      // Residual rows one block ahead of the block being finished (32 VGPRs), bias / gamma / beta through the same path,
+      // bounds through the buffer descriptors (reads of rows past M return 0, writes are dropped): no branch, no
+      // compiler-placed vmcnt(0).  VMEM order per tile: B B | L0 L1 | S0 L2 | S1 L3 | ... | S5 L7 | S6 G | S7 (L / S / G four
+      // instructions each); gfx9 retires them in order, so "block b's rows have landed" is a count of the younger
+      // instructions.  Same arithmetic in the same order as the other form (patch value + bias, + residual).
+      const int rows = min(RL_TM, g.M - m0);
+      auto desc = [&](const void* base, long first_row, int ld, int n_rows) {
+        const unsigned long long pa = (unsigned long long)base + (unsigned long long)first_row * ld * 4;
+        u32x4_t r;
+        r.x = __builtin_amdgcn_readfirstlane((unsigned)pa);
+        r.y = __builtin_amdgcn_readfirstlane((unsigned)(pa >> 32) & 0xffffu);
+        r.z = __builtin_amdgcn_readfirstlane((unsigned)(base ? n_rows * ld * 4 : 0));
+        r.w = 0x00020000u;
+        return r;
+      };
+      const u32x4_t rsR = desc(g.resid, m0, g.ldr, rows), rsO = desc(g.out_f32, m0, g.ldc, rows);
+      const u32x4_t rsB = desc(g.bias, 0, RL_N, 1), rsG = desc(gamma, 0, RL_N, 1), rsT = desc(beta, 0, RL_N, 1);
+      asm volatile("s_nop 4" ::: "memory");  // descriptors fresh from v_readfirstlane -> buffer_* inside asm strings
+      const int colb = (wave * 64 + rslot * 4) * 4;
+      auto off = [&](int blk, int pass, int ld) -> unsigned {
+        return (unsigned)((((blk >> 1) * 32 + pass * 8 + rrow) * ld + (blk & 1) * 32) * 4 + colb);
+      };
+      f32x4_t bias4[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(bias4[j]) : "v"((unsigned)(colb + j * 128)), "s"(rsB) : "memory");
+      f32x4_t rr[2][4];
+      auto load_resid = [&](int blk, f32x4_t (&r)[4]) {
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass)
+          asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(r[pass]) : "v"(off(blk, pass, g.ldr)), "s"(rsR) : "memory");
+      };
+      load_resid(0, rr[0]); load_resid(1, rr[1]);
+#pragma unroll
+      for (int blk = 0; blk < 8; ++blk) {
+        const int i = blk >> 1, j = blk & 1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int slot = (2 * q + half) ^ (l31 & 7);
+          *(float4*)(patch + l31 * 128 + slot * 16) =
+              make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+        }
+        f32x4_t(&r)[4] = rr[blk & 1];
+        if (blk == 0)  // younger: L1
+          asm volatile("s_waitcnt vmcnt(4)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(bias4[j]) : : "memory");
+        else  // younger: the previous block's stores and the next block's rows (block 7: S6 and G)
+          asm volatile("s_waitcnt vmcnt(8)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(bias4[j]) : : "memory");
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+          const int rw = pass * 8 + rrow;
+          const float4 t = *(const float4*)(patch + rw * 128 + ((rslot ^ (rw & 7)) << 4));
+          f32x4_t v;
+          v[0] = t.x + bias4[j][0]; v[1] = t.y + bias4[j][1]; v[2] = t.z + bias4[j][2]; v[3] = t.w + bias4[j][3];
+          v[0] += r[pass][0]; v[1] += r[pass][1]; v[2] += r[pass][2]; v[3] += r[pass][3];
+          // s_nop 1: a > 64-bit asm store must not be followed at once by a write of its data registers
+          asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" : : "v"(v), "v"(off(blk, pass, g.ldc)), "s"(rsO) : "memory");
+          vx[i][j][pass] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        if (blk + 2 < 8) load_resid(blk + 2, rr[blk & 1]);
+        if (blk == 6) {
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) {
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(gmv[jj]) : "v"((unsigned)(colb + jj * 128)), "s"(rsG) : "memory");
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(btv[jj]) : "v"((unsigned)(colb + jj * 128)), "s"(rsT) : "memory");
+          }
+        }
+      }
+    } else {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -1028,6 +1101,7 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(GemmArgs g, const float
           vx[i][j][pass] = v;
         }
       }
+    }
     }
     // mean: this wave's 64-column partial per row -> its patch [0, 512); then every row group sums the eight partials
     float mean[4][4], rstd[4][4];
@@ -1074,11 +1148,19 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(GemmArgs g, const float
       }
     HT* oa = (HT*)g.out_act;
     const bool odd = rslot & 1;
+    if constexpr (AE)  // gamma / beta have landed: the only younger VMEM instructions are the stores of block 7
+      asm volatile("s_waitcnt vmcnt(4)" : "+v"(gmv[0]), "+v"(gmv[1]), "+v"(btv[0]), "+v"(btv[1]) : : "memory");
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int col = wave * 64 + j * 32 + rslot * 4;
-      const float4 gm = *(const float4*)(gamma + col);
-      const float4 bt = *(const float4*)(beta + col);
+      float4 gm, bt;
+      if constexpr (AE) {
+        gm = make_float4(gmv[j][0], gmv[j][1], gmv[j][2], gmv[j][3]);
+        bt = make_float4(btv[j][0], btv[j][1], btv[j][2], btv[j][3]);
+      } else {
+        gm = *(const float4*)(gamma + col);
+        bt = *(const float4*)(beta + col);
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         uint2 pk[4];
@@ -1112,7 +1194,7 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(GemmArgs g, const float
 }  // namespace
 
 int g_gemm256_min_m = 8192;  // below: the tiled kernel (64-wide tiles on small grids) is 1.6-2x faster at 2-5 k rows, equal at 9.6 k (tools/probes/mid_m_gemm.py)
-int g_w_dbg = 0;  // gemm256x A/B switches (test option w_dbg): bit0 no s_setprio, bit1 DMA after the fragment reads, bit3 compiler-scheduled fp32 epilogue instead of the asm-counted one; bits 8.. timing ablations
+int g_w_dbg = 0;  // gemm256x / gemm_rowln A/B switches (test option w_dbg): bit0 no s_setprio, bit1 DMA after the fragment reads, bit3 compiler-scheduled fp32 epilogue (gemm_rowln: x phase) instead of the asm-counted one; bits 8.. timing ablations
 
 // x <- x + A.W^T + b with y = LayerNorm(x) from the same launch (gemm_rowln_kernel): N = 512 rows only.
 int g_rowln_min_m = 8192;  // below: tiled GEMM + LayerNorm pass (19 vs 27 us at 4.8 k rows, equal at 9.6 k; tools/probes/mid_m_rowln.py)
@@ -1125,6 +1207,8 @@ int launch_gemm_rowln(const GemmArgs& g, hipStream_t st) {
   static const LaunchInit init = launch_init([](LaunchInit&) -> int {
     CZC_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_rowln_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, RL_LDS));
     CZC_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_rowln_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, RL_LDS));
+    CZC_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_rowln_kernel<false, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, RL_LDS));
+    CZC_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_rowln_kernel<true, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, RL_LDS));
     return 0;
   });
   if (init.rc) return launch_init_failed("gemm_rowln");
@@ -1148,7 +1232,10 @@ int launch_gemm_rowln(const GemmArgs& g, hipStream_t st) {
     return 0;
   }
 #endif
-  if (g.f16) hipLaunchKernelGGL(gemm_rowln_kernel<true>, grid, block, RL_LDS, st, g, g.ln_gamma, g.ln_beta, tiles_m);
+  if (g_w_dbg & 8) {  // compiler-scheduled x phase (A/B, bit-identical)
+    if (g.f16) hipLaunchKernelGGL((gemm_rowln_kernel<true, 0, false>), grid, block, RL_LDS, st, g, g.ln_gamma, g.ln_beta, tiles_m);
+    else hipLaunchKernelGGL((gemm_rowln_kernel<false, 0, false>), grid, block, RL_LDS, st, g, g.ln_gamma, g.ln_beta, tiles_m);
+  } else if (g.f16) hipLaunchKernelGGL(gemm_rowln_kernel<true>, grid, block, RL_LDS, st, g, g.ln_gamma, g.ln_beta, tiles_m);
   else hipLaunchKernelGGL(gemm_rowln_kernel<false>, grid, block, RL_LDS, st, g, g.ln_gamma, g.ln_beta, tiles_m);
   CZC_HIP_CHECK(hipGetLastError());
   return 0;

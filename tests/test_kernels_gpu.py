@@ -538,6 +538,21 @@ def test_full_row_kernel_and_gemm_plus_layernorm_agree_bitwise(prec):
     np.testing.assert_array_equal(x, x2)
     y2 = E.test_layernorm(prec, x2, gamma, beta, 1e-5)
     np.testing.assert_array_equal(y, y2)
+    # the asm-counted x phase of the epilogue (default) against the compiler-scheduled one it replaces, twice (a mis-counted
+    # wait shows up as a few stale lanes on some run), with and without a bias, ragged last tile
+    lib = native.load()
+    for bias in (b, None):
+        outs = []
+        try:
+            for dbg in (0, 8, 0):
+                assert lib.czc_test_set_option(b"w_dbg", dbg) == 0
+                outs.append(E.test_gemm_rowln(prec, A, W, bias, resid, gamma, beta, 1e-5))
+        finally:
+            lib.czc_test_set_option(b"w_dbg", 0)
+        for xo, yo in outs[1:]:
+            np.testing.assert_array_equal(xo, outs[0][0])
+            np.testing.assert_array_equal(yo, outs[0][1])
+    np.testing.assert_array_equal(outs[0][0], E.test_gemm(prec, A, W, resid=resid))
 
 
 @pytest.mark.parametrize("act", [0, 1])
