@@ -351,6 +351,24 @@ __device__ __forceinline__ void tile_at(int i, int tiles_m, int tiles_n, int& tm
   tile_of(blockIdx.x + i * gridDim.x, tiles_m, tiles_n, tm, tn);
 }
 
+// Start stagger of a persistent grid whose tiles end in an HBM burst (fp32 residual in, fp32 row out): left alone all
+// work-groups run in lock-step -- every CU in its main loop (HBM nearly idle), then every CU in its epilogue (HBM the
+// bound) -- and a work-group's epilogue takes as long as the whole chip's.  Work-group b starts `phase` x tau microseconds
+// late (phase 0..7, the same for the work-groups that share an A tile), and the work-groups that have one tile less than
+// the others (b >= nt % grid: they would idle at the end anyway) another `bonus` microseconds: the epilogues of different
+// work-groups then fall on different moments and overlap other work-groups' main loops.  stagger = tau | bonus << 8.
+// Only the start time changes: results are bit-identical.  (profiles/r03_rowln_stagger_ab.txt)
+__device__ __forceinline__ void start_stagger(int stagger, int nt, int share) {
+  if (!stagger) return;
+  const int b = (int)blockIdx.x, tau = stagger & 255, bonus = stagger >> 8;
+  const int rem = nt % (int)gridDim.x;
+  unsigned long long dt = (unsigned long long)(((b >> 3) / share) & 7) * tau;
+  if (rem && b >= rem) dt += bonus;
+  dt *= 100ull;  // s_memrealtime counts at 100 MHz
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while (__builtin_amdgcn_s_memrealtime() - t0 < dt) __builtin_amdgcn_s_sleep(8);
+}
+
 // ================================================================================================
 // gemm256q: 12 waves per work-group: waves 0-7 are MFMA waves (never issue a global load), waves 8-11 are LOADER
 // waves that only issue the LDS-DMA of later K steps (8 x 1 KiB each per step).  The K-step sequence is continuous
@@ -534,6 +552,7 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(GemmArgs g, int tiles_m, 
   const int grp = wave >> 2;
   const int nk = g.K >> 5;  // 32-wide K steps
   const int lda_b = g.lda * 2, ldw_b = g.ldw * 2;
+  start_stagger(var >> 8, tiles_m * tiles_n, tiles_n);
   const int my_tiles = tile_count(tiles_m, tiles_n);
   const int total = my_tiles * nk;
   const bool prio = !(var & 1), dma_late = var & 2;
@@ -844,12 +863,13 @@ constexpr int RL_LDS = RL_PATCH + 8 * 4096;  // 160 KiB
 // for the block's residual rows AND the previous block's stores: eight full memory round trips per tile.
 template <bool F16, int DBG = 0, bool AE = true>
 __global__ __launch_bounds__(512) void gemm_rowln_kernel(GemmArgs g, const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, int tiles_m) {
+                                                          const float* __restrict__ beta, int tiles_m, int stagger_us = 0) {  // stagger_us: start_stagger()
   using HT = std::conditional_t<F16, f16_t, bf16_t>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  start_stagger(stagger_us, tiles_m, 1);
   const int nk = g.K >> 5;
   const int lda_b = g.lda * 2, ldw_b = g.ldw * 2;
   const int my_tiles = (tiles_m - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
@@ -1232,11 +1252,17 @@ int launch_gemm_rowln(const GemmArgs& g, hipStream_t st) {
     return 0;
   }
 #endif
+  // start stagger (start_stagger): 2 us per phase + 16 us for the work-groups with a tile less, from four tiles per
+  // work-group on (fewer: the delay costs more than the de-synchronised epilogues return); w_dbg bit 2 = off, bits 4-7 /
+  // 8.. = tau / bonus of an A/B run
+  int stagger = tiles_m / (int)grid.x >= 4 ? (2 | 16 << 8) : 0;
+  if (g_w_dbg & 4) stagger = 0;
+  if (g_w_dbg >> 4) stagger = ((g_w_dbg >> 4) & 15) | ((g_w_dbg >> 8) << 8);
   if (g_w_dbg & 8) {  // compiler-scheduled x phase (A/B, bit-identical)
     if (g.f16) hipLaunchKernelGGL((gemm_rowln_kernel<true, 0, false>), grid, block, RL_LDS, st, g, g.ln_gamma, g.ln_beta, tiles_m);
     else hipLaunchKernelGGL((gemm_rowln_kernel<false, 0, false>), grid, block, RL_LDS, st, g, g.ln_gamma, g.ln_beta, tiles_m);
-  } else if (g.f16) hipLaunchKernelGGL(gemm_rowln_kernel<true>, grid, block, RL_LDS, st, g, g.ln_gamma, g.ln_beta, tiles_m);
-  else hipLaunchKernelGGL(gemm_rowln_kernel<false>, grid, block, RL_LDS, st, g, g.ln_gamma, g.ln_beta, tiles_m);
+  } else if (g.f16) hipLaunchKernelGGL(gemm_rowln_kernel<true>, grid, block, RL_LDS, st, g, g.ln_gamma, g.ln_beta, tiles_m, stagger);
+  else hipLaunchKernelGGL(gemm_rowln_kernel<false>, grid, block, RL_LDS, st, g, g.ln_gamma, g.ln_beta, tiles_m, stagger);
   CZC_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -1298,7 +1324,14 @@ int launch_gemm256(const GemmArgs& g, hipStream_t st) {
       else { if (f32) CZC_GO(K_, ACT_NONE, true, false, T_, ##__VA_ARGS__); else CZC_GO(K_, ACT_NONE, false, false, T_, ##__VA_ARGS__); }                             \
     }                                                                                                                      \
   } while (0)
-  if (pp) CZC_DISPATCH(gemm256x_kernel, 512, g_w_dbg & 255);
+  // gemm256x with the fp32-residual epilogue (the HBM burst at the end of every tile): start stagger (start_stagger) of 2 us
+  // per phase + 32 us for the work-groups with a tile less, from four tiles per work-group on: fc2 -1.7 % at 312 k rows,
+  // -1.9 % at 156 k (its epilogue is a fifth of a tile; gemm_rowln's is two thirds and gains 10 %).  w_dbg bit 2 = off,
+  // bits 4-7 / 8.. = tau / bonus of an A/B run
+  int stagger256 = (f32 && tiles_m * tiles_n / (int)gq.x >= 4) ? (2 | 32 << 8) : 0;
+  if (g_w_dbg & 4) stagger256 = 0;
+  if (f32 && (g_w_dbg >> 4)) stagger256 = ((g_w_dbg >> 4) & 15) | ((g_w_dbg >> 8) << 8);
+  if (pp) CZC_DISPATCH(gemm256x_kernel, 512, (g_w_dbg & 15) | stagger256 << 8);
   else CZC_DISPATCH(gemm256q_kernel, 768);
 #undef CZC_DISPATCH
 #undef CZC_GO
