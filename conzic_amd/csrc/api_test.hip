@@ -209,6 +209,7 @@ int czc_test_set_option(const char* name, int value) {
   if (!strcmp(name, "gemm256s")) { g_use_gemm256s = value; return 0; }
   if (!strcmp(name, "bench_pad")) { g_bench_pad = value; return 0; }
   if (!strcmp(name, "w_dbg")) { g_w_dbg = value; return 0; }
+  if (!strcmp(name, "ln_lean")) { g_ln_lean = value; return 0; }
   if (!strcmp(name, "rowln_min_m")) { g_rowln_min_m = value; return 0; }
   if (!strcmp(name, "wreg_min_m")) { g_wreg_min_m = value; return 0; }
   if (!strcmp(name, "gemm256_min_m")) { g_gemm256_min_m = value; return 0; }

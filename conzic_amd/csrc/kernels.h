@@ -32,6 +32,7 @@ bool gemm256s_eligible(const GemmArgs& g);  // split-fp16 operands, same 256x256
 int launch_gemm256s(const GemmArgs& g, hipStream_t st);
 extern int g_use_gemm256s;
 extern int g_w_dbg;
+extern int g_ln_lean;
 bool gemm_rowln_eligible(const GemmArgs& g);  // gemm256.hip: 128 x 512 full-row kernel, LayerNorm in the epilogue
 int launch_gemm_rowln(const GemmArgs& g, hipStream_t st);
 extern int g_rowln_min_m;

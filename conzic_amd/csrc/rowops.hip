@@ -44,9 +44,26 @@ __device__ __forceinline__ void ln_row(float4 (&v)[NV], int H, int lane, const f
 
 // sum over the wave in the association order of gemm_rowln_kernel's epilogue (gemm256.hip): lane = 8*w + r sums its
 // neighbours r^1, r^2, r^4 first (the 64-column partial of "wave" w there), then w^1, w^2, w^4
+// LEAN: partners 1 .. 16 through ds_swizzle's bit-mask mode (no address registers; same partners in the same order, so the
+// same bits): layernorm512_kernel then needs 30 VGPRs instead of 35, i.e. one 32-register allocation step -- a wave of it
+// fits beside the two 240-register waves per SIMD of the weight-stationary GEMM (2 x 240 + 32 = 512), so with two image
+// sub-batches on two streams one stream's LayerNorm pass can run on the CUs the other stream's qkv / fc1 GEMM occupies
+// instead of waiting for its work-groups to leave.
+template <bool LEAN>
 __device__ __forceinline__ float wave_sum_rowln_order(float v) {
+  if (LEAN) {
+#define CZC_SWZ_XOR(M_) __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x1f | ((M_) << 10)))
+    v += CZC_SWZ_XOR(1);
+    v += CZC_SWZ_XOR(2);
+    v += CZC_SWZ_XOR(4);
+    v += CZC_SWZ_XOR(8);
+    v += CZC_SWZ_XOR(16);
+#undef CZC_SWZ_XOR
+    v += __shfl_xor(v, 32, 64);
+  } else {
 #pragma unroll
-  for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+    for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+  }
   return v;
 }
 
@@ -55,7 +72,7 @@ __device__ __forceinline__ float wave_sum_rowln_order(float v) {
 // exact two-pass statistics; identical reduction tree), so that a row normalised by this kernel (few packed rows:
 // the out-projection runs on the tiled GEMM) and by the full-row GEMM (many rows) come out bit-identical -- the
 // engine's results must not depend on the batch size through the choice between the two.
-template <typename T>
+template <typename T, bool LEAN>
 __global__ __launch_bounds__(256) void layernorm512_kernel(const float* x, const int* row_idx, const float* gamma,
                                                            const float* beta, float eps, int M, T* y_act, float* y_f32) {
   const int lane = threadIdx.x & 63;
@@ -65,7 +82,7 @@ __global__ __launch_bounds__(256) void layernorm512_kernel(const float* x, const
   const float* xr = x + src * 512L;
   const int c0 = (lane >> 3) * 64 + (lane & 7) * 4;
   const float4 u = *(const float4*)(xr + c0), w = *(const float4*)(xr + c0 + 32);
-  const float mean = wave_sum_rowln_order(((u.x + u.y) + (u.z + u.w)) + ((w.x + w.y) + (w.z + w.w))) / 512.0f;
+  const float mean = wave_sum_rowln_order<LEAN>(((u.x + u.y) + (u.z + u.w)) + ((w.x + w.y) + (w.z + w.w))) / 512.0f;
   float q = 0.f;
   {
     const float a = u.x - mean, b = u.y - mean, c = u.z - mean, d = u.w - mean;
@@ -75,7 +92,7 @@ __global__ __launch_bounds__(256) void layernorm512_kernel(const float* x, const
     const float a = w.x - mean, b = w.y - mean, c = w.z - mean, d = w.w - mean;
     q += (a * a + b * b) + (c * c + d * d);
   }
-  const float rstd = rsqrtf(wave_sum_rowln_order(q) / 512.0f + eps);
+  const float rstd = rsqrtf(wave_sum_rowln_order<LEAN>(q) / 512.0f + eps);
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int c = c0 + 32 * j;
@@ -115,6 +132,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const in
   }
 }
 
+int g_ln_lean = 1;  // test option ln_lean = 0: the 35-VGPR form of layernorm512_kernel (shuffles through ds_bpermute)
+
 int launch_layernorm(int prec, const float* x, const int* row_idx, const float* gamma, const float* beta, float eps,
                      int M, int H, void* y_act, float* y_f32, hipStream_t st) {
   if (M <= 0) return 0;
@@ -123,10 +142,14 @@ int launch_layernorm(int prec, const float* x, const int* row_idx, const float* 
     return 1;
   }
   dim3 grid(cdiv(M, 4)), block(256);
-  if (H == 512 && prec == PREC_BF16)
-    hipLaunchKernelGGL(layernorm512_kernel<bf16_t>, grid, block, 0, st, x, row_idx, gamma, beta, eps, M, (bf16_t*)y_act, y_f32);
+  if (H == 512 && prec == PREC_BF16 && g_ln_lean)
+    hipLaunchKernelGGL((layernorm512_kernel<bf16_t, true>), grid, block, 0, st, x, row_idx, gamma, beta, eps, M, (bf16_t*)y_act, y_f32);
+  else if (H == 512 && prec == PREC_F16 && g_ln_lean)
+    hipLaunchKernelGGL((layernorm512_kernel<f16_t, true>), grid, block, 0, st, x, row_idx, gamma, beta, eps, M, (f16_t*)y_act, y_f32);
+  else if (H == 512 && prec == PREC_BF16)
+    hipLaunchKernelGGL((layernorm512_kernel<bf16_t, false>), grid, block, 0, st, x, row_idx, gamma, beta, eps, M, (bf16_t*)y_act, y_f32);
   else if (H == 512 && prec == PREC_F16)
-    hipLaunchKernelGGL(layernorm512_kernel<f16_t>, grid, block, 0, st, x, row_idx, gamma, beta, eps, M, (f16_t*)y_act, y_f32);
+    hipLaunchKernelGGL((layernorm512_kernel<f16_t, false>), grid, block, 0, st, x, row_idx, gamma, beta, eps, M, (f16_t*)y_act, y_f32);
   else if (prec == PREC_BF16)
     hipLaunchKernelGGL(layernorm_kernel<bf16_t>, grid, block, 0, st, x, row_idx, gamma, beta, eps, M, H,
                        (bf16_t*)y_act, y_f32);

@@ -538,6 +538,13 @@ def test_full_row_kernel_and_gemm_plus_layernorm_agree_bitwise(prec):
     np.testing.assert_array_equal(x, x2)
     y2 = E.test_layernorm(prec, x2, gamma, beta, 1e-5)
     np.testing.assert_array_equal(y, y2)
+    # the 30-VGPR LayerNorm kernel (ds_swizzle partners, default) against the ds_bpermute form: same tree, same bits
+    lib = native.load()
+    try:
+        assert lib.czc_test_set_option(b"ln_lean", 0) == 0
+        np.testing.assert_array_equal(E.test_layernorm(prec, x2, gamma, beta, 1e-5), y2)
+    finally:
+        lib.czc_test_set_option(b"ln_lean", 1)
     # the asm-counted x phase of the epilogue (default) against the compiler-scheduled one it replaces, twice (a mis-counted
     # wait shows up as a few stale lanes on some run), with and without a bias, ragged last tile
     lib = native.load()
