@@ -236,7 +236,7 @@ def main():
         for kv in opts:
             k, v = kv.split("=")
             if k.startswith("test:"):  # kernel-level A/B switches (czc_test_set_option)
-                assert native.load().czc_test_set_option(k[5:].encode(), int(v)) == 0, k
+                assert native.load_test().czc_test_set_option(k[5:].encode(), int(v)) == 0, k
             else:
                 eng.set_option(k, int(v))
         # the images are polished as `streams` contiguous sub-batches, each by its own engine replica (same weights, own

@@ -1,10 +1,11 @@
-// Kernel-level parity hooks of include/conzic_hip.h (czc_test_*): run ONE kernel on host data.
-// Used only by tests/ (-m gpu) to compare each HIP kernel with the CPU oracle.
+// Kernel-level parity hooks of include/conzic_hip_test.h (czc_test_*): run ONE kernel on host data.
+// Used only by tests/ (-m gpu) to compare each HIP kernel with the CPU oracle, and by tools/ for kernel A/B timing.
+// Built into libconzic_hip_test.so, which links against the product library; the product library exports none of it.
 #include <vector>
 #include <cstring>
 #include <algorithm>
 
-#include "../../include/conzic_hip.h"
+#include "../../include/conzic_hip_test.h"
 #include "kernels.h"
 #include "bridge_hash.h"
 

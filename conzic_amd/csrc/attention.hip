@@ -947,7 +947,8 @@ int launch_attention_shared(const void* qkv, const SegTable& tab, int B, int K, 
   if (g_use_attention_image && heads % 4 == 0 && max_keys <= 32 && K <= 1024 &&
       (B * (heads / 4) >= 128 || g_use_attention_image == 2)) {
     // one-time set-up behind a function-local static (two engines launch from two host threads)
-    static const LaunchInit init = launch_init([](LaunchInit&) -> int {
+    static PerDeviceInit per_dev;
+  const LaunchInit init = per_dev.get([](LaunchInit&) -> int {
       CZC_HIP_CHECK(hipFuncSetAttribute((const void*)attention_image_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, A2_LDS));
       CZC_HIP_CHECK(hipFuncSetAttribute((const void*)attention_image_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, A2_LDS));
       return 0;

@@ -1,6 +1,8 @@
 // Shared device/host helpers for the gfx950 kernels of the polishing engine.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
+#include <mutex>
 #include <stdint.h>
 #include <stdio.h>
 
@@ -192,6 +194,27 @@ inline LaunchInit launch_init(F attrs) {
   }();
   return li;
 }
+// The same, once per DEVICE: hipFuncSetAttribute and the CU count belong to the device that is current when they are
+// made, and czc_create takes a device id -- engines on two GPUs of one process each get their own set-up.  A failed
+// set-up is not latched: the next launch on that device tries again.
+struct PerDeviceInit {
+  static constexpr int MAX_DEV = 32;
+  std::mutex mu;
+  std::atomic<bool> done[MAX_DEV];
+  LaunchInit li[MAX_DEV];
+  PerDeviceInit() { for (auto& d : done) d.store(false); }
+  template <typename F>
+  LaunchInit get(F attrs) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) { LaunchInit bad; bad.rc = 2; return bad; }
+    if (done[dev].load(std::memory_order_acquire)) return li[dev];
+    std::lock_guard<std::mutex> lk(mu);
+    if (done[dev].load(std::memory_order_relaxed)) return li[dev];
+    LaunchInit r = launch_init(attrs);
+    if (r.rc == 0) { li[dev] = r; done[dev].store(true, std::memory_order_release); }
+    return r;
+  }
+};
 inline int launch_init_failed(const char* what) {
   snprintf(g_err, sizeof(g_err), "%s: one-time launch set-up failed (hipFuncSetAttribute / device query)", what);
   return 2;

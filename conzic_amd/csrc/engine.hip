@@ -85,7 +85,7 @@ struct czc_engine {
   float* d_img_n = nullptr; int img_B = 0;
   float logit_scale_exp = 1.f;
   int* h_totals = nullptr;  // pinned, 64 ints: [0..7] plan totals, [8],[9] non-finite flags, [16..27] refine-plan totals
-  int last_BT = 0;
+  int last_BT = 0, last_B = 0, last_T = 0;  // shape of the forward whose rows b_x / b_xg hold (n_mask = 0 re-use needs the same B AND T)
   int bert_prune = 1;       // last BERT layer behind the attention on the one row per sequence the MLM head reads (n_mask == 1 steps)
   int bert_pruned_idx = -1; // row the previous forward kept (-1: all rows of b_x are valid)
   int share_prefix = 1;  // encode the candidates' common causal prefix once per image
@@ -99,6 +99,10 @@ struct czc_engine {
   std::map<std::string, ProfKind> pk;
   int64_t stat_clip_rows = 0, stat_clip_seqs = 0, stat_bert_rows = 0, stat_steps = 0;
   int64_t stat_refine_rows = 0, stat_refine_seqs = 0;
+  // czc_set_control_callback: the host scores the K candidate sentences of every image itself (the reference's own
+  // nltk scorer where it is installed) between the two halves of a step; replaces the table look-ups of the bridge kernel
+  czc_control_fn ctl_fn = nullptr; void* ctl_user = nullptr;
+  std::vector<int32_t> h_ctl_ids; std::vector<float> h_ctl_scores;
 };
 
 namespace {
@@ -564,6 +568,25 @@ int step_phase_a(czc_engine* e, const StepArgs& a) {
   return 0;
 }
 
+// Control scores from the host (czc_set_control_callback): rows as the reference decodes them at
+// control_gen_utils.py:54-57 / :158-160 -- `inp` with [MASK] at gen_idx, candidate k of image b replaces it by cand[b][k]
+int control_from_host(czc_engine* e, const StepArgs& a) {
+  StepBufs b;
+  const size_t n_seq = (size_t)a.B * a.K, n_inp = (size_t)a.B * a.T;
+  E_CHECK(step_bufs(e, (int)n_seq, &b));
+  e->h_ctl_ids.resize(n_inp + n_seq);
+  e->h_ctl_scores.assign(n_seq, 0.f);
+  E_HIP(hipMemcpyAsync(e->h_ctl_ids.data(), a.d_inp, n_inp * 4, hipMemcpyDeviceToHost, e->st));
+  E_HIP(hipMemcpyAsync(e->h_ctl_ids.data() + n_inp, b.cand, n_seq * 4, hipMemcpyDeviceToHost, e->st));
+  E_HIP(hipStreamSynchronize(e->st));
+  const int rc = e->ctl_fn(e->ctl_user, e->h_ctl_ids.data(), e->h_ctl_ids.data() + n_inp, a.B, a.T, a.K, a.gen_idx,
+                           e->h_ctl_scores.data());
+  if (rc) return fail(e, CZC_ERR_STATE, "the control callback reported an error%s");
+  E_HIP(hipMemcpyAsync(b.senti, e->h_ctl_scores.data(), n_seq * 4, hipMemcpyHostToDevice, e->st));
+  E_HIP(hipStreamSynchronize(e->st));  // h_ctl_scores is pageable and re-used by the next step
+  return 0;
+}
+
 // CLIP text tower on the planned rows -> cosine / softmax_K / fusion / argmax / write-back
 int step_phase_b(czc_engine* e, const StepArgs& a, int M, int max_len, int max_branch, int n_trunk) {
   const czc_config& c = e->cfg;
@@ -647,15 +670,19 @@ int step_device(czc_engine* e, int* d_inp, int B, int T, int gen_idx, int n_mask
   if (!e->d_img_n || e->img_B != B) return fail(e, CZC_ERR_STATE, "image embeds not set for this batch size%s");
   if (T > CZC_MAX_BERT_LEN || gen_idx < 0 || gen_idx >= T || K > CZC_MAX_TOPK)
     return fail(e, CZC_ERR_ARG, "step: bad T/gen_idx/K%s");
-  if (hp->control == 1 && !e->d_lex && !e->d_lex_pos) return fail(e, CZC_ERR_STATE, "sentiment path needs a lexicon%s");
-  if (hp->control == 2 && !e->d_pos_tags) return fail(e, CZC_ERR_STATE, "POS path needs czc_set_pos%s");
-  if (n_mask <= 0 && e->last_BT != B * T) return fail(e, CZC_ERR_STATE, "n_mask=0 needs a previous forward of the same shape%s");
+  if (hp->control == 1 && !e->ctl_fn && !e->d_lex && !e->d_lex_pos)
+    return fail(e, CZC_ERR_STATE, "sentiment path needs a lexicon (czc_set_lexicon / czc_set_lexicon_pos) or czc_set_control_callback%s");
+  if (hp->control == 2 && !e->ctl_fn && !e->d_pos_tags)
+    return fail(e, CZC_ERR_STATE, "POS path needs czc_set_pos or czc_set_control_callback%s");
+  if (n_mask <= 0 && (e->last_B != B || e->last_T != T))
+    return fail(e, CZC_ERR_STATE, "n_mask=0 needs a previous forward of the same [B,T] shape%s");
   StepArgs a{d_inp, B, T, gen_idx, n_mask, dot_allowed, K, *hp};
   E_CHECK(step_phase_a(e, a));
-  if (n_mask > 0) { e->stat_bert_rows += B * T; e->last_BT = B * T; }
+  if (n_mask > 0) { e->stat_bert_rows += B * T; e->last_BT = B * T; e->last_B = B; e->last_T = T; }
   E_HIP(hipStreamSynchronize(e->st));  // the one host round trip per step (the reference has one too, gen_utils.py:81)
   int M, max_len, max_branch, n_trunk;
   E_CHECK(read_totals(e, &M, &max_len, &max_branch, &n_trunk));
+  if (hp->control && e->ctl_fn) E_CHECK(control_from_host(e, a));
   E_CHECK(step_phase_b(e, a, M, max_len, max_branch, n_trunk));
   e->stat_clip_rows += M;
   e->stat_clip_seqs += B * K;
@@ -1144,6 +1171,13 @@ int czc_generate(czc_engine* e, int B, int T, int L, int seed_len, const int32_t
   E_HIP(hipMemcpyAsync(e->h_totals + 9, e->ws["s_nonfinite"].p, 4, hipMemcpyDeviceToHost, e->st));
   E_HIP(hipStreamSynchronize(e->st));
   if (e->h_totals[9]) return fail(e, CZC_ERR_OVERFLOW, "non-finite CLIP cosine (fp16 operand overflow in a tower? use CZC_PREC_SPLIT)%s");
+  return CZC_OK;
+}
+
+int czc_set_control_callback(czc_engine* e, czc_control_fn fn, void* user) {
+  if (!e) return CZC_ERR_ARG;
+  e->ctl_fn = fn;
+  e->ctl_user = fn ? user : nullptr;
   return CZC_OK;
 }
 

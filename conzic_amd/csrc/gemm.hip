@@ -311,9 +311,10 @@ int g_gemm_deep = 1;  // 0 never, 1 when the launch has at most one work-group p
 // tile per CU that is not split along K) +1.5 % at 128; 256 images unchanged (profiles/r03_small_tiles_ab.txt)
 int g_gemm_small_tiles = 4;
 
-static int gemm_n_cu() {
-  static const int n_cu = []() { int d = 0; hipDeviceProp_t pr; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 256; }();
-  return n_cu;
+static int gemm_n_cu() {  // CU count of the CURRENT device (engines may live on different GPUs of one process)
+  static PerDeviceInit per_dev;
+  const LaunchInit li = per_dev.get([](LaunchInit&) -> int { return 0; });
+  return li.rc == 0 && li.n_cu > 0 ? li.n_cu : 256;
 }
 
 // split_small: a split-K launch whose K slices were sized for 64-wide tiles (try_splitk)

@@ -1224,7 +1224,8 @@ bool gemm_rowln_eligible(const GemmArgs& g) {
          (!g.resid || g.ldr % 4 == 0) && (long)RL_TM * g.lda * 2 < (1L << 31) && (long)RL_N * g.ldw * 2 < (1L << 31);
 }
 int launch_gemm_rowln(const GemmArgs& g, hipStream_t st) {
-  static const LaunchInit init = launch_init([](LaunchInit&) -> int {
+  static PerDeviceInit per_dev;
+  const LaunchInit init = per_dev.get([](LaunchInit&) -> int {
     CZC_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_rowln_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, RL_LDS));
     CZC_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_rowln_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, RL_LDS));
     CZC_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_rowln_kernel<false, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, RL_LDS));
@@ -1277,7 +1278,8 @@ bool gemm256_eligible(const GemmArgs& g) {
 // it is activation-typed; 3 / 5 pin gemm256q / gemm256x for every epilogue (A/B runs and kernel tests)
 int launch_gemm256(const GemmArgs& g, hipStream_t st) {
   constexpr int shp = QS * QSTAGE + 8 * 4096;  // ring + one 4 KiB epilogue patch per MFMA wave = the full 160 KiB
-  static const LaunchInit init = launch_init([](LaunchInit&) -> int {
+  static PerDeviceInit per_dev;
+  const LaunchInit init = per_dev.get([](LaunchInit&) -> int {
 #define CZC_ATTR(K_) CZC_HIP_CHECK(hipFuncSetAttribute((const void*)K_, hipFuncAttributeMaxDynamicSharedMemorySize, shp))
 #define CZC_ATTR4(K_) CZC_ATTR((K_<ACT_NONE, false, false>)); CZC_ATTR((K_<ACT_NONE, true, false>)); \
                       CZC_ATTR((K_<ACT_QUICK_GELU, false, false>)); CZC_ATTR((K_<ACT_QUICK_GELU, true, false>)); \
@@ -1350,7 +1352,8 @@ bool gemm256s_eligible(const GemmArgs& g) {
 
 int launch_gemm256s(const GemmArgs& g, hipStream_t st) {
   constexpr int shp = QS * QSTAGE + 8 * 4096;
-  static const LaunchInit init = launch_init([](LaunchInit&) -> int {
+  static PerDeviceInit per_dev;
+  const LaunchInit init = per_dev.get([](LaunchInit&) -> int {
 #define CZC_ATTR(K_) CZC_HIP_CHECK(hipFuncSetAttribute((const void*)K_, hipFuncAttributeMaxDynamicSharedMemorySize, shp))
     CZC_ATTR((gemm256sq_kernel<ACT_NONE, false>));
     CZC_ATTR((gemm256sq_kernel<ACT_NONE, true>));

@@ -274,7 +274,8 @@ bool gemm_wreg_eligible(const GemmArgs& g) {
 
 int launch_gemm_wreg(const GemmArgs& g, hipStream_t st) {
   // one-time set-up behind a function-local static: engines on two host threads launch concurrently (EngineGroup)
-  static const LaunchInit init = launch_init([](LaunchInit& li) -> int {
+  static PerDeviceInit per_dev;
+  const LaunchInit init = per_dev.get([](LaunchInit& li) -> int {
     li.n_cu &= ~7;
 #define CZC_ATTR(K_) CZC_HIP_CHECK(hipFuncSetAttribute((const void*)K_, hipFuncAttributeMaxDynamicSharedMemorySize, WR_LDS))
     CZC_ATTR((gemm_wreg_kernel<ACT_NONE, false>));

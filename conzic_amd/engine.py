@@ -461,7 +461,7 @@ class EngineGroup:
 # ---- kernel-level hooks (tests) ----------------------------------------------------------------------
 
 def test_gemm(prec, A, W, bias=None, resid=None, act=0, typed_out=False):
-    lib = native.load()
+    lib = native.load_test()
     if typed_out:
         act |= 0x100
     A = np.ascontiguousarray(A, np.float32)
@@ -478,7 +478,7 @@ def test_gemm(prec, A, W, bias=None, resid=None, act=0, typed_out=False):
 
 def test_gemm_rowln(prec, A, W, bias, resid, gamma, beta, eps):
     """x = resid + A.W^T + bias and y = LayerNorm(x) from the full-row kernel (W has 512 rows)."""
-    lib = native.load()
+    lib = native.load_test()
     A = np.ascontiguousarray(A, np.float32)
     W = np.ascontiguousarray(W, np.float32)
     M, K = A.shape
@@ -496,7 +496,7 @@ def test_gemm_rowln(prec, A, W, bias, resid, gamma, beta, eps):
 
 
 def test_layernorm(prec, x, gamma, beta, eps):
-    lib = native.load()
+    lib = native.load_test()
     x = np.ascontiguousarray(x, np.float32)
     g = np.ascontiguousarray(gamma, np.float32)
     b = np.ascontiguousarray(beta, np.float32)
@@ -507,7 +507,7 @@ def test_layernorm(prec, x, gamma, beta, eps):
 
 
 def test_attention(prec, qkv, seq_len, heads, causal, scale):
-    lib = native.load()
+    lib = native.load_test()
     qkv = np.ascontiguousarray(qkv, np.float32)
     sl = np.ascontiguousarray(seq_len, np.int32)
     out = np.empty((qkv.shape[0], heads * 64), np.float32)
@@ -517,7 +517,7 @@ def test_attention(prec, qkv, seq_len, heads, causal, scale):
 
 
 def test_topk(logits, mask, K, temperature, dot_id, dot_allowed):
-    lib = native.load()
+    lib = native.load_test()
     lg = np.ascontiguousarray(logits, np.float32)
     mk = np.ascontiguousarray(np.asarray(mask, np.float32).reshape(-1))
     B, V = lg.shape
@@ -531,7 +531,7 @@ def test_topk(logits, mask, K, temperature, dot_id, dot_allowed):
 
 
 def test_bridge(tables: BridgeArrays, rows):
-    lib = native.load()
+    lib = native.load_test()
     rows = np.ascontiguousarray(rows, np.int32)
     n, T = rows.shape
     ids = np.empty((n, native.CLIP_MAX_LEN), np.int32)
@@ -543,7 +543,7 @@ def test_bridge(tables: BridgeArrays, rows):
 
 
 def test_combine(text_feat, img_embeds, logit_scale, probs, hyper, senti_raw=None, repeats=None):
-    lib = native.load()
+    lib = native.load_test()
     tf = np.ascontiguousarray(text_feat, np.float32)
     ie = np.ascontiguousarray(img_embeds, np.float32)
     pr = np.ascontiguousarray(probs, np.float32)

@@ -13,6 +13,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # CZC_LIB_PATH: a differently-built library for the kernel tools (`make EXPERIMENTS=1 LIB=...`: timing-ablation kernels)
 LIB_PATH = os.environ.get("CZC_LIB_PATH") or os.path.join(_HERE, "lib", "libconzic_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "conzic_hip.h")
+# kernel-level parity hooks + GEMM microbenchmark: a second library over the product one, for tests/ and tools/ only
+TEST_LIB_PATH = os.environ.get("CZC_TEST_LIB_PATH") or os.path.join(os.path.dirname(LIB_PATH), "libconzic_hip_test.so")
+TEST_HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "conzic_hip_test.h")
 
 PREC_BF16 = 0
 PREC_F32 = 1
@@ -67,6 +70,10 @@ class StepOut(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in STEP_OUT_FIELDS]
 
 
+# czc_control_fn (include/conzic_hip.h): host scorer of the K candidate sentences of every image, called once per step
+CONTROL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int,
+                         C.c_int, C.POINTER(C.c_float))
+
 # every entry point include/conzic_hip.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
 _I = C.c_int
@@ -82,6 +89,7 @@ SIGNATURES = {
     "czc_set_lexicon": (_I, [_P, _P, _I]),
     "czc_set_lexicon_pos": (_I, [_P, _P, _P, _I]),
     "czc_set_pos": (_I, [_P, _P, _I, _P, _I]),
+    "czc_set_control_callback": (_I, [_P, _P, _P]),
     "czc_encode_images": (_I, [_P, _P, _I, _P]),
     "czc_preprocess_u8": (_I, [_P, _P, _I, _I, _P, _P, _I, _P]),
     "czc_encode_staged": (_I, [_P, _I, _P]),
@@ -98,6 +106,9 @@ SIGNATURES = {
     "czc_sync": (_I, [_P]),
     "czc_stats": (_I, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "czc_refine_stats": (_I, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+}
+# every entry point include/conzic_hip_test.h declares (libconzic_hip_test.so)
+TEST_SIGNATURES = {
     "czc_test_gemm": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _I, _P]),
     "czc_test_gemm_rowln": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, C.c_float, _P, _P]),
     "czc_bench_gemm": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(C.c_double)]),
@@ -110,6 +121,7 @@ SIGNATURES = {
 }
 
 _lib: Optional[C.CDLL] = None
+_test_lib: Optional[C.CDLL] = None
 
 
 def load() -> C.CDLL:
@@ -126,6 +138,23 @@ def load() -> C.CDLL:
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    return lib
+
+
+def load_test() -> C.CDLL:
+    """dlopen the kernel-level hook library (tests / tools only) on top of the product library."""
+    global _test_lib
+    if _test_lib is not None:
+        return _test_lib
+    load()  # RTLD_GLOBAL: the hook library resolves the product library's launchers and switches against it
+    if not os.path.exists(TEST_LIB_PATH):
+        raise NativeError(f"{TEST_LIB_PATH} not found: `make -C conzic_amd/csrc` builds it next to the product library")
+    lib = C.CDLL(TEST_LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in TEST_SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _test_lib = lib
     return lib
 
 

@@ -173,6 +173,21 @@ int czc_set_lexicon_pos(czc_engine* e, const float* table, const uint8_t* class_
  * position (0xFFFF = the reference's "" wildcard); n_template <= 32. */
 int czc_set_pos(czc_engine* e, const uint8_t* tag_of_token, int vocab, const uint16_t* template_masks, int n_template);
 
+/* Control scores from the host instead of the tables above: the reference scores every candidate SENTENCE with nltk
+ * (sentiments_classifer.py:9-33: word_tokenize -> context-dependent pos_tag -> SentiWordNet; POS_classifier.py:12-29:
+ * pos_tag(tagset="universal") against the template), which the per-token tables can only approximate.  With a callback
+ * set, every step with czc_hyper.control != 0 calls it once between the BERT half and the CLIP half of the step:
+ *   inp   int32 [B,T]  the current rows, [MASK] at column gen_idx          (control_gen_utils.py:49-50)
+ *   cand  int32 [B,K]  the candidate ids, idxs * token_mask[idxs]           (control_gen_utils.py:52)
+ *   scores fp32 [B,K]  out: the raw control score of row b with cand[b][k] at gen_idx -- the sentence sentiment AFTER the
+ *                      sign flip of "negative" (sentiments_classifer.py:30-32), or the template match fraction
+ *                      (POS_classifier.py:17-29); softmax_K / gamma / the repeat penalty stay in the combine kernel
+ * and a non-zero return fails the step with CZC_ERR_STATE.  All pointers are host memory owned by the engine and valid
+ * during the call only; the call happens on the thread that called czc_step / czc_generate.  fn == NULL removes it. */
+typedef int (*czc_control_fn)(void* user, const int32_t* inp, const int32_t* cand, int B, int T, int K, int gen_idx,
+                              float* scores);
+int czc_set_control_callback(czc_engine* e, czc_control_fn fn, void* user);
+
 /* ---- once per image: clip/clip.py:48-62 after the image processor ------------------------ */
 /* pixels fp32 [B,3,S,S] -> un-normalised image_embeds [B,proj] (out may be NULL).  The engine
  * keeps the L2-normalised embeds resident for the following step/generate calls (the north
@@ -244,37 +259,6 @@ int czc_stats(czc_engine* e, int64_t* clip_rows, int64_t* clip_seqs, int64_t* be
 /* CZC_PREC_REFINE engines: candidate sequences / packed rows re-encoded by the split-fp16 tower since czc_profile_reset
  * (of the clip_seqs / clip_rows the screening pass saw); zero for the other precisions. */
 int czc_refine_stats(czc_engine* e, int64_t* refine_seqs, int64_t* refine_rows);
-
-/* ---- kernel-level parity hooks (tests only; host pointers, synchronous) -------------------- */
-/* C[M,N] = A[M,K] * W[N,K]^T (+bias) (+activation: 0 none, 1 quick_gelu, 2 gelu_erf) (+resid[M,N]).
- * act | 0x100: take the result through the activation-typed output path (bf16 / split-fp16 / f32 per
- * `precision`, resid must be NULL) instead of the fp32 one -- the path the tower-internal layers use. */
-int czc_test_gemm(int precision, int M, int N, int K, const float* A, const float* W, const float* bias,
-                  const float* resid, int act, float* C);
-/* Full-row GEMM with the following LayerNorm in its epilogue (bf16 / fp16 operands, 512 columns, K % 32 == 0):
- *   x_out[M,512] = resid + A[M,K] * W[512,K]^T + bias;  y_out = LayerNorm(x_out; gamma, beta, eps) in the operand type */
-int czc_test_gemm_rowln(int precision, int M, int K, const float* A, const float* W, const float* bias, const float* resid,
-                        const float* gamma, const float* beta, float eps, float* x_out, float* y_out);
-/* GEMM microbenchmark on device-resident data: ms per launch (tools/bench_gemm.py); use256: 0 128x128 kernel,
- * 1 the default choice among the 256x256 LDS-DMA ring kernels, 3 the loader-wave ring kernel, 7 the ping-pong ring
- * kernel, 6 the weight-stationary kernel where eligible. */
-int czc_bench_gemm(int precision, int M, int N, int K, int act, int out_mode, int iters, int use256, double* ms_out);
-/* Process-wide kernel-family switches for tests and tools: "gemm256" 0|1|3|5, "wreg" 0|1, "gemm256s" 0|1, "skinny",
- * "splitk", "gemm_deep" 0|1|2, "mfma_attention", "attention_image" 0|1|2 (2 = force), the "*_min_m" row-count thresholds, "w_dbg"
- * (ping-pong kernel A/B bits), "bench_pad" (row padding of czc_bench_gemm operands). */
-int czc_test_set_option(const char* name, int value);
-int czc_test_layernorm(int precision, int M, int H, const float* x, const float* gamma, const float* beta, float eps,
-                       float* y);
-/* qkv [sum(len), 3*heads*64] packed sequences; causal 0/1; scale; out [sum(len), heads*64] */
-int czc_test_attention(int precision, int n_seq, const int32_t* seq_len, int heads, int causal, float scale,
-                       const float* qkv, float* out);
-int czc_test_topk(int B, int V, int K, const float* logits, const float* mask, float temperature, int dot_id,
-                  int dot_allowed, float* probs, int32_t* idxs, int32_t* cand);
-int czc_test_bridge(const czc_bridge_tables* t, const czc_config* cfg, int n_rows, int T, const int32_t* rows,
-                    int32_t* clip_ids, int32_t* clip_len);
-int czc_test_combine(int B, int K, int D, const float* text_feat, const float* img_embeds, float logit_scale,
-                     const float* probs, const float* senti_raw, const float* repeats, const czc_hyper* hp,
-                     float* clip_score, float* clip_ref, float* final_score, int32_t* best);
 
 #ifdef __cplusplus
 }

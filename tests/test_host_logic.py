@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     exported by the shared library and typed in native.SIGNATURES (no compute calls here)."""
     hdr = open(native.HEADER_PATH).read()
     declared = set(re.findall(r"\b(czc_[a-z_0-9]+)\s*\(", hdr))
-    declared -= {"czc_engine"}
+    declared -= {"czc_engine", "czc_control_fn"}
     assert declared, "no declarations parsed"
     lib = native.load()
     for name in sorted(declared):
@@ -27,6 +27,23 @@ def test_library_exports_every_declared_symbol():
         assert name in native.SIGNATURES, f"{name} has no ctypes signature"
     assert set(native.SIGNATURES) <= declared
     assert lib.czc_version() >= 100
+
+
+def test_test_hooks_live_in_their_own_library():
+    """The kernel-level parity hooks and the GEMM microbenchmark (include/conzic_hip_test.h) are test infrastructure:
+    libconzic_hip_test.so exports every one of them, the product library and its header none."""
+    import subprocess
+    thdr = open(native.TEST_HEADER_PATH).read()
+    declared = set(re.findall(r"\b(czc_[a-z_0-9]+)\s*\(", thdr))
+    assert declared and all(n.startswith(("czc_test_", "czc_bench_")) for n in declared), declared
+    assert declared == set(native.TEST_SIGNATURES)
+    tlib = native.load_test()
+    for name in sorted(declared):
+        assert hasattr(tlib, name), name
+    product = subprocess.run(["nm", "-D", "--defined-only", native.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "czc_create" in product
+    assert "czc_test_" not in product and "czc_bench_" not in product
+    assert not re.search(r"czc_(test|bench)_", open(native.HEADER_PATH).read())
 
 
 def test_struct_sizes_match_header_layout():

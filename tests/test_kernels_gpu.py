@@ -241,7 +241,7 @@ def test_combine_first_argmax_on_ties():
 def test_gemm256_variants(variant, M, N, K, act, resid):
     """The 256x256 LDS-DMA ring kernels (3: loader-wave kernel, 5: ping-pong kernel, for every epilogue; 1: the
     product's choice between them): ragged M and N edges, many tiles per work-group, all epilogues."""
-    lib = native.load()
+    lib = native.load_test()
     rng = np.random.default_rng(M + N + K + act)
     A = rng.standard_normal((M, K)).astype(np.float32)
     W = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
@@ -264,7 +264,7 @@ def test_gemm_weight_stationary(M, N, act):
     """K = 512 bf16-output layers (CLIP-text qkv / fc1) take the weights-in-registers kernel: ragged M
     (partial last 32-row block), N not a multiple of the 256-column group, both activations; compared with
     the fp64 product of the bf16-rounded operands and with the tiled kernel on the same inputs."""
-    lib = native.load()
+    lib = native.load_test()
     K = 512
     rng = np.random.default_rng(M + N + act)
     A = rng.standard_normal((M, K)).astype(np.float32)
@@ -317,7 +317,7 @@ def test_split_fp16_skinny_gemm(M, N, K, act, resid):
     ref = _act((A.astype(np.float64) @ W.astype(np.float64).T + bias).astype(np.float32), act) + (R if resid else 0)
     tol = 1e-5 * np.sqrt(K / 64) * 4
     assert np.abs(C - ref).max() < tol
-    lib = native.load()
+    lib = native.load_test()
     try:
         assert lib.czc_test_set_option(b"skinny", 0) == 0
         C2 = E.test_gemm(F16X3, A, W, bias=bias, resid=R, act=act)
@@ -332,7 +332,7 @@ def test_split_fp16_gemm_split_k(M, N, K, resid):
     """Few-tile, long-K fp32-output layers (BERT out-proj / fc2 at B = 256) run split-K with a fixed-order
     reduction: fp32-class accuracy, bit-identical from run to run, and equal to the unsplit kernel up to
     fp32 summation order."""
-    lib = native.load()
+    lib = native.load_test()
     rng = np.random.default_rng(M + N + K)
     A = (rng.standard_normal((M, K)) * 2).astype(np.float32)
     W = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
@@ -415,7 +415,7 @@ def test_split_fp16_gemm_256_tile_kernel(M, N, K, act, mode):
     ref = _act((A.astype(np.float64) @ W.astype(np.float64).T + bias).astype(np.float32), act) + (R if R is not None else 0)
     tol = 1e-5 * np.sqrt(K / 64) * 4 + (2e-6 * np.abs(ref).max() if mode == "typed" else 0)  # typed: hi+lo storage ~2^-22
     assert np.abs(C - ref).max() < tol, np.abs(C - ref).max()
-    lib = native.load()
+    lib = native.load_test()
     for variant in (0,):  # 0: the 128x128 kernel (default 1: the four-stage ring kernel)
         try:
             assert lib.czc_test_set_option(b"gemm256s", variant) == 0
@@ -447,7 +447,7 @@ def test_split_fp16_mfma_attention(causal):
         out = E.test_attention(F16X3, qkv, lens, heads, causal, 0.125)
         ref = _attn_ref(qkv, lens, heads, causal, 0.125)
         assert np.abs(out - ref).max() < 3e-5, np.abs(out - ref).max()
-        lib = native.load()
+        lib = native.load_test()
         try:
             assert lib.czc_test_set_option(b"mfma_attention", 0) == 0
             out2 = E.test_attention(F16X3, qkv, lens, heads, causal, 0.125)
@@ -500,7 +500,7 @@ def test_fp16_attention(causal):
 def test_tiled_and_ring_gemms_agree_bitwise_on_fp32_residual_layers(prec, N, K):
     """out-proj / fc2 / text projection: the 128x128 kernel (few rows) and the 256x256 ring kernels (>= 2048 rows) sum k
     in the same single ascending chain and apply bias and residual in the same order."""
-    lib = native.load()
+    lib = native.load_test()
     rng = np.random.default_rng(N + K + prec)
     M = 2048 + 333
     A = rng.standard_normal((M, K)).astype(np.float32)
@@ -539,7 +539,7 @@ def test_full_row_kernel_and_gemm_plus_layernorm_agree_bitwise(prec):
     y2 = E.test_layernorm(prec, x2, gamma, beta, 1e-5)
     np.testing.assert_array_equal(y, y2)
     # the 30-VGPR LayerNorm kernel (ds_swizzle partners, default) against the ds_bpermute form: same tree, same bits
-    lib = native.load()
+    lib = native.load_test()
     try:
         assert lib.czc_test_set_option(b"ln_lean", 0) == 0
         np.testing.assert_array_equal(E.test_layernorm(prec, x2, gamma, beta, 1e-5), y2)
@@ -547,7 +547,7 @@ def test_full_row_kernel_and_gemm_plus_layernorm_agree_bitwise(prec):
         lib.czc_test_set_option(b"ln_lean", 1)
     # the asm-counted x phase of the epilogue (default) against the compiler-scheduled one it replaces, twice (a mis-counted
     # wait shows up as a few stale lanes on some run), with and without a bias, ragged last tile
-    lib = native.load()
+    lib = native.load_test()
     for bias in (b, None):
         outs = []
         try:
@@ -581,7 +581,7 @@ def test_kernel_families_agree_bitwise_on_random_shapes():
     kernel, the loader-wave ring kernel and the ping-pong ring kernel (asm-counted epilogue), twice each: bit-identical
     across kernels and across repetitions (a mis-counted wait or an unpadded hazard shows up as a few wrong lanes on some
     launches, not as rounding noise)."""
-    lib = native.load()
+    lib = native.load_test()
     rng = np.random.default_rng(20260929)
     try:
         assert lib.czc_test_set_option(b"gemm256_min_m", 1) == 0
@@ -611,7 +611,7 @@ def test_tiled_gemm_prefetch_depth_does_not_change_results(prec):
     """The 128 x 128 kernel requests its operands one K step ahead, or two for launches of at most one work-group per CU
     (option gemm_deep): same summation order, bit-identical outputs -- odd and even step counts, a single step, ragged
     edges, split-K slices."""
-    lib = native.load()
+    lib = native.load_test()
     rng = np.random.default_rng(3 + prec)
     try:
         assert lib.czc_test_set_option(b"gemm256", 0) == 0 and lib.czc_test_set_option(b"wreg", 0) == 0
@@ -637,7 +637,7 @@ def test_tiled_gemm_small_tiles_do_not_change_results(prec):
     """Launches that would put 128-wide tiles on less than a quarter of the CUs (one or two images) run the same kernel with
     64-wide tiles (option gemm_small_tiles, default 4 = whenever the 128-wide tiles would not fill the CUs): four times the work-groups, the same k order per output element -- bit-identical
     outputs, with and without residual / activation, ragged rows and columns, one K step and many."""
-    lib = native.load()
+    lib = native.load_test()
     rng = np.random.default_rng(11 + prec)
     try:
         assert lib.czc_test_set_option(b"gemm256", 0) == 0 and lib.czc_test_set_option(b"wreg", 0) == 0
@@ -667,7 +667,7 @@ def test_bridge_token_table_equals_the_merge_loop(label):
     device fills once with the same BPE code; every other chunk ('##' continuations glued to a word, digits, punctuation,
     contractions) runs the merge loop.  Random rows over the whole vocabulary, with and without the table: identical
     ids and lengths, and the table really serves most words."""
-    lib = native.load()
+    lib = native.load_test()
     sv = harness.cached_vocab(label == "tiny")
     bt, ct = tokenizers_from_vocab(sv)
     t = tables_from_tokenizers(bt, ct)

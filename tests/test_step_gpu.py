@@ -482,7 +482,7 @@ def test_step_parity_full_size_bf16_per_image_attention(name):
     """Same bar with the per-image persistent branch attention kernel forced on (the B = 2 goldens are below
     the batch size at which the engine selects it)."""
     meta, arr = load_case(name)
-    lib = native.load()
+    lib = native.load_test()
     assert lib.czc_test_set_option(b"attention_image", 2) == 0
     try:
         teacher_forced(meta, arr, BF16, n_steps=10)
@@ -637,7 +637,7 @@ def one_gemm_family():
     and the tiled kernel the other would add fp32 summation-order noise that has nothing to do with what these
     tests check (prefix sharing / packing / pooling are the same math).  Its own parity is in test_kernels_gpu.py
     and every golden-vector test in this file runs with it enabled."""
-    lib = native.load()
+    lib = native.load_test()
     assert lib.czc_test_set_option(b"wreg", 0) == 0
     yield
     lib.czc_test_set_option(b"wreg", 1)
@@ -739,7 +739,7 @@ def test_packed_branch_attention_matches_per_segment(name, kernel, one_gemm_fami
     meta, arr = load_case(name)
     if kernel == "per_image" and meta["tiny"]:
         pytest.skip("needs heads % 4 == 0")
-    lib = native.load()
+    lib = native.load_test()
     assert lib.czc_test_set_option(b"attention_image", 2 if kernel == "per_image" else 0) == 0
     try:
         _packed_vs_per_segment(meta, arr)
@@ -774,7 +774,7 @@ def test_fused_layernorm_matches_layernorm_kernel(name, steps, prec):
     that also emit the LayerNorm that follows them, against the same steps with the stand-alone LayerNorm kernel: the
     same two-pass statistics on the same fp32 rows, so only last-place flips of the normalised rows remain.  With
     both fused the LayerNorm kernel all but disappears from the profile (layer 0's LN1 and the pooled rows keep it)."""
-    lib = native.load()
+    lib = native.load_test()
     meta, arr = load_case(name)
     su = setup_for(meta, prec)
     eng = su.engine
@@ -905,7 +905,7 @@ def test_config3_shape_k512_l15_kernel_families_agree():
     with each other, and with the oracle within the 1e-3 bar."""
     from oracle import models as M, step as S, text as T
     su = harness.build_synthetic(False, BF16)
-    lib = native.load()
+    lib = native.load_test()
     try:
         sv = su.sv
         o = S.Oracle(M.to_torch(synth.make_bert_weights(su.bert_cfg, 11)), su.bert_cfg,
@@ -990,7 +990,7 @@ def test_large_batch_kernel_families_agree():
     gemm_wreg / attention_image against the kernels that do not rely on them, on the same step.
     A mis-counted wait would show up here as a handful of wildly wrong rows, not as rounding noise."""
     su = harness.build_synthetic(False, BF16)
-    lib = native.load()
+    lib = native.load_test()
     try:
         from oracle import step as S, models as M, text as T
         B, L, K = 64, 10, 200
@@ -1031,7 +1031,7 @@ def test_first_sweep_large_batch_kernel_families_agree():
     packing factor G all change from step to step) at B = 64, K = 200, teacher-forced on the default kernels'
     own write-backs: default kernels vs the tiled-GEMM / per-group-attention family at every position."""
     su = harness.build_synthetic(False, BF16)
-    lib = native.load()
+    lib = native.load_test()
     try:
         from oracle import step as S, models as M, text as T
         B, L, K = 64, 10, 200

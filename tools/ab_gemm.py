@@ -8,7 +8,7 @@ import sys
 sys.path.insert(0, __file__.rsplit('/', 2)[0])
 from conzic_amd import native  # noqa: E402
 
-lib = native.load()
+lib = native.load_test()
 M, N, K, act, mode = (int(v) for v in sys.argv[1:6])
 def _arm(text):
     f = [int(x) for x in text.split(':')]

@@ -7,7 +7,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from conzic_amd import native
 
-lib = native.load()
+lib = native.load_test()
 if 'CZC_W_DBG' in os.environ:
     lib.czc_test_set_option(b'w_dbg', int(os.environ['CZC_W_DBG']))
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 768000

@@ -2,7 +2,7 @@ import numpy as np, sys, torch
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
 from conzic_amd import engine as E, native
 from test_kernels_gpu import _attn_ref
-lib = native.load()
+lib = native.load_test()
 heads = 12
 lens = [64]
 for seed in range(6):

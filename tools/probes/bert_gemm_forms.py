@@ -8,7 +8,7 @@ import sys
 sys.path.insert(0, __file__.rsplit('/', 3)[0])
 from conzic_amd import native  # noqa: E402
 
-lib = native.load()
+lib = native.load_test()
 Ms = [int(v) for v in sys.argv[1:]] or [60, 120, 240, 480, 960, 1920, 3840]
 ARMS = {"splitk": (1, 4), "unsplit64": (0, 4), "unsplit128": (0, 0)}
 for K in (768, 3072):

@@ -8,7 +8,7 @@ import sys
 sys.path.insert(0, __file__.rsplit('/', 3)[0])
 from conzic_amd import native  # noqa: E402
 
-lib = native.load()
+lib = native.load_test()
 Ms = [int(v) for v in sys.argv[1:]] or [2400, 4800, 9600, 19200, 38400, 76800]
 ARMS = {"ring256": (7, 1, 4), "tile128": (0, 0, 0), "tile128_deep": (0, 2, 0), "tile64_deep": (0, 2, 1 << 20)}
 for K in (2048, 512):

@@ -8,7 +8,7 @@ import sys
 sys.path.insert(0, __file__.rsplit('/', 3)[0])
 from conzic_amd import native  # noqa: E402
 
-lib = native.load()
+lib = native.load_test()
 Ms = [int(v) for v in sys.argv[1:]] or [4800, 9600, 19200, 38400, 76800, 156000]
 ARMS = {"rowln": (4, 7, 2048), "ring256+LN": (5, 7, 2048), "tiled+LN": (5, 0, 1 << 30)}
 for M in Ms:

@@ -4,7 +4,7 @@ import json, os, runpy, subprocess, sys
 if len(sys.argv) > 1 and sys.argv[1] == "--one":
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
     from conzic_amd import native
-    native.load().czc_test_set_option(b"gemm_small_tiles", int(sys.argv[3]))
+    native.load_test().czc_test_set_option(b"gemm_small_tiles", int(sys.argv[3]))
     sys.argv = ["bench.py", "--images", sys.argv[2], "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-alt", "--no-invariance", "--no-profile"]
     try:
         runpy.run_path("bench.py", run_name="__main__")
