@@ -1,0 +1,154 @@
+"""Control scores of the controllable path (control_gen_utils.py:30-195) for the native engine.
+
+The reference scores every candidate SENTENCE on the host with nltk: sentiment = sum over the words of the mean
+SentiWordNet `pos - neg` of the word under the coarse class of its (context-dependent) Penn tag
+(sentiments_classifer.py:9-33); POS = fraction of template positions whose universal tag is accepted
+(POS_classifier.py:12-29).  Two ways to feed the engine's fused score-combine kernel with them:
+
+``table``  (default, `CZC_CONTROL=table|auto`) -- per-BERT-token tables evaluated inside the text-bridge kernel, no host
+           work per step: `sentiment.build_sentiwordnet_tables` / `sentiment.build_pos_tag_table` run nltk ONCE per
+           tokenizer over the vocabulary.  Context-free by construction (a token is tagged alone; a multi-piece word
+           scores as its first piece): an approximation of the reference's scorer, quantified in DESIGN.md §2.
+``exact``  (`CZC_CONTROL=exact`) -- the reference's own arithmetic on the decoded candidate strings, called back from the
+           engine once per step (`czc_set_control_callback`): identical to the reference whatever the tagger does with
+           context, at the reference's own host cost (O(B*K) tagger calls per step).
+
+A caller may still hand tables over explicitly (`clip.lexicon`, `clip.lexicon_pos`, `clip.pos_tags`: synthetic runs,
+bench.py); they win over both modes.  Without nltk and without tables the path raises -- there is no silent fallback.
+"""
+from __future__ import annotations
+
+import os
+import weakref
+from typing import Callable, Optional, Sequence
+
+import numpy as np
+
+from . import sentiment, synth
+
+NLTK_HELP = ("the controllable path scores candidates with nltk (sentiments_classifer.py:1-3, POS_classifier.py:1-2): "
+             "install nltk with the punkt / averaged_perceptron_tagger / wordnet / sentiwordnet data (app.py:280-283), "
+             "or hand tables over yourself (clip.lexicon [V] or clip.lexicon_pos ([V,5], [V]) for sentiment, "
+             "clip.pos_tags [V] for POS; conzic_amd/sentiment.py)")
+
+
+def import_nltk():
+    """The nltk module with the three entry points the reference imports, or None."""
+    try:
+        import nltk
+        from nltk.corpus import sentiwordnet  # noqa: F401
+        from nltk.tokenize import word_tokenize  # noqa: F401
+        nltk.pos_tag  # noqa: B018
+        return nltk
+    except (ImportError, AttributeError, LookupError):
+        return None
+
+
+def control_mode() -> str:
+    m = os.environ.get("CZC_CONTROL", "auto").lower()
+    if m not in ("auto", "table", "exact"):
+        raise ValueError(f"CZC_CONTROL={m!r}: expected auto | table | exact")
+    return m
+
+
+def vocab_tokens(tokenizer) -> Sequence[str]:
+    if hasattr(tokenizer, "convert_ids_to_tokens"):
+        n = getattr(tokenizer, "vocab_size", None) or len(tokenizer.get_vocab())
+        return tokenizer.convert_ids_to_tokens(list(range(n)))
+    vocab = tokenizer.vocab if hasattr(tokenizer, "vocab") else tokenizer.get_vocab()
+    out = [""] * len(vocab)
+    for t, i in vocab.items():
+        out[int(i)] = t
+    return out
+
+
+# one set of tables per tokenizer object (building them walks the vocabulary through nltk once: seconds)
+_TABLES = weakref.WeakKeyDictionary()
+
+
+def tables_for(tokenizer, kind: str, nltk_module):
+    """kind 'sentiment' -> (table [V,5], class_of_token [V]); 'pos' -> tag_of_token [V]; built once per tokenizer."""
+    try:
+        slot = _TABLES.setdefault(tokenizer, {})
+    except TypeError:  # not weak-referenceable: cache on the object
+        slot = tokenizer.__dict__.setdefault("_czc_control_tables", {})
+    key = (kind, id(nltk_module))
+    if key not in slot:
+        toks = vocab_tokens(tokenizer)
+        slot[key] = (sentiment.build_sentiwordnet_tables(toks, nltk_module) if kind == "sentiment"
+                     else sentiment.build_pos_tag_table(toks, nltk_module))
+    return slot[key]
+
+
+# ---- the reference's scorers on a decoded string (exact mode) --------------------------------------------------------
+
+def sentence_sentiment(text: str, ctl_signal: Optional[str], nltk_module) -> float:
+    """sentiments_classifer.py:14-33 for one sentence."""
+    words = nltk_module.tokenize.word_tokenize(text)
+    score = 0.0
+    for word, tag in nltk_module.pos_tag(words):
+        score += sentiment.word_score(nltk_module.corpus.sentiwordnet.senti_synsets, word, sentiment.TAG_MAP.get(tag, ''))
+    return -score if ctl_signal == "negative" else score
+
+
+def sentence_pos_match(text: str, template, nltk_module) -> float:
+    """POS_classifier.py:12-29 for one sentence: the share of template slots whose tag is accepted ("" accepts anything;
+    a sentence shorter than the template is padded with "" tags, a longer one is cut)."""
+    tags = [t for _, t in nltk_module.pos_tag(nltk_module.tokenize.word_tokenize(text), tagset="universal")]
+    total = len(template)
+    cur = (tags + [""] * (total - len(tags)))[:total]
+    correct = sum(1 for i, t in enumerate(cur) if template[i] == "" or t in template[i])
+    return correct / total
+
+
+class HostScorer:
+    """czc_control_fn over a tokenizer: decodes the B*K candidate rows as the reference does
+    (control_gen_utils.py:54-55 / :158-159, `batch_decode(skip_special_tokens=True)`) and scores each string."""
+
+    def __init__(self, tokenizer, score_text: Callable[[str], float]):
+        self.tokenizer = tokenizer
+        self.score_text = score_text
+        self.error: Optional[BaseException] = None
+        self.calls = 0
+
+    def __call__(self, inp: np.ndarray, cand: np.ndarray, gen_idx: int) -> np.ndarray:
+        B, K = cand.shape
+        rows = np.repeat(inp[:, None, :], K, axis=1)
+        rows[:, :, gen_idx] = cand
+        texts = self.tokenizer.batch_decode(rows.reshape(B * K, -1).tolist(), skip_special_tokens=True)
+        self.calls += 1
+        return np.array([self.score_text(t) for t in texts], dtype=np.float32).reshape(B, K)
+
+
+def configure(eng, clip, tokenizer, *, pos_template=None, ctl_signal="positive") -> str:
+    """Point `eng` at the control scores of one *_generation call; returns what was chosen
+    ('caller-tables' | 'table' | 'exact').  pos_template None -> sentiment control."""
+    is_pos = pos_template is not None
+    explicit = (getattr(clip, "pos_tags", None) is not None) if is_pos else (
+        getattr(clip, "lexicon_pos", None) is not None or getattr(clip, "lexicon", None) is not None)
+    mode = control_mode()
+    eng.set_control_callback(None)
+    if explicit and mode != "exact":
+        if is_pos:
+            eng.set_pos(clip.pos_tags, synth.pos_template_masks(pos_template))
+        elif getattr(clip, "lexicon_pos", None) is not None:  # (table [V,5], class_of_token [V])
+            eng.set_lexicon_pos(*clip.lexicon_pos)
+        else:
+            eng.set_lexicon_pos(None, None)
+            eng.set_lexicon(clip.lexicon)
+        return "caller-tables"
+    nltk_module = import_nltk()
+    if nltk_module is None:
+        raise RuntimeError(NLTK_HELP)
+    if mode == "exact":
+        if is_pos:
+            scorer = HostScorer(tokenizer, lambda t: sentence_pos_match(t, pos_template, nltk_module))
+        else:
+            scorer = HostScorer(tokenizer, lambda t: sentence_sentiment(t, ctl_signal, nltk_module))
+        eng.set_control_callback(scorer)
+        return "exact"
+    if is_pos:
+        eng.set_pos(tables_for(tokenizer, "pos", nltk_module), synth.pos_template_masks(pos_template))
+    else:
+        eng.set_lexicon_pos(*tables_for(tokenizer, "sentiment", nltk_module))
+    return "table"

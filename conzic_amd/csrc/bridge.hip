@@ -167,8 +167,9 @@ __global__ __launch_bounds__(BR_THREADS) void bridge_kernel(BridgeDev bd, const 
   for (int q = nt + 2; q < BR_LEN; ++q) outp[q] = bd.eos_id;
   clip_len[row] = nt + 2;
   if (pos.tag_of_token) {
-    // template positions past the last word only match the "" wildcard (POS_classifier.py:19-27)
-    for (int w = n_words; w < pos.n; ++w) pos_ok += pos.masks[w] == 0xFFFFu ? 1 : 0;
+    // template positions past the last word carry the "" padding tag (POS_classifier.py:19-20): it matches the ""
+    // wildcard and any entry that accepts it (bit 15: a string entry, `"" in "NOUN"`, or a list that holds "")
+    for (int w = n_words; w < pos.n; ++w) pos_ok += (pos.masks[w] & 0x8000u) ? 1 : 0;
     if (senti_raw) senti_raw[row] = (float)pos_ok / (float)pos.n;
   } else if (senti_raw) {
     senti_raw[row] = negative ? -senti : senti;

@@ -48,7 +48,13 @@ def get_args(argv=None):
     p.add_argument("--stop_words_path", type=str, default=None)
     p.add_argument("--synthetic", action="store_true", help="random-init weights + synthetic vocab/images (no checkpoints)")
     p.add_argument("--tiny", action="store_true", help="with --synthetic: tiny model dims")
-    return p.parse_args(argv)
+    p.add_argument("--control_scores", default=None, choices=["auto", "table", "exact"],
+                   help="controllable runs: per-token tables built from nltk inside the engine's kernels (table, default) or "
+                        "the reference's own nltk sentence scorer called back once per step (exact); sets CZC_CONTROL")
+    a = p.parse_args(argv)
+    if a.control_scores:
+        os.environ["CZC_CONTROL"] = a.control_scores
+    return a
 
 
 def main(argv=None):
@@ -72,8 +78,12 @@ def main(argv=None):
         lm_tokenizer, clip_tok = tokenizers_from_vocab(sv)
         lm_model = SyntheticLM(bcfg)
         clip = CLIP.from_state(ccfg, synth.make_clip_weights(ccfg, 12), clip_tok)
-        clip.lexicon = synth.make_lexicon(len(sv.bert_tokens))
-        clip.pos_tags = synth.make_pos_tags(len(sv.bert_tokens))
+        from conzic_amd import control
+        if control.import_nltk() is None:
+            # no nltk: synthetic per-token control tables (with nltk the runtime builds the tables from it, as it does
+            # for real checkpoints -- conzic_amd/control.py; --control_scores exact calls the reference's scorer per step)
+            clip.lexicon = synth.make_lexicon(len(sv.bert_tokens))
+            clip.pos_tags = synth.make_pos_tags(len(sv.bert_tokens))
         token_mask = synth.make_token_mask(sv)
         from PIL import Image
         images = [Image.fromarray(u) for u in synth.make_images_u8(args.batch_size, ccfg.v_image)]

@@ -189,6 +189,38 @@ class Engine:
         self._ck(self.lib.czc_set_pos(self.h, t.ctypes.data, t.size, m.ctypes.data, m.size), "czc_set_pos")
         self._record("pos", "set_pos", t, m)
 
+    def set_control_callback(self, scorer):
+        """czc_set_control_callback: `scorer(inp int32 [B,T], cand int32 [B,K], gen_idx) -> fp32 [B,K]` is called once per
+        controlled step and replaces the control-score tables (conzic_amd/control.py: the reference's own nltk scorer on
+        the decoded strings); None removes it.  An exception raised by the scorer fails the step and is re-raised by the
+        generate / step call that triggered it."""
+        if scorer is None:
+            self._ck(self.lib.czc_set_control_callback(self.h, None, None), "czc_set_control_callback")
+            self._ctl_fn = self._ctl_scorer = None
+        else:
+            def trampoline(_user, inp_p, cand_p, B, T, K, gen_idx, out_p):
+                try:
+                    inp = np.ctypeslib.as_array(inp_p, shape=(B, T)).copy()
+                    cand = np.ctypeslib.as_array(cand_p, shape=(B, K)).copy()
+                    sc = np.ascontiguousarray(scorer(inp, cand, int(gen_idx)), dtype=np.float32)
+                    if sc.shape != (B, K):
+                        raise ValueError(f"control scorer returned shape {sc.shape}, expected {(B, K)}")
+                    np.ctypeslib.as_array(out_p, shape=(B, K))[...] = sc
+                    return 0
+                except BaseException as exc:  # noqa: BLE001 -- must not unwind through the C frames
+                    self._ctl_error = exc
+                    return 1
+            fn = native.CONTROL_FN(trampoline)
+            self._ck(self.lib.czc_set_control_callback(self.h, C.cast(fn, C.c_void_p), None), "czc_set_control_callback")
+            self._ctl_fn, self._ctl_scorer = fn, scorer  # the C side keeps the pointer: keep the thunk alive
+        self._ctl_error = None
+        self._record("control_callback", "set_control_callback", scorer)
+
+    def _raise_scorer_error(self):
+        exc, self._ctl_error = getattr(self, "_ctl_error", None), None
+        if exc is not None:
+            raise exc
+
     def set_bridge(self, tables: BridgeArrays):
         st = tables.as_struct()
         self._ck(self.lib.czc_set_bridge(self.h, C.byref(st)), "czc_set_bridge")
@@ -281,8 +313,11 @@ class Engine:
             shp, dt = shapes[name]
             res[name] = np.empty(shp, dtype=dt)
             setattr(out, name, res[name].ctypes.data)
-        self._ck(self.lib.czc_step(self.h, inp.ctypes.data, B, T, gen_idx, n_mask, 1 if dot_allowed else 0, K,
-                                   C.byref(hyper), C.byref(out)), "czc_step")
+        rc = self.lib.czc_step(self.h, inp.ctypes.data, B, T, gen_idx, n_mask, 1 if dot_allowed else 0, K,
+                               C.byref(hyper), C.byref(out))
+        if rc:
+            self._raise_scorer_error()
+        self._ck(rc, "czc_step")
         return res
 
     def generate(self, B: int, init_ids: Sequence[int], L: int, seed_len: int, top_k: int, positions: Sequence[int],
@@ -296,9 +331,12 @@ class Engine:
         S = len(pos) // every
         ids = np.empty((S, B, T), dtype=np.int32)
         cos = np.empty((S, B), dtype=np.float32)
-        self._ck(self.lib.czc_generate(self.h, B, T, L, seed_len, init.ctypes.data, top_k, len(pos), pos.ctypes.data,
-                                       None if nm is None else nm.ctypes.data, every, C.byref(hyper),
-                                       ids.ctypes.data, cos.ctypes.data), "czc_generate")
+        rc = self.lib.czc_generate(self.h, B, T, L, seed_len, init.ctypes.data, top_k, len(pos), pos.ctypes.data,
+                                   None if nm is None else nm.ctypes.data, every, C.byref(hyper),
+                                   ids.ctypes.data, cos.ctypes.data)
+        if rc:
+            self._raise_scorer_error()
+        self._ck(rc, "czc_generate")
         return ids, cos
 
     def set_option(self, name: str, value: int):

@@ -75,8 +75,12 @@ def main(argv=None):
         lm_tokenizer, clip_tok = tokenizers_from_vocab(sv)
         lm_model = SyntheticLM(bcfg)
         clip = CLIP.from_state(ccfg, synth.make_clip_weights(ccfg, 12), clip_tok)
-        clip.lexicon = synth.make_lexicon(len(sv.bert_tokens))
-        clip.pos_tags = synth.make_pos_tags(len(sv.bert_tokens))
+        from conzic_amd import control
+        if control.import_nltk() is None:
+            # no nltk: synthetic per-token control tables (with nltk the runtime builds the tables from it, as it does
+            # for real checkpoints -- conzic_amd/control.py; --control_scores exact calls the reference's scorer per step)
+            clip.lexicon = synth.make_lexicon(len(sv.bert_tokens))
+            clip.pos_tags = synth.make_pos_tags(len(sv.bert_tokens))
         token_mask = synth.make_token_mask(sv)
     else:
         from transformers import AutoModelForMaskedLM, AutoTokenizer

@@ -228,19 +228,14 @@ def run_generation(order: str, img_name, model, clip, tokenizer, image_instance,
     batch = ref_utils.get_init_text(tokenizer, prompt, max_len, batch_size)  # gen_utils.py:57
     clip.compute_image_representation_from_image_instance(image_instance)    # gen_utils.py:58 (cached in the engine)
     eng.set_token_mask(_mask_to_numpy(token_mask))
-    if gamma is not None and pos_template is not None:
-        if getattr(clip, "pos_tags", None) is None:
-            raise RuntimeError("the POS path needs a per-token tag table: set clip.pos_tags (see DESIGN.md)")
-        eng.set_pos(clip.pos_tags, synth.pos_template_masks(pos_template))
-    elif gamma is not None:
-        if getattr(clip, "lexicon_pos", None) is not None:   # (table [V,5], class_of_token [V]): conzic_amd/sentiment.py
-            eng.set_lexicon_pos(*clip.lexicon_pos)
-        elif getattr(clip, "lexicon", None) is not None:
-            eng.set_lexicon_pos(None, None)
-            eng.set_lexicon(clip.lexicon)
-        else:
-            raise RuntimeError("the sentiment path needs a sentiment table: set clip.lexicon (per token) or "
-                               "clip.lexicon_pos (per word-start piece and coarse POS, conzic_amd/sentiment.py)")
+    if gamma is not None:
+        # control scores: caller-provided tables, else tables built once per tokenizer from nltk (default), else -- with
+        # CZC_CONTROL=exact -- the reference's own sentence scorer called back per step; raises without nltk and tables
+        from . import control
+        chosen = control.configure(eng, clip, tokenizer, pos_template=pos_template, ctl_signal=ctl_signal)
+        if chosen != getattr(eng, "_control_logged", None):
+            logger.info(f"control scores: {chosen}")
+            eng._control_logged = chosen
     order_list = random_positions = None
     if order == "shuffle":
         order_list = list(range(max_len))

@@ -8,9 +8,12 @@ WordNet class ('' n v a r), and adds up, per word, the mean of `pos_score() - ne
     class_of_token[V]  the class a CONTEXT-FREE tagger gives the token (nltk.pos_tag([word]))
 
 A word is addressed by its first piece; '##' continuations add nothing (so multi-piece words score as their first
-piece -- the one approximation besides the context-free tagger).  nltk and its corpora are absent from this image
-and from the GPU box, so `build_sentiwordnet_tables` is exercised with a stand-in `nltk` only and the values stay
-"parity unpinned" (DESIGN.md §2); the arithmetic around the table is pinned by the goldens."""
+piece -- the one approximation besides the context-free tagger).  `conzic_amd/control.py` builds these tables once per
+tokenizer whenever the controllable path runs without caller-provided tables (and offers the reference's own
+sentence-level scorer as `CZC_CONTROL=exact`).  nltk and its corpora are absent from this image and from the GPU box, so
+the builders are exercised with a stand-in `nltk` (tests/nltk_standin.py: a context-DEPENDENT tagger) and the values
+stay "parity unpinned" (DESIGN.md §2); the arithmetic around the tables is pinned by the goldens, and what the
+context-free approximation costs against a context-dependent tagger is measured on the `*_ctx` goldens."""
 from __future__ import annotations
 
 from typing import Sequence, Tuple
@@ -55,3 +58,25 @@ def build_sentiwordnet_tables(bert_tokens: Sequence[str], nltk_module=None) -> T
         tag = nltk_module.pos_tag([tok])[0][1]
         cls_of[i] = CLASSES.index(TAG_MAP.get(tag, ''))
     return table, cls_of
+
+
+def build_pos_tag_table(bert_tokens: Sequence[str], nltk_module=None) -> np.ndarray:
+    """tag_of_token uint8 [V]: index into synth.UNIVERSAL_TAGS of the universal tag a CONTEXT-FREE call of the reference's
+    tagger (`pos_tag([token], tagset="universal")`, POS_classifier.py:13-14) gives every word-start token; tags outside
+    the twelve universal ones map to "X".  '##' continuations and special tokens never start a word (their entry is
+    never read by the bridge kernel)."""
+    from .synth import UNIVERSAL_TAGS
+    if nltk_module is None:
+        try:
+            import nltk as nltk_module  # noqa: F811
+        except ImportError as exc:
+            raise ImportError("build_pos_tag_table needs nltk with the averaged_perceptron_tagger / universal_tagset "
+                              "data; hand a per-token tag table over (clip.pos_tags) without it") from exc
+    x = UNIVERSAL_TAGS.index("X")
+    out = np.full(len(bert_tokens), x, np.uint8)
+    for i, tok in enumerate(bert_tokens):
+        if tok.startswith("##") or (tok.startswith("[") and tok.endswith("]")):
+            continue
+        tag = nltk_module.pos_tag([tok], tagset="universal")[0][1]
+        out[i] = UNIVERSAL_TAGS.index(tag) if tag in UNIVERSAL_TAGS else x
+    return out

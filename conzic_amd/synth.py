@@ -414,14 +414,18 @@ def make_pos_tags(V: int, seed: int = 77) -> np.ndarray:
 
 
 def pos_template_masks(template) -> np.ndarray:
-    """Template (list of lists of tag names, "" = wildcard, as demo.py:40-45) -> uint16 bit masks."""
+    """Template (list of lists of tag names, "" = wildcard, as demo.py:40-45) -> uint16 bit masks: bit t = universal tag
+    t accepted, 0xFFFF = the "" wildcard.  POS_classifier.py:25 tests `cur_tag in template[w]`: a list entry is a
+    membership test, a plain STRING entry a substring test -- the same thing for the twelve tag names (none contains
+    another), except that the "" tag a too-short sentence is padded with (POS_classifier.py:19-20) is a substring of any
+    string: bit 15 = "the padding tag matches too" carries that."""
     out = []
     for entry in template:
         if entry == "" or entry == [""]:
             out.append(0xFFFF)
             continue
         names = [entry] if isinstance(entry, str) else list(entry)
-        m = 0
+        m = 0x8000 if isinstance(entry, str) or "" in names else 0
         for n in names:
             if n in UNIVERSAL_TAGS:
                 m |= 1 << UNIVERSAL_TAGS.index(n)

@@ -170,7 +170,8 @@ int czc_set_lexicon_pos(czc_engine* e, const float* table, const uint8_t* class_
 
 /* POS control (control_gen_utils.py:136-195 / POS_classifier.py:6-31): per-BERT-token universal-tagset id
  * (stand-in for nltk.pos_tag) and the template as one bit mask of accepted tag ids per word
- * position (0xFFFF = the reference's "" wildcard); n_template <= 32. */
+ * position (0xFFFF = the reference's "" wildcard; bit 15 = the "" tag that pads a too-short sentence matches as well,
+ * POS_classifier.py:19-25 with a string entry); n_template <= 32. */
 int czc_set_pos(czc_engine* e, const uint8_t* tag_of_token, int vocab, const uint16_t* template_masks, int n_template);
 
 /* Control scores from the host instead of the tables above: the reference scores every candidate SENTENCE with nltk
@@ -213,7 +214,10 @@ int czc_encode_text(czc_engine* e, const int32_t* clip_ids, const int32_t* clip_
  * or device).  gen_idx = seed_len + position; n_mask = how many consecutive positions starting
  * at gen_idx are overwritten with [MASK] before the BERT forward (1 normally, 2 for the first
  * step of a span, 0 = re-use the previous forward, gen_utils.py:164-166); dot_allowed = the
- * update_token_mask rule (utils.py:53-59). */
+ * update_token_mask rule (utils.py:53-59).  n_mask = 0 needs a previous czc_step / czc_generate forward of the same
+ * [B,T]; after an n_mask = 1 step only row gen_idx of that forward exists (option "bert_prune"), so n_mask = 0 at
+ * another gen_idx returns CZC_ERR_STATE -- the reference only re-uses a forward after masking two positions
+ * (gen_utils.py:164-166), which is n_mask = 2 here and keeps every row. */
 int czc_step(czc_engine* e, int32_t* inp, int B, int T, int gen_idx, int n_mask, int dot_allowed, int top_k,
              const czc_hyper* hp, const czc_step_out* out);
 

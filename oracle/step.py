@@ -46,6 +46,8 @@ class Oracle:
     lexicon: Optional[np.ndarray] = None
     pos_tags: Optional[np.ndarray] = None
     lexicon_pos: Optional[tuple] = None  # (table [V,5], class_of_token [V]): score keyed per word and coarse POS
+    nltk: Optional[object] = None  # an nltk-shaped module: the control scores are then the reference's own sentence-level
+                                   # arithmetic on the decoded strings (tests: tests/nltk_standin.py, context-dependent tagger)
     vocab: Dict[str, int] = field(default_factory=dict)
 
     def __post_init__(self):
@@ -99,8 +101,39 @@ def generate_caption_step(logits_row: torch.Tensor, mask: torch.Tensor, temperat
     return probs.topk(top_k, dim=-1)
 
 
+_PENN_TO_WORDNET = {'NN': 'n', 'NNP': 'n', 'NNPS': 'n', 'NNS': 'n', 'UH': 'n', 'VB': 'v', 'VBD': 'v', 'VBG': 'v', 'VBN': 'v',
+                    'VBP': 'v', 'VBZ': 'v', 'JJ': 'a', 'JJR': 'a', 'JJS': 'a', 'RB': 'r', 'RBR': 'r', 'RBS': 'r', 'RP': 'r',
+                    'WRB': 'r'}  # sentiments_classifer.py:19-22
+
+
+def text_sentiment(nltk, text: str, ctl_signal: str) -> float:
+    """sentiments_classifer.py:14-33 on one decoded sentence, over the nltk-shaped module `nltk`."""
+    tagged = nltk.pos_tag(nltk.tokenize.word_tokenize(text))
+    total = 0.0
+    for word, tag in tagged:
+        syn = list(nltk.corpus.sentiwordnet.senti_synsets(word, _PENN_TO_WORDNET.get(tag, '')))
+        if syn:
+            total += sum(x.pos_score() - x.neg_score() for x in syn) / len(syn)
+    return -total if ctl_signal == "negative" else total
+
+
+def text_pos_match(nltk, text: str, template) -> float:
+    """POS_classifier.py:12-29 on one decoded sentence."""
+    tags = [t for _, t in nltk.pos_tag(nltk.tokenize.word_tokenize(text), tagset="universal")]
+    n = len(template)
+    cur = tags + [""] * (n - len(tags)) if len(tags) <= n else tags[:n]
+    ok = 0
+    for w in range(len(cur)):
+        if template[w] == "" or cur[w] in template[w]:
+            ok += 1
+    return ok / n
+
+
 def senti_scores(o: Oracle, rows: torch.Tensor, ctl_signal: str) -> torch.Tensor:
     """Stand-in for sentiments_classifer.py:35-45 (see module docstring): [N] scores."""
+    if o.nltk is not None:
+        return torch.tensor([text_sentiment(o.nltk, o.decode(r, skip_special_tokens=True), ctl_signal) for r in rows.tolist()],
+                            dtype=torch.float32)
     if o.lexicon_pos is not None:
         # per word (addressed by its first piece; '##' continuations add nothing) under the coarse POS class of that
         # piece: sentiments_classifer.py:14-30 with a context-free tagger
@@ -130,6 +163,9 @@ def pos_scores(o: Oracle, rows: torch.Tensor, template) -> torch.Tensor:
     ('##'), tag of a word = table tag of its first piece; acc = matches / len(template) with the
     reference's padding/wildcard rules (POS_classifier.py:17-29)."""
     from conzic_amd.synth import UNIVERSAL_TAGS
+    if o.nltk is not None:
+        return torch.tensor([text_pos_match(o.nltk, o.decode(r, skip_special_tokens=True), template) for r in rows.tolist()],
+                            dtype=torch.float32)
     out = torch.zeros(rows.shape[0])
     for r, row in enumerate(rows.tolist()):
         tags = []

@@ -33,6 +33,13 @@ def pytest_collection_modifyitems(config, items):
 def pytest_terminal_summary(terminalreporter):
     """Measured parity figures of the GPU tests (tests/test_step_gpu.py::ERR_LOG / DIVERGENCE_LOG / REFINE_LOG), so that a
     GPU run leaves the numbers DESIGN.md quotes in its log."""
+    cmod = sys.modules.get("test_control_gpu")
+    flips = getattr(cmod, "FLIPS", None) if cmod else None
+    if flips:
+        terminalreporter.write_line("controllable path against the reference's own scorers over a context-dependent tagger "
+                                    "(case, mode: winners that differ / image-steps, worst |d final_score|):")
+        for name, mode, fl, steps, worst in flips:
+            terminalreporter.write_line(f"  {name:22s} {mode:6s}: {fl}/{steps}   {worst:.3e}")
     mod = sys.modules.get("test_step_gpu")
     if not mod:
         return

@@ -37,17 +37,13 @@ from conzic_amd import synth  # noqa: E402
 
 # ---- shims ----------------------------------------------------------------------------
 sys.modules["colorlog"] = types.SimpleNamespace(ColoredFormatter=lambda fmt, **kw: logging.Formatter(fmt))
-_nltk = types.ModuleType("nltk")
-_nltk.pos_tag = lambda words, tagset=None: [(w, "NN") for w in words]
-_nltk_tok = types.ModuleType("nltk.tokenize")
-_nltk_tok.word_tokenize = lambda text: text.split()
-_nltk_corpus = types.ModuleType("nltk.corpus")
-_nltk_corpus.sentiwordnet = types.SimpleNamespace(senti_synsets=lambda w, p: [])
-_nltk.tokenize = _nltk_tok
-_nltk.corpus = _nltk_corpus
-sys.modules["nltk"] = _nltk
-sys.modules["nltk.tokenize"] = _nltk_tok
-sys.modules["nltk.corpus"] = _nltk_corpus
+# nltk and its corpora are absent: tests/nltk_standin.py (a deterministic, context-DEPENDENT tagger + a SentiWordNet-shaped
+# table) is what the reference's `from nltk import pos_tag` etc. bind to.  The `*_ctx` cases run the reference's scorers
+# unchanged over it; the older control cases replace the scorers' inputs by per-token tables (Tap below).
+sys.path.insert(0, os.path.dirname(HERE))
+import nltk_standin  # noqa: E402
+nltk_standin.install()
+sys.path.pop(0)
 # The repo root carries drop-in modules with the reference's names (utils, gen_utils, ...): make sure
 # the REAL reference is what gets imported below, and only `conzic_amd` comes from the repo.
 sys.path = [p_ for p_ in sys.path if os.path.abspath(p_ or ".") != REPO]
@@ -109,7 +105,8 @@ def build_hf(bcfg: synth.BertCfg, ccfg: synth.ClipCfg, sv: synth.SynthVocab, bse
 class Tap:
     """Wraps the reference's call sites from outside and records what flows through them."""
 
-    def __init__(self, model, clip, tok, lexicon=None, sign=1.0, pos_tags=None):
+    def __init__(self, model, clip, tok, lexicon=None, sign=1.0, pos_tags=None, ctx=False):
+        self.ctx = ctx
         self.steps = []
         self.snaps = []
         self.cur = None
@@ -198,6 +195,32 @@ class Tap:
             return res
         tok.batch_decode = bd
 
+        if ctx:
+            # the reference's scorers run UNCHANGED over the stand-in nltk (sentiments_classifer.py:9-48,
+            # POS_classifier.py:6-31); only their return values are recorded, from outside, at the call sites in
+            # control_gen_utils.py:56-57 / :160
+            orig_s = ref_ctl.batch_texts_POS_Sentiments_analysis
+
+            def rec_s(*a, **k):
+                out = orig_s(*a, **k)
+                self._ctl_raw = out[1].clone().numpy().astype(np.float32)
+                return out
+            ref_ctl.batch_texts_POS_Sentiments_analysis = rec_s
+            orig_p = ref_ctl.batch_texts_POS_analysis
+
+            def rec_p(texts, templ, device="cuda"):
+                tags, sc = orig_p(texts, templ, device=device)
+                self._ctl_raw = sc.clone().numpy().astype(np.float32)
+                return tags, sc
+            ref_ctl.batch_texts_POS_analysis = rec_p
+            inner_sim = clip.compute_image_text_similarity_via_raw_text
+
+            def sim2(image_embeds, text_list):
+                self.cur["ctl_raw"] = self._ctl_raw.reshape(-1)  # scored just before (control_gen_utils.py:56-58 / :160-163)
+                return inner_sim(image_embeds, text_list)
+            clip.compute_image_text_similarity_via_raw_text = sim2
+            return
+
         def senti_stub(text, sentiment_ctl=None):
             # stands in for sentiments_classifer.py:9-33 (nltk + SentiWordNet are absent)
             return self._senti_queue.pop(0), [], []
@@ -211,7 +234,7 @@ class Tap:
 
 def run_case(name, *, tiny, B, L, K, I, order, alpha=0.02, beta=2.0, temperature=0.1, gamma=None, style="positive", pos=None,
              seed=42, bseed=11, cseed=12, logit_scale=2.6592, image="synthetic", regular_only=False, tmp=None,
-             keep_step_tensors=None):
+             keep_step_tensors=None, ctx=False):
     t0 = time.time()
     if tiny:
         sv = synth.make_vocab_tiny()
@@ -224,9 +247,9 @@ def run_case(name, *, tiny, B, L, K, I, order, alpha=0.02, beta=2.0, temperature
     ccfg.logit_scale = logit_scale
     model, tok, clip = build_hf(bcfg, ccfg, sv, bseed, cseed, tmp)
     V = len(sv.bert_tokens)
-    lexicon = synth.make_lexicon(V) if (gamma is not None and pos is None) else None
+    lexicon = synth.make_lexicon(V) if (gamma is not None and pos is None and not ctx) else None
     tap = Tap(model, clip, tok, lexicon, -1.0 if style == "negative" else 1.0,
-              pos_tags=synth.make_pos_tags(V) if pos is not None else None)
+              pos_tags=synth.make_pos_tags(V) if (pos is not None and not ctx) else None, ctx=ctx)
     token_mask = torch.from_numpy(synth.make_token_mask(sv, regular_only=regular_only))
     from PIL import Image
     if image == "synthetic":
@@ -262,7 +285,7 @@ def run_case(name, *, tiny, B, L, K, I, order, alpha=0.02, beta=2.0, temperature
     seed_len = 4
     meta = dict(name=name, tiny=tiny, B=B, L=L, K=K, I=I, order=order, alpha=alpha, beta=beta,
                 temperature=temperature, gamma=gamma, style=style, pos=pos, seed=seed, bseed=bseed, cseed=cseed,
-                logit_scale=logit_scale, image=image, regular_only=regular_only, prompt="Image of a",
+                logit_scale=logit_scale, image=image, regular_only=regular_only, prompt="Image of a", ctx=ctx,
                 order_list=orders_logged[0] if orders_logged else None,
                 positions=[int(s["gen_idx"]) - seed_len for s in steps],
                 reuse=[int(s.get("reuse", 0)) for s in steps],
@@ -284,6 +307,8 @@ def run_case(name, *, tiny, B, L, K, I, order, alpha=0.02, beta=2.0, temperature
                   clip_score=np.stack([s["clip_score"] for s in steps[:nkeep]]),
                   clip_ref=np.stack([s["clip_ref"] for s in steps[:nkeep]]),
                   clip_ids=cid, clip_lens=np.stack([s["clip_lens"] for s in steps[:nkeep]]))
+    if ctx:  # raw control score of every candidate as the reference's own scorer returned it
+        arrays["ctl_raw"] = np.stack([s["ctl_raw"].reshape(B, K) for s in steps[:nkeep]])
     # one full logits row (first step) for the BERT/MLM-head parity test; top-64 of every kept step
     arrays["logits_row0"] = steps[0]["logits_row"].astype(np.float32)
     meta["texts_step0"] = steps[0]["texts"][: min(8, len(steps[0]["texts"]))]
@@ -375,6 +400,11 @@ CASES = dict(
     tiny_pos_seq=dict(tiny=True, B=2, L=5, K=12, I=2, order="sequential", gamma=5.0,
                       pos=[["DET"], ["ADJ", "NOUN"], "", ["NOUN"], ["VERB"], ["ADV"], ["ADP"], ["DET", "NOUN"], ["NOUN", "."]]),
     tiny_scale100=dict(tiny=True, B=2, L=4, K=12, I=2, order="sequential", logit_scale=4.6052),
+    # the reference's own sentence scorers, unchanged, over the context-dependent stand-in tagger (tests/nltk_standin.py)
+    tiny_senti_ctx=dict(tiny=True, B=2, L=5, K=12, I=2, order="sequential", gamma=5.0, style="positive", ctx=True),
+    tiny_senti_ctx_neg=dict(tiny=True, B=2, L=5, K=12, I=2, order="shuffle", gamma=5.0, style="negative", ctx=True),
+    tiny_pos_ctx=dict(tiny=True, B=2, L=5, K=12, I=2, order="sequential", gamma=5.0, ctx=True,
+                      pos=[["DET"], ["ADJ", "NOUN"], "", ["NOUN"], ["VERB"], ["ADV"], ["ADP"], ["DET", "NOUN"], ["NOUN", "."]]),
     full_cfg1=dict(tiny=False, B=1, L=10, K=200, I=10, order="sequential", image="examples/girl.jpg",
                    keep_step_tensors=20),
     full_synth_b2=dict(tiny=False, B=2, L=10, K=200, I=1, order="shuffle", image="synthetic"),
@@ -386,6 +416,11 @@ CASES = dict(
     # BASELINE configs[4] shape: sentiment control, gamma=5, L=12, K=200 (control_gen_utils.py:30-80)
     full_senti=dict(tiny=False, B=2, L=12, K=200, I=1, order="sequential", image="synthetic", gamma=5.0, style="positive"),
     # POS control on full-size towers (control_gen_utils.py:136-195), the template demo.py:40-45 ships
+    full_senti_ctx=dict(tiny=False, B=2, L=12, K=200, I=1, order="sequential", image="synthetic", gamma=5.0, style="positive",
+                        ctx=True),
+    full_pos_ctx=dict(tiny=False, B=2, L=10, K=200, I=1, order="sequential", image="synthetic", gamma=5.0, ctx=True,
+                      pos=[["DET"], ["ADJ", "NOUN"], ["NOUN"], ["VERB"], ["VERB"], ["ADV"], ["ADP"], ["DET", "NOUN"], ["NOUN"],
+                           ["NOUN", "."], [".", "NOUN"], [".", "NOUN"]]),
     full_pos=dict(tiny=False, B=2, L=10, K=200, I=1, order="sequential", image="synthetic", gamma=5.0,
                   pos=[["DET"], ["ADJ", "NOUN"], ["NOUN"], ["VERB"], ["VERB"], ["ADV"], ["ADP"], ["DET", "NOUN"], ["NOUN"],
                        ["NOUN", "."], [".", "NOUN"], [".", "NOUN"]]),

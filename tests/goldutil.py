@@ -31,7 +31,8 @@ def case_assets(meta):
     bw = synth.make_bert_weights(bcfg, meta["bseed"])
     cw = synth.make_clip_weights(ccfg, meta["cseed"])
     mask = synth.make_token_mask(sv, regular_only=meta["regular_only"])
-    lex = synth.make_lexicon(len(sv.bert_tokens)) if (meta["gamma"] is not None and not meta.get("pos")) else None
+    lex = synth.make_lexicon(len(sv.bert_tokens)) if (meta["gamma"] is not None and not meta.get("pos")
+                                                       and not meta.get("ctx")) else None
     return sv, bcfg, ccfg, bw, cw, mask, lex
 
 
@@ -41,5 +42,8 @@ def make_oracle(meta):
     sv, bcfg, ccfg, bw, cw, mask, lex = case_assets(meta)
     o = S.Oracle(M.to_torch(bw), bcfg, M.to_torch(cw), ccfg, sv.bert_tokens,
                  T.ClipBpe(sv.clip_vocab, sv.clip_merges), lexicon=lex,
-                 pos_tags=synth.make_pos_tags(len(sv.bert_tokens)) if meta.get("pos") else None)
+                 pos_tags=synth.make_pos_tags(len(sv.bert_tokens)) if (meta.get("pos") and not meta.get("ctx")) else None)
+    if meta.get("ctx"):  # the `*_ctx` goldens: the reference's scorers ran over tests/nltk_standin.py
+        import nltk_standin
+        o.nltk = nltk_standin.install()
     return o, sv, torch.from_numpy(mask.copy())

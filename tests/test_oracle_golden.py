@@ -14,7 +14,7 @@ from oracle import step as S
 from oracle import text as T
 
 TINY_CASES = ["tiny_seq", "tiny_shuffle", "tiny_span", "tiny_random", "tiny_senti_seq", "tiny_senti_shuffle",
-              "tiny_scale100", "tiny_pos_seq"]
+              "tiny_scale100", "tiny_pos_seq", "tiny_senti_ctx", "tiny_senti_ctx_neg", "tiny_pos_ctx"]
 
 
 def _run_oracle(meta, arr):
@@ -48,6 +48,8 @@ def test_oracle_reproduces_reference_trajectory(name):
         np.testing.assert_array_equal(t["clip_lens"].numpy(), ln)
         for r in range(len(ln)):
             np.testing.assert_array_equal(t["clip_ids"][r, :ln[r]].numpy(), arr["clip_ids"][i][r, :ln[r]])
+        if "ctl_raw" in arr:  # raw control scores as the reference's own nltk scorers returned them
+            np.testing.assert_allclose(t["senti_raw"].numpy(), arr["ctl_raw"][i], atol=1e-6, rtol=0)
     # sweep snapshots (ids after every sweep, as the reference's batch_decode(inp) saw them)
     for s, snap in enumerate(ids):
         np.testing.assert_array_equal(snap.numpy(), arr["snaps"][s])
@@ -107,7 +109,8 @@ def test_oracle_imageproc_matches_reference_processor(label, S):
     np.testing.assert_array_equal(preprocess(imgs, S), synth.pixels_from_u8(z["crops"]))
 
 
-@pytest.mark.parametrize("name,step", [("full_scale100", 6), ("full_senti", 7), ("full_shuffle_k512", 3), ("full_pos", 5)])
+@pytest.mark.parametrize("name,step", [("full_scale100", 6), ("full_senti", 7), ("full_shuffle_k512", 3), ("full_pos", 5),
+                                       ("full_senti_ctx", 6), ("full_pos_ctx", 4)])
 def test_oracle_full_size_mid_trajectory_step(name, step):
     """The oracle on the full-size goldens added for the published logit scale (x100, clip/clip.py:95-98), the
     sentiment control path at configs[4] shape (gamma=5, L=12; control_gen_utils.py:53-63) and configs[3] shape
@@ -125,5 +128,7 @@ def test_oracle_full_size_mid_trajectory_step(name, step):
     np.testing.assert_allclose(r["probs"].numpy(), arr["probs"][step], rtol=2e-4, atol=1e-7)
     np.testing.assert_allclose(r["clip_ref"].numpy(), arr["clip_ref"][step], atol=3e-6)
     np.testing.assert_allclose(r["clip_score"].numpy(), arr["clip_score"][step], atol=2e-6, rtol=2e-4)
+    if "ctl_raw" in arr:
+        np.testing.assert_allclose(r["senti_raw"].numpy(), arr["ctl_raw"][step], atol=1e-6, rtol=0)
     if step + 1 < arr["inp_before"].shape[0]:
         np.testing.assert_array_equal(r["inp_after"].numpy()[:, gen_idx], arr["inp_before"][step + 1][:, gen_idx])
