@@ -8,7 +8,12 @@ One *step* = one full `generate_caption` pass over one batch of synthetic images
 BASELINE.json configs[2] -- 256 random-pixel 224x224 images per GPU, sequential order, L=10,
 K=200, I=10 sweeps, alpha=0.02, beta=2.0, tau=0.1, prompt "Image of a" -- including the CLIP
 vision encode of the batch (once per image).  value = captions/s of the whole job
-(N * 256 * K / max-over-ranks time).  Weak scaling: per-GPU work is fixed.
+(N * 256 * K / max-over-ranks time).  Weak scaling: per-GPU work is fixed; `--total-images N` fixes the TOTAL instead
+(strong scaling: BASELINE configs[3] 2048 / configs[4] 512 images split over the ranks by `dist.shard_range`).
+
+Two legs, SAME steps and warm-up: `value` = the bf16 engine on HF-init weights (logit scale 14.3, the engine north_star
+names); `scale100_mode.value` (= `value_scale100`) = the engine `runtime.choose_precision` selects for the published
+checkpoints (logit scale 100: screen-then-refine).  `roofline` divides out of the timed region `value` is measured on.
 """
 import argparse
 import json
@@ -147,7 +152,10 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event kernel timing (roofline)")
     ap.add_argument("--no-alt", action="store_true", help="skip the second leg (the engine the product path selects at the published logit scale)")
     ap.add_argument("--alt-steps", type=int, default=None,
-                    help="timed steps of the scale-100 leg (default: min(--steps, 4); warm-up = --warmup, capped at 1 when --steps > 4)")
+                    help="timed steps of the scale-100 leg (default: --steps, with --warmup warm-up steps: both legs on equal footing)")
+    ap.add_argument("--total-images", type=int, default=None,
+                    help="strong scaling: polish this many images in total, split over the ranks by dist.shard_range "
+                         "(BASELINE configs[3]: 2048, configs[4]: 512); default: --images per GPU (weak scaling)")
     ap.add_argument("--alt-split", action="store_true", help="also time the all-split-fp16 engine at the published logit scale (the round-2 product mode)")
     ap.add_argument("--no-invariance", action="store_true", help="skip the batch-invariance check after the timed loop")
     ap.add_argument("--streams", type=int, default=2,
@@ -196,10 +204,17 @@ def main():
           native.PREC_SPLIT: "split-fp16 (fp16 hi+lo planes, 3 MFMA passes, fp32 accumulate)",
           native.PREC_REFINE: "fp16 screening pass + split-fp16 refine pass (fp32 accumulate)"}
     if a.alt_steps is None:
-        a.alt_steps = min(a.steps, 4)  # same as the headline leg at the default (2 steps, 1 warm-up); bounded under the driver's 20 / 5
-    a.alt_warmup = min(a.warmup, 1) if a.steps > 4 else a.warmup
+        a.alt_steps = a.steps  # both legs: the same steps and warm-up
+    a.alt_warmup = a.warmup
     B, L, K, I = a.images, a.L, a.topk, a.iters
-    lo = rank * B  # weak scaling: rank r polishes images [r*B, (r+1)*B)
+    if a.total_images is not None:
+        lo, hi = czd.shard_range(a.total_images, rank, world)  # strong scaling: the total is fixed, ranks own contiguous shards
+        B = hi - lo
+        if B < 1:
+            sys.exit(f"bench.py: --total-images {a.total_images} leaves rank {rank} of {world} without an image")
+    else:
+        lo = rank * B  # weak scaling: rank r polishes images [r*B, (r+1)*B)
+    n_total = a.total_images if a.total_images is not None else world * B
     u8 = synth.make_images_u8(B, first=lo)
     pixels = torch.from_numpy(synth.pixels_from_u8(u8)).to(dev)  # resident in HBM before the clock starts
     seed_len = 4
@@ -266,14 +281,22 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         grp.profile(False)
+        per_rank = [(B, dt)]
         if world > 1:
             import torch.distributed as dist
-            t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        kinds = ["gemm_clip_text", "gemm_clip_refine", "gemm_bert", "gemm_vision", "attention", "rowops", "topk", "bridge", "combine"]
+            t = torch.tensor([float(B), dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            allt = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(allt, t)  # every rank's own image count and wall time: a straggler shows up per rank
+            per_rank = [(int(x[0].item()), float(x[1].item())) for x in allt]
+            dt = max(d for _, d in per_rank)
+        kinds = ["gemm_clip_text", "gemm_clip_refine", "attention_clip_text", "rowops_clip_text", "gemm_bert", "gemm_vision",
+                 "attention", "rowops", "topk", "bridge", "combine"]
         fam = ("gemm_clip_text", "gemm_clip_refine")  # the roofline family (the second only exists in the refine engine)
-        prof_timed = {k: grp.profile_get(k) for k in fam} if profile else {}
+        tower = fam + ("attention_clip_text", "rowops_clip_text")  # everything the CLIP-text K-candidate batch runs
+        prof_timed = {k: grp.profile_get(k) for k in tower} if profile else {}
+        if profile:  # time the GPU spent in ANY kernel of the text tower (union over classes and streams)
+            from conzic_amd.engine import union_ms
+            prof_timed["_tower_busy_ms"] = union_ms([e_.profile_intervals(k, grp.engines[0]) for e_ in grp.engines for k in tower])
         stats = grp.stats()
         prof, breakdown, single_ms = prof_timed, {}, None
 
@@ -295,14 +318,14 @@ def main():
                 eng.sync()
                 single_ms = (time.perf_counter() - t1) * 1e3
                 eng.profile(False)
-                prof = {k: eng.profile_get(k) for k in fam}
+                prof = {k: eng.profile_get(k) for k in tower}
             eng.profile_reset()
             eng.profile(1)
             single_step()
             eng.profile(False)
             breakdown = {k: eng.profile_get(k) for k in kinds}
         res = dict(dt=dt, prof=prof, prof_timed=prof_timed, breakdown=breakdown, stats=stats, setup_s=t_setup, invariance=None,
-                   streams=n_streams, single_ms=single_ms)
+                   streams=n_streams, single_ms=single_ms, per_rank=per_rank, steps=steps)
         if invariance and rank == 0 and B > 2:
             # batch invariance: images 0-1 encoded and polished ALONE (B = 2) by the same engine must come out as they did
             # inside the batch of B (per-image work is independent: gen_utils.py:65-81 has no cross-image term), with no
@@ -322,40 +345,64 @@ def main():
     main_res = run_mode(prec, a.logit_scale, a.steps, a.warmup, not a.no_profile, opts=a.opt,
                         invariance=not a.no_invariance)
     alt_res = split_res = None
-    if world == 1 and not a.no_alt and prec == native.PREC_BF16 and a.logit_scale < 4.0:
+    if not a.no_alt and prec == native.PREC_BF16 and a.logit_scale < 4.0:
         # the engine the product path selects for the published checkpoints (logit_scale = ln 100): screen-then-refine,
         # same steps and warm-up as the headline leg at the defaults (bounded when the caller asks for many steps)
         alt_res = run_mode(native.PREC_REFINE, 4.6052, a.alt_steps, a.alt_warmup, not a.no_profile)
         if a.alt_split:
             split_res = run_mode(native.PREC_SPLIT, 4.6052, a.alt_steps, a.alt_warmup, not a.no_profile)
 
-    def roofline_of(res, prec_):
-        prof = res["prof"]
-        if not prof or not prof["gemm_clip_text"]["launches"]:
-            return None
-        passes = 3 if prec_ == native.PREC_SPLIT else 1  # split-fp16: every product is three fp16 MFMA passes
+    def family_of(prof, passes):
+        """Executed MFMA work and event time of the CLIP-text linear layers (screening GEMMs: `passes` MFMA passes per
+        product; the refine pass's split-fp16 GEMMs: three)."""
         g = dict(prof["gemm_clip_text"])
         g["flops"] *= passes
+        g.setdefault("busy_ms", g["ms"])
         r = prof.get("gemm_clip_refine")
-        if r and r["launches"]:  # refine engine: the family is the screening GEMMs (1 pass) + the refine pass's (3 passes)
-            g = dict(ms=g["ms"] + r["ms"], launches=g["launches"] + r["launches"], flops=g["flops"] + 3 * r["flops"])
+        if r and r["launches"]:
+            g = dict(ms=g["ms"] + r["ms"], launches=g["launches"] + r["launches"], flops=g["flops"] + 3 * r["flops"],
+                     busy_ms=g["busy_ms"] + r.get("busy_ms", r["ms"]))
+        return g, (r if r and r["launches"] else None)
+
+    def tower_util(prof, passes, peak, busy_ms=None):
+        """north_star's quantity: MFMA utilisation of the whole CLIP-text K-candidate batch = executed FLOPs of its linear
+        layers AND its attention / (time in ALL of its kernels: GEMMs, attention, LayerNorm / embedding / gathers) / peak."""
+        g, _ = family_of(prof, passes)
+        at, ro = prof.get("attention_clip_text"), prof.get("rowops_clip_text")
+        if not at or not at["launches"]:
+            return None
+        fl = g["flops"] + passes * at["flops"]
+        ms = busy_ms if busy_ms else g["ms"] + at["ms"] + ro["ms"]
+        return dict(frac=round(fl / (ms * 1e-3) / 1e12 / peak, 4), executed_tflop=round(fl / 1e12, 2), kernel_ms=round(ms, 1),
+                    gemm_ms=round(g["ms"], 1), attention_ms=round(at["ms"], 1), rowops_ms=round(ro["ms"], 1),
+                    attention_tflop=round(passes * at["flops"] / 1e12, 2))
+
+    def roofline_of(res, prec_):
+        pt, ps = res["prof_timed"], res["prof"]
+        if not pt or not pt["gemm_clip_text"]["launches"]:
+            return None
+        passes = 3 if prec_ == native.PREC_SPLIT else 1  # split-fp16: every product is three fp16 MFMA passes
         peak = 157.3 if prec_ == native.PREC_F32 else PEAK_BF16_TFLOPS
-        ach = g["flops"] / (g["ms"] * 1e-3) / 1e12
+        g, r = family_of(pt, passes)
+        # the figures below divide out of the SAME execution `value` is timed on: executed FLOPs of the family in the
+        # timed region / the time the GPU spent on the family there (union of its launch intervals over the streams)
+        ach = g["flops"] / (g["busy_ms"] * 1e-3) / 1e12
         # HBM bytes per launch come from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same
         # command (not measurable inside the run); only quoted for the workload and precision they were taken on
         traffic, src = None, None
-        tp = os.path.join(ROOT, "profiles", "r03_bench_gemm_traffic.json")
         key = {native.PREC_BF16: "bf16", native.PREC_REFINE: "refine"}.get(prec_)
-        if key and os.path.exists(tp) and (B, L, K, I, a.order, a.gamma) == (256, 10, 200, 10, "sequential", None):
-            tj = json.load(open(tp))
-            if key in tj:
-                traffic = tj[key]["hbm_bytes_per_launch"]
-                src = ("profiles/r03_bench_gemm_traffic.json (tools/probes/pmc_bench_traffic.sh: separate rocprofv3 --pmc FETCH_SIZE / "
-                       "WRITE_SIZE passes over one caption batch of this workload, gfx950 FETCH_SIZE x2 correction)")
+        for tp in ("r04_bench_gemm_traffic.json", "r03_bench_gemm_traffic.json"):
+            tp = os.path.join(ROOT, "profiles", tp)
+            if key and os.path.exists(tp) and (a.images, L, K, I, a.order, a.gamma, a.total_images) == (256, 10, 200, 10, "sequential", None, None):
+                tj = json.load(open(tp))
+                if key in tj:
+                    traffic = tj[key]["hbm_bytes_per_launch"]
+                    src = (f"profiles/{os.path.basename(tp)} (tools/probes/pmc_bench_traffic.sh: separate rocprofv3 --pmc FETCH_SIZE / "
+                           "WRITE_SIZE passes over one caption batch of this workload, gfx950 FETCH_SIZE x2 correction)")
+                    break
         fused = not any(kv.replace(" ", "") == "fuse_ln=0" for kv in a.opt)
         half = ("CLIP-text linear layers: czc::gemm_wreg_kernel<%s> (qkv, fc1; weights in registers) + "
-                + ("czc::gemm_rowln_kernel<%s> (out-proj on full 512-wide rows; its launches also do the LayerNorm that follows -- "
-                   "without that fusion the same family measures frac 0.344 and 1.3 %% fewer captions/s, profiles/r02_fuse_ln_ab.json) + "
+                + ("czc::gemm_rowln_kernel<%s> (out-proj on full 512-wide rows; its launches also do the LayerNorm that follows) + "
                    "czc::gemm256x_kernel<%s> (fc2; 256x256 LDS-DMA ring, two wave groups one phase apart)" if fused else
                    "czc::gemm256x_kernel<%s> (out-proj, fc2; 256x256 LDS-DMA ring, two wave groups one phase apart)"))
         kern = {native.PREC_BF16: half % (("bf16",) * (3 if fused else 2)),
@@ -365,41 +412,36 @@ def main():
                 native.PREC_F32: "CLIP-text linear layers: czc::gemm_kernel<float> (v_mfma_f32_32x32x2_f32)"}
         kern[native.PREC_REFINE] = ("screening pass: " + kern[native.PREC_FP16] + "; refine pass (the candidates that carry the "
                                     "softmax_K mass): " + kern[native.PREC_SPLIT])
-        kern = kern[prec_]
-        return dict(bound="mfma", kernel=kern, achieved=round(ach, 1), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
-                    traffic=traffic, traffic_source=src, launches=g["launches"], avg_launch_ms=round(g["ms"] / g["launches"], 4),
-                    flops_per_launch=g["flops"] / g["launches"], mfma_passes_per_product=passes,
-                    refine_pass=None if not (r and r["launches"]) else dict(
-                        launches=r["launches"], ms=round(r["ms"], 1), mfma_tflop=round(3 * r["flops"] / 1e12, 2),
-                        share_of_family_time=round(r["ms"] / g["ms"], 3)),
-                    **timed_region_of(res, passes, peak))
-
-    def timed_region_of(res, passes, peak):
-        """What the family's events say inside the timed region when it ran more than one stream."""
-        if res["streams"] <= 1:
-            return dict(measured_on="the timed region (one engine, one stream)")
-        t = dict(res["prof_timed"]["gemm_clip_text"])
-        t["flops"] *= passes
-        r = res["prof_timed"].get("gemm_clip_refine")
-        if r and r["launches"]:
-            t = dict(ms=t["ms"] + r["ms"], launches=t["launches"] + r["launches"], flops=t["flops"] + 3 * r["flops"],
-                     busy_ms=t["busy_ms"] + r["busy_ms"])
-        return dict(
-            measured_on="one extra pass of the same step on ONE stream, run by bench.py right after the timed region: "
-                        "HIP events on the engine's stream around every launch of the family",
-            timed_region=dict(
-                streams=res["streams"], launches=t["launches"],
-                avg_launch_ms_contended=round(t["ms"] / max(t["launches"], 1), 4),
-                family_busy_union_ms=round(t["busy_ms"], 1),
-                frac_of_peak_over_union=round(t["flops"] / (t["busy_ms"] * 1e-3) / 1e12 / peak, 4),
-                note="the timed region polishes the images as concurrent sub-batches on separate streams: a launch there "
-                     "carries half the rows and its duration includes the time its kernel shared the GPU with the other "
-                     "stream's kernels of every class (this is the duration rocprofv3 --stats of the default command "
-                     "reports); the union of the family's launch intervals over both streams still contains that "
-                     "sharing, so neither is a kernel-quality figure"))
+        out = dict(bound="mfma", kernel=kern[prec_], achieved=round(ach, 1), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
+                   traffic=traffic, traffic_source=src, launches=g["launches"],
+                   avg_launch_ms=round(g["ms"] / g["launches"], 4), family_busy_ms_per_step=round(g["busy_ms"] / res["steps"], 1),
+                   flops_per_launch=g["flops"] / g["launches"], mfma_passes_per_product=passes,
+                   measured_on=("the timed region: HIP events on each engine's own stream around every launch of the family; "
+                                + ("achieved = executed FLOPs / the UNION of the family's launch intervals over the %d streams (the time "
+                                   "the GPU spent on the family; a launch's own duration there -- avg_launch_ms, what rocprofv3 --stats of "
+                                   "this command reports -- includes the time it shared the chip with the other stream's kernels)"
+                                   % res["streams"] if res["streams"] > 1 else "achieved = executed FLOPs / the sum of the launch durations")),
+                   refine_pass=None if not r else dict(
+                       launches=r["launches"], ms=round(r["ms"], 1), mfma_tflop=round(3 * r["flops"] / 1e12, 2),
+                       share_of_family_time=round(r["ms"] / g["ms"], 3)),
+                   clip_text_mfma_util=tower_util(pt, passes, peak, pt.get("_tower_busy_ms")))
+        if out["clip_text_mfma_util"]:
+            out["clip_text_mfma_util"]["note"] = ("executed FLOPs of the CLIP-text linear layers + attention (4 * hidden * causal (query, key) pairs "
+                                                   "per layer) / the time the GPU spent in ANY CLIP-text kernel in the timed region (GEMMs, attention, "
+                                                   "LayerNorm / embedding / gathers; union over classes and streams) / peak -- north_star's "
+                                                   "'MFMA utilisation on the CLIP-text K-candidate batch' (target 0.40)")
+        if res["streams"] > 1 and ps is not pt and ps.get("gemm_clip_text", {}).get("launches"):
+            g1, _ = family_of(ps, passes)
+            a1 = g1["flops"] / (g1["ms"] * 1e-3) / 1e12
+            out["single_stream_pass"] = dict(
+                achieved=round(a1, 1), frac=round(a1 / peak, 4), avg_launch_ms=round(g1["ms"] / g1["launches"], 4), launches=g1["launches"],
+                clip_text_mfma_util=tower_util(ps, passes, peak),
+                note="kernel-quality figure: one extra pass of the same step on ONE engine / ONE stream right after the timed region "
+                     "(every launch carries all the images and runs alone on the GPU); rocprofv3 --stats of `bench.py --streams 1` agrees with it")
+        return out
 
     if rank == 0:
-        captions = world * B * a.steps
+        captions = n_total * a.steps
         value = captions / main_res["dt"]
         prof, st = main_res["prof"], main_res["stats"]
         if (L, K, I, a.order, a.gamma) == (10, 200, 10, "sequential", None):
@@ -415,17 +457,24 @@ def main():
         gemm_fl = sum(v["flops"] for k, v in bd.items() if k.startswith("gemm")) if bd else None
         out = dict(metric="captions/sec (L=10, K=200, seq order)", value=round(value, 4), unit="captions/s",
                    n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(main_res["dt"] / a.steps * 1e3, 2),
-                   higher_is_better=True, scaling="weak", vs_baseline=None, dtype=DT[prec], data="synthetic",
-                   config=dict(workload=f"{cfg_name}: {B} random-pixel 224x224 images per GPU, {a.order}, "
+                   higher_is_better=True, scaling="strong" if a.total_images is not None else "weak", vs_baseline=None,
+                   dtype=DT[prec], data="synthetic",
+                   config=dict(workload=f"{cfg_name}: " + (f"{n_total} random-pixel 224x224 images in total ({B} on rank 0)" if a.total_images is not None
+                                                           else f"{B} random-pixel 224x224 images per GPU") + f", {a.order}, "
                                         f"L={L}, K={K}, I={I}, alpha=0.02 beta=2.0 tau=0.1, bert-base + CLIP ViT-B/32 shapes, "
-                                        f"random-init weights (logit_scale {a.logit_scale}), synthetic vocab (1 CLIP token per word)",
-                               images_per_gpu=B, sentence_len=L, candidate_k=K, num_iterations=I, order=a.order,
+                                        f"random-init weights (logit_scale {a.logit_scale}), synthetic vocab (1 CLIP token per word); "
+                                        f"`value` = the {a.precision} engine at exp(logit_scale) = {np.exp(a.logit_scale):.1f}; "
+                                        "`value_scale100` / `scale100_mode` = the same workload, same steps and warm-up, through the engine the "
+                                        "product path selects for the published checkpoints (logit scale 100)",
+                               images_per_gpu=B, total_images=n_total, sentence_len=L, candidate_k=K, num_iterations=I, order=a.order,
                                gamma=a.gamma, sentiment=a.sentiment if a.gamma is not None else None,
                                logit_scale=a.logit_scale, parallelism=f"image-sharded x{world} (no per-step collective); {main_res['streams']} concurrent "
                                            f"image sub-batches per GPU on separate HIP streams over one set of weights"
                                            + (f"; TEST RUN: {world} ranks share {torch.cuda.device_count()} device(s), {backend} rendezvous" if shared_gpu else "")),
                    ranks=dict(world_size=world, backend=("rccl (torch 'nccl')" if backend == "nccl" else backend) if world > 1 else None,
-                              reported_by_backend=dist_world, devices_visible=torch.cuda.device_count(), shared_gpu=shared_gpu),
+                              reported_by_backend=dist_world, devices_visible=torch.cuda.device_count(), shared_gpu=shared_gpu,
+                              per_rank_images=[n for n, _ in main_res["per_rank"]],
+                              per_rank_captions_per_s=[round(n * a.steps / d, 3) for n, d in main_res["per_rank"]]),
                    image_position_steps_per_s=round(value * L * I, 2),
                    algorithmic_tflop_per_caption=round(f_cap / 1e12, 3),
                    executed_tflop_per_caption=None if not gemm_fl else round(gemm_fl / B / 1e12, 3),
@@ -436,9 +485,8 @@ def main():
                    clip_rows_per_step=st["clip_rows"] // max(1, a.steps), setup_s=round(main_res["setup_s"], 1),
                    single_stream=None if main_res["single_ms"] is None else dict(
                        ms_per_step=round(main_res["single_ms"], 2), value=round(B / main_res["single_ms"] * 1e3, 4),
-                       note="the same step on ONE engine / ONE stream, wall-clock around the pass `roofline` is measured on "
-                            "(same instrumentation as the timed region: events around the roofline family only): `roofline` "
-                            "and this step time come from one execution, `value` from the concurrent-sub-batch region"),
+                       note="the same step on ONE engine / ONE stream (rank 0's images), wall-clock around the pass "
+                            "`roofline.single_stream_pass` is measured on; `value` and `roofline.frac` come from the timed region"),
                    batch_invariance=main_res["invariance"])
         if prec == native.PREC_REFINE:
             out["refine"] = dict(candidate_seqs=st["clip_seqs"], re_encoded=st["refine_seqs"],
@@ -446,7 +494,7 @@ def main():
                                  rows=st["clip_rows"], re_encoded_rows=st["refine_rows"])
 
         def alt_block(res, prec_, what):
-            av = B * a.alt_steps / res["dt"]
+            av = n_total * a.alt_steps / res["dt"]
             blk = dict(what=what, value=round(av, 4), unit="captions/s", dtype=DT[prec_], logit_scale=4.6052, steps=a.alt_steps,
                        warmup=a.alt_warmup, ms_per_step=round(res["dt"] / a.alt_steps * 1e3, 2), roofline=roofline_of(res, prec_),
                        single_stream_ms_per_step=None if res["single_ms"] is None else round(res["single_ms"], 2),
@@ -461,12 +509,13 @@ def main():
         if alt_res is not None:
             out["scale100_mode"] = alt_block(
                 alt_res, native.PREC_REFINE,
-                "same workload (steps / warm-up as reported here: equal to the headline leg's at the defaults), through the engine the product path selects for the published "
+                "same workload, SAME steps and warm-up as the headline leg, through the engine the product path selects for the published "
                 "checkpoints (logit_scale = ln 100, clip/clip.py:95-98; conzic_amd.runtime.choose_precision): screen-then-refine "
                 "-- all K candidates through the single-pass fp16 text tower, the candidates that carry the softmax_K mass "
                 "re-encoded by the split-fp16 tower; fused score within 1e-3 on all K candidates and reference trajectories "
                 "reproduced id for id (tests/test_step_gpu.py::test_step_parity_full_size_refine, "
                 "::test_generate_free_running_full_size_refine)")
+            out["value_scale100"] = out["scale100_mode"]["value"]
         if split_res is not None:
             out["scale100_all_split"] = alt_block(split_res, native.PREC_SPLIT,
                                                   "the same with every tower on split-fp16 MFMA (the round-2 product mode)")

@@ -24,20 +24,20 @@ def _wrap(a: np.ndarray):
 
 
 def _fingerprint(im):
-    """Cheap content key of an image object for the one-entry embed cache: geometry, pixel type and a fixed subsample of
-    the pixels (257 values / 64 points).  None for objects it does not know (those are encoded on every call, like
-    the reference does, gen_utils.py:58)."""
+    """Content key of an image object for the one-entry embed cache: geometry, pixel type and a 128-bit hash of ALL the
+    pixel bytes (blake2b: ~0.15 ms for a 224x224x3 image, two orders of magnitude below the ViT encode it saves), so a
+    caller that refills the same buffer / PIL object in place never gets stale embeddings, wherever the change is.
+    None for objects it does not know (those are encoded on every call, like the reference does, gen_utils.py:58)."""
+    import hashlib
     try:
         if isinstance(im, np.ndarray):
-            flat = im.reshape(-1)
-            step = max(1, flat.size // 257)
-            return ("nd", im.shape, str(im.dtype), flat[::step][:257].tobytes())
-        if hasattr(im, "getpixel") and hasattr(im, "size") and hasattr(im, "mode"):  # PIL.Image
+            buf = im if im.flags.c_contiguous else np.ascontiguousarray(im)
+            return ("nd", im.shape, str(im.dtype), hashlib.blake2b(memoryview(buf).cast("B"), digest_size=16).digest())
+        if hasattr(im, "tobytes") and hasattr(im, "size") and hasattr(im, "mode"):  # PIL.Image
             w, h = im.size
             if w <= 0 or h <= 0:
                 return None
-            pts = [((i * 37 + 11) % w, (i * 53 + 7) % h) for i in range(64)]
-            return ("pil", (w, h), im.mode, tuple(im.getpixel(p) for p in pts))
+            return ("pil", (w, h), im.mode, hashlib.blake2b(im.tobytes(), digest_size=16).digest())
     except Exception:
         return None
     return None
@@ -131,7 +131,7 @@ class CLIP:
         # (demo.py:83 loops samples_num times over one image) are encoded once
         imgs = image if isinstance(image, (list, tuple)) else [image]
         # identity alone would serve stale embeddings to a caller that refills the same buffer / PIL object in place:
-        # the key also carries a content fingerprint (size, mode / dtype and a fixed pixel subsample); objects that
+        # the key also carries a content fingerprint (size, mode / dtype and a hash of every pixel byte); objects that
         # cannot be fingerprinted are never cached
         prints = [_fingerprint(im) for im in imgs]
         key = None if any(fp is None for fp in prints) else tuple((id(im), fp) for im, fp in zip(imgs, prints))

@@ -266,9 +266,9 @@ int launch_scan(const int* len, int n, int* off, int* totals, hipStream_t st) {
 __global__ __launch_bounds__(256) void prefix_plan_kernel(const int* cids, const int* clen, int B, int K, int share,
                                                           int* own_len, int* pre_len, int* seg_src, int* seg_pos0,
                                                           int* max_len_out, int* img_max) {
-  __shared__ int s_p, s_max;
+  __shared__ int s_p, s_max, s_keys;
   const int b = blockIdx.x, tid = threadIdx.x;
-  if (tid == 0) { s_p = 1 << 30; s_max = 0; }
+  if (tid == 0) { s_p = 1 << 30; s_max = 0; s_keys = 0; }
   __syncthreads();
   const int* r0 = cids + (long)b * K * BR_LEN;
   const int l0 = clen[b * K];
@@ -292,13 +292,19 @@ __global__ __launch_bounds__(256) void prefix_plan_kernel(const int* cids, const
     atomicMax(max_len_out + 1, s_max - pb);  // longest branch (own rows of one candidate)
     if (img_max) img_max[b] = s_max - pb;
   }
+  int keys = 0;  // causal (query, key) pairs of this image's segments: what the attention of one layer and head multiplies
   for (int k = tid; k < K; k += blockDim.x) {
     const int s = B + b * K + k;
-    own_len[s] = clen[b * K + k] - pb;
+    const int own = clen[b * K + k] - pb;
+    own_len[s] = own;
     pre_len[s] = pb;
     seg_src[s] = b * K + k;
     seg_pos0[s] = pb;
+    keys += own * pb + own * (own + 1) / 2;
   }
+  atomicAdd(&s_keys, keys);
+  __syncthreads();
+  if (tid == 0) atomicAdd(max_len_out + 4, s_keys + pb * (pb + 1) / 2);  // totals[7] (profiling: attention FLOPs)
 }
 
 int launch_prefix_plan(const int* clip_ids, const int* clip_len, int B, int K, int share, int* own_len, int* pre_len,
@@ -361,7 +367,9 @@ __global__ __launch_bounds__(256) void refine_plan_kernel(const int* clen, const
     rlist[o + i] = flat;
     mx = max(mx, len);
     mxb = max(mxb, len - pb);
+    atomicAdd(max_len_out + 4, (len - pb) * pb + (len - pb) * (len - pb + 1) / 2);  // rtot[7]: (query, key) pairs
   }
+  if (tid == 0 && n > 0) atomicAdd(max_len_out + 4, pb * (pb + 1) / 2);
   if (mx) { atomicMax(max_len_out, mx); atomicMax(max_len_out + 1, mxb); atomicMax(&s_mxb, mxb); }
   __syncthreads();
   if (tid == 0 && img_max) img_max[b] = s_mxb;

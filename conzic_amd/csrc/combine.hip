@@ -75,6 +75,19 @@ __global__ __launch_bounds__(CB_THREADS) void combine_kernel(CombineArgs a) {
     ds = blk_reduce(ds, red, 0);
     dw = blk_reduce(dw, red, 0);
     const float mu = dw > 0.f ? ds / dw : 0.f;
+    // Guard (runtime check of the bound the selection rests on): a candidate that keeps its screening cosine carries the
+    // error (d_k - mu); its fused score moves by at most theta_x * |d_k - mu|.  Every re-encoded candidate -- the sample
+    // and the mass carriers, ~16 per image -- shows its own |d_k - mu|: their maximum is recorded, and an image where it
+    // exceeds the budget (checkpoints whose activations the single-pass fp16 tower does not carry as well as the
+    // validated ones) is counted, for the host to re-run the call on the all-split engine (conzic_amd/runtime.py)
+    float dev = 0.f;
+    for (int k = tid; k < K; k += CB_THREADS)
+      if (a.refine_kind[(long)b * K + k]) dev = fmaxf(dev, fabsf(s_cos[k] - a.refine_cos[(long)b * K + k] - mu));
+    dev = blk_reduce(dev, red, 1);
+    if (tid == 0 && a.nonfinite && dev == dev) {
+      atomicMax(a.nonfinite + 1, __float_as_int(dev));  // non-negative floats order like their bit patterns
+      if (a.refine_guard > 0.f && dev > a.refine_guard) atomicAdd(a.nonfinite + 2, 1);
+    }
     __syncthreads();
     for (int k = tid; k < K; k += CB_THREADS)
       s_cos[k] = a.refine_kind[(long)b * K + k] ? a.refine_cos[(long)b * K + k] : s_cos[k] - mu;

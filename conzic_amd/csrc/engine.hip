@@ -68,6 +68,10 @@ struct czc_engine {
   bool refine = false;
   float refine_theta_x = 4.0f;  // mass threshold theta = refine_theta_x / (beta * exp(logit_scale)): 0.02 at beta 2, scale 100
   int refine_samples = 12;      // strata of the sample among the candidates below the threshold
+  // guard: an image-step whose re-encoded candidates show |screening error - mean| above refine_guard_dev voids the 1e-3
+  // bound for that step (theta_x * dev <= 1e-3 needs dev <= 2.5e-4 at the default theta_x; trip point 0.8 of that)
+  float refine_guard_dev = 2.0e-4f;
+  float guard_max_dev = 0.f; int64_t guard_trips = 0;   // since the last czc_refine_guard(reset = 1)
 
   std::map<std::string, Tensor> w;
   std::vector<LayerW> bert, ctext, cvis, ctext_x;
@@ -84,6 +88,7 @@ struct czc_engine {
   std::vector<void*> bridge_allocs;
   float* d_img_n = nullptr; int img_B = 0;
   float logit_scale_exp = 1.f;
+  double plan_pairs = 0;    // causal (query, key) pairs of the text-tower plan about to run (totals[7]): attention FLOPs = 4 * H * pairs per layer
   int* h_totals = nullptr;  // pinned, 64 ints: [0..7] plan totals, [8],[9] non-finite flags, [16..27] refine-plan totals
   int last_BT = 0, last_B = 0, last_T = 0;  // shape of the forward whose rows b_x / b_xg hold (n_mask = 0 re-use needs the same B AND T)
   int bert_prune = 1;       // last BERT layer behind the attention on the one row per sequence the MLM head reads (n_mask == 1 steps)
@@ -151,7 +156,9 @@ struct ProfScope {
   ProfKind* k = nullptr;
   ProfScope(czc_engine* e_, const char* kind, double flops) : e(e_) {
     if (!e->prof) return;
-    if (e->prof == 2 && strcmp(kind, "gemm_clip_text") != 0 && strcmp(kind, "gemm_clip_refine") != 0) return;
+    // level 2: the CLIP-text tower only -- its linear layers (the roofline family) and its attention / row kernels
+    if (e->prof == 2 && strncmp(kind, "gemm_clip_text", 14) != 0 && strcmp(kind, "gemm_clip_refine") != 0 &&
+        !strstr(kind, "_clip_text")) return;
     k = &e->pk[kind];
     if (k->used + 2 > k->ev.size()) {
       for (int i = 0; i < 2; ++i) {
@@ -270,6 +277,12 @@ int clip_stack(czc_engine* e, int P, const char* gk, std::vector<LayerW>& L, flo
   E_CHECK(ensure(e, "cs_ctx", (size_t)M * H * esz, &ctx));
   E_CHECK(ensure(e, "cs_h", (size_t)M * I * esz, &hbuf));
   const float scale = 1.0f / sqrtf(64.0f);
+  // the text tower's attention / row kernels are timed under their own classes (bench.py: MFMA utilisation of the whole
+  // CLIP-text K-candidate batch, not only of its linear layers)
+  const bool text = !strcmp(gk, "gemm_clip_text") || !strcmp(gk, "gemm_clip_refine");
+  const char* ak = text ? "attention_clip_text" : "attention";
+  const char* rk = text ? "rowops_clip_text" : "rowops";
+  const double attn_flops = text ? 4.0 * H * e->plan_pairs : 0.0;
   // LayerNorm fused into the producer: out-proj (fuse_ln >= 1) and fc2 (fuse_ln >= 2) run on full 512-wide rows and
   // leave y = LN(x) beside the new fp32 x; the LayerNorm kernel then only runs where no such producer exists.
   const bool rowln = prec_is_half(P) && e->fuse_ln && H == 512 && M >= g_rowln_min_m && I % 32 == 0;
@@ -290,11 +303,11 @@ int clip_stack(czc_engine* e, int P, const char* gk, std::vector<LayerW>& L, flo
   for (size_t n = 0; n < L.size(); ++n) {
     LayerW& l = L[n];
     if (!have_y) {
-      ProfScope ps(e, "rowops", 0);
+      ProfScope ps(e, rk, 0);
       E_CHECK(launch_layernorm(P, x, nullptr, l.ln1_g, l.ln1_b, eps, M, H, y, nullptr, e->st));
     }
     E_CHECK(gemm(e, P, gk, y, H, l.qkv_w, H, l.qkv_b, nullptr, 0, qkv, nullptr, 3 * H, M, 3 * H, H, ACT_NONE));
-    { ProfScope ps(e, "attention", 0);
+    { ProfScope ps(e, ak, attn_flops);
       int rc = -1;
       if (plan_B > 0 && prec_is_half(P) && g_use_mfma_attention && e->pack_branches)
         rc = launch_attention_shared(qkv, tab, plan_B, plan_K, plan_max_own, max_keys, heads, scale, ctx, e->st, P == PREC_F16);
@@ -308,11 +321,11 @@ int clip_stack(czc_engine* e, int P, const char* gk, std::vector<LayerW>& L, flo
       E_CHECK(ensure(e, "cs_y_e", (size_t)n_pool * H * esz, &y_e));
       E_CHECK(ensure(e, "cs_h_e", (size_t)n_pool * I * esz, &h_e));
       E_CHECK(ensure(e, "cs_x_e", (size_t)n_pool * H * 4, (void**)&x_e));
-      { ProfScope ps(e, "rowops", 0);
+      { ProfScope ps(e, rk, 0);
         E_CHECK(launch_gather_rows_bytes(ctx, pool_idx, n_pool, H * (int)esz, ctx_e, e->st));
         E_CHECK(launch_gather_rows_f32(x, pool_idx, n_pool, H, x_e, e->st)); }
       E_CHECK(gemm(e, P, gk, ctx_e, H, l.o_w, H, l.o_b, x_e, H, nullptr, x_e, H, n_pool, H, H, ACT_NONE));
-      { ProfScope ps(e, "rowops", 0);
+      { ProfScope ps(e, rk, 0);
         E_CHECK(launch_layernorm(P, x_e, nullptr, l.ln2_g, l.ln2_b, eps, n_pool, H, y_e, nullptr, e->st)); }
       E_CHECK(gemm(e, P, gk, y_e, H, l.fc1_w, H, l.fc1_b, nullptr, 0, h_e, nullptr, I, n_pool, I, H, ACT_QUICK_GELU));
       E_CHECK(gemm(e, P, gk, h_e, I, l.fc2_w, I, l.fc2_b, x_e, H, nullptr, x_e, H, n_pool, H, I, ACT_NONE));
@@ -322,7 +335,7 @@ int clip_stack(czc_engine* e, int P, const char* gk, std::vector<LayerW>& L, flo
     if (rowln) E_CHECK(resid_ln_gemm(ctx, H, l.o_w, l.o_b, H, l.ln2_g, l.ln2_b));
     else {
       E_CHECK(resid_gemm(ctx, H, l.o_w, l.o_b, H));
-      ProfScope ps(e, "rowops", 0);
+      ProfScope ps(e, rk, 0);
       E_CHECK(launch_layernorm(P, x, nullptr, l.ln2_g, l.ln2_b, eps, M, H, y, nullptr, e->st));
     }
     E_CHECK(gemm(e, P, gk, y, H, l.fc1_w, H, l.fc1_b, nullptr, 0, hbuf, nullptr, I, M, I, H, ACT_QUICK_GELU));
@@ -476,13 +489,13 @@ int clip_tower_on(czc_engine* e, int P, std::vector<LayerW>& L, const void* tpro
   E_CHECK(need(e, "text_model.embeddings.position_embedding.weight", (size_t)c.clip_max_pos * H, &pos));
   E_CHECK(need(e, "text_model.final_layer_norm.weight", H, &fg));
   E_CHECK(need(e, "text_model.final_layer_norm.bias", H, &fb));
-  { ProfScope ps(e, "rowops", 0);
+  { ProfScope ps(e, "rowops_clip_text", 0);
     E_CHECK(launch_clip_embed(cids, CZC_CLIP_MAX_LEN, p.src, p.pos0, p.own_off, p.own_len, n_seg, max_len, H, tok, pos, x, e->st)); }
   SegTable tab{p.pre_off, p.pre_len, p.own_off, p.own_len, n_seg, 0, plan_B > 0 ? p.img_max : nullptr};
   float* pooled = nullptr;
   E_CHECK(clip_stack(e, P, gk, L, x, M, H, c.clip_inter, c.clip_heads, c.clip_eps, tab, max_len, 1, plan_B,
                      plan_K, max_branch, p.eidx, n_pool, &pooled));
-  { ProfScope ps(e, "rowops", 0);
+  { ProfScope ps(e, "rowops_clip_text", 0);
     if (pooled) E_CHECK(launch_layernorm(P, pooled, nullptr, fg, fb, c.clip_eps, n_pool, H, pa, nullptr, e->st));
     else E_CHECK(launch_layernorm(P, x, p.eidx, fg, fb, c.clip_eps, n_pool, H, pa, nullptr, e->st)); }
   E_CHECK(gemm(e, P, gk, pa, H, tproj, H, nullptr, nullptr, 0, nullptr, feat, c.clip_proj, n_pool, c.clip_proj, H, ACT_NONE));
@@ -505,6 +518,7 @@ int clip_tower(czc_engine* e, const int* cids, int B, int K, int share, int M, i
 int read_totals(czc_engine* e, int* M, int* max_len, int* max_branch, int* n_trunk) {
   const czc_config& c = e->cfg;
   *M = e->h_totals[0]; *max_len = e->h_totals[3]; *max_branch = e->h_totals[4]; *n_trunk = e->h_totals[6];
+  e->plan_pairs = (double)e->h_totals[7];
   if (e->h_totals[8]) return fail(e, CZC_ERR_OVERFLOW, "non-finite CLIP cosine (fp16 operand overflow in a tower? use CZC_PREC_SPLIT)%s");
   if (e->h_totals[2]) return fail(e, CZC_ERR_OVERFLOW, "text bridge overflow (row text > CZC_BRIDGE_MAX_BYTES)%s");
   if (*max_len > c.clip_max_pos || *max_len > CZC_CLIP_MAX_LEN)
@@ -646,6 +660,7 @@ int step_phase_b(czc_engine* e, const StepArgs& a, int M, int max_len, int max_b
   if (R < 0 || R > n_seq || M2 < 0 || Kr < 0 || Kr > a.K) return fail(e, CZC_ERR_STATE, "refine plan returned impossible sizes%s");
   if (R > 0) {
     float* feat2;
+    e->plan_pairs = (double)e->h_totals[16 + 7];
     // regular B x Kr plan (empty slots have no rows): the packed-branch split attention serves it like the screening plan
     E_CHECK(clip_tower_on(e, PREC_F16X3, e->ctext_x, e->tproj_wx, "gemm_clip_refine", b.cids, rp, a.B + a.B * Kr, R, M2, max_len2,
                           a.B, Kr, max_branch2, "c_feat2", &feat2));
@@ -653,7 +668,7 @@ int step_phase_b(czc_engine* e, const StepArgs& a, int M, int max_len, int max_b
     E_CHECK(launch_refine_cosine(feat2, e->d_img_n, rlist, count_off + a.B, R, a.K, c.clip_proj, rcos, ca.nonfinite, e->st));
   }
   { ProfScope ps(e, "combine", 0);
-    ca.text_feat = nullptr; ca.inp = a.d_inp; ca.refine_kind = kind; ca.refine_cos = rcos;
+    ca.text_feat = nullptr; ca.inp = a.d_inp; ca.refine_kind = kind; ca.refine_cos = rcos; ca.refine_guard = e->refine_guard_dev;
     E_CHECK(launch_combine(ca, e->st)); }
   e->stat_refine_rows += M2;
   e->stat_refine_seqs += R;
@@ -1134,9 +1149,10 @@ int czc_step(czc_engine* e, int32_t* inp, int B, int T, int gen_idx, int n_mask,
     E_CHECK(copy_out(e, out->logits, "b_logits", (size_t)B * e->cfg.bert_vocab * 4));
   }
   E_HIP(hipMemcpyAsync(inp, d_inp, (size_t)B * T * 4, hipMemcpyDefault, e->st));
-  E_HIP(hipMemcpyAsync(e->h_totals + 9, e->ws["s_nonfinite"].p, 4, hipMemcpyDeviceToHost, e->st));
+  E_HIP(hipMemcpyAsync(e->h_totals + 9, e->ws["s_nonfinite"].p, 12, hipMemcpyDeviceToHost, e->st));
   E_HIP(hipStreamSynchronize(e->st));
   if (e->h_totals[9]) return fail(e, CZC_ERR_OVERFLOW, "non-finite CLIP cosine (fp16 operand overflow in a tower? use CZC_PREC_SPLIT)%s");
+  { float dev; memcpy(&dev, e->h_totals + 10, 4); e->guard_max_dev = fmaxf(e->guard_max_dev, dev); e->guard_trips += e->h_totals[11]; }
   return CZC_OK;
 }
 
@@ -1168,9 +1184,10 @@ int czc_generate(czc_engine* e, int B, int T, int L, int seed_len, const int32_t
       ++snap;
     }
   }
-  E_HIP(hipMemcpyAsync(e->h_totals + 9, e->ws["s_nonfinite"].p, 4, hipMemcpyDeviceToHost, e->st));
+  E_HIP(hipMemcpyAsync(e->h_totals + 9, e->ws["s_nonfinite"].p, 12, hipMemcpyDeviceToHost, e->st));
   E_HIP(hipStreamSynchronize(e->st));
   if (e->h_totals[9]) return fail(e, CZC_ERR_OVERFLOW, "non-finite CLIP cosine (fp16 operand overflow in a tower? use CZC_PREC_SPLIT)%s");
+  { float dev; memcpy(&dev, e->h_totals + 10, 4); e->guard_max_dev = fmaxf(e->guard_max_dev, dev); e->guard_trips += e->h_totals[11]; }
   return CZC_OK;
 }
 
@@ -1190,6 +1207,7 @@ int czc_set_option(czc_engine* e, const char* name, int value) {
   if (!strcmp(name, "fuse_ln")) { e->fuse_ln = value; return CZC_OK; }  // 0 off, 1 out-proj -> LN2, 2 also fc2 -> next LN1
   if (!strcmp(name, "refine_samples")) { e->refine_samples = value < 0 ? 0 : value; return CZC_OK; }
   if (!strcmp(name, "refine_theta_x1000")) { e->refine_theta_x = (float)value / 1000.f; return CZC_OK; }
+  if (!strcmp(name, "refine_guard_x1e6")) { e->refine_guard_dev = (float)value * 1e-6f; return CZC_OK; }
   return fail(e, CZC_ERR_ARG, "unknown option %s", name);
 }
 
@@ -1281,6 +1299,14 @@ int czc_refine_stats(czc_engine* e, int64_t* refine_seqs, int64_t* refine_rows) 
   if (!e) return CZC_ERR_ARG;
   if (refine_seqs) *refine_seqs = e->stat_refine_seqs;
   if (refine_rows) *refine_rows = e->stat_refine_rows;
+  return CZC_OK;
+}
+
+int czc_refine_guard(czc_engine* e, int reset, float* max_dev, int64_t* tripped) {
+  if (!e) return CZC_ERR_ARG;
+  if (max_dev) *max_dev = e->guard_max_dev;
+  if (tripped) *tripped = e->guard_trips;
+  if (reset) { e->guard_max_dev = 0.f; e->guard_trips = 0; }
   return CZC_OK;
 }
 

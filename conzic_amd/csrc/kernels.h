@@ -179,6 +179,9 @@ struct CombineArgs {
   // screen-then-refine: candidates with refine_kind != 0 take their cosine from refine_cos (see combine.hip)
   const int* refine_kind = nullptr;                          // [B,K]
   const float* refine_cos = nullptr;                         // [B,K]
+  // guard of the screen-then-refine scores: nonfinite[1] <- max over the re-encoded candidates of |screening error - its
+  // estimated mean| (float bits), nonfinite[2] += images where that exceeds refine_guard (0 = no guard)
+  float refine_guard = 0.f;
 };
 // text_feat == null: clip_ref already holds the cosines
 int launch_combine(const CombineArgs& a, hipStream_t st);

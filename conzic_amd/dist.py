@@ -74,13 +74,32 @@ def broadcast_state(state: Optional[Dict[str, np.ndarray]], device, src: int = 0
     return out
 
 
-def gather_ids(local_ids: np.ndarray, world: int):
-    """Optional end-of-run gather of int32 ids [S, B_local, T] along the image axis (tiny)."""
+def gather_along(local: np.ndarray, world: int, axis: int = 1) -> np.ndarray:
+    """All-gather of per-rank arrays that differ in length along `axis` (uneven image shards: 7 images on 2 ranks are
+    4 + 3): the lengths travel first, every rank pads its block to the longest one, one all_gather, blocks are trimmed
+    back and concatenated in rank order -- i.e. global image order for `shard_range` shards."""
     import torch
     import torch.distributed as dist
-    t = torch.from_numpy(np.ascontiguousarray(local_ids))
-    if dist.get_backend() == "nccl":
+    a = np.ascontiguousarray(np.moveaxis(local, axis, 0))
+    on_gpu = dist.get_backend() == "nccl"
+    n = torch.tensor([a.shape[0]], dtype=torch.int64)
+    if on_gpu:
+        n = n.cuda()
+    lens = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(lens, n)
+    lens = [int(x.item()) for x in lens]
+    longest = max(lens + [1])
+    pad = np.zeros((longest,) + a.shape[1:], dtype=a.dtype)
+    pad[: a.shape[0]] = a
+    t = torch.from_numpy(pad)
+    if on_gpu:
         t = t.cuda()
     outs = [torch.empty_like(t) for _ in range(world)]
     dist.all_gather(outs, t)
-    return np.concatenate([o.cpu().numpy() for o in outs], axis=1)
+    full = np.concatenate([o.cpu().numpy()[:ln] for o, ln in zip(outs, lens)], axis=0)
+    return np.moveaxis(full, 0, axis)
+
+
+def gather_ids(local_ids: np.ndarray, world: int):
+    """Optional end-of-run gather of int32 ids [S, B_local, T] along the image axis (tiny; shards may be uneven)."""
+    return gather_along(local_ids, world, axis=1)

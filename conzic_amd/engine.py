@@ -98,9 +98,13 @@ class Engine:
         """A second engine on the same GPU over the SAME weights (czc_replicate): own stream, workspace, image
         embeddings and tables.  Every setter call made on this engine so far is replayed on it, later ones are
         forwarded.  Closed with (before) its parent."""
-        parent = self._parent() if self._parent is not None else None
-        if parent is not None:
+        if self._parent is not None:
+            parent = self._parent()
+            if parent is None or parent.h is None:
+                raise NativeError("replica(): the parent engine of this replica was closed (it owns the weights)")
             return parent.replica()
+        if self.h is None:
+            raise NativeError("replica(): this engine is closed")
         r = object.__new__(Engine)
         r.lib, r.cfg, r.bert_cfg, r.clip_cfg, r.precision = self.lib, self.cfg, self.bert_cfg, self.clip_cfg, self.precision
         import weakref
@@ -125,6 +129,9 @@ class Engine:
             pass
 
     def _ck(self, rc, what):
+        if rc != 0 and getattr(self, "h", None) is None:
+            raise NativeError(f"{what}: this engine is closed" + (" (a replica is closed with its parent, which owns the weights)"
+                                                                  if self._parent is not None else ""))
         native.check(rc, self.h, what)
 
     # ---- frozen state -------------------------------------------------------------------------
@@ -364,6 +371,13 @@ class Engine:
         return dict(clip_rows=a.value, clip_seqs=b.value, bert_rows=c_.value, steps=d.value, refine_seqs=rs.value,
                     refine_rows=rr.value)
 
+    def refine_guard(self, reset: bool = True):
+        """(max |screening error - mean| seen on re-encoded candidates, image-steps above the trip point) of a
+        CZC_PREC_REFINE engine since the last reset (czc_refine_guard)."""
+        dev, trips = C.c_float(), C.c_int64()
+        self._ck(self.lib.czc_refine_guard(self.h, 1 if reset else 0, C.byref(dev), C.byref(trips)), "czc_refine_guard")
+        return dict(max_dev=float(dev.value), tripped=int(trips.value))
+
     def sync(self):
         self._ck(self.lib.czc_sync(self.h), "czc_sync")
 
@@ -480,6 +494,10 @@ class EngineGroup:
     def stats(self):
         ss = [e.stats() for e in self.engines]
         return {k: sum(s_[k] for s_ in ss) for k in ss[0]}
+
+    def refine_guard(self, reset: bool = True):
+        gs = [e.refine_guard(reset) for e in self.engines]
+        return dict(max_dev=max(g["max_dev"] for g in gs), tripped=sum(g["tripped"] for g in gs))
 
     def close(self, parent: bool = True):
         """Close the replicas (and the thread pool); the first engine too unless parent=False."""

@@ -106,6 +106,7 @@ SIGNATURES = {
     "czc_sync": (_I, [_P]),
     "czc_stats": (_I, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "czc_refine_stats": (_I, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "czc_refine_guard": (_I, [_P, _I, C.POINTER(C.c_float), C.POINTER(C.c_int64)]),
 }
 # every entry point include/conzic_hip_test.h declares (libconzic_hip_test.so)
 TEST_SIGNATURES = {

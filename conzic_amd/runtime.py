@@ -149,9 +149,13 @@ def special_ids_of(tokenizer) -> Dict[str, int]:
     return {k: int(vocab[k]) for k in ("[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]", ".")}
 
 
-def get_engine(model, clip, tokenizer, device: int = 0) -> Engine:
-    """One engine per (model, clip, tokenizer) object triple, created on first use."""
-    prec = choose_precision(_logit_scale_of(clip))
+PRECISION_NAMES = {native.PREC_BF16: "bf16", native.PREC_F32: "f32", native.PREC_SPLIT: "split-fp16", native.PREC_FP16: "fp16",
+                   native.PREC_REFINE: "screen-then-refine (fp16 + split-fp16)", native.PREC_ALL_BF16: "all-bf16"}
+
+
+def get_engine(model, clip, tokenizer, device: int = 0, precision: Optional[int] = None) -> Engine:
+    """One engine per (model, clip, tokenizer, precision) on first use; precision None = `choose_precision`."""
+    prec = choose_precision(_logit_scale_of(clip)) if precision is None else precision
     key = (id(model), id(clip), id(tokenizer), prec, device)
     objs = (model, clip, tokenizer)
     eng = _lookup(key, objs)
@@ -162,6 +166,8 @@ def get_engine(model, clip, tokenizer, device: int = 0) -> Engine:
         eng.load_state(clip.clip_state_dict())
         eng.finalize()
         eng.set_bridge(tables_from_tokenizers(tokenizer, clip.tokenizer))
+        if prec == native.PREC_REFINE and os.environ.get("CZC_REFINE_GUARD_X1E6"):
+            eng.set_option("refine_guard_x1e6", int(os.environ["CZC_REFINE_GUARD_X1E6"]))  # trip point of the guard, 1e-6 of cosine
         _store(key, eng, objs)
     clip._engine = eng
     return eng
@@ -227,15 +233,11 @@ def run_generation(order: str, img_name, model, clip, tokenizer, image_instance,
     seed_len = len(prompt.split()) + 1                                   # gen_utils.py:56
     batch = ref_utils.get_init_text(tokenizer, prompt, max_len, batch_size)  # gen_utils.py:57
     clip.compute_image_representation_from_image_instance(image_instance)    # gen_utils.py:58 (cached in the engine)
-    eng.set_token_mask(_mask_to_numpy(token_mask))
-    if gamma is not None:
-        # control scores: caller-provided tables, else tables built once per tokenizer from nltk (default), else -- with
-        # CZC_CONTROL=exact -- the reference's own sentence scorer called back per step; raises without nltk and tables
-        from . import control
-        chosen = control.configure(eng, clip, tokenizer, pos_template=pos_template, ctl_signal=ctl_signal)
-        if chosen != getattr(eng, "_control_logged", None):
-            logger.info(f"control scores: {chosen}")
-            eng._control_logged = chosen
+    if getattr(eng, "_precision_logged", None) is None:
+        scale = _logit_scale_of(clip)
+        logger.info(f"engine precision: {PRECISION_NAMES.get(eng.precision, eng.precision)}"
+                    + (f" (exp(logit_scale) = {math.exp(scale):.1f})" if scale is not None else ""))
+        eng._precision_logged = True
     order_list = random_positions = None
     if order == "shuffle":
         order_list = list(range(max_len))
@@ -250,17 +252,50 @@ def run_generation(order: str, img_name, model, clip, tokenizer, image_instance,
         positions, n_mask, every = order_positions(order, max_len, iters, order_list=order_list)
     hp = Engine.hyper(alpha, beta, temperature, gamma, ctl_signal == "negative",
                       control="pos" if pos_template is not None else None)
-    runner = _group_for(eng, batch_size)
-    if runner is not eng:
-        # two (CZC_STREAMS) contiguous image sub-batches on their own HIP streams over the same weights: the same
-        # captions image for image (images are independent, gen_utils.py:64-81), their kernels overlap on the GPU
-        from clip.clip import ImageEmbeds
-        emb = image_instance.embeds if isinstance(image_instance, ImageEmbeds) else clip.last_image_embeds()
-        runner.set_image_embeds(emb)
-    ids, cos = runner.generate(batch_size, batch[0], max_len, seed_len, top_k, positions, hp, n_mask=n_mask,
-                               snapshot_every=every)
-    if runner is not eng:
-        eng.set_image_embeds(emb)  # the first engine holds the whole batch again, as after a single-stream call
+
+    def polish(eng):
+        """One whole *_generation call on `eng` (which must hold the batch's image embeddings)."""
+        eng.set_token_mask(_mask_to_numpy(token_mask))
+        if gamma is not None:
+            # control scores: caller-provided tables, else tables built once per tokenizer from nltk (default), else -- with
+            # CZC_CONTROL=exact -- the reference's own sentence scorer called back per step; raises without nltk and tables
+            from . import control
+            chosen = control.configure(eng, clip, tokenizer, pos_template=pos_template, ctl_signal=ctl_signal)
+            if chosen != getattr(eng, "_control_logged", None):
+                logger.info(f"control scores: {chosen}")
+                eng._control_logged = chosen
+        runner = _group_for(eng, batch_size)
+        emb = None
+        if runner is not eng:
+            # two (CZC_STREAMS) contiguous image sub-batches on their own HIP streams over the same weights: the same
+            # captions image for image (images are independent, gen_utils.py:64-81), their kernels overlap on the GPU
+            from clip.clip import ImageEmbeds
+            emb = image_instance.embeds if isinstance(image_instance, ImageEmbeds) else clip.last_image_embeds()
+            runner.set_image_embeds(emb)
+        if eng.precision == native.PREC_REFINE:
+            runner.refine_guard(reset=True)
+        out = runner.generate(batch_size, batch[0], max_len, seed_len, top_k, positions, hp, n_mask=n_mask,
+                              snapshot_every=every)
+        if runner is not eng:
+            eng.set_image_embeds(emb)  # the first engine holds the whole batch again, as after a single-stream call
+        return out, runner
+
+    (ids, cos), runner = polish(eng)
+    guard_mode = os.environ.get("CZC_REFINE_GUARD", "rerun").lower()
+    if eng.precision == native.PREC_REFINE and guard_mode != "off":
+        # the screen-then-refine engine's 1e-3 bound rests on the single-pass fp16 tower's error staying near what it is
+        # on the validated weights; every step measures that error on the candidates it re-encodes exactly
+        g = runner.refine_guard(reset=True)
+        if g["tripped"]:
+            logger.info(f"screen-then-refine guard: |screening error - mean| reached {g['max_dev']:.2e} on {g['tripped']} "
+                        f"image-steps (budget 2.5e-4)" + ("; repeating the call on the all-split engine" if guard_mode == "rerun" else ""))
+            if guard_mode == "rerun":
+                from clip.clip import ImageEmbeds
+                emb = image_instance.embeds if isinstance(image_instance, ImageEmbeds) else clip.last_image_embeds()
+                eng2 = get_engine(model, clip, tokenizer, precision=native.PREC_SPLIT)
+                eng2.set_image_embeds(emb)   # the refine engine's vision tower is the split-fp16 one: same embeddings
+                (ids, cos), _ = polish(eng2)
+                clip._engine = eng
     # utils.update_token_mask mutates the caller's mask in place (utils.py:53-59): leave it as the
     # reference would after the last visited position
     if positions:

@@ -242,13 +242,17 @@ int czc_generate(czc_engine* e, int B, int T, int L, int seed_len, const int32_t
  *                         kernel that also emits LN2 of its result (no LayerNorm pass for it); 2 = fc2 -> the next
  *                         layer's LN1 as well (measured slower), 0 = off
  *   "refine_samples" (12), "refine_theta_x1000" (4000): CZC_PREC_REFINE selection -- strata of the mass-stratified sample
- *                         and the softmax_K mass threshold theta = value / 1000 / (beta * exp(logit_scale)) */
+ *                         and the softmax_K mass threshold theta = value / 1000 / (beta * exp(logit_scale))
+ *   "refine_guard_x1e6" (200): trip point of czc_refine_guard, in units of 1e-6 of cosine */
 int czc_set_option(czc_engine* e, const char* name, int value);
 
 /* ---- measurement ------------------------------------------------------------------------- */
 /* HIP-event timing of kernel classes on the engine's own stream (bench.py roofline leg).  on: 0 off, 1 an event pair
- * around every kernel class (3 % slower at B = 256, 37 % at B = 1), 2 only around "gemm_clip_text" / "gemm_clip_refine" (the roofline family).
- * kind: "gemm_clip_text" | "gemm_clip_refine" (second pass of CZC_PREC_REFINE) | "gemm_bert" | "gemm_vision" | "attention" | "rowops" | "topk" | "bridge" | "combine" */
+ * around every kernel class (3 % slower at B = 256, 37 % at B = 1), 2 only around the CLIP-text tower's classes: its
+ * linear layers "gemm_clip_text" / "gemm_clip_refine" (the roofline family), "attention_clip_text" (flops = 4 * hidden *
+ * causal (query, key) pairs per layer) and "rowops_clip_text" (embedding, LayerNorm, gathers).
+ * kind: those four | "gemm_bert" | "gemm_vision" | "attention" (BERT, vision) | "rowops" (BERT, vision, head) | "topk" |
+ * "bridge" | "combine" */
 int czc_profile_enable(czc_engine* e, int on);
 int czc_profile_reset(czc_engine* e);
 int czc_profile_get(czc_engine* e, const char* kind, double* total_ms, int64_t* launches, double* flops);
@@ -263,6 +267,14 @@ int czc_stats(czc_engine* e, int64_t* clip_rows, int64_t* clip_seqs, int64_t* be
 /* CZC_PREC_REFINE engines: candidate sequences / packed rows re-encoded by the split-fp16 tower since czc_profile_reset
  * (of the clip_seqs / clip_rows the screening pass saw); zero for the other precisions. */
 int czc_refine_stats(czc_engine* e, int64_t* refine_seqs, int64_t* refine_rows);
+/* CZC_PREC_REFINE engines, runtime guard of the 1e-3 bound: candidates that keep their screening (single-pass fp16) cosine
+ * carry its error minus the estimated mean, and move their fused score by at most theta_x * |that| (theta_x = 4).  Every
+ * step records, over the ~16 candidates per image it re-encodes exactly, the largest |screening error - mean|
+ * (*max_dev, since the last reset) and counts the image-steps where it exceeds option "refine_guard_x1e6" * 1e-6
+ * (default 200: 0.8 of the 2.5e-4 the bound allows) in *tripped.  The bound was validated on random-weight towers; a
+ * checkpoint whose activations the fp16 tower carries worse trips the guard, and conzic_amd/runtime.py then repeats the
+ * call on the all-split engine (CZC_REFINE_GUARD=rerun | warn | off). */
+int czc_refine_guard(czc_engine* e, int reset, float* max_dev, int64_t* tripped);
 
 #ifdef __cplusplus
 }

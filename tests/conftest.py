@@ -58,6 +58,11 @@ def pytest_terminal_summary(terminalreporter):
                                     "while on the trajectory, images still on it at the end, reference top-2 margin at each first divergence):")
         for name, prec, tot, same, alive, B, margins in dlog:
             terminalreporter.write_line(f"  {name:22s} prec={prec}: {same}/{tot} tokens, {alive}/{B} images, margins {[f'{m:.1e}' for m in margins]}")
+    glog = getattr(mod, "GUARD_LOG", None)
+    if glog:
+        terminalreporter.write_line("screen-then-refine guard (case: max |screening error - mean| on re-encoded candidates, tripped image-steps; budget 2.5e-4):")
+        for name, dev, trips in glog:
+            terminalreporter.write_line(f"  {name:22s} {dev:.3e}  tripped {trips}")
     rlog = getattr(mod, "REFINE_LOG", None)
     if rlog:
         terminalreporter.write_line("screen-then-refine engine: candidate sequences re-encoded by the split-fp16 tower (case: seqs, rows):")

@@ -52,6 +52,17 @@ def _worker(rank, world, port, q):
         local = np.stack([np.full((hi - lo, T), 0, np.int32) + np.arange(lo, hi, dtype=np.int32)[:, None]] * 2)
         full = czd.gather_ids(local, world)
         ok = ok and full.shape == (2, n_img, T) and (full[0, :, 0] == np.arange(n_img)).all()
+        # uneven shards (7 images on 2 ranks: 4 + 3) and a per-image score vector ride the same gather
+        lo7, hi7 = czd.shard_range(7, rank, world)
+        ids7 = np.arange(lo7, hi7, dtype=np.int32)[None, :, None] * np.ones((3, 1, T), np.int32)
+        full7 = czd.gather_ids(ids7, world)
+        ok = ok and full7.shape == (3, 7, T) and (full7[1, :, 2] == np.arange(7)).all()
+        cos7 = czd.gather_along(np.arange(lo7, hi7, dtype=np.float32)[None, :] * 0.5, world, axis=1)
+        ok = ok and cos7.shape == (1, 7) and np.array_equal(cos7[0], np.arange(7, dtype=np.float32) * 0.5)
+        # a rank with NO images (3 ranks' worth of work on 1 image) contributes an empty block
+        lo1, hi1 = czd.shard_range(1, rank, world)
+        one = czd.gather_ids(np.full((2, hi1 - lo1, T), 9, np.int32), world)
+        ok = ok and one.shape == (2, 1, T)
         # synthetic image stream: any shard can be generated independently of the others
         a = synth.make_images_u8(hi - lo, 8, first=lo)
         b = synth.make_images_u8(n_img, 8)[lo:hi]

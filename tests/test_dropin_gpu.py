@@ -236,3 +236,52 @@ def test_demo_harness_runs_every_run_type(argv, caplog):
     text = "\n".join(r.getMessage() for r in caplog.records)
     assert text.count("Sample ") == 2
     assert "final caption" in text.lower() or "best caption" in text.lower()
+
+
+def test_refine_guard_trip_repeats_the_call_on_the_split_engine(monkeypatch):
+    """runtime.run_generation under the screen-then-refine engine: when the guard trips (forced here by a 1e-6 trip point)
+    the call is repeated on the all-split-fp16 engine and returns exactly what CZC_PRECISION=split returns; with the
+    default trip point nothing trips and the refine engine's own result stands; CZC_REFINE_GUARD=warn only logs."""
+    import utils
+    from conzic_amd import native, runtime
+    from gen_utils import generate_caption
+    meta, _ = load_case("tiny_scale100")
+    names = [f"img{j}" for j in range(meta["B"])]
+    kw = dict(prompt=meta["prompt"], batch_size=meta["B"], max_len=meta["L"], top_k=meta["K"],
+              temperature=meta["temperature"], max_iter=meta["I"], alpha=meta["alpha"], beta=meta["beta"],
+              generate_order=meta["order"])
+
+    class Log:
+        def __init__(self):
+            self.lines = []
+
+        def info(self, s):
+            self.lines.append(str(s))
+
+    def run(prec, guard_x=None, mode=None):
+        monkeypatch.setenv("CZC_PRECISION", prec)
+        for k, v in (("CZC_REFINE_GUARD_X1E6", guard_x), ("CZC_REFINE_GUARD", mode)):
+            if v is None:
+                monkeypatch.delenv(k, raising=False)
+            else:
+                monkeypatch.setenv(k, v)
+        lm, clip, tok, imgs, mask = _objects(meta)
+        utils.set_seed(meta["seed"])
+        log = Log()
+        out = generate_caption(names, lm, clip, tok, imgs, mask, log, **kw)
+        precs = sorted(k[3] for k in runtime._ENGINES if len(k) == 5)
+        runtime.evict()
+        return out, log.lines, precs
+
+    split, _, _ = run("split")
+    plain, lines, precs = run("refine")
+    assert precs == [native.PREC_REFINE] and not any("guard" in ln for ln in lines)
+    assert any("engine precision: screen-then-refine" in ln for ln in lines)
+    forced, lines, precs = run("refine", guard_x="1")
+    assert precs == [native.PREC_SPLIT, native.PREC_REFINE]
+    assert any("repeating the call on the all-split engine" in ln for ln in lines)
+    assert forced[0] == split[0]
+    np.testing.assert_array_equal(np.array(forced[1]), np.array(split[1]))
+    warned, lines, precs = run("refine", guard_x="1", mode="warn")
+    assert precs == [native.PREC_REFINE] and any("screen-then-refine guard" in ln for ln in lines)
+    assert warned[0] == plain[0]

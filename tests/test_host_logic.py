@@ -312,6 +312,16 @@ def test_image_cache_key_follows_the_pixels_not_only_the_object():
     im.paste((9, 9, 9), (0, 0, 33, 21))
     assert _fingerprint(im) != k1
     assert _fingerprint(object()) is None   # unknown objects are never cached
+    # a change ANYWHERE is seen (every pixel byte is hashed: a frame with a static border, a one-pixel edit), also through a
+    # non-contiguous view
+    b = np.random.default_rng(3).integers(0, 255, (64, 48, 3), dtype=np.uint8)
+    kb, kv = _fingerprint(b), _fingerprint(b[:, ::2])
+    b[37, 22, 1] ^= 1
+    assert _fingerprint(b) != kb and _fingerprint(b[:, ::2]) != kv
+    im2 = Image.fromarray(b)
+    k2 = _fingerprint(im2)
+    im2.putpixel((5, 60), (1, 2, 3))
+    assert _fingerprint(im2) != k2
 
 
 def test_visiting_orders_and_partitions_hold_their_invariants():

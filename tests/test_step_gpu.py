@@ -427,6 +427,33 @@ def test_refine_engine_vs_split_engine_many_image_steps():
     assert worst < 1e-3, worst
 
 
+GUARD_LOG = []  # (case, max |screening error - mean| on re-encoded candidates, tripped image-steps)
+
+
+@pytest.mark.parametrize("name", ["full_scale100", "full_senti", "full_shuffle_k512"])
+def test_refine_guard_measures_the_screening_error(name):
+    """czc_refine_guard: every screen-then-refine step records, on the candidates it re-encodes exactly, how far the
+    single-pass fp16 cosine is from the exact one once the estimated mean error is removed.  On the validated weights the
+    figure stays inside the 2.5e-4 the 1e-3 bound needs and nothing trips at the default trip point (2.0e-4); with the
+    trip point at 1e-6 every image-step trips."""
+    meta, arr = load_case(name)
+    su = setup_for(meta, REFINE)
+    eng = su.engine
+    eng.refine_guard(reset=True)
+    teacher_forced(meta, arr, REFINE, n_steps=6)
+    g = eng.refine_guard(reset=True)
+    GUARD_LOG.append((name, g["max_dev"], g["tripped"]))
+    assert 0.0 < g["max_dev"] < 2.0e-4 and g["tripped"] == 0, g
+    try:
+        eng.set_option("refine_guard_x1e6", 1)
+        teacher_forced(meta, arr, REFINE, n_steps=2)
+        g2 = eng.refine_guard(reset=True)
+        assert g2["tripped"] == 2 * meta["B"], g2
+    finally:
+        eng.set_option("refine_guard_x1e6", 200)
+    assert eng.refine_guard()["tripped"] == 0
+
+
 def test_refine_engine_encode_text_and_images_are_exact():
     """Outside the polishing step the refine engine answers with its exact towers: czc_encode_text through the split-fp16
     text tower, czc_encode_images through the split-fp16 vision tower (compute_image_text_similarity_via_* callers)."""
@@ -792,7 +819,7 @@ def test_fused_layernorm_matches_layernorm_kernel(name, steps, prec):
                 inp = np.ascontiguousarray(arr["inp_before"][i], dtype=np.int32)
                 rows.append(eng.step(inp, SEED_LEN + meta["positions"][i], meta["K"], hp,
                                      dot_allowed=(meta["positions"][i] == meta["L"] - 1)))
-            outs.append((rows, eng.profile_get("rowops")))
+            outs.append((rows, eng.profile_get("rowops_clip_text")))
             eng.profile(0)
     finally:
         lib.czc_test_set_option(b"rowln_min_m", 8192)

@@ -103,3 +103,59 @@ def test_group_profile_counts_overlapping_launches_once():
         assert max(p["ms"] for p in per) * 0.5 < g["busy_ms"] <= g["ms"] * 1.001
     finally:
         grp.close()
+
+
+def test_orphan_replica_reports_a_closed_parent():
+    """A replica only borrows its parent's weights: once the parent is closed the replica is closed with it, and calls on
+    it (or asking it for another replica) say so instead of handing a NULL handle to the C ABI."""
+    from conzic_amd import harness, native
+    su = harness.build_synthetic(True, native.PREC_F32)
+    rep = su.engine.replica()
+    su.engine.close()
+    with pytest.raises(native.NativeError, match="closed"):
+        rep.replica()
+    with pytest.raises(native.NativeError, match="closed"):
+        rep.set_option("fuse_ln", 1)
+    with pytest.raises(native.NativeError, match="closed"):
+        su.engine.replica()
+
+
+def test_configs2_batch_at_full_size_holds_the_reference_trajectories():
+    """BASELINE configs[2] at its real size under pytest: 256 images, L = 10, K = 200, sequential, polished the way bench.py
+    polishes them (EngineGroup: two 128-image sub-batches on two streams, czc_encode_images + czc_generate), one sweep.
+    Images 0-1 of the synthetic stream are the two images of the `full_regular` golden, so inside the batch of 256
+    (a) the split-fp16 engine reproduces the reference's trajectory for them id for id, and (b) the bf16 engine gives them,
+    bit for bit, what it gives them polished alone at B = 2 (no kernel switches: different kernel families serve the two
+    row counts)."""
+    meta, arr = load_case("full_regular")
+    B, L, K = 256, meta["L"], meta["K"]
+    assert (L, K, meta["order"], meta["I"]) == (10, 200, "sequential", 1)
+    u8 = synth.make_images_u8(B)
+    pixels = synth.pixels_from_u8(u8)
+    hp = Engine.hyper(meta["alpha"], meta["beta"], meta["temperature"])
+    pos, nm, every = harness.order_positions("sequential", L, 1)
+    for prec in (native.PREC_SPLIT, native.PREC_BF16):
+        su = harness.build_synthetic(False, prec, meta["bseed"], meta["cseed"], meta["logit_scale"], regular_only=True)
+        try:
+            init = su.bert_tok.encode(meta["prompt"] + su.bert_tok.mask_token * L)
+            grp = EngineGroup(su.engine, streams=2, min_images=32)
+            assert [hi - lo for lo, hi in grp.parts(B)] == [128, 128]
+            emb = grp.encode_images(pixels)
+            ids, cos = grp.generate(B, init, L, 4, K, pos, hp, n_mask=nm, snapshot_every=every)
+            assert ids.shape == (1, B, len(init)) and np.isfinite(cos).all()
+            if prec == native.PREC_SPLIT:
+                np.testing.assert_allclose(emb[:2], arr["image_embeds"], atol=5e-5 * max(1.0, float(np.abs(arr["image_embeds"]).max())))
+                np.testing.assert_array_equal(ids[:, :2], arr["snaps"])
+                np.testing.assert_allclose(cos[:, :2], np.array(meta["scores"][:-1], dtype=np.float32), atol=2e-5)
+            else:
+                grp.close(parent=False)
+                emb2 = su.engine.encode_images(pixels[:2])
+                ids2, cos2 = su.engine.generate(2, init, L, 4, K, pos, hp, n_mask=nm, snapshot_every=every)
+                np.testing.assert_array_equal(emb2, emb[:2])
+                np.testing.assert_array_equal(ids2, ids[:, :2])
+                np.testing.assert_array_equal(cos2, cos[:, :2])
+            # every image left the all-[MASK] state, and the images do not all share one caption
+            assert (ids[0, :, 4:4 + L] != su.bert_tok.vocab["[MASK]"]).all()
+            assert len({tuple(r) for r in ids[0].tolist()}) > B // 2
+        finally:
+            su.engine.close()
