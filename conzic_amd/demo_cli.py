@@ -49,8 +49,9 @@ def get_args(argv=None):
     p.add_argument("--synthetic", action="store_true", help="random-init weights + synthetic vocab/images (no checkpoints)")
     p.add_argument("--tiny", action="store_true", help="with --synthetic: tiny model dims")
     p.add_argument("--control_scores", default=None, choices=["auto", "table", "exact"],
-                   help="controllable runs: per-token tables built from nltk inside the engine's kernels (table, default) or "
-                        "the reference's own nltk sentence scorer called back once per step (exact); sets CZC_CONTROL")
+                   help="controllable runs: the reference's own nltk sentence scorer called back once per step (exact; what "
+                        "auto picks when nltk imports) or per-token tables built from nltk and evaluated inside the engine's "
+                        "kernels (table: the throughput mode, context-free approximation); sets CZC_CONTROL")
     a = p.parse_args(argv)
     if a.control_scores:
         os.environ["CZC_CONTROL"] = a.control_scores

@@ -5,10 +5,10 @@ nltk does not exist on the GPU box, so `tests/nltk_standin.py` (a deterministic,
 SentiWordNet-shaped table) is installed as `nltk` in sys.modules; the `*_ctx` goldens were produced by the UNCHANGED
 reference scorers over that same module (tests/golden/make_goldens.py).  Checked here:
 
-* `CZC_CONTROL=exact` (the reference's sentence scorer called back from the engine once per step,
+* the default (`CZC_CONTROL=auto` -> exact: the reference's sentence scorer called back from the engine once per step,
   `czc_set_control_callback`) reproduces the reference's raw control scores exactly, its fused scores within the
   precision bar and its captions id for id;
-* the default mode builds the per-token tables from nltk by itself (no attributes set on `clip`), runs, and the number
+* `CZC_CONTROL=table` builds the per-token tables from nltk by itself (no attributes set on `clip`), runs, and the number
   of winners its context-free approximation flips against the reference is measured (DESIGN.md §2);
 * without nltk and without tables the path fails loudly.
 """
@@ -75,13 +75,18 @@ def _call_like_demo_py(meta, lm, clip, tok, imgs, mask):
     return control_generate_caption(names, lm, clip, tok, imgs, mask, logging.getLogger("control-test"), **kw)
 
 
+@pytest.mark.parametrize("mode", [None, "exact"])
 @pytest.mark.parametrize("name", CTX_TINY)
-def test_exact_mode_reproduces_the_reference_captions(name, standin, monkeypatch):
-    """control_generate_caption called as demo.py calls it, CZC_CONTROL=exact: the captions and scores the reference
-    produced with its own nltk scorers (context-dependent tagger), id for id."""
+def test_default_mode_reproduces_the_reference_captions(name, mode, standin, monkeypatch):
+    """control_generate_caption called as demo.py calls it, nothing configured (CZC_CONTROL unset = auto) or
+    CZC_CONTROL=exact: the captions and scores the reference produced with its own nltk scorers (context-dependent
+    tagger), id for id."""
     from conzic_amd import runtime
     monkeypatch.setenv("CZC_PRECISION", "f32")
-    monkeypatch.setenv("CZC_CONTROL", "exact")
+    if mode is None:
+        monkeypatch.delenv("CZC_CONTROL", raising=False)
+    else:
+        monkeypatch.setenv("CZC_CONTROL", mode)
     meta, arr = load_case(name)
     lm, clip, tok, imgs, mask = _objects(meta)
     assert clip.lexicon is None and clip.pos_tags is None and getattr(clip, "lexicon_pos", None) is None
@@ -94,12 +99,12 @@ def test_exact_mode_reproduces_the_reference_captions(name, standin, monkeypatch
 
 
 @pytest.mark.parametrize("name", CTX_TINY)
-def test_default_mode_builds_its_tables_from_nltk(name, standin, monkeypatch):
-    """The default (table) mode with nothing set on `clip`: the tables come from nltk (here the stand-in) once per
+def test_table_mode_builds_its_tables_from_nltk(name, standin, monkeypatch):
+    """CZC_CONTROL=table with nothing set on `clip`: the tables come from nltk (here the stand-in) once per
     tokenizer, the call returns the reference's list structure, and a second sample re-uses the cached tables."""
     from conzic_amd import runtime
     monkeypatch.setenv("CZC_PRECISION", "f32")
-    monkeypatch.delenv("CZC_CONTROL", raising=False)
+    monkeypatch.setenv("CZC_CONTROL", "table")
     meta, arr = load_case(name)
     lm, clip, tok, imgs, mask = _objects(meta)
     calls = {"n": 0}
