@@ -324,8 +324,14 @@ def main():
             single_step()
             eng.profile(False)
             breakdown = {k: eng.profile_get(k) for k in kinds}
+        # the captions of the last timed step over ALL ranks (image order = rank order = shard order), as a checksum: an N-rank
+        # strong-scaling run must reproduce the 1-rank run's ids exactly (tests/test_dist_gpu.py)
+        import zlib
+        all_ids = czd.gather_along(ids, world, axis=1) if world > 1 else ids
+        ids_crc = zlib.crc32(np.ascontiguousarray(all_ids, dtype=np.int32).tobytes()) & 0xFFFFFFFF
         res = dict(dt=dt, prof=prof, prof_timed=prof_timed, breakdown=breakdown, stats=stats, setup_s=t_setup, invariance=None,
-                   streams=n_streams, single_ms=single_ms, per_rank=per_rank, steps=steps)
+                   streams=n_streams, single_ms=single_ms, per_rank=per_rank, steps=steps, ids_crc=ids_crc,
+                   n_ids=int(all_ids.shape[1]))
         if invariance and rank == 0 and B > 2:
             # batch invariance: images 0-1 encoded and polished ALONE (B = 2) by the same engine must come out as they did
             # inside the batch of B (per-image work is independent: gen_utils.py:65-81 has no cross-image term), with no
@@ -487,7 +493,10 @@ def main():
                        ms_per_step=round(main_res["single_ms"], 2), value=round(B / main_res["single_ms"] * 1e3, 4),
                        note="the same step on ONE engine / ONE stream (rank 0's images), wall-clock around the pass "
                             "`roofline.single_stream_pass` is measured on; `value` and `roofline.frac` come from the timed region"),
-                   batch_invariance=main_res["invariance"])
+                   batch_invariance=main_res["invariance"],
+                   captions_crc32=dict(value=main_res["ids_crc"], images=main_res["n_ids"],
+                                       note="crc32 of the final token ids of every image of the last timed step, gathered over the ranks in "
+                                            "image order: equal between an N-rank --total-images run and the 1-rank run of the same images"))
         if prec == native.PREC_REFINE:
             out["refine"] = dict(candidate_seqs=st["clip_seqs"], re_encoded=st["refine_seqs"],
                                  re_encoded_frac=round(st["refine_seqs"] / max(st["clip_seqs"], 1), 4),

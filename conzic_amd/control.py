@@ -85,12 +85,21 @@ def tables_for(tokenizer, kind: str, nltk_module):
 
 # ---- the reference's scorers on a decoded string (exact mode) --------------------------------------------------------
 
-def sentence_sentiment(text: str, ctl_signal: Optional[str], nltk_module) -> float:
-    """sentiments_classifer.py:14-33 for one sentence."""
+def sentence_sentiment(text: str, ctl_signal: Optional[str], nltk_module, memo: Optional[dict] = None) -> float:
+    """sentiments_classifer.py:14-33 for one sentence.  `memo` caches the SentiWordNet mean per (word, class): a pure
+    function of its key, and the K candidate sentences of a step share all but one word (the look-up is what nltk spends
+    its time on)."""
     words = nltk_module.tokenize.word_tokenize(text)
     score = 0.0
     for word, tag in nltk_module.pos_tag(words):
-        score += sentiment.word_score(nltk_module.corpus.sentiwordnet.senti_synsets, word, sentiment.TAG_MAP.get(tag, ''))
+        key = (word, sentiment.TAG_MAP.get(tag, ''))
+        if memo is None:
+            w = sentiment.word_score(nltk_module.corpus.sentiwordnet.senti_synsets, *key)
+        else:
+            w = memo.get(key)
+            if w is None:
+                w = memo[key] = sentiment.word_score(nltk_module.corpus.sentiwordnet.senti_synsets, *key)
+        score += w
     return -score if ctl_signal == "negative" else score
 
 
@@ -147,7 +156,8 @@ def configure(eng, clip, tokenizer, *, pos_template=None, ctl_signal="positive")
         if is_pos:
             scorer = HostScorer(tokenizer, lambda t: sentence_pos_match(t, pos_template, nltk_module))
         else:
-            scorer = HostScorer(tokenizer, lambda t: sentence_sentiment(t, ctl_signal, nltk_module))
+            memo = {}
+            scorer = HostScorer(tokenizer, lambda t: sentence_sentiment(t, ctl_signal, nltk_module, memo))
         eng.set_control_callback(scorer)
         return "exact"
     if is_pos:

@@ -63,6 +63,12 @@ def pytest_terminal_summary(terminalreporter):
         terminalreporter.write_line("screen-then-refine guard (case: max |screening error - mean| on re-encoded candidates, tripped image-steps; budget 2.5e-4):")
         for name, dev, trips in glog:
             terminalreporter.write_line(f"  {name:22s} {dev:.3e}  tripped {trips}")
+    olog = getattr(mod, "OUTLIER_LOG", None)
+    if olog:
+        terminalreporter.write_line("screen-then-refine engine on towers with outlier LayerNorm channels (gain factor: worst |d final_score| vs the split "
+                                    "engine, guard max_dev, tripped / image-steps):")
+        for f_, worst, dev, trips, n in olog:
+            terminalreporter.write_line(f"  x{f_:<5g} {worst:.3e}  {dev:.3e}  {trips}/{n}")
     rlog = getattr(mod, "REFINE_LOG", None)
     if rlog:
         terminalreporter.write_line("screen-then-refine engine: candidate sequences re-encoded by the split-fp16 tower (case: seqs, rows):")

@@ -161,6 +161,31 @@ def test_bench_gpus_2_spawns_two_ranks_on_a_shared_gpu():
     assert out["value"] > 0 and out["config"]["images_per_gpu"] == 64
 
 
+def test_bench_strong_scaling_two_ranks_reproduce_the_one_rank_captions():
+    """`--total-images N` fixes the TOTAL (BASELINE configs[3]/[4] are fixed-total runs): 130 images split 65 + 65 over two
+    ranks (uneven per-stream sub-batches inside each rank) give, image for image, the captions of the same 130 images on
+    one rank -- compared through the crc32 of the gathered final ids; the line says `scaling: strong`, reports per-rank
+    captions/s, and carries the scale-100 leg under world > 1 too."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    common = ["--steps", "1", "--warmup", "0", "--iters", "2", "--no-cpu-baseline", "--no-invariance", "--no-profile"]
+
+    def run(extra):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra + common,
+                           capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    one = run(["--gpus", "1", "--images", "130", "--no-alt"])
+    two = run(["--gpus", "2", "--share-gpu", "--total-images", "130"])
+    assert two["scaling"] == "strong" and one["scaling"] == "weak"
+    assert two["config"]["total_images"] == 130 and two["ranks"]["per_rank_images"] == [65, 65]
+    assert len(two["ranks"]["per_rank_captions_per_s"]) == 2 and min(two["ranks"]["per_rank_captions_per_s"]) > 0
+    assert two["captions_crc32"]["images"] == 130 == one["captions_crc32"]["images"]
+    assert two["captions_crc32"]["value"] == one["captions_crc32"]["value"]
+    assert two["scale100_mode"]["value"] > 0 and two["scale100_mode"]["steps"] == two["steps"]
+    assert abs(two["value"] - sum(two["ranks"]["per_rank_captions_per_s"])) / two["value"] < 0.2
+
+
 def test_bench_gpus_2_without_the_flag_fails_on_one_gpu():
     import subprocess
     import torch
