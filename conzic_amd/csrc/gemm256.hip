@@ -706,6 +706,194 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(GemmArgs g, int tiles_m, 
 }
 
 // ================================================================================================
+// gemm256r (round 4, A/B arm: test option gemm256 = 9): the vendor library's structure for the fp32-residual layers --
+// FOUR waves, each 128 x 128 of C (16 v_mfma_f32_32x32x16 accumulators = 256 registers, one wave per SIMD), operands
+// REGISTER-staged: every lane requests its 8 sixteen-byte pieces of a k32 stage (buffer loads, descriptor bounds) three
+// stages before they are needed, holds them in VGPRs for two stages (two alternating sets, 64 registers) and writes
+// them into the 4-slot LDS ring with ds_write_b128 two stages before they are read; one s_barrier per stage; the
+// fragments of the next half stage are read while the current half's 16 MFMAs run.  Per half stage a wave issues 16
+// MFMAs and 16 other instructions (8 ds_read_b128, 4 buffer loads, 4 ds_write_b128), pinned one to one behind the
+// MFMAs with sched_group_barrier.  LDS reads per FLOP are a third lower than with eight 128 x 64 waves, and there is
+// no M0 / s_nop traffic of the LDS-DMA form.  Same k order per accumulator and the same epilogue code as gemm256x:
+// bit-identical results.  Ring slot protocol (QS = 4): stage s is read from slot s & 3 during stage s (its first
+// fragments already during stage s - 1), written during stage s - 2; the barrier at the end of every stage orders
+// both hand-overs.
+// ================================================================================================
+// DBG (timing ablations, results are garbage): 1 no MFMA, 2 no global loads, 4 no ring writes, 8 no epilogue, 16 no fragment reads
+template <bool F16, int DBG = 0>
+__global__ __launch_bounds__(256) void gemm256r_kernel(GemmArgs g, int tiles_m, int tiles_n, int var) {
+  using HT = std::conditional_t<F16, f16_t, bf16_t>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nk = g.K >> 5;
+  const int lda_b = g.lda * 2, ldw_b = g.ldw * 2;
+  start_stagger(var >> 8, tiles_m * tiles_n, tiles_n);
+  const int my_tiles = tile_count(tiles_m, tiles_n);
+  const int total = my_tiles * nk;
+
+  // staging map: lane moves chunk (lane & 3) of rows wave * 64 + 16 * p + (lane >> 2), p = 0..3, of both operands
+  const int srow = wave * 64 + (lane >> 2), sc = lane & 3;
+  const int voA = srow * lda_b + sc * 16, voW = srow * ldw_b + sc * 16;
+  const int soff = swzq(srow, sc);  // rows + 16 p: same swizzle phase, + 1024 p bytes
+  const auto rsNone = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, (short)0, 0, 0x00020000);
+  auto rsA = rsNone, rsW = rsNone;
+  int cur_ti = -1;
+  u32x4_t st0[8], st1[8];
+  auto load_stage = [&](int s, u32x4_t (&r)[8]) {
+    const int ti = s / nk, kt = s - ti * nk;
+    if (s < total && ti != cur_ti) {
+      cur_ti = ti;
+      int tm, tn;
+      tile_at(ti, tiles_m, tiles_n, tm, tn);
+      const int m0 = tm * TM, n0 = tn * TN;
+      rsA = __builtin_amdgcn_make_buffer_rsrc((void*)((const unsigned char*)g.A + (long)m0 * lda_b), (short)0, min(TM, g.M - m0) * lda_b, 0x00020000);
+      rsW = __builtin_amdgcn_make_buffer_rsrc((void*)((const unsigned char*)g.W + (long)n0 * ldw_b), (short)0, min(TN, g.N - n0) * ldw_b, 0x00020000);
+    }
+    const auto ra = s < total ? rsA : rsNone;
+    const auto rw = s < total ? rsW : rsNone;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      r[p] = __builtin_amdgcn_raw_buffer_load_b128(ra, voA + 16 * p * lda_b, kt * QROWB, 0);
+      r[4 + p] = __builtin_amdgcn_raw_buffer_load_b128(rw, voW + 16 * p * ldw_b, kt * QROWB, 0);
+    }
+  };
+  auto store_stage = [&](int s, const u32x4_t (&r)[8]) {
+    unsigned char* dst = smem + (s & (QS - 1)) * QSTAGE + soff;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      *(u32x4_t*)(dst + 1024 * p) = r[p];
+      *(u32x4_t*)(dst + QA_BYTES + 1024 * p) = r[4 + p];
+    }
+  };
+  const int half = lane >> 5;
+  const int arow = wm * 128 + (lane & 31);
+  const int brow = wn * 128 + (lane & 31);
+  uint4 fa[2][4], fb[2][4];
+  auto read_frags = [&](int s, int ks, uint4 (&a)[4], uint4 (&b)[4]) {
+    const unsigned char* sA = smem + (s & (QS - 1)) * QSTAGE;
+    const unsigned char* sB = sA + QA_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (DBG & 16) { b[i] = make_uint4(lane, s, ks, i); a[i] = make_uint4(lane, s, i, ks); continue; }
+      b[i] = *(const uint4*)(sB + swzq(brow + 32 * i, 2 * ks + half));
+      a[i] = *(const uint4*)(sA + swzq(arow + 32 * i, 2 * ks + half));
+    }
+  };
+  // prologue: stages 0, 1 into the ring, 2 and 3 in flight in the two register sets
+  load_stage(0, st0);
+  load_stage(1, st1);
+  store_stage(0, st0);
+  load_stage(2, st0);
+  store_stage(1, st1);
+  load_stage(3, st1);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  read_frags(0, 0, fa[0], fb[0]);
+  // steady state at stage s (even: set 0, odd: set 1): the set holds stage s + 2, is written to the ring and refilled with s + 4
+  int step = 0;
+  int ti4 = 3 / nk, kt4 = 3 - ti4 * nk;  // (tile, k step) of the last stage requested so far; rsA / rsW are that tile's
+  if (ti4 >= my_tiles) { rsA = rsNone; rsW = rsNone; }
+  for (int ti = 0; ti < my_tiles; ++ti) {
+    int tm, tn;
+    tile_at(ti, tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * TM, n0 = tn * TN;
+    f32x16_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#define CZC_R_HALF(FA_, FB_)                                                                       \
+  if (DBG & 1) {                                                                                    \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) { asm volatile("" ::"v"(__builtin_bit_cast(u32x4_t, FA_[i]))); asm volatile("" ::"v"(__builtin_bit_cast(u32x4_t, FB_[i]))); } \
+  } else {                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                    \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[i][j] = Half<HT>::mfma(FB_[j], FA_[i], acc[i][j]); \
+  }
+#define CZC_R_PIN()                                                                                 \
+  _Pragma("unroll") for (int q = 0; q < 8; ++q) {                                                    \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                              \
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                              \
+  }                                                                                                 \
+  _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                    \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                              \
+    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                              \
+  }                                                                                                 \
+  _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                    \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                              \
+    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                                              \
+  }
+    // one stage: WR = the set that holds stage s + 2 (written to the ring, then refilled with stage s + 4).  The scalar
+    // bookkeeping of the refill (descriptors of the tile stage s + 4 belongs to) sits in front, so that everything from
+    // the first fragment read to the barrier is ONE basic block the interleave can be pinned in.
+#define CZC_R_STAGE(WR_)                                                                            \
+  {                                                                                                 \
+    const int s = step;                                                                             \
+    if (++kt4 == nk) {                                                                              \
+      kt4 = 0;                                                                                      \
+      ++ti4;                                                                                        \
+      if (ti4 < my_tiles) {                                                                         \
+        int tm4, tn4;                                                                               \
+        tile_at(ti4, tiles_m, tiles_n, tm4, tn4);                                                   \
+        const int mm = tm4 * TM, nn = tn4 * TN;                                                     \
+        rsA = __builtin_amdgcn_make_buffer_rsrc((void*)((const unsigned char*)g.A + (long)mm * lda_b), (short)0, min(TM, g.M - mm) * lda_b, 0x00020000); \
+        rsW = __builtin_amdgcn_make_buffer_rsrc((void*)((const unsigned char*)g.W + (long)nn * ldw_b), (short)0, min(TN, g.N - nn) * ldw_b, 0x00020000); \
+      } else {                                                                                      \
+        rsA = rsNone;                                                                               \
+        rsW = rsNone;                                                                               \
+      }                                                                                             \
+    }                                                                                               \
+    const int so4 = kt4 * QROWB;                                                                    \
+    unsigned char* wdst = smem + ((s + 2) & (QS - 1)) * QSTAGE + soff;                              \
+    __builtin_amdgcn_sched_barrier(0);                                                              \
+    /* first half: MFMAs of k16 step 0 | fragments of step 1, the A half of the ring write and of the refill */ \
+    read_frags(s, 1, fa[1], fb[1]);                                                                 \
+    _Pragma("unroll") for (int p = 0; p < 4; ++p) {                                                 \
+      if (DBG & 4) asm volatile("" ::"v"(WR_[p])); else *(u32x4_t*)(wdst + 1024 * p) = WR_[p];      \
+      if (DBG & 2) WR_[p].x += 1; else WR_[p] = __builtin_amdgcn_raw_buffer_load_b128(rsA, voA + 16 * p * lda_b, so4, 0); \
+    }                                                                                               \
+    CZC_R_HALF(fa[0], fb[0])                                                                        \
+    CZC_R_PIN()                                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                              \
+    /* second half: MFMAs of step 1 | first fragments of stage s + 1, the W half of the write and of the refill */ \
+    read_frags(s + 1, 0, fa[0], fb[0]);                                                             \
+    _Pragma("unroll") for (int p = 0; p < 4; ++p) {                                                 \
+      if (DBG & 4) asm volatile("" ::"v"(WR_[4 + p])); else *(u32x4_t*)(wdst + QA_BYTES + 1024 * p) = WR_[4 + p]; \
+      if (DBG & 2) WR_[4 + p].x += 1; else WR_[4 + p] = __builtin_amdgcn_raw_buffer_load_b128(rsW, voW + 16 * p * ldw_b, so4, 0); \
+    }                                                                                               \
+    CZC_R_HALF(fa[1], fb[1])                                                                        \
+    CZC_R_PIN()                                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                              \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                              \
+    __builtin_amdgcn_s_barrier();                                                                   \
+    asm volatile("" ::: "memory");                                                                  \
+    ++step;                                                                                         \
+  }
+    for (int kt = 0; kt < nk; ++kt) {  // nk is even (K % 64 == 0): even stages use set 0, odd ones set 1
+      CZC_R_STAGE(st0)
+      ++kt;
+      CZC_R_STAGE(st1)
+    }
+    if (DBG & 8) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
+    } else {
+      tile_epilogue_f32_asm<4, 0>(g, acc, smem + QS * QSTAGE + wave * 4096, m0, n0, wm, wn * 128, lane);
+    }
+  }
+#undef CZC_R_STAGE
+#undef CZC_R_PIN
+#undef CZC_R_HALF
+}
+
+// ================================================================================================
 // gemm256sq: gemm256q's 4-deep ring of 32 KiB stages for the SPLIT-fp16 precision.  A 64-byte tile row holds 16
 // elements ([8 hi | 8 lo] x 2 groups) = one k16 MFMA step, three fp16 passes per product: 24 MFMAs per stage and
 // wave on 12 ds_read_b128, loaders up to three stages ahead with counted vmcnt.
@@ -1287,6 +1475,8 @@ int launch_gemm256(const GemmArgs& g, hipStream_t st) {
                       CZC_ATTR((K_<ACT_QUICK_GELU, false, true>)); CZC_ATTR((K_<ACT_QUICK_GELU, true, true>))
     CZC_ATTR4(gemm256q_kernel);
     CZC_ATTR4(gemm256x_kernel);
+    CZC_ATTR((gemm256r_kernel<false>));
+    CZC_ATTR((gemm256r_kernel<true>));
 #undef CZC_ATTR4
 #undef CZC_ATTR
     return 0;
@@ -1298,7 +1488,7 @@ int launch_gemm256(const GemmArgs& g, hipStream_t st) {
   dim3 gq(tiles_m * tiles_n < n_cu ? tiles_m * tiles_n : n_cu);
   const bool pp = g_use_gemm256 == 5 || (g_use_gemm256 != 3 && f32);
 #ifdef CZC_EXPERIMENTS
-  if (pp && (g_w_dbg >> 8) && f32 && g.act == ACT_NONE && !g.f16) {  // timing ablations of the ping-pong kernel
+  if (pp && g_use_gemm256 != 9 && (g_w_dbg >> 8) && f32 && g.act == ACT_NONE && !g.f16) {  // timing ablations of the ping-pong kernel
 #define CZC_GOXD(D_)                                                                                                     \
   case D_:                                                                                                               \
     CZC_HIP_CHECK(hipFuncSetAttribute((const void*)gemm256x_kernel<ACT_NONE, true, false, D_>, hipFuncAttributeMaxDynamicSharedMemorySize, shp)); \
@@ -1333,7 +1523,24 @@ int launch_gemm256(const GemmArgs& g, hipStream_t st) {
   int stagger256 = (f32 && tiles_m * tiles_n / (int)gq.x >= 4) ? (2 | 32 << 8) : 0;
   if (g_w_dbg & 4) stagger256 = 0;
   if (f32 && (g_w_dbg >> 4)) stagger256 = ((g_w_dbg >> 4) & 15) | ((g_w_dbg >> 8) << 8);
-  if (pp) CZC_DISPATCH(gemm256x_kernel, 512, (g_w_dbg & 15) | stagger256 << 8);
+  if (g_use_gemm256 == 9 && f32 && g.act == ACT_NONE && g.resid && g.out_f32 && !g.out_act) {  // register-staged four-wave arm (A/B)
+#ifdef CZC_EXPERIMENTS
+    if ((g_w_dbg >> 8) && !g.f16) {
+#define CZC_GORD(D_) case D_: \
+      CZC_HIP_CHECK(hipFuncSetAttribute((const void*)gemm256r_kernel<false, D_>, hipFuncAttributeMaxDynamicSharedMemorySize, shp)); \
+      hipLaunchKernelGGL((gemm256r_kernel<false, D_>), gq, dim3(256), shp, st, g, tiles_m, tiles_n, stagger256 << 8); break
+      switch (g_w_dbg >> 8) {
+        CZC_GORD(1); CZC_GORD(2); CZC_GORD(4); CZC_GORD(8); CZC_GORD(16); CZC_GORD(3); CZC_GORD(6); CZC_GORD(9); CZC_GORD(10); CZC_GORD(14); CZC_GORD(22); CZC_GORD(30); CZC_GORD(29); CZC_GORD(17); CZC_GORD(24);
+        default: snprintf(g_err, sizeof(g_err), "gemm256r: ablation %d not built", g_w_dbg >> 8); return 1;
+      }
+#undef CZC_GORD
+      CZC_HIP_CHECK(hipGetLastError());
+      return 0;
+    }
+#endif
+    if (g.f16) hipLaunchKernelGGL((gemm256r_kernel<true>), gq, dim3(256), shp, st, g, tiles_m, tiles_n, stagger256 << 8);
+    else hipLaunchKernelGGL((gemm256r_kernel<false>), gq, dim3(256), shp, st, g, tiles_m, tiles_n, stagger256 << 8);
+  } else if (pp) CZC_DISPATCH(gemm256x_kernel, 512, (g_w_dbg & 15) | stagger256 << 8);
   else CZC_DISPATCH(gemm256q_kernel, 768);
 #undef CZC_DISPATCH
 #undef CZC_GO

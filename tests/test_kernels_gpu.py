@@ -258,6 +258,33 @@ def test_gemm256_variants(variant, M, N, K, act, resid):
     assert err < 3e-3 * np.sqrt(K / 64), err
 
 
+@pytest.mark.parametrize("M,N,K", [(2500, 512, 2048), (70000, 512, 512), (2304, 320, 192), (12345, 512, 2048), (300, 512, 128),
+                                   (700, 256, 64), (100, 40, 64), (80000, 512, 2048)])
+def test_register_staged_four_wave_gemm_equals_the_ring_kernel_bitwise(M, N, K):
+    """Round-4 A/B arm `gemm256 = 9` (gemm256r: four waves x 128 x 128 accumulators, operands staged through registers
+    two stages ahead, ds_write into the ring, MFMAs interleaved one to one with the memory instructions) on the
+    fp32-residual layers: same k order per accumulator and the same epilogue as the ping-pong ring kernel (gemm256 = 5), so
+    the fp32 outputs are identical bit for bit -- ragged M / N edges, one to many tiles per work-group, two to 64 stages."""
+    lib = native.load_test()
+    rng = np.random.default_rng(M + N + K)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    R = rng.standard_normal((M, N)).astype(np.float32)
+    out = {}
+    try:
+        assert lib.czc_test_set_option(b"gemm256_min_m", 1) == 0
+        for v in (5, 9):
+            assert lib.czc_test_set_option(b"gemm256", v) == 0
+            out[v] = E.test_gemm(BF16, A, W, bias=bias, resid=R)
+    finally:
+        lib.czc_test_set_option(b"gemm256", 1)
+        lib.czc_test_set_option(b"gemm256_min_m", 8192)
+    ref = (_bf16_round(A).astype(np.float64) @ _bf16_round(W).astype(np.float64).T + bias).astype(np.float32) + R
+    assert np.abs(out[5] - ref).max() < 3e-3 * np.sqrt(K / 64)
+    np.testing.assert_array_equal(out[9], out[5])
+
+
 @pytest.mark.parametrize("M,N,act", [(2048, 512, 0), (3000, 1536, 0), (5000, 2048, 1), (70001, 512, 1), (2304, 320, 0),
                                      (2049, 1536, 1), (40000, 2048, 0)])
 def test_gemm_weight_stationary(M, N, act):
