@@ -246,3 +246,25 @@ def test_scorer_exception_reaches_the_caller(standin):
     with pytest.raises(native.NativeError, match="lexicon"):
         su.engine.step(inp, SEED_LEN, meta["K"], hp)
     su.engine.close()
+
+
+def test_exact_mode_on_two_streams_gives_the_one_stream_captions(standin, monkeypatch):
+    """64 images: the runtime polishes two sub-batches on two HIP streams from two host threads, so the host scorer is
+    called back concurrently from both (the replica gets the callback through the setter replay).  Same captions and
+    scores as on one stream, and every step of every sub-batch reached the scorer."""
+    from conzic_amd import runtime
+    monkeypatch.setenv("CZC_PRECISION", "f32")
+    monkeypatch.delenv("CZC_CONTROL", raising=False)
+    meta, _ = load_case("tiny_senti_ctx")
+    meta = dict(meta, B=64, I=1)
+    out = {}
+    for streams in ("1", "2"):
+        monkeypatch.setenv("CZC_STREAMS", streams)
+        lm, clip, tok, imgs, mask = _objects(meta)
+        out[streams] = _call_like_demo_py(meta, lm, clip, tok, imgs, mask)
+        eng = runtime.get_engine(lm, clip, tok)
+        calls = eng._ctl_scorer.calls
+        assert calls == meta["L"] * (2 if streams == "2" else 1), calls
+        runtime.evict()
+    assert out["1"][0] == out["2"][0]
+    np.testing.assert_array_equal(np.array(out["1"][1]), np.array(out["2"][1]))
