@@ -1,6 +1,7 @@
 """CPU tests of the host side: C-ABI symbol export, product tokenizers, bridge tables."""
 import json
 import os
+import sys
 import re
 
 import numpy as np
@@ -380,3 +381,90 @@ def test_visiting_orders_and_partitions_hold_their_invariants():
         assert len(p) == 1 or all(hi - lo >= min_images for lo, hi in p)
         assert 1 <= len(p) <= streams
     parts()
+
+
+@pytest.mark.parametrize("name", ["tiny_senti_ctx", "tiny_senti_ctx_neg", "tiny_pos_ctx", "full_senti_ctx", "full_pos_ctx"])
+def test_host_control_scorer_reproduces_the_reference_scores(name):
+    """The product's exact-mode scorer (conzic_amd/control.py: what `czc_set_control_callback` calls once per step) on the
+    candidate rows of the `*_ctx` goldens: the raw control score of every candidate equals what the reference's UNCHANGED
+    `text_POS_Sentiments_analysis` / `batch_texts_POS_analysis` returned over the same stand-in nltk (no GPU involved:
+    decode + score only)."""
+    import nltk_standin
+    from conzic_amd import control
+    from conzic_amd.text import tokenizers_from_vocab
+    from goldutil import load_case
+    meta, arr = load_case(name)
+    sv = harness.cached_vocab(meta["tiny"])
+    tok, _ = tokenizers_from_vocab(sv)
+    m = nltk_standin.install()
+    try:
+        if meta.get("pos"):
+            scorer = control.HostScorer(tok, lambda t: control.sentence_pos_match(t, meta["pos"], m))
+        else:
+            memo = {}
+            scorer = control.HostScorer(tok, lambda t: control.sentence_sentiment(t, meta["style"], m, memo))
+        mask = synth.make_token_mask(sv, regular_only=meta["regular_only"])[0]
+        n = arr["ctl_raw"].shape[0] if meta["tiny"] else 3
+        for i in range(n):
+            pos = meta["positions"][i]
+            mk = mask.copy()
+            mk[tok.vocab["."]] = 1.0 if pos == meta["L"] - 1 else 0.0
+            cand = (arr["idxs"][i] * mk[arr["idxs"][i]]).astype(np.int32)      # control_gen_utils.py:52
+            got = scorer(arr["inp_before"][i].astype(np.int32), cand, 4 + pos)
+            np.testing.assert_allclose(got, arr["ctl_raw"][i], atol=1e-6, rtol=0)
+        assert scorer.calls == n
+    finally:
+        nltk_standin.uninstall()
+
+
+def test_control_mode_selection(monkeypatch):
+    """control.configure: caller tables win under auto / table; with nltk importable auto = the reference's scorer through the
+    callback, CZC_CONTROL=table builds the tables once per tokenizer; without nltk and tables it raises."""
+    import nltk_standin
+    from conzic_amd import control
+    from conzic_amd.text import tokenizers_from_vocab
+
+    class FakeEngine:
+        def __init__(self):
+            self.calls = []
+
+        def __getattr__(self, name):
+            if name.startswith("set_"):
+                return lambda *a: self.calls.append((name, a))
+            raise AttributeError(name)
+
+    class Clip:
+        lexicon = None
+        lexicon_pos = None
+        pos_tags = None
+
+    sv = harness.cached_vocab(True)
+    tok, _ = tokenizers_from_vocab(sv)
+    V = len(sv.bert_tokens)
+    for k in ("nltk", "nltk.tokenize", "nltk.corpus"):
+        monkeypatch.setitem(sys.modules, k, None)
+    monkeypatch.delenv("CZC_CONTROL", raising=False)
+    e, c = FakeEngine(), Clip()
+    with pytest.raises(RuntimeError, match="nltk"):
+        control.configure(e, c, tok)
+    c.lexicon = np.zeros(V, np.float32)
+    assert control.configure(e, c, tok) == "caller-tables" and e.calls[-1][0] == "set_lexicon"
+    c.pos_tags = np.zeros(V, np.uint8)
+    assert control.configure(e, c, tok, pos_template=[["NOUN"], ""]) == "caller-tables" and e.calls[-1][0] == "set_pos"
+    m = nltk_standin.install()
+    try:
+        e, c = FakeEngine(), Clip()
+        assert control.configure(e, c, tok) == "exact"
+        assert e.calls[-1][0] == "set_control_callback" and isinstance(e.calls[-1][1][0], control.HostScorer)
+        monkeypatch.setenv("CZC_CONTROL", "table")
+        n0 = len(e.calls)
+        assert control.configure(e, c, tok) == "table" and e.calls[-1][0] == "set_lexicon_pos"
+        t1 = e.calls[-1][1]
+        assert control.configure(e, c, tok) == "table" and e.calls[-1][1][0] is t1[0]       # cached per tokenizer
+        assert control.configure(e, c, tok, pos_template=[["NOUN"]]) == "table" and e.calls[-1][0] == "set_pos"
+        assert e.calls[n0][0] == "set_control_callback" and e.calls[n0][1] == (None,)         # a table call clears the callback
+        monkeypatch.setenv("CZC_CONTROL", "bogus")
+        with pytest.raises(ValueError):
+            control.configure(e, c, tok)
+    finally:
+        nltk_standin.uninstall()
