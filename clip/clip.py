@@ -60,8 +60,10 @@ class CLIP:
         self.czc_cfg = None
         self._state = None
         self._engine = None
-        self.lexicon = None  # fp32 [bert_vocab] sentiment table for control_gen_utils
-        self.pos_tags = None  # uint8 [bert_vocab] universal-tag ids for POS control (DESIGN.md)
+        # optional caller-provided control tables (conzic_amd/control.py; unset = nltk's own scorer / tables built from nltk)
+        self.lexicon = None  # fp32 [bert_vocab] per-token sentiment score
+        self.lexicon_pos = None  # (fp32 [bert_vocab, 5], uint8 [bert_vocab]): score per word-start piece and coarse POS class
+        self.pos_tags = None  # uint8 [bert_vocab] universal-tag ids for POS control
         self.cuda_has_been_checked = False
         if model_name is not None:
             print('Initializing CLIP model...')

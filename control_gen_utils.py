@@ -1,14 +1,16 @@
-"""Drop-in for the reference's control_gen_utils.py (sentiment control; signatures as in
-control_gen_utils.py:30-33, 82-85, 197-200).
+"""Drop-in for the reference's control_gen_utils.py (sentiment and POS control; signatures as in
+control_gen_utils.py:30-33, 82-85, 136-139, 197-200).
 
-The reference scores every candidate sentence through nltk + SentiWordNet on the host
-(sentiments_classifer.py:9-48).  Here the sentence score is the sum of a per-BERT-token lexicon
-(`clip.lexicon`, fp32 [vocab]) over the sentence's non-special tokens, evaluated inside the text
-bridge kernel, and softmax_K / gamma / repeat penalty are fused into the score-combine kernel
-(control_gen_utils.py:53-59).  POS control (control_gen_utils.py:136-195) works the same way: the
-tagger is a per-BERT-token universal-tag table (`clip.pos_tags`, uint8 [vocab]); the template match
-fraction of POS_classifier.py:17-29 is evaluated in the bridge kernel and softmax_K(acc/0.1) in the
-combine kernel."""
+The reference scores every candidate sentence through nltk on the host (sentiments_classifer.py:9-48,
+POS_classifier.py:6-31) and fuses `gamma * softmax_K(score)` (+ the repeat penalty) into the step's score
+(control_gen_utils.py:53-59, :160-168).  Here the fusion runs inside the score-combine kernel and the raw scores come from
+(conzic_amd/control.py, chosen per call, `CZC_CONTROL=auto|exact|table`):
+
+* the reference's own sentence arithmetic on the decoded candidate strings, called back from the engine once per step
+  (`czc_set_control_callback`) -- the default wherever nltk imports: captions equal the reference's;
+* per-BERT-token tables evaluated inside the text-bridge kernel (`CZC_CONTROL=table`: built once per tokenizer from nltk; or
+  handed over by the caller as `clip.lexicon` / `clip.lexicon_pos` / `clip.pos_tags`): no host work per step, a context-free
+  approximation of the tagger."""
 import time
 
 from conzic_amd.runtime import run_generation
