@@ -8,7 +8,8 @@ SentiWordNet `pos - neg` of the word under the coarse class of its (context-depe
 ``exact``  (default where nltk imports: `CZC_CONTROL=auto|exact`) -- the reference's own arithmetic on the decoded candidate
            strings, called back from the engine once per step (`czc_set_control_callback`): identical to the reference
            whatever the tagger does with context (the `*_ctx` goldens: id for id), at the reference's own host cost
-           (O(B*K) tagger calls per step).  Parity is the first gate, so this is what an unchanged demo.py gets.
+           (O(B*K) tagger calls per step; `CZC_CONTROL_WORKERS=N` spreads them over N spawned interpreters).  Parity is the
+           first gate, so this is what an unchanged demo.py gets.
 ``table``  (`CZC_CONTROL=table`) -- per-BERT-token tables evaluated inside the text-bridge kernel, no host work per step:
            `sentiment.build_sentiwordnet_tables` / `sentiment.build_pos_tag_table` run nltk ONCE per tokenizer over the
            vocabulary.  Context-free by construction (a token is tagged alone; a multi-piece word scores as its first
@@ -113,15 +114,68 @@ def sentence_pos_match(text: str, template, nltk_module) -> float:
     return correct / total
 
 
+def _worker_init(paths, hook):
+    """Pool initializer (spawned interpreter): the parent's import paths, then an optional hook (tests install their
+    stand-in nltk with it; a real nltk needs none)."""
+    import sys
+    for p_ in reversed(paths):
+        if p_ not in sys.path:
+            sys.path.insert(0, p_)
+    if hook is not None:
+        mod, fn = hook
+        getattr(__import__(mod), fn)()
+
+
+_WORKER_MEMO = {}
+
+
+def _score_chunk(job):
+    """Worker side: (kind, param, texts) -> list of scores with this process's nltk."""
+    kind, param, texts = job
+    nltk_module = import_nltk()
+    if nltk_module is None:
+        raise RuntimeError("control worker: nltk does not import in the worker process")
+    if kind == "pos":
+        return [sentence_pos_match(t, param, nltk_module) for t in texts]
+    return [sentence_sentiment(t, param, nltk_module, _WORKER_MEMO) for t in texts]
+
+
 class HostScorer:
     """czc_control_fn over a tokenizer: decodes the B*K candidate rows as the reference does
-    (control_gen_utils.py:54-55 / :158-159, `batch_decode(skip_special_tokens=True)`) and scores each string."""
+    (control_gen_utils.py:54-55 / :158-159, `batch_decode(skip_special_tokens=True)`) and scores each string with the
+    reference's arithmetic -- `kind` "sentiment" (param = ctl_signal) or "pos" (param = the template).
 
-    def __init__(self, tokenizer, score_text: Callable[[str], float]):
-        self.tokenizer = tokenizer
-        self.score_text = score_text
-        self.error: Optional[BaseException] = None
+    The reference scores the strings one after the other in Python; so does this class by default.  `workers` > 1
+    (`CZC_CONTROL_WORKERS`) spreads a step's strings over that many SPAWNED interpreters (no fork of the process that owns the
+    GPU context), each with its own nltk: every string is scored independently, so the scores are the serial ones; it is
+    what makes the exact mode practical at run.py batch sizes (B*K = 10^4..10^5 strings per step)."""
+
+    def __init__(self, tokenizer, kind: str, param, nltk_module, workers: int = 0, worker_hook=None):
+        assert kind in ("sentiment", "pos")
+        self.tokenizer, self.kind, self.param, self.nltk = tokenizer, kind, param, nltk_module
+        self.workers = int(workers)
+        self.worker_hook = worker_hook
+        self.memo = {}
         self.calls = 0
+        self._pool = None
+
+    def score_texts(self, texts):
+        if self.workers > 1 and len(texts) >= 4 * self.workers:
+            if self._pool is None:
+                import multiprocessing as mp
+                import sys
+                self._pool = mp.get_context("spawn").Pool(self.workers, initializer=_worker_init,
+                                                          initargs=(list(sys.path), self.worker_hook))
+            n = self.workers
+            per = (len(texts) + n - 1) // n
+            jobs = [(self.kind, self.param, texts[i:i + per]) for i in range(0, len(texts), per)]
+            out = []
+            for part in self._pool.map(_score_chunk, jobs):
+                out.extend(part)
+            return out
+        if self.kind == "pos":
+            return [sentence_pos_match(t, self.param, self.nltk) for t in texts]
+        return [sentence_sentiment(t, self.param, self.nltk, self.memo) for t in texts]
 
     def __call__(self, inp: np.ndarray, cand: np.ndarray, gen_idx: int) -> np.ndarray:
         B, K = cand.shape
@@ -129,7 +183,18 @@ class HostScorer:
         rows[:, :, gen_idx] = cand
         texts = self.tokenizer.batch_decode(rows.reshape(B * K, -1).tolist(), skip_special_tokens=True)
         self.calls += 1
-        return np.array([self.score_text(t) for t in texts], dtype=np.float32).reshape(B, K)
+        return np.array(self.score_texts(texts), dtype=np.float32).reshape(B, K)
+
+    def close(self):
+        if self._pool is not None:
+            self._pool.terminate()
+            self._pool = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def configure(eng, clip, tokenizer, *, pos_template=None, ctl_signal="positive") -> str:
@@ -153,11 +218,17 @@ def configure(eng, clip, tokenizer, *, pos_template=None, ctl_signal="positive")
     if nltk_module is None:
         raise RuntimeError(NLTK_HELP)
     if mode in ("exact", "auto"):
-        if is_pos:
-            scorer = HostScorer(tokenizer, lambda t: sentence_pos_match(t, pos_template, nltk_module))
+        workers = int(os.environ.get("CZC_CONTROL_WORKERS", "0"))
+        key = ("pos", repr(pos_template)) if is_pos else ("sentiment", ctl_signal)
+        prev = getattr(eng, "_control_scorer_cache", None)
+        if prev is not None and prev[0] == (key, id(tokenizer), id(nltk_module), workers):
+            scorer = prev[1]     # the same call again (samples_num loop): keep the scorer, its memo and its worker pool
         else:
-            memo = {}
-            scorer = HostScorer(tokenizer, lambda t: sentence_sentiment(t, ctl_signal, nltk_module, memo))
+            if prev is not None:
+                prev[1].close()
+            scorer = HostScorer(tokenizer, "pos" if is_pos else "sentiment", pos_template if is_pos else ctl_signal, nltk_module,
+                                workers=workers, worker_hook=getattr(nltk_module, "__worker_hook__", None))
+            eng._control_scorer_cache = ((key, id(tokenizer), id(nltk_module), workers), scorer)
         eng.set_control_callback(scorer)
         return "exact"
     if is_pos:

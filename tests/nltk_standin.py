@@ -90,6 +90,7 @@ def install():
     """Register the stand-in as `nltk` (+ `nltk.tokenize`, `nltk.corpus`) in sys.modules; returns the module."""
     m = types.ModuleType("nltk")
     m.__standin__ = True
+    m.__worker_hook__ = ("nltk_standin", "install")  # how a spawned scorer process gets the same stand-in (conzic_amd/control.py)
     m.pos_tag = pos_tag
     tok = types.ModuleType("nltk.tokenize")
     tok.word_tokenize = word_tokenize

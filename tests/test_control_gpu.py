@@ -168,9 +168,9 @@ def _teacher_forced(meta, arr, mode, standin_mod, prec=F32):
     toks = su.sv.bert_tokens
     if mode == "exact":
         if meta.get("pos"):
-            eng.set_control_callback(control.HostScorer(su.bert_tok, lambda t: control.sentence_pos_match(t, meta["pos"], standin_mod)))
+            eng.set_control_callback(control.HostScorer(su.bert_tok, "pos", meta["pos"], standin_mod))
         else:
-            eng.set_control_callback(control.HostScorer(su.bert_tok, lambda t: control.sentence_sentiment(t, meta["style"], standin_mod)))
+            eng.set_control_callback(control.HostScorer(su.bert_tok, "sentiment", meta["style"], standin_mod))
     elif meta.get("pos"):
         eng.set_pos(sentiment.build_pos_tag_table(toks, standin_mod), synth.pos_template_masks(meta["pos"]))
     else:

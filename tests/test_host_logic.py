@@ -399,10 +399,9 @@ def test_host_control_scorer_reproduces_the_reference_scores(name):
     m = nltk_standin.install()
     try:
         if meta.get("pos"):
-            scorer = control.HostScorer(tok, lambda t: control.sentence_pos_match(t, meta["pos"], m))
+            scorer = control.HostScorer(tok, "pos", meta["pos"], m)
         else:
-            memo = {}
-            scorer = control.HostScorer(tok, lambda t: control.sentence_sentiment(t, meta["style"], m, memo))
+            scorer = control.HostScorer(tok, "sentiment", meta["style"], m)
         mask = synth.make_token_mask(sv, regular_only=meta["regular_only"])[0]
         n = arr["ctl_raw"].shape[0] if meta["tiny"] else 3
         for i in range(n):
@@ -466,5 +465,34 @@ def test_control_mode_selection(monkeypatch):
         monkeypatch.setenv("CZC_CONTROL", "bogus")
         with pytest.raises(ValueError):
             control.configure(e, c, tok)
+    finally:
+        nltk_standin.uninstall()
+
+
+def test_host_control_scorer_worker_pool_gives_the_serial_scores():
+    """`CZC_CONTROL_WORKERS`: a step's candidate strings scored by spawned interpreters (each with its own nltk -- here the
+    stand-in, installed through the worker hook) are the serially scored ones, for both control types."""
+    import nltk_standin
+    from conzic_amd import control
+    from conzic_amd.text import tokenizers_from_vocab
+    from goldutil import load_case
+    m = nltk_standin.install()
+    try:
+        for name in ("full_senti_ctx", "full_pos_ctx"):
+            meta, arr = load_case(name)
+            sv = harness.cached_vocab(False)
+            tok, _ = tokenizers_from_vocab(sv)
+            kind, param = ("pos", meta["pos"]) if meta.get("pos") else ("sentiment", meta["style"])
+            serial = control.HostScorer(tok, kind, param, m)
+            pooled = control.HostScorer(tok, kind, param, m, workers=3, worker_hook=m.__worker_hook__)
+            try:
+                inp = arr["inp_before"][2].astype(np.int32)
+                cand = arr["idxs"][2].astype(np.int32)
+                a, b = serial(inp, cand, 4 + meta["positions"][2]), pooled(inp, cand, 4 + meta["positions"][2])
+                assert pooled._pool is not None            # 400 strings: the pool was used
+                np.testing.assert_array_equal(a, b)
+                np.testing.assert_allclose(a, arr["ctl_raw"][2], atol=1e-6, rtol=0)
+            finally:
+                pooled.close()
     finally:
         nltk_standin.uninstall()
