@@ -148,6 +148,44 @@ def test_softmax_mask_topk(V, K):
         assert (np.diff(p, axis=1) <= 0).all()
 
 
+@pytest.mark.parametrize("K", [200, 256, 300])
+def test_topk_with_a_trained_models_logit_range(K):
+    """A trained BERT's logits span 15-25 units, so `softmax(logits / 0.1)` underflows: beyond a gap of ~8.7 from the maximum
+    the fp32 probabilities are DENORMAL, beyond ~10.3 exactly zero (the random-weight towers of the other tests never get
+    there).  300 plausible tokens spread over a gap of 0..10.4 above a bulk that underflows: K = 200 ends in the normal
+    range, 256 in the denormal range (kept, not flushed: torch keeps them and they decide the candidate SET), 300 beyond the
+    non-zero count (zero-probability fill-ins from the lowest ids; `torch.topk`'s own choice among equal zeros is
+    unspecified)."""
+    V, B = 30522, 3
+    rng = np.random.default_rng(K)
+    logits = rng.standard_normal((B, V)).astype(np.float32)
+    hot = np.stack([rng.choice(np.arange(1000, V), size=300, replace=False) for _ in range(B)])
+    for b in range(B):
+        logits[b, hot[b]] = np.linspace(16.0, 5.6, 300).astype(np.float32) + rng.uniform(-0.01, 0.01, 300).astype(np.float32)
+    mask = np.ones(V, np.float32)
+    mask[:999] = 0.0
+    p, i, c = E.test_topk(logits, mask, K, 0.1, 1012, False)
+    m = torch.from_numpy(mask.copy())
+    m[1012] = 0.0
+    probs = (torch.softmax(torch.from_numpy(logits) / 0.1, -1) * m).numpy()
+    for b in range(B):
+        nz = int((probs[b] > 0).sum())
+        assert 250 < nz < 300, nz                      # the construction: some of the 300 underflow to exactly zero
+        order = np.argsort(-probs[b], kind="stable")
+        n = min(K, nz)
+        # non-zero part: same ids; values to fp32 rounding in the normal range, to a few denormal quanta below it
+        ref_p = probs[b][order[:n]]
+        got_p = p[b, :n]
+        assert (got_p > 0).all() and (np.diff(p[b]) <= 0).all()
+        normal = ref_p > 1.2e-38
+        np.testing.assert_allclose(got_p[normal], ref_p[normal], rtol=3e-5)
+        np.testing.assert_allclose(got_p[~normal], ref_p[~normal], rtol=0.02, atol=3e-45)
+        assert set(i[b, :n].tolist()) == set(order[:n].tolist()) or \
+            len(set(i[b, :n].tolist()) ^ set(order[:n].tolist())) <= 2      # a swap at the K-th place between near-equal denormals
+        if K > nz:   # fill-ins: exact zeros, lowest ids first, all masked here -> [PAD]
+            assert (p[b, nz:] == 0).all() and i[b, nz:].tolist() == list(range(K - nz)) and (c[b, nz:] == 0).all()
+
+
 def test_topk_ties_and_all_masked():
     """Fewer than K non-zero probabilities: zeros are taken in ascending id, cand -> 0 ([PAD])."""
     V, K = 1000, 16
