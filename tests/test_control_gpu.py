@@ -268,3 +268,31 @@ def test_exact_mode_on_two_streams_gives_the_one_stream_captions(standin, monkey
         runtime.evict()
     assert out["1"][0] == out["2"][0]
     np.testing.assert_array_equal(np.array(out["1"][1]), np.array(out["2"][1]))
+
+
+def test_pos_template_string_entries_and_padding_follow_the_reference():
+    """POS_classifier.py:25 tests `cur_tag in pos_templete[word_id]`: membership for a list entry, SUBSTRING for a plain string
+    entry -- the same for the twelve tag names, except that the "" tag a too-short sentence is padded with (:19-20) is a
+    substring of every string.  A 14-slot template over 8-word sentences, string and list entries in the padded slots: the
+    engine's template match fraction equals the oracle's (which applies Python's `in` like the reference) on every candidate."""
+    from goldutil import make_oracle
+    from oracle import step as S
+    meta, arr = load_case("tiny_pos_seq")
+    template = ["DET", ["ADJ", "NOUN"], "", "NOUN", ["VERB"], "ADV", ["ADP"], "NOUN", ["NOUN", "."], "VERB", ["DET"], "", "X", ["X"]]
+    su = harness.build_synthetic(True, F32, meta["bseed"], meta["cseed"])
+    tags = synth.make_pos_tags(len(su.sv.bert_tokens))
+    su.engine.set_pos(tags, synth.pos_template_masks(template))
+    su.engine.set_image_embeds(arr["image_embeds"])
+    hp = Engine.hyper(meta["alpha"], meta["beta"], meta["temperature"], meta["gamma"], control="pos")
+    o, _, _ = make_oracle(meta)
+    for i in (0, 3, 7):
+        pos = meta["positions"][i]
+        inp = np.ascontiguousarray(arr["inp_before"][i], dtype=np.int32)
+        before = inp.copy()
+        res = su.engine.step(inp, SEED_LEN + pos, meta["K"], hp, dot_allowed=(pos == meta["L"] - 1), want=("cand_ids", "senti_raw"))
+        rows = np.repeat(before[:, None, :], meta["K"], axis=1)
+        rows[:, :, SEED_LEN + pos] = res["cand_ids"]
+        ref = S.pos_scores(o, torch.from_numpy(rows.reshape(-1, rows.shape[-1]).astype(np.int64)), template).numpy()
+        np.testing.assert_allclose(res["senti_raw"].reshape(-1), ref, atol=1e-7)
+        assert len(set(np.round(ref, 4))) > 1     # the template discriminates between candidates
+    su.engine.close()
