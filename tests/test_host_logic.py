@@ -496,3 +496,32 @@ def test_host_control_scorer_worker_pool_gives_the_serial_scores():
                 pooled.close()
     finally:
         nltk_standin.uninstall()
+
+
+def test_headers_are_plain_c_and_match_the_ctypes_layout(tmp_path):
+    """The boundary is a C ABI: both headers compile as C99 with gcc (no C++-isms, no torch / HIP types), a C translation unit
+    can name every entry point with the declared prototype, and the struct sizes / field offsets a C compiler derives are the
+    ones conzic_amd/native.py hands over through ctypes."""
+    import ctypes as C
+    import subprocess
+    inc = os.path.dirname(native.HEADER_PATH)
+    src = tmp_path / "abi_probe.c"
+    names = sorted(native.SIGNATURES) + sorted(native.TEST_SIGNATURES)
+    src.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "conzic_hip.h"\n#include "conzic_hip_test.h"\n'
+        "int main(void) {\n"
+        + "".join(f"  (void)&{n};\n" for n in names) +
+        '  printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(czc_config), sizeof(czc_hyper), sizeof(czc_step_out), sizeof(czc_bridge_tables),\n'
+        "         offsetof(czc_config, precision), offsetof(czc_bridge_tables, merge_out), offsetof(czc_hyper, negative));\n"
+        "  czc_control_fn fn = 0; (void)fn;\n  return 0;\n}\n")
+    exe = tmp_path / "abi_probe"
+    r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", inc, str(src), "-o", str(exe),
+                        "-L", os.path.dirname(native.LIB_PATH), "-lconzic_hip_test", "-lconzic_hip",
+                        "-Wl,-rpath," + os.path.dirname(native.LIB_PATH), "-Wl,--unresolved-symbols=ignore-in-shared-libs"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()
+    got = [int(v) for v in out]
+    want = [C.sizeof(native.Config), C.sizeof(native.Hyper), C.sizeof(native.StepOut), C.sizeof(native.BridgeTables),
+            native.Config.precision.offset, native.BridgeTables.merge_out.offset, native.Hyper.negative.offset]
+    assert got == want, (got, want)
