@@ -351,7 +351,7 @@ static void launch_t(const GemmArgs& g, int tiles_m, int tiles_n, bool vec, hipS
 // one row.  Partial sums meet in LDS; wave 0 applies bias / activation / residual and stores.
 typedef __attribute__((ext_vector_type(4))) float f32x4v_t;
 
-template <int ACT, bool TWO>
+template <int ACT, bool TWO, int SK_U = 6>
 __global__ __launch_bounds__(256) void gemm_skinny_split_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float red[3][2][64][4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -368,8 +368,22 @@ __global__ __launch_bounds__(256) void gemm_skinny_split_kernel(GemmArgs g) {
 #define CZC_F16(v_) __builtin_bit_cast(f16x8_t, v_)
   // The kernel is a chain of L2 / HBM round trips (a wave owns steps wave, wave+4, ...: 6 of them at K = 768), so the
   // operands of SK_U steps are requested together before their MFMAs run: one exposed latency per SK_U steps instead of
-  // one per step.  The MFMAs keep their order (same sums).
-  constexpr int SK_U = 6;
+  // one per step (SK_U = 12 for the K = 3072 layer at <= 16 rows: two round trips instead of four).  The MFMAs keep their
+  // order (same sums).  The epilogue's operands (bias, residual) are requested up front as well (round 4): they used to
+  // cost wave 0 one more exposed round trip behind the LDS reduction.
+  const int ep_col = n0 + 4 * kb;
+  float ep_bias[4] = {0.f, 0.f, 0.f, 0.f}, ep_res[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  if (wave == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = min(ep_col + r, g.N - 1);
+      if (g.bias) ep_bias[r] = g.bias[c];
+      if (g.resid) {
+        ep_res[0][r] = g.resid[(long)m_a * g.ldr + c];
+        if (two) ep_res[1][r] = g.resid[(long)m_b * g.ldr + c];
+      }
+    }
+  }
   int s2 = wave;
   for (; s2 + 4 * (SK_U - 1) < steps; s2 += 4 * SK_U) {
     uint4 wh[SK_U], wl[SK_U], ah[SK_U], al[SK_U], bh[SK_U], bl[SK_U];
@@ -425,13 +439,12 @@ __global__ __launch_bounds__(256) void gemm_skinny_split_kernel(GemmArgs g) {
     const int m = t * 16 + nl;
     if (m >= g.M) continue;
     const f32x4v_t a = t ? acc1 : acc0;
-    const int col = n0 + 4 * kb;
+    const int col = ep_col;
     float v[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int c = min(col + r, g.N - 1);
-      v[r] = apply_act<float, ACT>(a[r] + (g.bias ? g.bias[c] : 0.f));
-      if (g.resid) v[r] += g.resid[(long)m * g.ldr + c];
+      v[r] = apply_act<float, ACT>(a[r] + ep_bias[r]);   // ep_bias is 0 without a bias: a + 0.f == a
+      if (g.resid) v[r] += ep_res[t][r];
     }
     if (col + 3 < g.N && (g.ldc & 3) == 0) {
       if (g.out_f32) *(float4*)(g.out_f32 + (long)m * g.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
@@ -453,6 +466,7 @@ static bool launch_skinny(const GemmArgs& g, hipStream_t st) {
   if (!g_use_skinny || g.M > 32 || (g.K & 31) || (g.lda & 7) || (g.ldw & 7)) return false;
   dim3 grid(cdiv(g.N, 16)), block(256);
 #define CZC_SK(A_) do { if (g.M > 16) hipLaunchKernelGGL((gemm_skinny_split_kernel<A_, true>), grid, block, 0, st, g); \
+                       else if (g.K >= 1536) hipLaunchKernelGGL((gemm_skinny_split_kernel<A_, false, 12>), grid, block, 0, st, g); \
                        else hipLaunchKernelGGL((gemm_skinny_split_kernel<A_, false>), grid, block, 0, st, g); } while (0)
   if (g.act == ACT_QUICK_GELU) CZC_SK(ACT_QUICK_GELU);
   else if (g.act == ACT_GELU_ERF) CZC_SK(ACT_GELU_ERF);
