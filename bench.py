@@ -273,9 +273,10 @@ def main():
         grp.profile_reset()
         # timed region: HIP events only around the roofline kernel family (an event pair around EVERY kernel costs 3 %
         # at B = 256 and 37 % at B = 1); the per-class breakdown comes from one extra, untimed, fully profiled step
-        # below 8 images a step is a chain of ~200 launches of 5-15 us and the event pairs themselves cost 30-45 % of it: the
-        # timed region then runs without events and the tower's figures come from ONE extra pass of the same step
-        events_in_region = profile and B >= 8
+        # the event pairs around the CLIP-text tower's launches cost 0-1 % of a step at 256 images but 4.5 % at 64, 7.5 % at 32,
+        # 18 % at 8 and 30-45 % at one image (a chain of ~200 launches of 5-15 us): below 128 images per GPU the timed region
+        # runs WITHOUT events and the tower's figures come from ONE extra pass of the same step
+        events_in_region = profile and B >= 128
         grp.profile(2 if events_in_region else 0)
         barrier()
         t0 = time.perf_counter()
@@ -433,8 +434,8 @@ def main():
                    avg_launch_ms=round(g["ms"] / g["launches"], 4), family_busy_ms_per_step=round(g["busy_ms"] / res["steps"], 1),
                    flops_per_launch=g["flops"] / g["launches"], mfma_passes_per_product=passes,
                    measured_on=(("the timed region" if res.get("events_in_region", True) else
-                                 "ONE extra pass of the same step right after the timed region (fewer than 8 images: the event pairs cost "
-                                 "30-45 % of a launch-bound step, so the timed region carries none)")
+                                 "ONE extra pass of the same step right after the timed region (fewer than 128 images per GPU: the event "
+                                 "pairs would cost 4-45 % of the step, so the timed region carries none)")
                                 + ": HIP events on each engine's own stream around every launch of the family; "
                                 + ("achieved = executed FLOPs / the UNION of the family's launch intervals over the %d streams (the time "
                                    "the GPU spent on the family; a launch's own duration there -- avg_launch_ms, what rocprofv3 --stats of "
