@@ -138,8 +138,8 @@ typedef struct czc_step_out {
 int czc_create(const czc_config* cfg, int device_id, czc_engine** out_engine);
 int czc_destroy(czc_engine* e);
 /* A second engine on the same GPU that SHARES `parent`'s resident weights (no copy, no reload) and owns everything
- * else: stream, workspace, image embeddings, token mask / bridge / lexicon / POS tables (set them on the replica
- * as on the parent), options (copied at creation), profile.  Images are independent (gen_utils.py:64-81 has no
+ * else: stream, workspace, image embeddings, token mask / bridge / lexicon / POS tables and the control callback (set
+ * them on the replica as on the parent), options (copied at creation), profile.  Images are independent (gen_utils.py:64-81 has no
  * cross-image term), so a host that drives parent and replica(s) from separate threads on disjoint sub-batches gets
  * the same captions image for image while their kernels overlap on the GPU.  `parent` must be finalized and must
  * outlive its replicas; czc_destroy(replica) frees only what the replica owns. */
