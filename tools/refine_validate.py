@@ -48,6 +48,7 @@ for th in THETAS:
         su.engine.set_option("refine_samples", m)
         su.engine.set_option("refine_theta_x1000", th)
         su.engine.profile_reset()
+        su.engine.refine_guard(reset=True)
         errs, agree, n, margins = [], 0, 0, []
         for p, (before, r) in enumerate(gold):
             res = su.engine.step(before.copy(), SEED_LEN + (p % L), K, hp, dot_allowed=(p % L == L - 1), want=("idxs", "final_score", "best"))
@@ -61,7 +62,8 @@ for th in THETAS:
             margins += [float(srt[b, 0] - srt[b, 1]) for b in range(B) if not same[b]]
         e = np.concatenate(errs)
         st = su.engine.stats()
-        print(json.dumps(dict(images=B, positions=P, K=K, logit_scale=SCALE, refine_samples=m, theta_x=th / 1000.0,
+        gd = su.engine.refine_guard(reset=True)
+        print(json.dumps(dict(guard_max_dev=gd["max_dev"], guard_tripped_image_steps=gd["tripped"], images=B, positions=P, K=K, logit_scale=SCALE, refine_samples=m, theta_x=th / 1000.0,
                               max_abs_dfinal=float(e.max()), p999=float(np.quantile(e, 0.999)), mean=float(e.mean()),
                               image_steps=n, winners_identical=agree, reference_margin_at_flips=margins,
                               re_encoded_seq_frac=round(st["refine_seqs"] / max(st["clip_seqs"], 1), 4),
