@@ -60,7 +60,7 @@ extern "C" {
                          /* softmax_K mass (p_k > 4 / (beta * exp(logit_scale)), the two best fused scores, and a mass-stratified  */
                          /* sample of the rest that measures the screening tower's mean error) are re-encoded by the split-fp16   */
                          /* tower and the scores are formed from the mixed cosines: fused score inside 1e-3 (measured 8.4e-4 worst */
-                         /* on the goldens, 5.5e-4 over 256 k more candidates) at 1.8x the CZC_PREC_SPLIT throughput.  Vision tower */
+                         /* on the goldens, 7.1e-4 over 256 k more candidates) at 1.8x the CZC_PREC_SPLIT throughput.  Vision tower */
                          /* and BERT: split-fp16.  Options "refine_samples" (12) / "refine_theta_x1000" (4000) tune the selection.  */
 #define CZC_MAX_TOPK 1024
 #define CZC_MAX_BERT_LEN 64
