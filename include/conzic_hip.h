@@ -271,7 +271,9 @@ int czc_refine_stats(czc_engine* e, int64_t* refine_seqs, int64_t* refine_rows);
  * carry its error minus the estimated mean, and move their fused score by at most theta_x * |that| (theta_x = 4).  Every
  * step records, over the ~16 candidates per image it re-encodes exactly, the largest |screening error - mean|
  * (*max_dev, since the last reset) and counts the image-steps where it exceeds option "refine_guard_x1e6" * 1e-6
- * (default 200: 0.8 of the 2.5e-4 the bound allows) in *tripped.  The bound was validated on random-weight towers; a
+ * (default 200) in *tripped.  It is a detector, not a certificate: the ~16 re-encoded candidates under-sample the worst of
+ * the ~185 that keep their screening cosine (validated towers: sample maximum 1.0-1.5e-4 with fused-score errors up to 8.4e-4;
+ * towers with emulated activation outliers: 3e-4 .. 3e-2, tripping from the point where the error nears the 1e-3 bar).  A
  * checkpoint whose activations the fp16 tower carries worse trips the guard, and conzic_amd/runtime.py then repeats the
  * call on the all-split engine (CZC_REFINE_GUARD=rerun | warn | off). */
 int czc_refine_guard(czc_engine* e, int reset, float* max_dev, int64_t* tripped);
