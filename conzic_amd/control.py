@@ -8,7 +8,9 @@ SentiWordNet `pos - neg` of the word under the coarse class of its (context-depe
 ``exact``  (default where nltk imports: `CZC_CONTROL=auto|exact`) -- the reference's own arithmetic on the decoded candidate
            strings, called back from the engine once per step (`czc_set_control_callback`): identical to the reference
            whatever the tagger does with context (the `*_ctx` goldens: id for id), at the reference's own host cost
-           (O(B*K) tagger calls per step; `CZC_CONTROL_WORKERS=N` spreads them over N spawned interpreters).  Parity is the
+           (O(B*K) tagger calls per step; `CZC_CONTROL_WORKERS=N` spreads them over N spawned interpreters; unset: min(32, cores / 2)
+           from 2048 strings per step on, the reference's serial loop below).  The engine calls the scorer while the CLIP tower of the
+           same step runs (csrc/engine.hip), so its wall time only shows where it exceeds the tower's.  Parity is the
            first gate, so this is what an unchanged demo.py gets.
 ``table``  (`CZC_CONTROL=table`) -- per-BERT-token tables evaluated inside the text-bridge kernel, no host work per step:
            `sentiment.build_sentiwordnet_tables` / `sentiment.build_pos_tag_table` run nltk ONCE per tokenizer over the
@@ -23,6 +25,8 @@ bench.py); with `auto` / `table` they win.  Without nltk and without tables the 
 from __future__ import annotations
 
 import os
+import threading
+import time
 import weakref
 from typing import Callable, Optional, Sequence
 
@@ -36,16 +40,41 @@ NLTK_HELP = ("the controllable path scores candidates with nltk (sentiments_clas
              "clip.pos_tags [V] for POS; conzic_amd/sentiment.py)")
 
 
+_NLTK_PROBE = {}
+
+
 def import_nltk():
-    """The nltk module with the three entry points the reference imports, or None."""
+    """The nltk module with the entry points the reference imports AND their data, or None.  Importing is not enough:
+    `nltk.corpus.sentiwordnet` is a lazy loader and `nltk.pos_tag` an attribute, so a box with nltk installed but without the
+    punkt / tagger / sentiwordnet data (app.py:280-283) only fails at the first call -- inside the engine's callback.  Each
+    entry point is therefore CALLED once here (result cached per module object); a LookupError means "not usable"."""
     try:
         import nltk
-        from nltk.corpus import sentiwordnet  # noqa: F401
-        from nltk.tokenize import word_tokenize  # noqa: F401
-        nltk.pos_tag  # noqa: B018
-        return nltk
+        from nltk.corpus import sentiwordnet
+        from nltk.tokenize import word_tokenize
     except (ImportError, AttributeError, LookupError):
         return None
+    ok = _NLTK_PROBE.get(id(nltk))
+    if ok is None:
+        try:
+            word_tokenize("a b")
+            nltk.pos_tag(["a"])
+            nltk.pos_tag(["a"], tagset="universal")
+            list(sentiwordnet.senti_synsets("good", "a"))
+            ok = True
+        except (LookupError, AttributeError, ImportError, OSError):
+            ok = False
+        _NLTK_PROBE[id(nltk)] = ok
+    return nltk if ok else None
+
+
+def default_workers(n_texts: int) -> int:
+    """Interpreters a step's strings are spread over when CZC_CONTROL_WORKERS is unset: the reference's serial loop for a
+    demo.py-sized step, min(32, cores / 2) from 2048 strings per step on (run.py-sized batches: B * K = 10^4..10^5 sentences
+    through a Python tagger per step would leave the GPU waiting for the host)."""
+    if n_texts < 2048:
+        return 0
+    return max(2, min(32, (os.cpu_count() or 2) // 2))
 
 
 def control_mode() -> str:
@@ -150,27 +179,43 @@ class HostScorer:
     GPU context), each with its own nltk: every string is scored independently, so the scores are the serial ones; it is
     what makes the exact mode practical at run.py batch sizes (B*K = 10^4..10^5 strings per step)."""
 
-    def __init__(self, tokenizer, kind: str, param, nltk_module, workers: int = 0, worker_hook=None):
+    def __init__(self, tokenizer, kind: str, param, nltk_module, workers: Optional[int] = 0, worker_hook=None):
         assert kind in ("sentiment", "pos")
         self.tokenizer, self.kind, self.param, self.nltk = tokenizer, kind, param, nltk_module
-        self.workers = int(workers)
+        self.workers = None if workers is None else int(workers)   # None: default_workers() of the first step's size
         self.worker_hook = worker_hook
         self.memo = {}
         self.calls = 0
+        self.host_seconds = 0.0   # wall time spent inside __call__ (decode + scoring), all calling threads
         self._pool = None
+        # one scorer serves the parent engine AND its replicas (EngineGroup forwards set_control_callback), i.e. two host
+        # threads: pool creation and the counters are guarded; Pool.map itself is thread-safe
+        self._lock = threading.Lock()
 
-    def score_texts(self, texts):
-        if self.workers > 1 and len(texts) >= 4 * self.workers:
-            if self._pool is None:
+    def _get_pool(self, n_texts):
+        with self._lock:
+            if self.workers is None:
+                self.workers = default_workers(n_texts)
+                if self.workers > 1:
+                    import logging
+                    logging.getLogger("conzic").info(
+                        "control scorer: %d strings per step -> %d worker interpreters (CZC_CONTROL_WORKERS overrides)",
+                        n_texts, self.workers)
+            if self.workers > 1 and n_texts >= 4 * self.workers and self._pool is None:
                 import multiprocessing as mp
                 import sys
                 self._pool = mp.get_context("spawn").Pool(self.workers, initializer=_worker_init,
                                                           initargs=(list(sys.path), self.worker_hook))
+            return self._pool if (self.workers or 0) > 1 and n_texts >= 4 * self.workers else None
+
+    def score_texts(self, texts):
+        pool = self._get_pool(len(texts))
+        if pool is not None:
             n = self.workers
             per = (len(texts) + n - 1) // n
             jobs = [(self.kind, self.param, texts[i:i + per]) for i in range(0, len(texts), per)]
             out = []
-            for part in self._pool.map(_score_chunk, jobs):
+            for part in pool.map(_score_chunk, jobs):
                 out.extend(part)
             return out
         if self.kind == "pos":
@@ -178,17 +223,22 @@ class HostScorer:
         return [sentence_sentiment(t, self.param, self.nltk, self.memo) for t in texts]
 
     def __call__(self, inp: np.ndarray, cand: np.ndarray, gen_idx: int) -> np.ndarray:
+        t0 = time.perf_counter()
         B, K = cand.shape
         rows = np.repeat(inp[:, None, :], K, axis=1)
         rows[:, :, gen_idx] = cand
         texts = self.tokenizer.batch_decode(rows.reshape(B * K, -1).tolist(), skip_special_tokens=True)
-        self.calls += 1
-        return np.array(self.score_texts(texts), dtype=np.float32).reshape(B, K)
+        out = np.array(self.score_texts(texts), dtype=np.float32).reshape(B, K)
+        with self._lock:
+            self.calls += 1
+            self.host_seconds += time.perf_counter() - t0
+        return out
 
     def close(self):
-        if self._pool is not None:
-            self._pool.terminate()
-            self._pool = None
+        with self._lock:
+            pool, self._pool = self._pool, None
+        if pool is not None:
+            pool.terminate()
 
     def __del__(self):
         try:
@@ -218,7 +268,8 @@ def configure(eng, clip, tokenizer, *, pos_template=None, ctl_signal="positive")
     if nltk_module is None:
         raise RuntimeError(NLTK_HELP)
     if mode in ("exact", "auto"):
-        workers = int(os.environ.get("CZC_CONTROL_WORKERS", "0"))
+        env_workers = os.environ.get("CZC_CONTROL_WORKERS", "")
+        workers = int(env_workers) if env_workers.strip() else None   # unset: by the size of the step (default_workers)
         key = ("pos", repr(pos_template)) if is_pos else ("sentiment", ctl_signal)
         prev = getattr(eng, "_control_scorer_cache", None)
         if prev is not None and prev[0] == (key, id(tokenizer), id(nltk_module), workers):

@@ -1,15 +1,52 @@
 // Kernel-level parity hooks of include/conzic_hip_test.h (czc_test_*): run ONE kernel on host data.
 // Used only by tests/ (-m gpu) to compare each HIP kernel with the CPU oracle, and by tools/ for kernel A/B timing.
-// Built into libconzic_hip_test.so, which links against the product library; the product library exports none of it.
+// Built into libconzic_hip_test.so, which links against the product library's C ABI only (czc_internal_hooks).
 #include <vector>
 #include <cstring>
 #include <algorithm>
+#include <cstdlib>
 
 #include "../../include/conzic_hip_test.h"
 #include "kernels.h"
 #include "bridge_hash.h"
 
+#include "../../include/conzic_hip.h"
+
 using namespace czc;
+
+// everything this file needs from inside libconzic_hip.so comes through its one internal door (the product library
+// exports its C ABI and nothing else): launchers, the calling thread's error buffer, the kernel-family switches
+static const Hooks& HK() {
+  static const Hooks* h = (const Hooks*)czc_internal_hooks(HOOKS_ABI);
+  if (!h) { fprintf(stderr, "libconzic_hip_test.so: libconzic_hip.so was built from another tree (hooks ABI)\n"); abort(); }
+  return *h;
+}
+#define launch_gemm HK().gemm
+#define launch_gemm_rowln HK().gemm_rowln
+#define launch_layernorm HK().layernorm
+#define launch_convert HK().convert
+#define launch_act_to_f32 HK().act_to_f32
+#define launch_attention HK().attention
+#define launch_softmax_mask_topk HK().softmax_mask_topk
+#define launch_bridge_precompute HK().bridge_precompute
+#define launch_bridge HK().bridge
+#define launch_l2_normalize HK().l2_normalize
+#define launch_combine HK().combine
+#define g_use_gemm256 (*HK().use_gemm256)
+#define g_use_skinny (*HK().use_skinny)
+#define g_use_splitk (*HK().use_splitk)
+#define g_gemm_deep (*HK().gemm_deep)
+#define g_gemm_small_tiles (*HK().gemm_small_tiles)
+#define g_use_wreg (*HK().use_wreg)
+#define g_use_gemm256s (*HK().use_gemm256s)
+#define g_w_dbg (*HK().w_dbg)
+#define g_ln_lean (*HK().ln_lean)
+#define g_rowln_min_m (*HK().rowln_min_m)
+#define g_wreg_min_m (*HK().wreg_min_m)
+#define g_gemm256_min_m (*HK().gemm256_min_m)
+#define g_use_mfma_attention (*HK().use_mfma_attention)
+#define g_use_attention_image (*HK().use_attention_image)
+#define TEST_ERR (HK().err_buf())
 
 static int g_bench_pad = 0;
 static int g_bridge_no_table = 0;  // czc_test_bridge: 1 = every chunk through the merge loop (option "bridge_no_table")  // czc_bench_gemm: extra elements per row of A and W (row pitch vs L2 channel experiments)
@@ -36,13 +73,13 @@ struct DevPool {
   do {                                                                                                \
     hipError_t _h = (expr);                                                                           \
     if (_h != hipSuccess) {                                                                           \
-      snprintf(czc::g_err, sizeof(czc::g_err), "%s:%d %s -> %s", __FILE__, __LINE__, #expr,           \
+      snprintf(TEST_ERR, 512, "%s:%d %s -> %s", __FILE__, __LINE__, #expr,           \
                hipGetErrorString(_h));                                                                \
       return CZC_ERR_HIP;                                                                             \
     }                                                                                                 \
   } while (0)
 #define T_CHECK(expr) do { int _r = (expr); if (_r) return _r; } while (0)
-#define T_PTR(p) do { if (!(p)) { snprintf(czc::g_err, sizeof(czc::g_err), "device allocation/copy failed"); return CZC_ERR_HIP; } } while (0)
+#define T_PTR(p) do { if (!(p)) { snprintf(TEST_ERR, 512, "device allocation/copy failed"); return CZC_ERR_HIP; } } while (0)
 
 // fp32 host -> device buffer in precision `prec`
 void* up_act(DevPool& pool, int prec, const float* src, size_t n) {
@@ -176,7 +213,7 @@ int czc_bench_gemm(int precision, int M, int N, int K, int act, int out_mode, in
 int czc_test_gemm_rowln(int precision, int M, int K, const float* A, const float* W, const float* bias, const float* resid,
                         const float* gamma, const float* beta, float eps, float* x_out, float* y_out) {
   const int H = 512;
-  if (precision != PREC_BF16 && precision != PREC_F16) { snprintf(czc::g_err, sizeof(czc::g_err), "gemm_rowln: bf16 / fp16 only"); return CZC_ERR_ARG; }
+  if (precision != PREC_BF16 && precision != PREC_F16) { snprintf(TEST_ERR, 512, "gemm_rowln: bf16 / fp16 only"); return CZC_ERR_ARG; }
   DevPool pool;
   void* dA = up_act(pool, precision, A, (size_t)M * K); T_PTR(dA);
   void* dW = up_act(pool, precision, W, (size_t)H * K); T_PTR(dW);
@@ -216,7 +253,7 @@ int czc_test_set_option(const char* name, int value) {
   if (!strcmp(name, "gemm256_min_m")) { g_gemm256_min_m = value; return 0; }
   if (!strcmp(name, "mfma_attention")) { g_use_mfma_attention = value; return 0; }
   if (!strcmp(name, "attention_image")) { g_use_attention_image = value; return 0; }
-  snprintf(czc::g_err, sizeof(czc::g_err), "unknown option %s", name);
+  snprintf(TEST_ERR, 512, "unknown option %s", name);
   return CZC_ERR_ARG;
 }
 
@@ -320,7 +357,7 @@ int czc_test_bridge(const czc_bridge_tables* t, const czc_config* cfg, int n_row
   T_HIP(hipMemcpy(&ovf, dovf, 4, hipMemcpyDeviceToHost));
   T_HIP(hipMemcpy(clip_ids, dids, (size_t)n_rows * CZC_CLIP_MAX_LEN * 4, hipMemcpyDeviceToHost));
   T_HIP(hipMemcpy(clip_len, dlen, (size_t)n_rows * 4, hipMemcpyDeviceToHost));
-  if (ovf) { snprintf(czc::g_err, sizeof(czc::g_err), "bridge overflow on %d rows", ovf); return CZC_ERR_OVERFLOW; }
+  if (ovf) { snprintf(TEST_ERR, 512, "bridge overflow on %d rows", ovf); return CZC_ERR_OVERFLOW; }
   return 0;
 }
 

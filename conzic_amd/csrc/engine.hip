@@ -807,6 +807,7 @@ int czc_replicate(czc_engine* p, czc_engine** out) {
   e->cfg = p->cfg; e->dev = p->dev; e->finalized = true; e->shares_weights = true;
   e->esz = p->esz; e->pb = p->pb; e->pc = p->pc; e->pv = p->pv; e->eb = p->eb;
   e->refine = p->refine; e->refine_theta_x = p->refine_theta_x; e->refine_samples = p->refine_samples;
+  e->refine_guard_dev = p->refine_guard_dev;
   e->w = p->w; e->bert = p->bert; e->ctext = p->ctext; e->cvis = p->cvis; e->ctext_x = p->ctext_x;
   e->mlm_dense_w = p->mlm_dense_w; e->decoder_w = p->decoder_w; e->tproj_w = p->tproj_w; e->vproj_w = p->vproj_w;
   e->patch_w = p->patch_w; e->tproj_wx = p->tproj_wx;
@@ -1308,6 +1309,16 @@ int czc_refine_guard(czc_engine* e, int reset, float* max_dev, int64_t* tripped)
   if (tripped) *tripped = e->guard_trips;
   if (reset) { e->guard_max_dev = 0.f; e->guard_trips = 0; }
   return CZC_OK;
+}
+
+const void* czc_internal_hooks(int abi) {
+  static const Hooks h = {
+      []() -> char* { return czc::g_err; },
+      &launch_gemm, &launch_gemm_rowln, &launch_layernorm, &launch_convert, &launch_act_to_f32, &launch_attention,
+      &launch_softmax_mask_topk, &launch_bridge_precompute, &launch_bridge, &launch_l2_normalize, &launch_combine,
+      &g_use_gemm256, &g_use_skinny, &g_use_splitk, &g_gemm_deep, &g_gemm_small_tiles, &g_use_wreg, &g_use_gemm256s, &g_w_dbg,
+      &g_ln_lean, &g_rowln_min_m, &g_wreg_min_m, &g_gemm256_min_m, &g_use_mfma_attention, &g_use_attention_image};
+  return abi == HOOKS_ABI ? &h : nullptr;
 }
 
 }  // extern "C"

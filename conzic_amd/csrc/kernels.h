@@ -199,4 +199,25 @@ int launch_refine_plan(const int* clip_len, const int* trunk_len, const int* lis
 int launch_refine_finish(const int* own_off, const int* own_len, const int* count, const int* count_off, const int* kr_dev, int B, int K,
                          int* pre_off, int* eos_idx, hipStream_t st);
 
+// ---- czc_internal_hooks (include/conzic_hip.h): what libconzic_hip_test.so may reach inside this library -----------
+// The product library has hidden visibility; the hook library (api_test.hip) gets the launchers it wraps and the
+// process-wide kernel-family switches it flips through this table instead of through exported C++ symbols.
+constexpr int HOOKS_ABI = 0x0501;
+struct Hooks {
+  char* (*err_buf)();  // the calling host thread's g_err [512]
+  decltype(&launch_gemm) gemm;
+  decltype(&launch_gemm_rowln) gemm_rowln;
+  decltype(&launch_layernorm) layernorm;
+  decltype(&launch_convert) convert;
+  decltype(&launch_act_to_f32) act_to_f32;
+  decltype(&launch_attention) attention;
+  decltype(&launch_softmax_mask_topk) softmax_mask_topk;
+  decltype(&launch_bridge_precompute) bridge_precompute;
+  decltype(&launch_bridge) bridge;
+  decltype(&launch_l2_normalize) l2_normalize;
+  decltype(&launch_combine) combine;
+  int *use_gemm256, *use_skinny, *use_splitk, *gemm_deep, *gemm_small_tiles, *use_wreg, *use_gemm256s, *w_dbg, *ln_lean,
+      *rowln_min_m, *wreg_min_m, *gemm256_min_m, *use_mfma_attention, *use_attention_image;
+};
+
 }  // namespace czc

@@ -14,7 +14,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CZC_LIB_PATH") or os.path.join(_HERE, "lib", "libconzic_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "conzic_hip.h")
 # kernel-level parity hooks + GEMM microbenchmark: a second library over the product one, for tests/ and tools/ only
-TEST_LIB_PATH = os.environ.get("CZC_TEST_LIB_PATH") or os.path.join(os.path.dirname(LIB_PATH), "libconzic_hip_test.so")
+# (csrc/Makefile puts it next to the product library it was linked against: libconzic_hip<tag>.so -> libconzic_hip<tag>_test.so)
+TEST_LIB_PATH = os.environ.get("CZC_TEST_LIB_PATH") or (LIB_PATH[:-3] + "_test.so" if LIB_PATH.endswith(".so")
+                                                        else os.path.join(os.path.dirname(LIB_PATH), "libconzic_hip_test.so"))
 TEST_HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "conzic_hip_test.h")
 
 PREC_BF16 = 0
@@ -107,6 +109,8 @@ SIGNATURES = {
     "czc_stats": (_I, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "czc_refine_stats": (_I, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "czc_refine_guard": (_I, [_P, _I, C.POINTER(C.c_float), C.POINTER(C.c_int64)]),
+    # not part of the boundary: the hook library's door into this one (nothing in conzic_amd/ calls it)
+    "czc_internal_hooks": (_P, [_I]),
 }
 # every entry point include/conzic_hip_test.h declares (libconzic_hip_test.so)
 TEST_SIGNATURES = {
@@ -147,7 +151,7 @@ def load_test() -> C.CDLL:
     global _test_lib
     if _test_lib is not None:
         return _test_lib
-    load()  # RTLD_GLOBAL: the hook library resolves the product library's launchers and switches against it
+    load()  # the hook library is linked against the product library's C ABI (czc_internal_hooks)
     if not os.path.exists(TEST_LIB_PATH):
         raise NativeError(f"{TEST_LIB_PATH} not found: `make -C conzic_amd/csrc` builds it next to the product library")
     lib = C.CDLL(TEST_LIB_PATH, mode=C.RTLD_GLOBAL)

@@ -257,8 +257,9 @@ def run_generation(order: str, img_name, model, clip, tokenizer, image_instance,
         """One whole *_generation call on `eng` (which must hold the batch's image embeddings)."""
         eng.set_token_mask(_mask_to_numpy(token_mask))
         if gamma is not None:
-            # control scores: caller-provided tables, else tables built once per tokenizer from nltk (default), else -- with
-            # CZC_CONTROL=exact -- the reference's own sentence scorer called back per step; raises without nltk and tables
+            # control scores: caller-provided tables, else (default, CZC_CONTROL=auto) the reference's own sentence scorer
+            # called back per step while the CLIP tower runs, else -- CZC_CONTROL=table -- tables built once per tokenizer
+            # from nltk; raises without nltk and tables
             from . import control
             chosen = control.configure(eng, clip, tokenizer, pos_template=pos_template, ctl_signal=ctl_signal)
             if chosen != getattr(eng, "_control_logged", None):

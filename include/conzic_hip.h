@@ -28,6 +28,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* libconzic_hip.so is built with -fvisibility=hidden: the functions declared between this push and its pop are the
+ * library's whole dynamic symbol table (tests/test_host_logic.py checks `nm -D`). */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #define CZC_OK 0
 #define CZC_ERR_ARG 1
@@ -278,6 +283,16 @@ int czc_refine_stats(czc_engine* e, int64_t* refine_seqs, int64_t* refine_rows);
  * call on the all-split engine (CZC_REFINE_GUARD=rerun | warn | off). */
 int czc_refine_guard(czc_engine* e, int reset, float* max_dev, int64_t* tripped);
 
+/* ---- not part of the drop-in boundary ------------------------------------------------------ */
+/* The one door through which libconzic_hip_test.so (include/conzic_hip_test.h: kernel-level parity hooks for tests/ and
+ * the GEMM microbenchmark for tools/) reaches this library's kernel launchers and its process-wide kernel-family
+ * switches; everything else inside the library has hidden visibility.  Returns a table whose layout is private to the
+ * build (csrc/kernels.h `czc::Hooks`), or NULL when `abi` is not that build's tag.  Nothing on the product path calls it. */
+const void* czc_internal_hooks(int abi);
+
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

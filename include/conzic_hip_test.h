@@ -4,8 +4,8 @@
  * TEST INFRASTRUCTURE, not part of the drop-in boundary: each czc_test_* call runs ONE kernel family of
  * libconzic_hip.so on host data so that tests/ (-m gpu) can compare it with the CPU oracle, czc_bench_gemm is the GEMM
  * microbenchmark behind tools/ab_gemm.py / tools/bench_gemm.py, and czc_test_set_option flips process-wide kernel-family
- * switches for A/B runs.  The product library (include/conzic_hip.h) exports none of these; this library links against
- * it and is loaded next to it by tests and tools only (conzic_amd/native.py: load_test()).
+ * switches for A/B runs.  The product library (include/conzic_hip.h) exports none of these; this library reaches its
+ * launchers and switches through czc_internal_hooks, links against nothing but its C ABI, and is loaded next to it by tests and tools only (conzic_amd/native.py: load_test()).
  */
 #ifndef CONZIC_HIP_TEST_H
 #define CONZIC_HIP_TEST_H
@@ -14,6 +14,9 @@
 
 #ifdef __cplusplus
 extern "C" {
+#endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
 #endif
 
 /* C[M,N] = A[M,K] * W[N,K]^T (+bias) (+activation: 0 none, 1 quick_gelu, 2 gelu_erf) (+resid[M,N]).
@@ -46,6 +49,9 @@ int czc_test_combine(int B, int K, int D, const float* text_feat, const float* i
                      const float* probs, const float* senti_raw, const float* repeats, const czc_hyper* hp,
                      float* clip_score, float* clip_ref, float* final_score, int32_t* best);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -30,6 +30,24 @@ def test_library_exports_every_declared_symbol():
     assert lib.czc_version() >= 100
 
 
+def test_product_library_exports_its_header_and_nothing_else():
+    """`nm -D --defined-only libconzic_hip.so` = the functions include/conzic_hip.h declares: no mangled launchers, kernel
+    handles, template instantiations or globals (-fvisibility=hidden + csrc/exports.map); the hook library reaches the
+    inside through czc_internal_hooks only and exports only czc_test_* / czc_bench_*."""
+    import subprocess
+    hdr = open(native.HEADER_PATH).read()
+    declared = set(re.findall(r"\b(czc_[a-z_0-9]+)\s*\(", hdr)) - {"czc_engine", "czc_control_fn"}
+    out = subprocess.run(["nm", "-D", "--defined-only", native.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    assert exported == declared, (sorted(exported - declared)[:10], sorted(declared - exported))
+    out = subprocess.run(["nm", "-D", "--defined-only", native.TEST_LIB_PATH], capture_output=True, text=True, check=True).stdout
+    texp = {ln.split()[-1] for ln in out.splitlines() if ln.strip() and not ln.split()[-1].startswith("__hip_cuid")}
+    assert texp == set(native.TEST_SIGNATURES), sorted(texp ^ set(native.TEST_SIGNATURES))
+    und = subprocess.run(["nm", "-D", "--undefined-only", native.TEST_LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "_ZN3czc" not in und  # no C++ symbol of the product library is needed
+    assert native.load().czc_internal_hooks(0) is None  # a wrong tag is refused
+
+
 def test_test_hooks_live_in_their_own_library():
     """The kernel-level parity hooks and the GEMM microbenchmark (include/conzic_hip_test.h) are test infrastructure:
     libconzic_hip_test.so exports every one of them, the product library and its header none."""
