@@ -44,12 +44,29 @@ def caption_flops(L, K, I, P=3):
     return tot + 8.7e9
 
 
-def cpu_baseline(L, K):
-    """The oracle (CPU restatement of the reference, oracle/) timed on this host: B=1, config-1
-    shape.  Thread count: a sweep over 8/16/32/64/all host threads on one full-length position-step picks the
-    fastest (plain torch oversubscribes badly at B=1 shapes), then the bounded sample runs with it: sweeps 1, 2 and
-    3 of 10 (3*L position-steps); sweeps 2..10 cost the same (all positions filled, Tc = T), so
-    caption time = t_sweep1 + 9 * min(t_sweep2, t_sweep3)."""
+def physical_cores():
+    """Physical cores of this host (distinct (package, core) pairs of /proc/cpuinfo), or None."""
+    try:
+        seen, pkg = set(), 0
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("physical id"):
+                pkg = int(ln.split(":")[1])
+            elif ln.startswith("core id"):
+                seen.add((pkg, int(ln.split(":")[1])))
+        return len(seen) or None
+    except OSError:
+        return None
+
+
+CPU_BASELINE_THREADS = 16
+
+
+def cpu_baseline(L, K, I=10, threads=None):
+    """The oracle (CPU restatement of the reference, oracle/) timed on this host: B=1, config-1 shape, ONE FULL caption
+    (image encode + I sweeps x L position-steps, nothing extrapolated).  Thread count: fixed at
+    min(CPU_BASELINE_THREADS, physical cores) -- plain torch at B = 1 shapes (3000 x 512 GEMMs) peaks there on the GPU boxes'
+    hosts (rounds 1-4 swept 8..256 threads on them: 16 was fastest every time, 0.40 s per full-length position-step; 128
+    threads 1.7 s, all 256 threads 64 s) and a fixed count takes the sweep's noise out of the figure; --cpu-threads overrides."""
     import torch
     from conzic_amd import synth
     from oracle import models as M, step as S, text as T
@@ -59,47 +76,35 @@ def cpu_baseline(L, K):
                  ccfg, sv.bert_tokens, T.ClipBpe(sv.clip_vocab, sv.clip_merges))
     mask = torch.from_numpy(synth.make_token_mask(sv, regular_only=True))
     pix = synth.pixels_from_u8(synth.make_images_u8(1))
-    ncpu = os.cpu_count() or 8
-    cands = sorted({t for t in (8, 16, 32, 64, 128) if t <= ncpu})
-    sweep = {}
+    ncpu, phys = os.cpu_count() or 8, physical_cores()
+    threads = int(threads) if threads else min(CPU_BASELINE_THREADS, phys or ncpu)
+    torch.set_num_threads(threads)
     with torch.no_grad():
+        # warm the thread pool and the allocator on one full-length step (untimed)
         regular = np.nonzero(mask[0].numpy() > 0)[0]
         probe = torch.tensor(o.init_text("Image of a", L, 1))
         probe[:, 4:4 + L] = torch.from_numpy(np.random.default_rng(0).choice(regular, size=(1, L)))
         emb0 = o.image_embeds(pix)
-        for t in cands:
-            torch.set_num_threads(t)
-            best = 1e9
-            for rep in range(2):  # first repetition warms the thread pool
-                inp = probe.clone()
-                inp[:, 4 + L // 2] = o.mask_id
-                t0 = time.time()
-                S.polish_step(o, inp, emb0, mask, 4 + L // 2, K, 0.1, 0.02, 2.0)
-                best = min(best, time.time() - t0)
-            sweep[t] = round(best, 3)
-            if best > 1.5 * min(sweep.values()):
-                break  # oversubscribed from here on (the sweep is ascending): larger counts only get slower
-        threads = min(sweep, key=sweep.get)
-        torch.set_num_threads(threads)
-        t0 = time.time()
+        probe[:, 4 + L // 2] = o.mask_id
+        S.polish_step(o, probe, emb0, mask, 4 + L // 2, K, 0.1, 0.02, 2.0)
+        t_start = time.time()
         emb = o.image_embeds(pix)
-        t_img = time.time() - t0
+        t_img = time.time() - t_start
         inp = torch.tensor(o.init_text("Image of a", L, 1))
         ts = []
-        for sw in range(3):
+        for sw in range(I):
             t0 = time.time()
             for ii in range(L):
                 o.update_token_mask(mask, L, ii)
                 inp[:, 4 + ii] = o.mask_id
                 S.polish_step(o, inp, emb, mask, 4 + ii, K, 0.1, 0.02, 2.0)
             ts.append(time.time() - t0)
-    t_full = min(ts[1], ts[2])  # sweeps 2 and 3 do the same work (every position filled): the faster one is the less disturbed
-    t_caption = t_img + ts[0] + 9 * t_full
+        t_caption = time.time() - t_start
     return dict(value=1.0 / t_caption, unit="captions/s", cores=threads, kind="port",
-                sample=f"oracle (plain torch fp32) B=1 L={L} K={K} on {threads} of {ncpu} host threads (best of the sweep "
-                       f"{sweep} s per full-length position-step): sweeps 1-3 of 10 timed "
-                       f"({ts[0]:.2f}s, {ts[1]:.2f}s, {ts[2]:.2f}s, image encode {t_img:.2f}s); sweeps 2..10 all cost what a full-length "
-                       f"sweep costs, caption = t1 + 9*min(t2, t3) = {t_caption:.1f}s")
+                host=dict(logical_cpus=ncpu, physical_cores=phys),
+                sample=f"oracle (plain torch fp32) B=1 L={L} K={K} I={I} on {threads} threads of this host ({phys} physical cores, "
+                       f"{ncpu} logical): ONE FULL caption timed end to end = {t_caption:.1f}s (image encode {t_img:.2f}s, sweeps "
+                       + ", ".join(f"{t:.2f}" for t in ts) + " s); nothing extrapolated")
 
 
 def spawn_ranks(n):
@@ -136,8 +141,32 @@ def spawn_ranks(n):
     return 0
 
 
+# BASELINE.json configs[1..4] as flag presets (explicit flags still win): what the driver's SCALE runs would launch
+CONFIG_PRESETS = {
+    1: dict(images=1),                                                              # configs[1]: single image, L=10 K=200 sequential
+    2: dict(images=256),                                                            # configs[2]: 256 images on one GPU (the default)
+    3: dict(total_images=2048, order="shuffle", L=15, topk=512, samples=3),         # configs[3]: 2048 images over the ranks, 3 samples
+    4: dict(total_images=512, gamma=5.0, L=12, topk=200),                           # configs[4]: controllable run, 512 images
+}
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--config", type=int, default=None, choices=sorted(CONFIG_PRESETS),
+                    help="BASELINE.json configs[N] as a preset of the flags below (explicit flags override it): "
+                         "1 single image; 2 256 images (default); 3 --total-images 2048 --order shuffle --len 15 --topk 512 --samples 3; "
+                         "4 --total-images 512 --gamma 5 --len 12")
+    ap.add_argument("--samples", type=int, default=1,
+                    help="samples_num (demo.py:83, run.py:180): polish every image this many times per step; the images are "
+                         "encoded ONCE per step and the embeddings re-used (north_star's cached image encode); in shuffle order "
+                         "every sample draws its own order from the one random.Random(42) stream, as the reference's loop does")
+    ap.add_argument("--control", default="table", choices=["table", "exact", "both"],
+                    help="with --gamma: where the control scores come from -- `table` a synthetic per-token sentiment table inside "
+                         "the bridge kernel (the approximate throughput mode), `exact` the product's HostScorer (the reference's "
+                         "sentence scorer, called back per step under the CLIP tower) over tests/nltk_standin.py installed as nltk "
+                         "with CZC_STANDIN_COST_US of busy CPU per 12-word sentence (default 300: roughly nltk's perceptron "
+                         "tagger), `both` = table as the headline leg and exact as a second leg")
+    ap.add_argument("--cpu-threads", type=int, default=None, help="threads of the CPU baseline (default min(16, physical cores))")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
@@ -168,6 +197,9 @@ def main():
     ap.add_argument("--share-gpu", action="store_true",
                     help="TEST ONLY: allow --gpus N ranks on fewer than N devices (rank r -> device r %% count, gloo rendezvous: "
                          "RCCL cannot put two ranks on one device).  Such a line says so in config.parallelism")
+    pre, _ = ap.parse_known_args()
+    if pre.config is not None:
+        ap.set_defaults(**CONFIG_PRESETS[pre.config])
     a = ap.parse_args()
     if a.share_gpu:
         os.environ["CZC_SHARE_GPU"] = "1"
@@ -220,12 +252,18 @@ def main():
     u8 = synth.make_images_u8(B, first=lo)
     pixels = torch.from_numpy(synth.pixels_from_u8(u8)).to(dev)  # resident in HBM before the clock starts
     seed_len = 4
-    order_list = None
-    if a.order == "shuffle":
-        import random
-        order_list = list(range(L))
-        random.Random(42).shuffle(order_list)
-    pos, nm, every = harness.order_positions(a.order, L, I, order_list=order_list)
+    # one visiting order per sample (gen_utils.py:110-111: one random.shuffle per call from the process-global stream,
+    # seeded once -- demo.py:107 -- and NOT reseeded between samples, demo.py:83)
+    sample_plans = []
+    import random
+    order_rng = random.Random(42)
+    for _ in range(max(1, a.samples)):
+        order_list = None
+        if a.order == "shuffle":
+            order_list = list(range(L))
+            order_rng.shuffle(order_list)
+        sample_plans.append(harness.order_positions(a.order, L, I, order_list=order_list))
+    pos, nm, every = sample_plans[0]
     hp = Engine.hyper(0.02, 2.0, 0.1, a.gamma, a.sentiment == "negative")
 
     def barrier():
@@ -234,8 +272,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run_mode(prec_, logit_scale, steps, warmup, profile, opts=(), invariance=False):
+    def run_mode(prec_, logit_scale, steps, warmup, profile, opts=(), invariance=False, control="table"):
         """Engine in one precision at one logit scale: warm up, time `steps` passes, return the measurements."""
+        exact = a.gamma is not None and control == "exact"
         bcfg, ccfg = synth.bert_base(), synth.clip_b32()
         ccfg.logit_scale = logit_scale  # make_clip_weights writes it into the "logit_scale" tensor
         # frozen weights: generated on rank 0, broadcast once over RCCL (xGMI), consumed in place
@@ -247,9 +286,23 @@ def main():
         else:
             bw, cw = synth.make_bert_weights(bcfg, 11), synth.make_clip_weights(ccfg, 12)
         su = harness.build_synthetic(False, prec_, logit_scale=logit_scale, regular_only=True, device=local, bert_w=bw,
-                                     clip_w=cw, bert_cfg=bcfg, clip_cfg=ccfg, lexicon=a.gamma is not None)
+                                     clip_w=cw, bert_cfg=bcfg, clip_cfg=ccfg, lexicon=a.gamma is not None and not exact)
         del bw, cw
         eng = su.engine
+        scorer = None
+        if exact:
+            # the product's exact control mode: conzic_amd.control.HostScorer (the reference's sentence scorer,
+            # sentiments_classifer.py:9-33) called back by the engine once per step WHILE the step's CLIP tower runs; nltk
+            # itself exists on neither box, so the tagger is tests/nltk_standin.py with a calibrated busy-CPU cost
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import nltk_standin
+            from conzic_amd import control as czcontrol
+            os.environ.setdefault("CZC_STANDIN_COST_US", "300")
+            nl = nltk_standin.install()
+            env_w = os.environ.get("CZC_CONTROL_WORKERS", "").strip()
+            scorer = czcontrol.HostScorer(su.bert_tok, "sentiment", a.sentiment, nl, workers=int(env_w) if env_w else None,
+                                          worker_hook=nl.__worker_hook__)
+            eng.set_control_callback(scorer)
         for kv in opts:
             k, v = kv.split("=")
             if k.startswith("test:"):  # kernel-level A/B switches (czc_test_set_option)
@@ -267,8 +320,10 @@ def main():
         last = {}
 
         def step():
-            last["embeds"] = grp.encode_images(pixels)
-            return grp.generate(B, init, L, seed_len, K, pos, hp, n_mask=nm, snapshot_every=every)
+            last["embeds"] = grp.encode_images(pixels)  # once per image and step; every sample re-uses the resident embeddings
+            for sp, sn, se in sample_plans:
+                out_ = grp.generate(B, init, L, seed_len, K, sp, hp, n_mask=sn, snapshot_every=se)
+            return out_
 
         for _ in range(warmup):
             step()
@@ -315,7 +370,9 @@ def main():
 
         def single_step():  # the same step on ONE engine and ONE stream (all B images in every launch)
             eng.encode_images(pixels)
-            return eng.generate(B, init, L, seed_len, K, pos, hp, n_mask=nm, snapshot_every=every)
+            for sp, sn, se in sample_plans:
+                out_ = eng.generate(B, init, L, seed_len, K, sp, hp, n_mask=sn, snapshot_every=se)
+            return out_
 
         if profile:
             if n_streams > 1:
@@ -342,7 +399,18 @@ def main():
         import zlib
         all_ids = czd.gather_along(ids, world, axis=1) if world > 1 else ids
         ids_crc = zlib.crc32(np.ascontiguousarray(all_ids, dtype=np.int32).tobytes()) & 0xFFFFFFFF
-        res = dict(dt=dt, prof=prof, prof_timed=prof_timed, breakdown=breakdown, stats=stats, setup_s=t_setup, invariance=None,
+        ctl = None
+        if scorer is not None:
+            ctl = dict(scorer="conzic_amd.control.HostScorer over tests/nltk_standin.py installed as nltk (a stand-in: nltk and its "
+                              "corpora exist on neither box); context-dependent tagger, the reference's arithmetic",
+                       cost_us_per_12_word_sentence=float(os.environ.get("CZC_STANDIN_COST_US", "0")),
+                       workers=scorer.workers, host_cpus=os.cpu_count(), callbacks=scorer.calls, sentences_asked=scorer.asked,
+                       sentences_scored=scorer.scored, memo_hit_frac=round(1.0 - scorer.scored / max(scorer.asked, 1), 4),
+                       host_seconds_in_scorer=round(scorer.host_seconds, 2),
+                       note="the callback runs on the host while the same step's CLIP tower runs on the GPU (csrc/engine.hip "
+                            "control_score); host_seconds_in_scorer sums over the streams' threads and all steps incl. warm-up")
+            scorer.close()
+        res = dict(dt=dt, prof=prof, prof_timed=prof_timed, breakdown=breakdown, stats=stats, setup_s=t_setup, invariance=None, control=ctl,
                    streams=n_streams, single_ms=single_ms, per_rank=per_rank, steps=prof_steps, events_in_region=events_in_region, ids_crc=ids_crc,
                    n_ids=int(all_ids.shape[1]))
         if invariance and rank == 0 and B > 2:
@@ -352,7 +420,8 @@ def main():
             # the batch took the ring / full-row GEMMs and the per-image attention kernel, and every kernel that can serve
             # a layer produces the same bits (tests/test_kernels_gpu.py, test_step_gpu.py::test_caption_does_not_depend_on_the_batch)
             emb2 = eng.encode_images(pixels[:2])
-            ids2, cos2 = eng.generate(2, init, L, seed_len, K, pos, hp, n_mask=nm, snapshot_every=every)
+            sp, sn, se = sample_plans[-1]  # `ids` are the last sample's
+            ids2, cos2 = eng.generate(2, init, L, seed_len, K, sp, hp, n_mask=sn, snapshot_every=se)
             same = (ids2 == ids[:, :2]).mean(axis=(0, 2))
             res["invariance"] = dict(images=2, batch=B, kernel_switches="none", identical_token_frac=[round(float(x), 4) for x in same],
                                      final_ids_identical=[bool((ids2[-1, j] == ids[-1, j]).all()) for j in range(2)],
@@ -362,7 +431,10 @@ def main():
         return res
 
     main_res = run_mode(prec, a.logit_scale, a.steps, a.warmup, not a.no_profile, opts=a.opt,
-                        invariance=not a.no_invariance)
+                        invariance=not a.no_invariance, control="exact" if a.control == "exact" else "table")
+    exact_res = None
+    if a.gamma is not None and a.control == "both":
+        exact_res = run_mode(prec, a.logit_scale, a.steps, a.warmup, False, opts=a.opt, control="exact")
     alt_res = split_res = None
     if not a.no_alt and prec == native.PREC_BF16 and a.logit_scale < 4.0:
         # the engine the product path selects for the published checkpoints (logit_scale = ln 100): screen-then-refine,
@@ -463,7 +535,7 @@ def main():
         return out
 
     if rank == 0:
-        captions = n_total * a.steps
+        captions = n_total * a.steps * max(1, a.samples)
         value = captions / main_res["dt"]
         prof, st = main_res["prof"], main_res["stats"]
         if (L, K, I, a.order, a.gamma) == (10, 200, 10, "sequential", None):
@@ -474,6 +546,10 @@ def main():
             cfg_name = "BASELINE configs[4] shape (per-GPU shard)"
         else:
             cfg_name = "custom shape"
+        if a.config is not None:
+            cfg_name = f"--config {a.config} = BASELINE configs[{a.config}]" + (f" ({cfg_name})" if "configs" not in cfg_name else "")
+        if a.samples > 1:
+            cfg_name += f", samples_num={a.samples} (images encoded once per step, embeddings re-used by every sample)"
         f_cap = caption_flops(L, K, I)
         bd = main_res["breakdown"]
         gemm_fl = sum(v["flops"] for k, v in bd.items() if k.startswith("gemm")) if bd else None
@@ -488,7 +564,7 @@ def main():
                                         f"`value` = the {a.precision} engine at exp(logit_scale) = {np.exp(a.logit_scale):.1f}; "
                                         "`value_scale100` / `scale100_mode` = the same workload, same steps and warm-up, through the engine the "
                                         "product path selects for the published checkpoints (logit scale 100)",
-                               images_per_gpu=B, total_images=n_total, sentence_len=L, candidate_k=K, num_iterations=I, order=a.order,
+                               preset=a.config, samples_num=a.samples, images_per_gpu=B, total_images=n_total, sentence_len=L, candidate_k=K, num_iterations=I, order=a.order,
                                gamma=a.gamma, sentiment=a.sentiment if a.gamma is not None else None,
                                logit_scale=a.logit_scale, parallelism=f"image-sharded x{world} (no per-step collective); {main_res['streams']} concurrent "
                                            f"image sub-batches per GPU on separate HIP streams over one set of weights"
@@ -506,20 +582,37 @@ def main():
                                   "region only carries events around the roofline family",
                    clip_rows_per_step=st["clip_rows"] // max(1, a.steps), setup_s=round(main_res["setup_s"], 1),
                    single_stream=None if main_res["single_ms"] is None else dict(
-                       ms_per_step=round(main_res["single_ms"], 2), value=round(B / main_res["single_ms"] * 1e3, 4),
+                       ms_per_step=round(main_res["single_ms"], 2), value=round(B * max(1, a.samples) / main_res["single_ms"] * 1e3, 4),
                        note="the same step on ONE engine / ONE stream (rank 0's images), wall-clock around the pass "
                             "`roofline.single_stream_pass` is measured on; `value` and `roofline.frac` come from the timed region"),
                    batch_invariance=main_res["invariance"],
                    captions_crc32=dict(value=main_res["ids_crc"], images=main_res["n_ids"],
                                        note="crc32 of the final token ids of every image of the last timed step, gathered over the ranks in "
                                             "image order: equal between an N-rank --total-images run and the 1-rank run of the same images"))
+        if a.gamma is not None:
+            def ctl_block(res, mode):
+                v = n_total * a.steps * max(1, a.samples) / res["dt"]
+                blk = dict(value=round(v, 4), unit="captions/s", ms_per_step=round(res["dt"] / a.steps * 1e3, 2), steps=a.steps, warmup=a.warmup)
+                if mode == "exact":
+                    blk["parity"] = ("the reference's sentence scorer on the decoded candidate strings: id for id on the *_ctx goldens "
+                                     "(tests/test_control_gpu.py)")
+                    blk["scorer"] = res["control"]
+                else:
+                    blk["parity"] = ("APPROXIMATE: a per-BERT-token table inside the bridge kernel (here a synthetic table); against a "
+                                     "context-dependent tagger 29-50 % of the image-steps of the full-size *_ctx goldens pick another winner")
+                return blk
+            main_mode = "exact" if a.control == "exact" else "table"
+            out["control_" + main_mode] = ctl_block(main_res, main_mode)
+            if exact_res is not None:
+                out["control_exact"] = ctl_block(exact_res, "exact")
+            out["config"]["control"] = a.control
         if prec == native.PREC_REFINE:
             out["refine"] = dict(candidate_seqs=st["clip_seqs"], re_encoded=st["refine_seqs"],
                                  re_encoded_frac=round(st["refine_seqs"] / max(st["clip_seqs"], 1), 4),
                                  rows=st["clip_rows"], re_encoded_rows=st["refine_rows"])
 
         def alt_block(res, prec_, what):
-            av = n_total * a.alt_steps / res["dt"]
+            av = n_total * a.alt_steps * max(1, a.samples) / res["dt"]
             blk = dict(what=what, value=round(av, 4), unit="captions/s", dtype=DT[prec_], logit_scale=4.6052, steps=a.alt_steps,
                        warmup=a.alt_warmup, ms_per_step=round(res["dt"] / a.alt_steps * 1e3, 2), roofline=roofline_of(res, prec_),
                        single_stream_ms_per_step=None if res["single_ms"] is None else round(res["single_ms"], 2),
@@ -545,7 +638,7 @@ def main():
             out["scale100_all_split"] = alt_block(split_res, native.PREC_SPLIT,
                                                   "the same with every tower on split-fp16 MFMA (the round-2 product mode)")
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(L, K)
+            out["cpu_baseline"] = cpu_baseline(L, K, I, a.cpu_threads)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

@@ -185,7 +185,8 @@ class HostScorer:
         self.workers = None if workers is None else int(workers)   # None: default_workers() of the first step's size
         self.worker_hook = worker_hook
         self.memo = {}
-        self.calls = 0
+        self.sent_memo = {}       # sentence string -> score
+        self.calls = self.asked = self.scored = 0   # callbacks, sentences asked for, sentences actually scored
         self.host_seconds = 0.0   # wall time spent inside __call__ (decode + scoring), all calling threads
         self._pool = None
         # one scorer serves the parent engine AND its replicas (EngineGroup forwards set_control_callback), i.e. two host
@@ -208,7 +209,25 @@ class HostScorer:
                                                           initargs=(list(sys.path), self.worker_hook))
             return self._pool if (self.workers or 0) > 1 and n_texts >= 4 * self.workers else None
 
+    SENT_MEMO_MAX = 1 << 21
+
     def score_texts(self, texts):
+        """Scores of `texts`.  A sentence's score is a pure function of its string (tokenise -> tag -> look-ups), so a
+        string already scored in an earlier step is not scored again: from the second sweep on most of a step's K candidate
+        sentences per image were candidates of that position before (same context wherever the caption did not change)."""
+        memo = self.sent_memo
+        todo = [t for t in dict.fromkeys(texts) if t not in memo]
+        if todo:
+            if len(memo) + len(todo) > self.SENT_MEMO_MAX:
+                memo.clear()
+            for t, v in zip(todo, self._score_new(todo)):
+                memo[t] = v
+        with self._lock:
+            self.scored += len(todo)
+            self.asked += len(texts)
+        return [memo[t] for t in texts]
+
+    def _score_new(self, texts):
         pool = self._get_pool(len(texts))
         if pool is not None:
             n = self.workers

@@ -107,7 +107,7 @@ struct czc_engine {
   // czc_set_control_callback: the host scores the K candidate sentences of every image itself (the reference's own
   // nltk scorer where it is installed) between the two halves of a step; replaces the table look-ups of the bridge kernel
   czc_control_fn ctl_fn = nullptr; void* ctl_user = nullptr;
-  std::vector<int32_t> h_ctl_ids; std::vector<float> h_ctl_scores;
+  int32_t* h_ctl_ids = nullptr; float* h_ctl_scores = nullptr; size_t h_ctl_cap = 0;  // pinned: [B*T + B*K] ids, [B*K] scores
 };
 
 namespace {
@@ -583,21 +583,44 @@ int step_phase_a(czc_engine* e, const StepArgs& a) {
 }
 
 // Control scores from the host (czc_set_control_callback): rows as the reference decodes them at
-// control_gen_utils.py:54-57 / :158-160 -- `inp` with [MASK] at gen_idx, candidate k of image b replaces it by cand[b][k]
-int control_from_host(czc_engine* e, const StepArgs& a) {
+// control_gen_utils.py:54-57 / :158-160 -- `inp` with [MASK] at gen_idx, candidate k of image b replaces it by cand[b][k].
+// The scores are only needed by the combine kernel, so the step fetches the ids with its size read (control_fetch, queued
+// in front of the step's one host round trip), launches the CLIP tower, and calls the host WHILE the tower runs
+// (control_score): the reference's Python scorer (control_gen_utils.py:56-57) disappears under the tower's GPU time wherever
+// it is the shorter of the two.
+int control_pinned(czc_engine* e, size_t n_inp, size_t n_seq) {
+  const size_t want = (n_inp + n_seq) * 4 + n_seq * 4;
+  if (e->h_ctl_cap < want) {
+    E_HIP(hipStreamSynchronize(e->st));
+    if (e->h_ctl_ids) (void)hipHostFree(e->h_ctl_ids);
+    e->h_ctl_ids = nullptr; e->h_ctl_cap = 0;
+    E_HIP(hipHostMalloc((void**)&e->h_ctl_ids, want + want / 4));
+    e->h_ctl_cap = want + want / 4;
+  }
+  e->h_ctl_scores = (float*)(e->h_ctl_ids + n_inp + n_seq);
+  return 0;
+}
+
+int control_fetch(czc_engine* e, const StepArgs& a) {
   StepBufs b;
   const size_t n_seq = (size_t)a.B * a.K, n_inp = (size_t)a.B * a.T;
   E_CHECK(step_bufs(e, (int)n_seq, &b));
-  e->h_ctl_ids.resize(n_inp + n_seq);
-  e->h_ctl_scores.assign(n_seq, 0.f);
-  E_HIP(hipMemcpyAsync(e->h_ctl_ids.data(), a.d_inp, n_inp * 4, hipMemcpyDeviceToHost, e->st));
-  E_HIP(hipMemcpyAsync(e->h_ctl_ids.data() + n_inp, b.cand, n_seq * 4, hipMemcpyDeviceToHost, e->st));
-  E_HIP(hipStreamSynchronize(e->st));
-  const int rc = e->ctl_fn(e->ctl_user, e->h_ctl_ids.data(), e->h_ctl_ids.data() + n_inp, a.B, a.T, a.K, a.gen_idx,
-                           e->h_ctl_scores.data());
+  E_CHECK(control_pinned(e, n_inp, n_seq));
+  E_HIP(hipMemcpyAsync(e->h_ctl_ids, a.d_inp, n_inp * 4, hipMemcpyDeviceToHost, e->st));
+  E_HIP(hipMemcpyAsync(e->h_ctl_ids + n_inp, b.cand, n_seq * 4, hipMemcpyDeviceToHost, e->st));
+  return 0;
+}
+
+// after the step's host round trip (the ids have landed) and after the tower's launches have been queued
+int control_score(czc_engine* e, const StepArgs& a) {
+  StepBufs b;
+  const size_t n_seq = (size_t)a.B * a.K, n_inp = (size_t)a.B * a.T;
+  E_CHECK(step_bufs(e, (int)n_seq, &b));
+  memset(e->h_ctl_scores, 0, n_seq * 4);
+  const int rc = e->ctl_fn(e->ctl_user, e->h_ctl_ids, e->h_ctl_ids + n_inp, a.B, a.T, a.K, a.gen_idx, e->h_ctl_scores);
   if (rc) return fail(e, CZC_ERR_STATE, "the control callback reported an error%s");
-  E_HIP(hipMemcpyAsync(b.senti, e->h_ctl_scores.data(), n_seq * 4, hipMemcpyHostToDevice, e->st));
-  E_HIP(hipStreamSynchronize(e->st));  // h_ctl_scores is pageable and re-used by the next step
+  // pinned source: the copy is queued behind the tower; the buffer is next written after the next step's round trip
+  E_HIP(hipMemcpyAsync(b.senti, e->h_ctl_scores, n_seq * 4, hipMemcpyHostToDevice, e->st));
   return 0;
 }
 
@@ -610,6 +633,7 @@ int step_phase_b(czc_engine* e, const StepArgs& a, int M, int max_len, int max_b
   E_CHECK(step_bufs(e, n_seq, &b));
   float* feat;
   E_CHECK(clip_tower(e, b.cids, a.B, a.K, e->share_prefix, M, max_len, max_branch, n_trunk, &feat));
+  if (hp->control && e->ctl_fn) E_CHECK(control_score(e, a));  // host scorer under the tower that was just queued
   float *cscore, *cref, *fin, *bcos; int* best;
   E_CHECK(ensure(e, "s_cscore", (size_t)n_seq * 4, (void**)&cscore));
   E_CHECK(ensure(e, "s_cref", (size_t)n_seq * 4, (void**)&cref));
@@ -694,10 +718,10 @@ int step_device(czc_engine* e, int* d_inp, int B, int T, int gen_idx, int n_mask
   StepArgs a{d_inp, B, T, gen_idx, n_mask, dot_allowed, K, *hp};
   E_CHECK(step_phase_a(e, a));
   if (n_mask > 0) { e->stat_bert_rows += B * T; e->last_BT = B * T; e->last_B = B; e->last_T = T; }
+  if (hp->control && e->ctl_fn) E_CHECK(control_fetch(e, a));  // ids for the host scorer ride on the same round trip
   E_HIP(hipStreamSynchronize(e->st));  // the one host round trip per step (the reference has one too, gen_utils.py:81)
   int M, max_len, max_branch, n_trunk;
   E_CHECK(read_totals(e, &M, &max_len, &max_branch, &n_trunk));
-  if (hp->control && e->ctl_fn) E_CHECK(control_from_host(e, a));
   E_CHECK(step_phase_b(e, a, M, max_len, max_branch, n_trunk));
   e->stat_clip_rows += M;
   e->stat_clip_seqs += B * K;
@@ -791,6 +815,7 @@ int czc_destroy(czc_engine* e) {
   for (auto& kv : e->pk) for (hipEvent_t ev : kv.second.ev) (void)hipEventDestroy(ev);
   if (e->prof_ref) (void)hipEventDestroy(e->prof_ref);
   if (e->h_totals) (void)hipHostFree(e->h_totals);
+  if (e->h_ctl_ids) (void)hipHostFree(e->h_ctl_ids);
   (void)hipStreamDestroy(e->st);
   delete e;
   return CZC_OK;

@@ -182,7 +182,10 @@ int czc_set_pos(czc_engine* e, const uint8_t* tag_of_token, int vocab, const uin
 /* Control scores from the host instead of the tables above: the reference scores every candidate SENTENCE with nltk
  * (sentiments_classifer.py:9-33: word_tokenize -> context-dependent pos_tag -> SentiWordNet; POS_classifier.py:12-29:
  * pos_tag(tagset="universal") against the template), which the per-token tables can only approximate.  With a callback
- * set, every step with czc_hyper.control != 0 calls it once between the BERT half and the CLIP half of the step:
+ * set, every step with czc_hyper.control != 0 calls it once, AFTER the step's CLIP text tower has been queued on the
+ * engine's stream and BEFORE the combine kernel that consumes the scores: the host scores while the GPU encodes the
+ * candidates (the reference runs the two one after the other, control_gen_utils.py:56-58), so the scorer's wall time only
+ * shows where it exceeds the tower's:
  *   inp   int32 [B,T]  the current rows, [MASK] at column gen_idx          (control_gen_utils.py:49-50)
  *   cand  int32 [B,K]  the candidate ids, idxs * token_mask[idxs]           (control_gen_utils.py:52)
  *   scores fp32 [B,K]  out: the raw control score of row b with cand[b][k] at gen_idx -- the sentence sentiment AFTER the

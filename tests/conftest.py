@@ -40,6 +40,9 @@ def pytest_terminal_summary(terminalreporter):
                                     "(case, mode: winners that differ / image-steps, worst |d final_score|):")
         for name, mode, fl, steps, worst in flips:
             terminalreporter.write_line(f"  {name:22s} {mode:6s}: {fl}/{steps}   {worst:.3e}")
+    for step_ms, cost_ms, ratio in (getattr(cmod, "OVERLAP", None) or []) if cmod else []:
+        terminalreporter.write_line(f"host control scorer under the CLIP tower: {cost_ms:.2f} ms of host work per {step_ms:.2f} ms step "
+                                    f"-> {ratio:.3f}x the wall time of a free scorer")
     mod = sys.modules.get("test_step_gpu")
     if not mod:
         return

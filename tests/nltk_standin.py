@@ -17,7 +17,9 @@ Everything is a pure function of the word strings (zlib.crc32), so golden genera
 """
 from __future__ import annotations
 
+import os
 import sys
+import time
 import types
 import zlib
 
@@ -56,7 +58,19 @@ def _penn(word: str, prev_tag):
     return base
 
 
+def _spin(n_words: int) -> None:
+    """Host cost of the real tagger, for throughput measurements only (bench.py --control exact): CZC_STANDIN_COST_US
+    microseconds of busy CPU per 12-word sentence (nltk's averaged-perceptron tagger: roughly 300), scaled by the sentence's
+    length; 0 / unset = free.  A busy loop, not a sleep: it occupies the core the way the tagger would."""
+    us = float(os.environ.get("CZC_STANDIN_COST_US", "0") or 0)
+    if us > 0:
+        end = time.perf_counter() + us * 1e-6 * max(n_words, 1) / 12.0
+        while time.perf_counter() < end:
+            pass
+
+
 def pos_tag(words, tagset=None):
+    _spin(len(words))
     out, prev = [], None
     for w in words:
         t = _penn(w, prev)
