@@ -443,6 +443,16 @@ def main():
         if a.alt_split:
             split_res = run_mode(native.PREC_SPLIT, 4.6052, a.alt_steps, a.alt_warmup, not a.no_profile)
 
+    def refine_block(st_):
+        return dict(candidate_seqs=st_["clip_seqs"], re_encoded=st_["refine_seqs"],
+                    re_encoded_frac=round(st_["refine_seqs"] / max(st_["clip_seqs"], 1), 4),
+                    rows=st_["clip_rows"], re_encoded_rows=st_["refine_rows"],
+                    image_steps=st_["gate_image_steps"], gated_image_steps=st_["gated_image_steps"],
+                    gated_frac=round(st_["gated_image_steps"] / max(st_["gate_image_steps"], 1), 4),
+                    gate="czc_generate margin gate (include/conzic_hip.h czc_refine_gate_stats): image-steps whose screening winner "
+                         "survives every cosine-error assignment within delta = 4e-4 skip the second pass (winner re-encoded at "
+                         "snapshot steps only, for the returned cosine); the others take the full selection")
+
     def family_of(prof, passes):
         """Executed MFMA work and event time of the CLIP-text linear layers (screening GEMMs: `passes` MFMA passes per
         product; the refine pass's split-fp16 GEMMs: three)."""
@@ -607,9 +617,7 @@ def main():
                 out["control_exact"] = ctl_block(exact_res, "exact")
             out["config"]["control"] = a.control
         if prec == native.PREC_REFINE:
-            out["refine"] = dict(candidate_seqs=st["clip_seqs"], re_encoded=st["refine_seqs"],
-                                 re_encoded_frac=round(st["refine_seqs"] / max(st["clip_seqs"], 1), 4),
-                                 rows=st["clip_rows"], re_encoded_rows=st["refine_rows"])
+            out["refine"] = refine_block(st)
 
         def alt_block(res, prec_, what):
             av = n_total * a.alt_steps * max(1, a.samples) / res["dt"]
@@ -619,9 +627,7 @@ def main():
                        kernel_ms_one_step={k: round(v["ms"], 1) for k, v in res["breakdown"].items()})
             rs = res["stats"]
             if prec_ == native.PREC_REFINE:
-                blk["refine"] = dict(candidate_seqs=rs["clip_seqs"], re_encoded=rs["refine_seqs"],
-                                     re_encoded_frac=round(rs["refine_seqs"] / max(rs["clip_seqs"], 1), 4),
-                                     rows=rs["clip_rows"], re_encoded_rows=rs["refine_rows"])
+                blk["refine"] = refine_block(rs)
             return blk
 
         if alt_res is not None:

@@ -81,16 +81,21 @@ __global__ __launch_bounds__(CB_THREADS) void combine_kernel(CombineArgs a) {
     // exceeds the budget (checkpoints whose activations the single-pass fp16 tower does not carry as well as the
     // validated ones) is counted, for the host to re-run the call on the all-split engine (conzic_amd/runtime.py)
     float dev = 0.f;
-    for (int k = tid; k < K; k += CB_THREADS)
-      if (a.refine_kind[(long)b * K + k]) dev = fmaxf(dev, fabsf(s_cos[k] - a.refine_cos[(long)b * K + k] - mu));
+    for (int k = tid; k < K; k += CB_THREADS) {
+      const int kd = a.refine_kind[(long)b * K + k] & 3;
+      if (kd == 1 || kd == 2) dev = fmaxf(dev, fabsf(s_cos[k] - a.refine_cos[(long)b * K + k] - mu));
+    }
     dev = blk_reduce(dev, red, 1);
     if (tid == 0 && a.nonfinite && dev == dev) {
       atomicMax(a.nonfinite + 1, __float_as_int(dev));  // non-negative floats order like their bit patterns
       if (a.refine_guard > 0.f && dev > a.refine_guard) atomicAdd(a.nonfinite + 2, 1);
     }
     __syncthreads();
-    for (int k = tid; k < K; k += CB_THREADS)
-      s_cos[k] = a.refine_kind[(long)b * K + k] ? a.refine_cos[(long)b * K + k] : s_cos[k] - mu;
+    // kind 3 (a margin-gated image's winner): exact cosine for the output only, its score keeps the screening cosine
+    for (int k = tid; k < K; k += CB_THREADS) {
+      const int kd = a.refine_kind[(long)b * K + k] & 3;
+      s_cos[k] = (kd == 1 || kd == 2) ? a.refine_cos[(long)b * K + k] : s_cos[k] - mu;
+    }
     __syncthreads();
   }
 
@@ -140,7 +145,7 @@ __global__ __launch_bounds__(CB_THREADS) void combine_kernel(CombineArgs a) {
   if (tid == 0) {
     const int bi = s_best < K ? s_best : 0;  // all-NaN scores: keep candidate 0
     a.best[b] = bi;
-    a.best_cos[b] = s_cos[bi];
+    a.best_cos[b] = (a.refine_kind && (a.refine_kind[(long)b * K + bi] & 3) == 3) ? a.refine_cos[(long)b * K + bi] : s_cos[bi];
     if (a.inp) a.inp[(long)b * a.T + a.gen_idx] = a.cand[(long)b * K + bi];
   }
 }
@@ -154,8 +159,18 @@ __global__ __launch_bounds__(CB_THREADS) void combine_kernel(CombineArgs a) {
 //           covers several strata.  Their exact cosines give the mass-weighted mean error of the screening tower over
 //           the candidates that are NOT re-encoded, which the final combine removes.
 // list[b][0..count[b]) = the chosen candidate indices in ascending order.
+//
+// Margin gate (czc_generate only; gate_h = exp(logit_scale) * delta > 0): a whole *_generation call exposes the winner's id
+// at every step and the winner's cosine at the snapshot steps (gen_utils.py:78-81, :92) -- not the K fused scores.  If the
+// screening winner w stays the winner under EVERY assignment of cosine errors |d_k - common| <= delta, the exact scores
+// would pick it too and the image needs no second pass: for each challenger r take the adversarial assignment (w's logit
+// down by h, r's up by h, all others up or down by h -- f_r - f_w is monotone in their common factor, so the two extremes
+// bound it) and require f_r < f_w.  Such an image re-encodes nothing (need_cos = 0) or only its winner, for the cosine the
+// caller reads back (kind 3: exact cosine for the OUTPUT, screening cosine in the scores, so that every score of the
+// image carries the same common error).  gated[0] counts those images, gated[1] all images.
 __global__ __launch_bounds__(CB_THREADS) void refine_select_kernel(const float* clip_score, const float* final_score, int K,
-                                                                   float theta, int m_samples, int* kind, int* list, int* count) {
+                                                                   float theta, int m_samples, float gate_h, float beta, int need_cos,
+                                                                   int* gated, int* kind, int* list, int* count) {
   __shared__ float s_p[CB_MAXK];
   __shared__ float s_f[CB_MAXK];
   __shared__ int s_kind[CB_MAXK];
@@ -168,6 +183,46 @@ __global__ __launch_bounds__(CB_THREADS) void refine_select_kernel(const float* 
     s_kind[k] = s_p[k] > theta ? 1 : 0;
   }
   __syncthreads();
+  if (gate_h > 0.f) {
+    float bm = -INFINITY;
+    for (int k = tid; k < K; k += CB_THREADS) bm = fmaxf(bm, s_f[k]);
+    bm = blk_reduce(bm, red, 1);
+    if (tid == 0) s_arg = K;
+    __syncthreads();
+    for (int k = tid; k < K; k += CB_THREADS)
+      if (s_f[k] == bm) atomicMin(&s_arg, k);
+    __syncthreads();
+    const int w = s_arg < K ? s_arg : 0;
+    const float pw = s_p[w], fw = s_f[w];
+    const float up = expf(gate_h), dn = expf(-gate_h);
+    const float ew = pw * dn, base_w = fw - beta * pw;
+    float worst = -INFINITY;  // max over challengers and both extremes of (f_r - f_w) under the adversarial errors
+    for (int k = tid; k < K; k += CB_THREADS) {
+      if (k == w) continue;
+      const float pr = s_p[k], er = pr * up, rest = fmaxf(1.0f - pw - pr, 0.f);
+      const float db = (s_f[k] - beta * pr) - base_w;
+      const float d_lo = db + beta * (er - ew) / (ew + er + rest * dn);
+      const float d_hi = db + beta * (er - ew) / (ew + er + rest * up);
+      const float d = fmaxf(d_lo, d_hi);
+      worst = fmaxf(worst, d == d ? d : INFINITY);  // a NaN score never passes the gate
+    }
+    worst = blk_reduce(worst, red, 1);
+    const bool pass = s_arg < K && worst < 0.f && fw == fw;
+    if (tid == 0) {
+      atomicAdd(gated + 1, 1);
+      if (pass) atomicAdd(gated, 1);
+    }
+    if (pass) {
+      if (tid == 0) {
+        int n = 0;
+        if (need_cos) list[(long)b * K + n++] = w;
+        count[b] = n;
+      }
+      for (int k = tid; k < K; k += CB_THREADS) kind[(long)b * K + k] = (need_cos && k == w) ? 3 : 0;
+      return;  // uniform over the work-group
+    }
+    __syncthreads();
+  }
   for (int round = 0; round < 2; ++round) {  // first argmax of the fused score, then the runner-up
     float bm = -INFINITY;
     for (int k = tid; k < K; k += CB_THREADS) bm = fmaxf(bm, s_f[k]);
@@ -203,14 +258,14 @@ __global__ __launch_bounds__(CB_THREADS) void refine_select_kernel(const float* 
   }
 }
 
-int launch_refine_select(const float* clip_score, const float* final_score, int B, int K, float theta, int m_samples, int* kind,
-                         int* list, int* count, hipStream_t st) {
+int launch_refine_select(const float* clip_score, const float* final_score, int B, int K, float theta, int m_samples, float gate_h,
+                         float beta, int need_cos, int* gated, int* kind, int* list, int* count, hipStream_t st) {
   if (K > CB_MAXK) {
     snprintf(g_err, sizeof(g_err), "refine_select: K=%d > %d", K, CB_MAXK);
     return 1;
   }
-  hipLaunchKernelGGL(refine_select_kernel, dim3(B), dim3(CB_THREADS), 0, st, clip_score, final_score, K, theta, m_samples, kind, list,
-                     count);
+  hipLaunchKernelGGL(refine_select_kernel, dim3(B), dim3(CB_THREADS), 0, st, clip_score, final_score, K, theta, m_samples, gate_h, beta,
+                     need_cos, gated, kind, list, count);
   CZC_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -72,6 +72,13 @@ struct czc_engine {
   // bound for that step (theta_x * dev <= 1e-3 needs dev <= 2.5e-4 at the default theta_x; trip point 0.8 of that)
   float refine_guard_dev = 2.0e-4f;
   float guard_max_dev = 0.f; int64_t guard_trips = 0;   // since the last czc_refine_guard(reset = 1)
+  // margin gate (czc_generate only; combine.hip refine_select_kernel): an image whose screening winner survives every
+  // assignment of cosine errors |d_k - common| <= refine_gate_delta skips the second pass (its winner alone is re-encoded at
+  // the snapshot steps, for the cosine the caller reads).  0 = off.  Default 4e-4 = 2x the largest |error - mean| measured
+  // over 256 k candidates (2.1e-4), 2.7x the guard's sample maximum (1.5e-4)
+  float refine_gate_delta = 4.0e-4f;
+  bool gate_now = false, gate_need_cos = true;  // set per step by czc_generate; czc_step never gates (all K scores are its output)
+  int64_t stat_gated = 0, stat_gate_images = 0;
 
   std::map<std::string, Tensor> w;
   std::vector<LayerW> bert, ctext, cvis, ctext_x;
@@ -469,7 +476,7 @@ int clip_plan(czc_engine* e, const int* cids, const int* clen, int B, int K, int
     E_CHECK(launch_prefix_finish(p.own_off, p.own_len, B, K, p.pre_off, p.eidx, totals + 6, e->st)); }
   E_HIP(hipMemcpyAsync(e->h_totals, totals, 32, hipMemcpyDeviceToHost, e->st));
   int* flag;
-  E_CHECK(ensure(e, "s_nonfinite", 16, (void**)&flag));
+  E_CHECK(ensure(e, "s_nonfinite", 32, (void**)&flag));
   E_HIP(hipMemcpyAsync(e->h_totals + 8, flag, 4, hipMemcpyDeviceToHost, e->st));  // the previous steps' cosine check
   return 0;
 }
@@ -645,7 +652,7 @@ int step_phase_b(czc_engine* e, const StepArgs& a, int M, int max_len, int max_b
   ca.senti_raw = b.senti; ca.repeats = b.reps; ca.alpha = hp->alpha; ca.beta = hp->beta; ca.gamma = hp->gamma;
   ca.use_senti = hp->control; ca.B = a.B; ca.K = a.K; ca.D = c.clip_proj; ca.clip_score = cscore; ca.clip_ref = cref;
   ca.final_score = fin; ca.best = best; ca.best_cos = bcos; ca.inp = a.d_inp; ca.T = a.T; ca.gen_idx = a.gen_idx;
-  E_CHECK(ensure(e, "s_nonfinite", 16, (void**)&ca.nonfinite));
+  E_CHECK(ensure(e, "s_nonfinite", 32, (void**)&ca.nonfinite));
   if (!e->refine) {
     ProfScope ps(e, "combine", 0);
     E_CHECK(launch_combine(ca, e->st));
@@ -669,7 +676,9 @@ int step_phase_b(czc_engine* e, const StepArgs& a, int M, int max_len, int max_b
   { ProfScope ps(e, "combine", 0);
     ca.inp = nullptr;
     E_CHECK(launch_combine(ca, e->st));
-    E_CHECK(launch_refine_select(cscore, fin, a.B, a.K, theta, e->refine_samples, kind, list, count, e->st)); }
+    const float gate_h = e->gate_now ? e->refine_gate_delta * e->logit_scale_exp : 0.f;
+    E_CHECK(launch_refine_select(cscore, fin, a.B, a.K, theta, e->refine_samples, gate_h, hp->beta, e->gate_need_cos ? 1 : 0,
+                                 ca.nonfinite + 4, kind, list, count, e->st)); }
   { ProfScope ps(e, "bridge", 0);
     E_HIP(hipMemsetAsync(rtot, 0, 64, e->st));
     E_HIP(hipMemsetAsync(rp.own_len, 0, (size_t)S * 4, e->st));
@@ -832,7 +841,7 @@ int czc_replicate(czc_engine* p, czc_engine** out) {
   e->cfg = p->cfg; e->dev = p->dev; e->finalized = true; e->shares_weights = true;
   e->esz = p->esz; e->pb = p->pb; e->pc = p->pc; e->pv = p->pv; e->eb = p->eb;
   e->refine = p->refine; e->refine_theta_x = p->refine_theta_x; e->refine_samples = p->refine_samples;
-  e->refine_guard_dev = p->refine_guard_dev;
+  e->refine_guard_dev = p->refine_guard_dev; e->refine_gate_delta = p->refine_gate_delta;
   e->w = p->w; e->bert = p->bert; e->ctext = p->ctext; e->cvis = p->cvis; e->ctext_x = p->ctext_x;
   e->mlm_dense_w = p->mlm_dense_w; e->decoder_w = p->decoder_w; e->tproj_w = p->tproj_w; e->vproj_w = p->vproj_w;
   e->patch_w = p->patch_w; e->tproj_wx = p->tproj_wx;
@@ -1140,7 +1149,7 @@ int czc_encode_text(czc_engine* e, const int32_t* clip_ids, const int32_t* clip_
   E_HIP(hipMemcpyAsync(cids, clip_ids, (size_t)n * CZC_CLIP_MAX_LEN * 4, hipMemcpyDefault, e->st));
   E_HIP(hipMemcpyAsync(clen, clip_len, (size_t)n * 4, hipMemcpyDefault, e->st));
   E_HIP(hipMemsetAsync(totals, 0, 32, e->st));
-  { int* flag; E_CHECK(ensure(e, "s_nonfinite", 16, (void**)&flag)); E_HIP(hipMemsetAsync(flag, 0, 16, e->st)); }
+  { int* flag; E_CHECK(ensure(e, "s_nonfinite", 32, (void**)&flag)); E_HIP(hipMemsetAsync(flag, 0, 32, e->st)); }
   float* feat;
   E_CHECK(clip_text_forward(e, cids, clen, n, 1, 0, totals, &feat, true));  // independent sequences: no sharing; exact tower
   E_HIP(hipMemcpyAsync(out_embeds, feat, (size_t)n * e->cfg.clip_proj * 4, hipMemcpyDefault, e->st));
@@ -1154,9 +1163,10 @@ int czc_step(czc_engine* e, int32_t* inp, int B, int T, int gen_idx, int n_mask,
   E_HIP(hipSetDevice(e->dev));
   e->err[0] = 0;
   int* d_inp;
-  { int* flag; E_CHECK(ensure(e, "s_nonfinite", 16, (void**)&flag)); E_HIP(hipMemsetAsync(flag, 0, 16, e->st)); }
+  { int* flag; E_CHECK(ensure(e, "s_nonfinite", 32, (void**)&flag)); E_HIP(hipMemsetAsync(flag, 0, 32, e->st)); }
   E_CHECK(ensure(e, "g_inp", (size_t)B * T * 4, (void**)&d_inp));
   E_HIP(hipMemcpyAsync(d_inp, inp, (size_t)B * T * 4, hipMemcpyDefault, e->st));
+  e->gate_now = false;  // parity granularity: every one of the K fused scores is an output, all of them are refined
   E_CHECK(step_device(e, d_inp, B, T, gen_idx, n_mask, dot_allowed, top_k, hp));
   const size_t bk = (size_t)B * top_k;
   if (out) {
@@ -1175,10 +1185,11 @@ int czc_step(czc_engine* e, int32_t* inp, int B, int T, int gen_idx, int n_mask,
     E_CHECK(copy_out(e, out->logits, "b_logits", (size_t)B * e->cfg.bert_vocab * 4));
   }
   E_HIP(hipMemcpyAsync(inp, d_inp, (size_t)B * T * 4, hipMemcpyDefault, e->st));
-  E_HIP(hipMemcpyAsync(e->h_totals + 9, e->ws["s_nonfinite"].p, 12, hipMemcpyDeviceToHost, e->st));
+  E_HIP(hipMemcpyAsync(e->h_totals + 9, e->ws["s_nonfinite"].p, 24, hipMemcpyDeviceToHost, e->st));
   E_HIP(hipStreamSynchronize(e->st));
   if (e->h_totals[9]) return fail(e, CZC_ERR_OVERFLOW, "non-finite CLIP cosine (fp16 operand overflow in a tower? use CZC_PREC_SPLIT)%s");
-  { float dev; memcpy(&dev, e->h_totals + 10, 4); e->guard_max_dev = fmaxf(e->guard_max_dev, dev); e->guard_trips += e->h_totals[11]; }
+  { float dev; memcpy(&dev, e->h_totals + 10, 4); e->guard_max_dev = fmaxf(e->guard_max_dev, dev); e->guard_trips += e->h_totals[11];
+    e->stat_gated += e->h_totals[13]; e->stat_gate_images += e->h_totals[14]; }
   return CZC_OK;
 }
 
@@ -1191,7 +1202,7 @@ int czc_generate(czc_engine* e, int B, int T, int L, int seed_len, const int32_t
   E_HIP(hipSetDevice(e->dev));
   e->err[0] = 0;
   int *d_inp, *d_row;
-  { int* flag; E_CHECK(ensure(e, "s_nonfinite", 16, (void**)&flag)); E_HIP(hipMemsetAsync(flag, 0, 16, e->st)); }
+  { int* flag; E_CHECK(ensure(e, "s_nonfinite", 32, (void**)&flag)); E_HIP(hipMemsetAsync(flag, 0, 32, e->st)); }
   E_CHECK(ensure(e, "g_inp", (size_t)B * T * 4, (void**)&d_inp));
   E_CHECK(ensure(e, "g_row", (size_t)T * 4, (void**)&d_row));
   E_HIP(hipMemcpyAsync(d_row, init_ids_host, (size_t)T * 4, hipMemcpyHostToDevice, e->st));
@@ -1201,6 +1212,9 @@ int czc_generate(czc_engine* e, int B, int T, int L, int seed_len, const int32_t
     const int pos = positions_host[s];
     if (pos < 0 || pos >= L) return fail(e, CZC_ERR_ARG, "generate: position out of range%s");
     const int nm = n_mask_host ? n_mask_host[s] : 1;
+    // what this call returns of a step: the ids it leaves in d_inp and, at the snapshot steps, the winner's cosine
+    e->gate_now = e->refine && e->refine_gate_delta > 0.f;
+    e->gate_need_cos = out_cos != nullptr && (s + 1) % snapshot_every == 0;
     E_CHECK(step_device(e, d_inp, B, T, seed_len + pos, nm, pos == L - 1 ? 1 : 0, top_k, hp));
     if ((s + 1) % snapshot_every == 0) {
       if (out_ids)
@@ -1210,10 +1224,11 @@ int czc_generate(czc_engine* e, int B, int T, int L, int seed_len, const int32_t
       ++snap;
     }
   }
-  E_HIP(hipMemcpyAsync(e->h_totals + 9, e->ws["s_nonfinite"].p, 12, hipMemcpyDeviceToHost, e->st));
+  E_HIP(hipMemcpyAsync(e->h_totals + 9, e->ws["s_nonfinite"].p, 24, hipMemcpyDeviceToHost, e->st));
   E_HIP(hipStreamSynchronize(e->st));
   if (e->h_totals[9]) return fail(e, CZC_ERR_OVERFLOW, "non-finite CLIP cosine (fp16 operand overflow in a tower? use CZC_PREC_SPLIT)%s");
-  { float dev; memcpy(&dev, e->h_totals + 10, 4); e->guard_max_dev = fmaxf(e->guard_max_dev, dev); e->guard_trips += e->h_totals[11]; }
+  { float dev; memcpy(&dev, e->h_totals + 10, 4); e->guard_max_dev = fmaxf(e->guard_max_dev, dev); e->guard_trips += e->h_totals[11];
+    e->stat_gated += e->h_totals[13]; e->stat_gate_images += e->h_totals[14]; }
   return CZC_OK;
 }
 
@@ -1234,6 +1249,7 @@ int czc_set_option(czc_engine* e, const char* name, int value) {
   if (!strcmp(name, "refine_samples")) { e->refine_samples = value < 0 ? 0 : value; return CZC_OK; }
   if (!strcmp(name, "refine_theta_x1000")) { e->refine_theta_x = (float)value / 1000.f; return CZC_OK; }
   if (!strcmp(name, "refine_guard_x1e6")) { e->refine_guard_dev = (float)value * 1e-6f; return CZC_OK; }
+  if (!strcmp(name, "refine_gate_x1e6")) { e->refine_gate_delta = value < 0 ? 0.f : (float)value * 1e-6f; return CZC_OK; }
   return fail(e, CZC_ERR_ARG, "unknown option %s", name);
 }
 
@@ -1259,6 +1275,7 @@ int czc_profile_reset(czc_engine* e) {
   for (auto& kv : e->pk) { kv.second.used = 0; kv.second.flops = 0; kv.second.launches = 0; }
   e->stat_clip_rows = e->stat_clip_seqs = e->stat_bert_rows = e->stat_steps = 0;
   e->stat_refine_rows = e->stat_refine_seqs = 0;
+  e->stat_gated = e->stat_gate_images = 0;
   return CZC_OK;
 }
 
@@ -1325,6 +1342,13 @@ int czc_refine_stats(czc_engine* e, int64_t* refine_seqs, int64_t* refine_rows) 
   if (!e) return CZC_ERR_ARG;
   if (refine_seqs) *refine_seqs = e->stat_refine_seqs;
   if (refine_rows) *refine_rows = e->stat_refine_rows;
+  return CZC_OK;
+}
+
+int czc_refine_gate_stats(czc_engine* e, int64_t* gated, int64_t* image_steps) {
+  if (!e) return CZC_ERR_ARG;
+  if (gated) *gated = e->stat_gated;
+  if (image_steps) *image_steps = e->stat_gate_images;
   return CZC_OK;
 }
 

@@ -186,8 +186,9 @@ struct CombineArgs {
 // text_feat == null: clip_ref already holds the cosines
 int launch_combine(const CombineArgs& a, hipStream_t st);
 // screen-then-refine engine (combine.hip): choose the candidates to re-encode / cosines of the re-encoded rows
-int launch_refine_select(const float* clip_score, const float* final_score, int B, int K, float theta, int m_samples, int* kind,
-                         int* list, int* count, hipStream_t st);
+// gate_h > 0: margin gate of czc_generate (combine.hip); gated[0] += images that passed it, gated[1] += images
+int launch_refine_select(const float* clip_score, const float* final_score, int B, int K, float theta, int m_samples, float gate_h,
+                         float beta, int need_cos, int* gated, int* kind, int* list, int* count, hipStream_t st);
 int launch_refine_cosine(const float* text_feat, const float* img_n, const int* rlist, const int* n_rows_dev, int n_rows_max, int K, int D,
                          float* cos_out, int* nonfinite, hipStream_t st);
 // segment plan of the refine pass (bridge.hip): B trunks (prefix lengths of the screening plan) + B x Kr branch slots

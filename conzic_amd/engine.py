@@ -368,8 +368,10 @@ class Engine:
         self._ck(self.lib.czc_stats(self.h, C.byref(a), C.byref(b), C.byref(c_), C.byref(d)), "czc_stats")
         rs, rr = C.c_int64(), C.c_int64()
         self._ck(self.lib.czc_refine_stats(self.h, C.byref(rs), C.byref(rr)), "czc_refine_stats")
+        g, gi = C.c_int64(), C.c_int64()
+        self._ck(self.lib.czc_refine_gate_stats(self.h, C.byref(g), C.byref(gi)), "czc_refine_gate_stats")
         return dict(clip_rows=a.value, clip_seqs=b.value, bert_rows=c_.value, steps=d.value, refine_seqs=rs.value,
-                    refine_rows=rr.value)
+                    refine_rows=rr.value, gated_image_steps=g.value, gate_image_steps=gi.value)
 
     def refine_guard(self, reset: bool = True):
         """(max |screening error - mean| seen on re-encoded candidates, image-steps above the trip point) of a

@@ -109,6 +109,7 @@ SIGNATURES = {
     "czc_stats": (_I, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "czc_refine_stats": (_I, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "czc_refine_guard": (_I, [_P, _I, C.POINTER(C.c_float), C.POINTER(C.c_int64)]),
+    "czc_refine_gate_stats": (_I, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     # not part of the boundary: the hook library's door into this one (nothing in conzic_amd/ calls it)
     "czc_internal_hooks": (_P, [_I]),
 }

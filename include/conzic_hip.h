@@ -251,7 +251,8 @@ int czc_generate(czc_engine* e, int B, int T, int L, int seed_len, const int32_t
  *                         layer's LN1 as well (measured slower), 0 = off
  *   "refine_samples" (12), "refine_theta_x1000" (4000): CZC_PREC_REFINE selection -- strata of the mass-stratified sample
  *                         and the softmax_K mass threshold theta = value / 1000 / (beta * exp(logit_scale))
- *   "refine_guard_x1e6" (200): trip point of czc_refine_guard, in units of 1e-6 of cosine */
+ *   "refine_guard_x1e6" (200): trip point of czc_refine_guard, in units of 1e-6 of cosine
+ *   "refine_gate_x1e6" (400): cosine-error bound delta of the margin gate of czc_generate (czc_refine_gate_stats), 0 = off */
 int czc_set_option(czc_engine* e, const char* name, int value);
 
 /* ---- measurement ------------------------------------------------------------------------- */
@@ -285,6 +286,15 @@ int czc_refine_stats(czc_engine* e, int64_t* refine_seqs, int64_t* refine_rows);
  * checkpoint whose activations the fp16 tower carries worse trips the guard, and conzic_amd/runtime.py then repeats the
  * call on the all-split engine (CZC_REFINE_GUARD=rerun | warn | off). */
 int czc_refine_guard(czc_engine* e, int reset, float* max_dev, int64_t* tripped);
+/* CZC_PREC_REFINE engines, margin gate of czc_generate: a whole *_generation call returns the winner's id of every step and
+ * the winner's cosine at the snapshot steps (gen_utils.py:78-81, :92), not the K fused scores.  An image-step whose screening
+ * (single-pass fp16) winner stays the winner under EVERY assignment of cosine errors |d_k - common| <= delta (delta = option
+ * "refine_gate_x1e6" * 1e-6, default 400 = 2x the largest deviation measured over 256 k candidates; the check is the
+ * adversarial one: winner's logit down, challenger's up, the rest both ways) needs no second pass for its id; only its
+ * winner is re-encoded, at snapshot steps, for the exact cosine.  Image-steps that fail the gate take the full selection.
+ * czc_step never gates: all K scores are its output and all of them are refined.  *gated of *image_steps since
+ * czc_profile_reset. */
+int czc_refine_gate_stats(czc_engine* e, int64_t* gated, int64_t* image_steps);
 
 /* ---- not part of the drop-in boundary ------------------------------------------------------ */
 /* The one door through which libconzic_hip_test.so (include/conzic_hip_test.h: kernel-level parity hooks for tests/ and

@@ -386,6 +386,43 @@ def test_generate_free_running_full_size_refine(name):
     np.testing.assert_allclose(cos, np.array(meta["scores"][:-1], dtype=np.float32), atol=2e-5)  # the winner is always re-encoded
 
 
+def test_margin_gate_skips_the_second_pass_without_changing_what_generate_returns():
+    """czc_generate of the screen-then-refine engine returns ids of every step and the winner's cosine at the snapshot steps.
+    With the margin gate (default: delta = 4e-4) an image-step whose screening winner survives every cosine-error assignment
+    within delta does no second pass; `full_scale100` (the published logit scale): same ids and cosines as the reference AND as
+    the ungated engine, most image-steps gated, far fewer candidates re-encoded; czc_step never gates."""
+    meta, arr = load_case("full_scale100")
+    su = setup_for(meta, REFINE)
+    eng = su.engine
+    eng.set_image_embeds(arr["image_embeds"])
+    hp = Engine.hyper(meta["alpha"], meta["beta"], meta["temperature"], meta["gamma"])
+    init = su.bert_tok.encode(meta["prompt"] + su.bert_tok.mask_token * meta["L"])
+    pos, nm, every = harness.order_positions(meta["order"], meta["L"], meta["I"], order_list=meta["order_list"])
+    res = {}
+    for gate in (400, 0):
+        eng.set_option("refine_gate_x1e6", gate)
+        eng.profile_reset()
+        ids, cos = eng.generate(meta["B"], init, meta["L"], SEED_LEN, meta["K"], pos, hp, n_mask=nm, snapshot_every=every)
+        res[gate] = (ids, cos, eng.stats())
+        np.testing.assert_array_equal(ids, arr["snaps"])
+        np.testing.assert_allclose(cos, np.array(meta["scores"][:-1], dtype=np.float32), atol=2e-5)
+    on, off = res[400][2], res[0][2]
+    assert off["gated_image_steps"] == 0 and off["gate_image_steps"] == 0
+    assert on["gate_image_steps"] == meta["B"] * len(pos)
+    frac = on["gated_image_steps"] / on["gate_image_steps"]
+    print(f"[margin gate] {on['gated_image_steps']}/{on['gate_image_steps']} image-steps gated; candidates re-encoded "
+          f"{on['refine_seqs']} (gate on) vs {off['refine_seqs']} (off)")
+    assert frac >= 0.5, frac
+    assert on["refine_seqs"] < 0.5 * off["refine_seqs"]
+    # parity granularity is untouched: a czc_step refines the full selection whatever the option says
+    eng.set_option("refine_gate_x1e6", 400)
+    eng.profile_reset()
+    inp = np.ascontiguousarray(arr["inp_before"][0], dtype=np.int32)
+    eng.step(inp, SEED_LEN + pos[0], meta["K"], hp, dot_allowed=(pos[0] == meta["L"] - 1))
+    st = eng.stats()
+    assert st["gate_image_steps"] == 0 and st["refine_seqs"] >= 2 * meta["B"]
+
+
 def test_refine_engine_vs_split_engine_many_image_steps():
     """The goldens hold ~20 image-steps per case; this holds the screen-then-refine engine to the all-split-fp16 engine
     (pinned to the reference within 8e-6) on 32 images x 6 positions at the published logit scale: same candidate lists,

@@ -7,7 +7,11 @@ on MANY image-steps at the published logit scale: the goldens give ~20 image-ste
 Both engines see the same random image embeddings and the same sentences (later-sweep state: every position filled);
 the BERT tower is the same split-fp16 code in both, so the candidate lists are identical and the fused scores compare
 one to one.  Reports the worst and the 99.9th-percentile |d final_score| over all B*P*K candidates, winner agreement,
-and the share of candidates / rows the refine pass re-encodes."""
+and the share of candidates / rows the refine pass re-encodes.
+
+Last line (`mode: generate`): the same two engines through czc_generate (GEN_SWEEPS sweeps from the initial [MASK] row) --
+the refine engine with its margin gate on (the product default): ids of every snapshot must be IDENTICAL to the split
+engine's, the returned winner cosines equal to fp32 class, and the share of image-steps the gate let skip the second pass."""
 import json
 import os
 import sys
@@ -39,6 +43,10 @@ for p in range(P):
     before = cur.copy()
     r = ref.engine.step(cur, SEED_LEN + (p % L), K, hp, dot_allowed=(p % L == L - 1), want=("idxs", "final_score", "best", "clip_ref"))
     gold.append((before, r))  # `cur` now carries the reference engine's winners: the next position's state
+GEN_SWEEPS = int(os.environ.get("GEN_SWEEPS", "3"))
+init = ref.bert_tok.encode("Image of a" + ref.bert_tok.mask_token * L)
+gpos, gnm, gevery = harness.order_positions("sequential", L, GEN_SWEEPS)
+ref_ids, ref_cos = ref.engine.generate(B, init, L, SEED_LEN, K, gpos, hp, n_mask=gnm, snapshot_every=gevery)
 ref.engine.close()
 
 su = harness.build_synthetic(False, native.PREC_REFINE, logit_scale=SCALE, regular_only=True)
@@ -68,6 +76,23 @@ for th in THETAS:
                               image_steps=n, winners_identical=agree, reference_margin_at_flips=margins,
                               re_encoded_seq_frac=round(st["refine_seqs"] / max(st["clip_seqs"], 1), 4),
                               re_encoded_row_frac=round(st["refine_rows"] / max(st["clip_rows"], 1), 4))), flush=True)
+su.engine.set_option("refine_samples", 12)
+su.engine.set_option("refine_theta_x1000", 4000)
+for gate in (400, 0):
+    su.engine.set_option("refine_gate_x1e6", gate)
+    su.engine.profile_reset()
+    su.engine.refine_guard(reset=True)
+    ids, cos = su.engine.generate(B, init, L, SEED_LEN, K, gpos, hp, n_mask=gnm, snapshot_every=gevery)
+    st = su.engine.stats()
+    gd = su.engine.refine_guard(reset=True)
+    same_img = (ids == ref_ids).all(axis=(0, 2))
+    print(json.dumps(dict(mode="generate", gate_delta=gate * 1e-6, images=B, sweeps=GEN_SWEEPS, image_steps=B * len(gpos),
+                          images_with_identical_ids=int(same_img.sum()), ids_identical=bool((ids == ref_ids).all()),
+                          max_abs_dcos_snapshots=float(np.abs(cos - ref_cos)[:, same_img].max()) if same_img.any() else None,
+                          gated_frac=round(st["gated_image_steps"] / max(st["gate_image_steps"], 1), 4),
+                          re_encoded_seq_frac=round(st["refine_seqs"] / max(st["clip_seqs"], 1), 4),
+                          re_encoded_row_frac=round(st["refine_rows"] / max(st["clip_rows"], 1), 4),
+                          guard_max_dev=gd["max_dev"], guard_tripped_image_steps=gd["tripped"])), flush=True)
 su.engine.close()
 sys.stdout.flush()
 os._exit(0)
