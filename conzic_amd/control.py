@@ -182,7 +182,8 @@ class HostScorer:
     def __init__(self, tokenizer, kind: str, param, nltk_module, workers: Optional[int] = 0, worker_hook=None):
         assert kind in ("sentiment", "pos")
         self.tokenizer, self.kind, self.param, self.nltk = tokenizer, kind, param, nltk_module
-        self.workers = None if workers is None else int(workers)   # None: default_workers() of the first step's size
+        self.auto = workers is None                 # CZC_CONTROL_WORKERS unset: default_workers() of a step's size
+        self.workers = 0 if workers is None else int(workers)
         self.worker_hook = worker_hook
         self.memo = {}
         self.sent_memo = {}       # sentence string -> score
@@ -194,20 +195,22 @@ class HostScorer:
         self._lock = threading.Lock()
 
     def _get_pool(self, n_texts):
+        """The worker pool for a batch of `n_texts` strings, or None (score them here).  With CZC_CONTROL_WORKERS unset the
+        decision is taken per call -- the first steps of a run repeat the same few strings (every image starts from the same
+        prompt) and are scored in place; the pool appears with the first batch of default_workers()' size."""
         with self._lock:
-            if self.workers is None:
-                self.workers = default_workers(n_texts)
-                if self.workers > 1:
-                    import logging
-                    logging.getLogger("conzic").info(
-                        "control scorer: %d strings per step -> %d worker interpreters (CZC_CONTROL_WORKERS overrides)",
-                        n_texts, self.workers)
-            if self.workers > 1 and n_texts >= 4 * self.workers and self._pool is None:
+            want = default_workers(n_texts) if self.auto else self.workers
+            if want > 1 and n_texts >= 4 * want and self._pool is None:
                 import multiprocessing as mp
                 import sys
-                self._pool = mp.get_context("spawn").Pool(self.workers, initializer=_worker_init,
+                if self.auto:
+                    import logging
+                    logging.getLogger("conzic").info(
+                        "control scorer: %d strings in one step -> %d worker interpreters (CZC_CONTROL_WORKERS overrides)", n_texts, want)
+                self._pool = mp.get_context("spawn").Pool(want, initializer=_worker_init,
                                                           initargs=(list(sys.path), self.worker_hook))
-            return self._pool if (self.workers or 0) > 1 and n_texts >= 4 * self.workers else None
+                self.workers = want
+            return self._pool if self._pool is not None and n_texts >= 4 * self.workers else None
 
     SENT_MEMO_MAX = 1 << 21
 
