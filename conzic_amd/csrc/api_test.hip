@@ -32,6 +32,7 @@ static const Hooks& HK() {
 #define launch_bridge HK().bridge
 #define launch_l2_normalize HK().l2_normalize
 #define launch_combine HK().combine
+#define launch_layernorm_x16 HK().layernorm_x16
 #define g_use_gemm256 (*HK().use_gemm256)
 #define g_use_skinny (*HK().use_skinny)
 #define g_use_splitk (*HK().use_splitk)
@@ -135,6 +136,37 @@ int czc_test_gemm(int precision, int M, int N, int K, const float* A, const floa
   return 0;
 }
 
+// The residual-add layers on a 2-byte residual stream (GemmArgs::x16): x_out = fp16(fp16(resid) + A.W^T + bias), in place on the
+// fp16 rows as the engine runs it; which kernel serves it follows the shape and the czc_test_set_option switches (weight-stationary
+// residual kernel at K = 512 / N % 256 == 0, ping-pong ring kernel from gemm256_min_m rows, tiled kernel otherwise).
+int czc_test_gemm_x16(int precision, int M, int N, int K, const float* A, const float* W, const float* bias, const float* resid,
+                      float* x_out) {
+  if (precision != PREC_BF16 && precision != PREC_F16) { snprintf(TEST_ERR, 512, "gemm_x16: bf16 / fp16 operands only"); return CZC_ERR_ARG; }
+  DevPool pool;
+  void* dA = up_act(pool, precision, A, (size_t)M * K); T_PTR(dA);
+  void* dW = up_act(pool, precision, W, (size_t)N * K); T_PTR(dW);
+  float* dB = bias ? (float*)pool.up(bias, (size_t)N * 4) : nullptr;
+  void* dx = up_act(pool, PREC_F16, resid, (size_t)M * N); T_PTR(dx);
+  GemmArgs g;
+  g.A = dA; g.lda = K; g.W = dW; g.ldw = K; g.bias = dB; g.resid = (const float*)dx; g.ldr = N; g.out_act = nullptr;
+  g.out_f32 = (float*)dx; g.ldc = N; g.M = M; g.N = N; g.K = K; g.act = ACT_NONE; g.x16 = 1;
+  T_CHECK(launch_gemm(precision, g, nullptr));
+  T_HIP(hipDeviceSynchronize());
+  return down_act(pool, PREC_F16, dx, (size_t)M * N, x_out);
+}
+
+// LayerNorm of fp16 rows (512 wide) into the operand type: y = LN(fp16(x))
+int czc_test_layernorm_x16(int precision, int M, const float* x, const float* gamma, const float* beta, float eps, float* y) {
+  DevPool pool;
+  void* dx = up_act(pool, PREC_F16, x, (size_t)M * 512); T_PTR(dx);
+  float* dg = (float*)pool.up(gamma, 512 * 4); T_PTR(dg);
+  float* db = (float*)pool.up(beta, 512 * 4); T_PTR(db);
+  void* dy = pool.alloc((size_t)M * 512 * 2); T_PTR(dy);
+  T_CHECK(launch_layernorm_x16(precision, dx, nullptr, dg, db, eps, M, 512, dy, nullptr));
+  T_HIP(hipDeviceSynchronize());
+  return down_act(pool, precision, dy, (size_t)M * 512, y);
+}
+
 // Microbenchmark of the GEMM kernels on device-resident random data (tools/bench_gemm.py).
 // out_mode 0: bf16/act output (+bias, act); 1: fp32 output with in-place fp32 residual (+bias).
 int czc_bench_gemm(int precision, int M, int N, int K, int act, int out_mode, int iters, int use256, double* ms_out) {
@@ -172,6 +204,7 @@ int czc_bench_gemm(int precision, int M, int N, int K, int act, int out_mode, in
   GemmArgs g;
   g.A = dA; g.lda = (int)Kp; g.W = dW; g.ldw = (int)Kp; g.bias = dB; g.resid = dOf; g.ldr = N; g.out_act = dOa; g.out_f32 = dOf;
   g.ldc = N; g.M = M; g.N = N; g.K = K; g.act = act;
+  if (out_mode == 6) { g.x16 = 1; }  // 6: fp16 residual stream in place (the fp32 buffer doubles as M x N fp16 rows)
   if (out_mode == 4 || out_mode == 5) {  // 4: full-row kernel with the LayerNorm in its epilogue; 5: the pair it replaces
     g.out_act = pool.alloc((size_t)M * N * 2); T_PTR(g.out_act);
     g.ln_gamma = dB; g.ln_beta = dB; g.ln_eps = 1e-5f; g.f16 = precision == PREC_F16;

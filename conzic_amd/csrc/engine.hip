@@ -107,6 +107,12 @@ struct czc_engine {
   int fuse_ln = 1;         // bf16 / fp16 CLIP-text tower: 1 = out-proj as a full-row kernel with LN2 in its epilogue
                            // (gemm_rowln_kernel; +1 % captions/s), 2 = fc2 -> next layer's LN1 as well (measured slower: the
                            // K = 2048 GEMM pays more for 128-row tiles than the LayerNorm pass costs), 0 = off
+  // 2-byte residual stream of the CLIP-TEXT tower (round 5): x lives in HBM as IEEE fp16 rows (fp32 accumulate / bias /
+  // residual add, one rounding per update), the out-projection runs on the weight-stationary kernel's residual form and the
+  // LayerNorms read 1 KiB rows.  1 (default): the bf16 engine; 2: the single-pass fp16 tower too (CZC_PREC_FP16 and the
+  // screening pass of CZC_PREC_REFINE: outside their validated error budget, experiments only); 0: fp32 residual everywhere.
+  // The split-fp16 / f32 towers and the vision tower always keep the fp32 stream.
+  int resid16 = 1;
   int prof = 0;  // 0 off, 1 every kernel class, 2 only the CLIP-text linear layers (the roofline kernel family)
   std::map<std::string, ProfKind> pk;
   int64_t stat_clip_rows = 0, stat_clip_seqs = 0, stat_bert_rows = 0, stat_steps = 0;
@@ -262,6 +268,17 @@ int gemm(czc_engine* e, int prec, const char* kind, const void* A, int lda, cons
   return 0;
 }
 
+// x <- fp16(x + A.W^T + b) on a 2-byte residual stream (GemmArgs::x16): x16 [M,N] fp16 rows, updated in place
+int gemm_x16(czc_engine* e, int prec, const char* kind, const void* A, int lda, const void* W, const float* bias, void* x16, int M,
+             int N, int K) {
+  GemmArgs g;
+  g.A = A; g.lda = lda; g.W = W; g.ldw = K; g.bias = bias; g.resid = (const float*)x16; g.ldr = N;
+  g.out_act = nullptr; g.out_f32 = (float*)x16; g.ldc = N; g.M = M; g.N = N; g.K = K; g.act = ACT_NONE; g.x16 = 1;
+  ProfScope ps(e, kind, 2.0 * M * (double)N * K);
+  E_CHECK(launch_gemm(prec, g, e->st));
+  return 0;
+}
+
 int gemm_ex(czc_engine* e, int prec, const char* kind, const GemmArgs& g) {
   ProfScope ps(e, kind, 2.0 * g.M * (double)g.N * g.K);
   E_CHECK(launch_gemm(prec, g, e->st));
@@ -274,9 +291,10 @@ int gemm_ex(czc_engine* e, int prec, const char* kind, const GemmArgs& g) {
 // tower).  The last layer then runs its out-projection and MLP on those rows only (K/V of every row
 // are still produced); the pooled residual rows are returned in *pooled (fp32 [n_pool, H]).
 // P = precision of the layer weights in L (the engine's CLIP precision, or PREC_F16X3 for the refine pass).
+// r16: x (and *pooled) are fp16 rows of a 2-byte residual stream (czc_engine::resid16; H = 512, half-precision P).
 int clip_stack(czc_engine* e, int P, const char* gk, std::vector<LayerW>& L, float* x, int M, int H, int I, int heads,
                float eps, const SegTable& tab, int max_keys, int causal, int plan_B = 0, int plan_K = 0,
-               int plan_max_own = 0, const int* pool_idx = nullptr, int n_pool = 0, float** pooled = nullptr) {
+               int plan_max_own = 0, const int* pool_idx = nullptr, int n_pool = 0, float** pooled = nullptr, bool r16 = false) {
   const size_t esz = prec_bytes(P);
   void *y, *qkv, *ctx, *hbuf;
   E_CHECK(ensure(e, "cs_y", (size_t)M * H * esz, &y));
@@ -292,8 +310,15 @@ int clip_stack(czc_engine* e, int P, const char* gk, std::vector<LayerW>& L, flo
   const double attn_flops = text ? 4.0 * H * e->plan_pairs : 0.0;
   // LayerNorm fused into the producer: out-proj (fuse_ln >= 1) and fc2 (fuse_ln >= 2) run on full 512-wide rows and
   // leave y = LN(x) beside the new fp32 x; the LayerNorm kernel then only runs where no such producer exists.
-  const bool rowln = prec_is_half(P) && e->fuse_ln && H == 512 && M >= g_rowln_min_m && I % 32 == 0;
+  const bool rowln = !r16 && prec_is_half(P) && e->fuse_ln && H == 512 && M >= g_rowln_min_m && I % 32 == 0;
+  auto ln = [&](const float* gm, const float* bt, int rows, const void* src, void* dst) -> int {  // dst <- LN(src rows)
+    ProfScope ps(e, rk, 0);
+    if (r16) E_CHECK(launch_layernorm_x16(P, src, nullptr, gm, bt, eps, rows, H, dst, e->st));
+    else E_CHECK(launch_layernorm(P, (const float*)src, nullptr, gm, bt, eps, rows, H, dst, nullptr, e->st));
+    return 0;
+  };
   auto resid_gemm = [&](const void* A, int lda, const void* W, const float* b, int K) -> int {  // x += A.W^T + b
+    if (r16) return gemm_x16(e, P, gk, A, lda, W, b, x, M, H, K);
     return gemm(e, P, gk, A, lda, W, K, b, x, H, nullptr, x, H, M, H, K, ACT_NONE);
   };
   auto resid_ln_gemm = [&](const void* A, int lda, const void* W, const float* b, int K, const float* gm,
@@ -309,10 +334,7 @@ int clip_stack(czc_engine* e, int P, const char* gk, std::vector<LayerW>& L, flo
   bool have_y = false;  // y already holds this layer's LN1 output (left by the previous layer's fc2)
   for (size_t n = 0; n < L.size(); ++n) {
     LayerW& l = L[n];
-    if (!have_y) {
-      ProfScope ps(e, rk, 0);
-      E_CHECK(launch_layernorm(P, x, nullptr, l.ln1_g, l.ln1_b, eps, M, H, y, nullptr, e->st));
-    }
+    if (!have_y) E_CHECK(ln(l.ln1_g, l.ln1_b, M, x, y));
     E_CHECK(gemm(e, P, gk, y, H, l.qkv_w, H, l.qkv_b, nullptr, 0, qkv, nullptr, 3 * H, M, 3 * H, H, ACT_NONE));
     { ProfScope ps(e, ak, attn_flops);
       int rc = -1;
@@ -330,20 +352,21 @@ int clip_stack(czc_engine* e, int P, const char* gk, std::vector<LayerW>& L, flo
       E_CHECK(ensure(e, "cs_x_e", (size_t)n_pool * H * 4, (void**)&x_e));
       { ProfScope ps(e, rk, 0);
         E_CHECK(launch_gather_rows_bytes(ctx, pool_idx, n_pool, H * (int)esz, ctx_e, e->st));
-        E_CHECK(launch_gather_rows_f32(x, pool_idx, n_pool, H, x_e, e->st)); }
-      E_CHECK(gemm(e, P, gk, ctx_e, H, l.o_w, H, l.o_b, x_e, H, nullptr, x_e, H, n_pool, H, H, ACT_NONE));
-      { ProfScope ps(e, rk, 0);
-        E_CHECK(launch_layernorm(P, x_e, nullptr, l.ln2_g, l.ln2_b, eps, n_pool, H, y_e, nullptr, e->st)); }
+        if (r16) E_CHECK(launch_gather_rows_bytes(x, pool_idx, n_pool, H * 2, x_e, e->st));
+        else E_CHECK(launch_gather_rows_f32(x, pool_idx, n_pool, H, x_e, e->st)); }
+      if (r16) E_CHECK(gemm_x16(e, P, gk, ctx_e, H, l.o_w, l.o_b, x_e, n_pool, H, H));
+      else E_CHECK(gemm(e, P, gk, ctx_e, H, l.o_w, H, l.o_b, x_e, H, nullptr, x_e, H, n_pool, H, H, ACT_NONE));
+      E_CHECK(ln(l.ln2_g, l.ln2_b, n_pool, x_e, y_e));
       E_CHECK(gemm(e, P, gk, y_e, H, l.fc1_w, H, l.fc1_b, nullptr, 0, h_e, nullptr, I, n_pool, I, H, ACT_QUICK_GELU));
-      E_CHECK(gemm(e, P, gk, h_e, I, l.fc2_w, I, l.fc2_b, x_e, H, nullptr, x_e, H, n_pool, H, I, ACT_NONE));
+      if (r16) E_CHECK(gemm_x16(e, P, gk, h_e, I, l.fc2_w, l.fc2_b, x_e, n_pool, H, I));
+      else E_CHECK(gemm(e, P, gk, h_e, I, l.fc2_w, I, l.fc2_b, x_e, H, nullptr, x_e, H, n_pool, H, I, ACT_NONE));
       *pooled = x_e;
       return 0;
     }
     if (rowln) E_CHECK(resid_ln_gemm(ctx, H, l.o_w, l.o_b, H, l.ln2_g, l.ln2_b));
     else {
       E_CHECK(resid_gemm(ctx, H, l.o_w, l.o_b, H));
-      ProfScope ps(e, rk, 0);
-      E_CHECK(launch_layernorm(P, x, nullptr, l.ln2_g, l.ln2_b, eps, M, H, y, nullptr, e->st));
+      E_CHECK(ln(l.ln2_g, l.ln2_b, M, x, y));
     }
     E_CHECK(gemm(e, P, gk, y, H, l.fc1_w, H, l.fc1_b, nullptr, 0, hbuf, nullptr, I, M, I, H, ACT_QUICK_GELU));
     have_y = rowln && e->fuse_ln >= 2 && n + 1 < L.size();
@@ -496,14 +519,18 @@ int clip_tower_on(czc_engine* e, int P, std::vector<LayerW>& L, const void* tpro
   E_CHECK(need(e, "text_model.embeddings.position_embedding.weight", (size_t)c.clip_max_pos * H, &pos));
   E_CHECK(need(e, "text_model.final_layer_norm.weight", H, &fg));
   E_CHECK(need(e, "text_model.final_layer_norm.bias", H, &fb));
+  const bool r16 = H == 512 && ((e->resid16 >= 1 && P == PREC_BF16) || (e->resid16 >= 2 && P == PREC_F16));
   { ProfScope ps(e, "rowops_clip_text", 0);
-    E_CHECK(launch_clip_embed(cids, CZC_CLIP_MAX_LEN, p.src, p.pos0, p.own_off, p.own_len, n_seg, max_len, H, tok, pos, x, e->st)); }
+    E_CHECK(launch_clip_embed(cids, CZC_CLIP_MAX_LEN, p.src, p.pos0, p.own_off, p.own_len, n_seg, max_len, H, tok, pos, x, e->st, r16 ? 1 : 0)); }
   SegTable tab{p.pre_off, p.pre_len, p.own_off, p.own_len, n_seg, 0, plan_B > 0 ? p.img_max : nullptr};
   float* pooled = nullptr;
   E_CHECK(clip_stack(e, P, gk, L, x, M, H, c.clip_inter, c.clip_heads, c.clip_eps, tab, max_len, 1, plan_B,
-                     plan_K, max_branch, p.eidx, n_pool, &pooled));
+                     plan_K, max_branch, p.eidx, n_pool, &pooled, r16));
   { ProfScope ps(e, "rowops_clip_text", 0);
-    if (pooled) E_CHECK(launch_layernorm(P, pooled, nullptr, fg, fb, c.clip_eps, n_pool, H, pa, nullptr, e->st));
+    if (r16) {
+      if (pooled) E_CHECK(launch_layernorm_x16(P, pooled, nullptr, fg, fb, c.clip_eps, n_pool, H, pa, e->st));
+      else E_CHECK(launch_layernorm_x16(P, x, p.eidx, fg, fb, c.clip_eps, n_pool, H, pa, e->st));
+    } else if (pooled) E_CHECK(launch_layernorm(P, pooled, nullptr, fg, fb, c.clip_eps, n_pool, H, pa, nullptr, e->st));
     else E_CHECK(launch_layernorm(P, x, p.eidx, fg, fb, c.clip_eps, n_pool, H, pa, nullptr, e->st)); }
   E_CHECK(gemm(e, P, gk, pa, H, tproj, H, nullptr, nullptr, 0, nullptr, feat, c.clip_proj, n_pool, c.clip_proj, H, ACT_NONE));
   *feat_out = feat;
@@ -847,7 +874,7 @@ int czc_replicate(czc_engine* p, czc_engine** out) {
   e->patch_w = p->patch_w; e->tproj_wx = p->tproj_wx;
   e->logit_scale_exp = p->logit_scale_exp;
   e->share_prefix = p->share_prefix; e->pack_branches = p->pack_branches; e->pool_last_layer = p->pool_last_layer;
-  e->fuse_ln = p->fuse_ln; e->bert_prune = p->bert_prune;
+  e->fuse_ln = p->fuse_ln; e->bert_prune = p->bert_prune; e->resid16 = p->resid16;
   memset(&e->bd, 0, sizeof(e->bd));
   if (hipSetDevice(e->dev) != hipSuccess || hipStreamCreate(&e->st) != hipSuccess ||
       hipHostMalloc((void**)&e->h_totals, 256) != hipSuccess) {
@@ -1246,6 +1273,7 @@ int czc_set_option(czc_engine* e, const char* name, int value) {
   if (!strcmp(name, "pack_branches")) { e->pack_branches = value ? 1 : 0; return CZC_OK; }
   if (!strcmp(name, "pool_last_layer")) { e->pool_last_layer = value ? 1 : 0; return CZC_OK; }
   if (!strcmp(name, "fuse_ln")) { e->fuse_ln = value; return CZC_OK; }  // 0 off, 1 out-proj -> LN2, 2 also fc2 -> next LN1
+  if (!strcmp(name, "resid16")) { e->resid16 = value < 0 ? 0 : value; return CZC_OK; }
   if (!strcmp(name, "refine_samples")) { e->refine_samples = value < 0 ? 0 : value; return CZC_OK; }
   if (!strcmp(name, "refine_theta_x1000")) { e->refine_theta_x = (float)value / 1000.f; return CZC_OK; }
   if (!strcmp(name, "refine_guard_x1e6")) { e->refine_guard_dev = (float)value * 1e-6f; return CZC_OK; }
@@ -1365,6 +1393,7 @@ const void* czc_internal_hooks(int abi) {
       []() -> char* { return czc::g_err; },
       &launch_gemm, &launch_gemm_rowln, &launch_layernorm, &launch_convert, &launch_act_to_f32, &launch_attention,
       &launch_softmax_mask_topk, &launch_bridge_precompute, &launch_bridge, &launch_l2_normalize, &launch_combine,
+      &launch_layernorm_x16,
       &g_use_gemm256, &g_use_skinny, &g_use_splitk, &g_gemm_deep, &g_gemm_small_tiles, &g_use_wreg, &g_use_gemm256s, &g_w_dbg,
       &g_ln_lean, &g_rowln_min_m, &g_wreg_min_m, &g_gemm256_min_m, &g_use_mfma_attention, &g_use_attention_image};
   return abi == HOOKS_ABI ? &h : nullptr;

@@ -102,6 +102,21 @@ __device__ __forceinline__ void epilogue(const GemmArgs& g, f32x16_t (&acc)[NB][
           }
           v.x = apply_act<T, ACT>(v.x); v.y = apply_act<T, ACT>(v.y);
           v.z = apply_act<T, ACT>(v.z); v.w = apply_act<T, ACT>(v.w);
+          if (sizeof(T) == 2 && g.x16) {
+            // 2-byte residual stream (GemmArgs::x16): fp16 rows in, fp16 rows out, the sum formed in fp32 and rounded once --
+            // the arithmetic of tile_epilogue_x16_asm (gemm256.hip), so the layer does not change its bits with the row count
+            const f16_t* rh = (const f16_t*)g.resid;
+            f16_t* oh = (f16_t*)g.out_f32;
+            if (rh) {
+              const uint2 r2 = *(const uint2*)(rh + rr + col);
+              v.x += (float)__builtin_bit_cast(_Float16, (unsigned short)(r2.x & 0xffffu));
+              v.y += (float)__builtin_bit_cast(_Float16, (unsigned short)(r2.x >> 16));
+              v.z += (float)__builtin_bit_cast(_Float16, (unsigned short)(r2.y & 0xffffu));
+              v.w += (float)__builtin_bit_cast(_Float16, (unsigned short)(r2.y >> 16));
+            }
+            if (oh) *(uint2*)(oh + ro + col) = make_uint2(pack2_f16(v.x, v.y), pack2_f16(v.z, v.w));
+            continue;
+          }
           if (g.resid) {
             const float4 r4 = *(const float4*)(g.resid + rr + col);
             v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
@@ -558,6 +573,11 @@ int launch_gemm(int prec, const GemmArgs& g_in, hipStream_t st) {
   if (g.K % kpt != 0 || g.N <= 0) {
     snprintf(g_err, sizeof(g_err), "gemm: K=%d must be a multiple of %d", g.K, kpt);
     return 1;
+  }
+  if (g.x16) {  // 2-byte residual stream: half-precision engines, vectorisable shapes, no activation-typed second output
+    const bool ok = prec_is_half(prec) && g.out_f32 && !g.out_act && g.N % 8 == 0 && g.ldc % 8 == 0 && (!g.resid || g.ldr % 8 == 0);
+    if (!ok) { snprintf(g_err, sizeof(g_err), "gemm: x16 (fp16 residual stream) needs a half-precision engine and N, ldc, ldr %% 8 == 0"); return 1; }
+    if (gemm_wreg_resid_eligible(g)) return launch_gemm_wreg_resid(g, st);
   }
   if (prec_is_half(prec) && gemm_wreg_eligible(g)) return launch_gemm_wreg(g, st);
   if (prec_is_half(prec) && g_use_gemm256 && gemm256_eligible(g)) return launch_gemm256(g, st);

@@ -277,6 +277,95 @@ __device__ __forceinline__ void tile_epilogue_f32_asm(const GemmArgs& g, f32x16_
   }
 }
 
+// The same epilogue for a 2-BYTE residual stream (GemmArgs::x16, round 5: the bf16 engine's CLIP-text tower keeps x as IEEE
+// fp16 rows -- 11 significand bits, fp32 accumulate / bias / residual add before the one rounding): resid and out_f32 point
+// to fp16 rows (ldr / ldc in elements).  A lane owns 8 consecutive columns (16 bytes) of a row, four lanes cover a 32-column
+// block row, 16 rows per pass and two passes per 32 x 32 block: every residual load and output store is again a full
+// 16 bytes per lane and 64 bytes per row, at half the bytes of the fp32 form (2 + 2 instead of 4 + 4 VMEM instructions per
+// block).  Same order of operations per element (patch value + bias, + residual), then one round-to-nearest-even to fp16
+// from the pinned fp32 value -- what the tiled kernel's epilogue (gemm.hip) does for the same layer at small row counts.
+template <int NJ>
+__device__ __forceinline__ void tile_epilogue_x16_asm(const GemmArgs& g, f32x16_t (&acc)[4][NJ], unsigned char* patch, int m0, int n0,
+                                                      int wm, int wcol0, int lane) {
+  const int half = lane >> 5, l31 = lane & 31, rrow = lane >> 2, rs = lane & 3;
+  const int rows = min(TM, g.M - m0);
+  auto desc = [&](const void* base, int ld, int n_rows) {
+    const unsigned long long pa = (unsigned long long)base + (unsigned long long)m0 * ld * 2;
+    u32x4_t r;
+    r.x = __builtin_amdgcn_readfirstlane((unsigned)pa);
+    r.y = __builtin_amdgcn_readfirstlane((unsigned)(pa >> 32) & 0xffffu);
+    r.z = __builtin_amdgcn_readfirstlane((unsigned)(n_rows * ld * 2));
+    r.w = 0x00020000u;
+    return r;
+  };
+  const u32x4_t rsR = desc(g.resid, g.ldr, rows), rsO = desc(g.out_f32, g.ldc, rows);
+  u32x4_t rsB;
+  {
+    const unsigned long long pb = (unsigned long long)g.bias;
+    rsB.x = __builtin_amdgcn_readfirstlane((unsigned)pb);
+    rsB.y = __builtin_amdgcn_readfirstlane((unsigned)(pb >> 32) & 0xffffu);
+    rsB.z = __builtin_amdgcn_readfirstlane((unsigned)(g.bias ? g.N * 4 : 0));  // no bias: every read returns 0
+    rsB.w = 0x00020000u;
+  }
+  asm volatile("s_nop 4" ::: "memory");  // descriptors fresh from v_readfirstlane -> buffer_* inside asm strings
+  constexpr int NB = 4 * NJ;
+  auto colof = [&](int blk) { return n0 + wcol0 + (blk % NJ) * 32 + rs * 8; };
+  auto off = [&](int blk, int pass, int ld) -> unsigned {
+    const int col = colof(blk);
+    const int row = wm * 128 + (blk / NJ) * 32 + pass * 16 + rrow;
+    return col < g.N ? (unsigned)((row * ld + col) * 2) : 0x7ffffff0u;
+  };
+  f32x4_t bias8[NJ][2];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int col = colof(j);
+    const unsigned bo = col < g.N ? (unsigned)(col * 4) : 0x7ffffff0u;
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(bias8[j][0]) : "v"(bo), "s"(rsB) : "memory");
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:16" : "=v"(bias8[j][1]) : "v"(bo), "s"(rsB) : "memory");
+  }
+  u32x4_t rr[2][2];
+  auto load_resid = [&](int blk, u32x4_t (&r)[2]) {
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass)
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(r[pass]) : "v"(off(blk, pass, g.ldr)), "s"(rsR) : "memory");
+  };
+  load_resid(0, rr[0]);
+#pragma unroll
+  for (int blk = 0; blk < NB; ++blk) {
+    const int i = blk / NJ, j = blk % NJ;
+    if (blk + 1 < NB) load_resid(blk + 1, rr[(blk + 1) & 1]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int slot = (2 * q + half) ^ (l31 & 7);
+      *(float4*)(patch + l31 * 128 + slot * 16) =
+          make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+    }
+    u32x4_t(&r)[2] = rr[blk & 1];
+    // this block's residual rows (and, first time round, the bias) have landed: younger = stores of block blk-1, loads of blk+1
+    if (blk == 0 || blk + 1 == NB)
+      asm volatile("s_waitcnt vmcnt(2)" : "+v"(r[0]), "+v"(r[1]), "+v"(bias8[j][0]), "+v"(bias8[j][1]) : : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(4)" : "+v"(r[0]), "+v"(r[1]), "+v"(bias8[j][0]), "+v"(bias8[j][1]) : : "memory");
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int rw = pass * 16 + rrow;
+      const float4 t0 = *(const float4*)(patch + rw * 128 + (((2 * rs) ^ (rw & 7)) << 4));
+      const float4 t1 = *(const float4*)(patch + rw * 128 + (((2 * rs + 1) ^ (rw & 7)) << 4));
+      float v[8] = {t0.x + bias8[j][0][0], t0.y + bias8[j][0][1], t0.z + bias8[j][0][2], t0.w + bias8[j][0][3],
+                    t1.x + bias8[j][1][0], t1.y + bias8[j][1][1], t1.z + bias8[j][1][2], t1.w + bias8[j][1][3]};
+      u32x4_t o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const unsigned pr = r[pass][e];
+        const float lo = (float)__builtin_bit_cast(_Float16, (unsigned short)(pr & 0xffffu));
+        const float hi = (float)__builtin_bit_cast(_Float16, (unsigned short)(pr >> 16));
+        o[e] = pack2_f16(v[2 * e] + lo, v[2 * e + 1] + hi);
+      }
+      asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" : : "v"(o), "v"(off(blk, pass, g.ldc)), "s"(rsO) : "memory");
+    }
+  }
+}
+
 // Split-fp16 activation output (qkv / fc1 of the split engine): same 32x32 fp32 round trip through the patch as the
 // fp32 path, then lanes rslot / rslot^1 swap one 4-column piece per pass pair so that every lane holds the 8
 // consecutive columns of one split_t group (16 bytes of fp16 hi parts followed by 16 bytes of lo parts).
@@ -693,7 +782,9 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(GemmArgs g, int tiles_m, 
 #pragma unroll
         for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[i][j]));
     } else {
-      if constexpr (OUT_F32 && ACT == ACT_NONE) {
+      if constexpr (DBG == 256) {  // 2-byte residual stream (GemmArgs::x16; launch_gemm256 only instantiates it for ACT_NONE, OUT_F32)
+        tile_epilogue_x16_asm<2>(g, acc, smem + QS * QSTAGE + wave * 4096, m0, n0, grp, wn * 64, lane);
+      } else if constexpr (OUT_F32 && ACT == ACT_NONE) {
         if (!(var & 8) && g.resid && g.out_f32 && !g.out_act)
           tile_epilogue_f32_asm<2, (DBG >> 6) & 3>(g, acc, smem + QS * QSTAGE + wave * 4096, m0, n0, grp, wn * 64, lane);
         else
@@ -1457,6 +1548,7 @@ int launch_gemm_rowln(const GemmArgs& g, hipStream_t st) {
 }
 
 bool gemm256_eligible(const GemmArgs& g) {
+  if (g.x16 && !(g.resid && g.out_f32 && !g.out_act && g.act == ACT_NONE && g.ldr % 8 == 0)) return false;  // x16: residual-add layers only
   return g.M >= g_gemm256_min_m && g.N % 8 == 0 && g.K % 64 == 0 && g.ldc % 8 == 0 && g.lda % 8 == 0 && g.ldw % 8 == 0 &&
          (!g.resid || g.ldr % 4 == 0) && (g.act == ACT_NONE || g.act == ACT_QUICK_GELU) && (long)256 * g.lda * 2 < (1L << 31) &&
          (long)256 * g.ldw * 2 < (1L << 31);
@@ -1477,6 +1569,8 @@ int launch_gemm256(const GemmArgs& g, hipStream_t st) {
     CZC_ATTR4(gemm256x_kernel);
     CZC_ATTR((gemm256r_kernel<false>));
     CZC_ATTR((gemm256r_kernel<true>));
+    CZC_ATTR((gemm256x_kernel<ACT_NONE, true, false, 256>));
+    CZC_ATTR((gemm256x_kernel<ACT_NONE, true, true, 256>));
 #undef CZC_ATTR4
 #undef CZC_ATTR
     return 0;
@@ -1523,7 +1617,10 @@ int launch_gemm256(const GemmArgs& g, hipStream_t st) {
   int stagger256 = (f32 && tiles_m * tiles_n / (int)gq.x >= 4) ? (2 | 32 << 8) : 0;
   if (g_w_dbg & 4) stagger256 = 0;
   if (f32 && (g_w_dbg >> 4)) stagger256 = ((g_w_dbg >> 4) & 15) | ((g_w_dbg >> 8) << 8);
-  if (g_use_gemm256 == 9 && f32 && g.act == ACT_NONE && g.resid && g.out_f32 && !g.out_act) {  // register-staged four-wave arm (A/B)
+  if (g.x16) {  // fp16 residual stream: ping-pong kernel with the 2-byte epilogue (eligibility: gemm256_eligible)
+    if (g.f16) hipLaunchKernelGGL((gemm256x_kernel<ACT_NONE, true, true, 256>), gq, dim3(512), shp, st, g, tiles_m, tiles_n, (g_w_dbg & 7) | stagger256 << 8);
+    else hipLaunchKernelGGL((gemm256x_kernel<ACT_NONE, true, false, 256>), gq, dim3(512), shp, st, g, tiles_m, tiles_n, (g_w_dbg & 7) | stagger256 << 8);
+  } else if (g_use_gemm256 == 9 && f32 && g.act == ACT_NONE && g.resid && g.out_f32 && !g.out_act) {  // register-staged four-wave arm (A/B)
 #ifdef CZC_EXPERIMENTS
     if ((g_w_dbg >> 8) && !g.f16) {
 #define CZC_GORD(D_) case D_: \

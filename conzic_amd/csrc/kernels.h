@@ -18,6 +18,10 @@ struct GemmArgs {
   int M, N, K;
   int act;
   int f16 = 0;  // 2-byte operands are IEEE fp16 instead of bf16 (set by launch_gemm from the precision)
+  // 2-byte residual stream (round 5; half-precision engines only): `resid` and `out_f32` point to IEEE fp16 rows (ldr / ldc in
+  // elements) instead of fp32 ones -- x <- fp16(x + A.W^T + b), the sum formed in fp32 and rounded once.  Served by the tiled
+  // kernel, the ping-pong ring kernel and the weight-stationary kernel's residual form; the others refuse it.
+  int x16 = 0;
   // Full-row kernel (gemm_rowln, N = 512): out_f32 <- resid + A.W^T + bias and out_act <- LayerNorm(out_f32; ln_gamma,
   // ln_beta, ln_eps) from one launch.
   const float* ln_gamma = nullptr;
@@ -42,6 +46,9 @@ extern int g_gemm_deep;
 extern int g_gemm_small_tiles;  // 128x128 kernel: two-deep operand prefetch 0 never / 1 for launches of <= one work-group per CU / 2 always
 bool gemm_wreg_eligible(const GemmArgs& g);
 int launch_gemm_wreg(const GemmArgs& g, hipStream_t st);  // gemm_wreg.hip: weights in registers, K = 512
+// the same kernel with a residual epilogue on a 2-byte residual stream (K = 512, N % 256 == 0, x16): x <- fp16(x + A.W^T + b)
+bool gemm_wreg_resid_eligible(const GemmArgs& g);
+int launch_gemm_wreg_resid(const GemmArgs& g, hipStream_t st);
 extern int g_use_wreg;
 extern int g_wreg_min_m, g_gemm256_min_m;  // row-count thresholds of the two big-batch GEMM families
 
@@ -55,6 +62,9 @@ int launch_clip_preprocess(const unsigned char* rgb_dev, int H, int W, int S, co
 // y = LN(x[row_idx ? row_idx[m] : m]) ; x fp32 [*,H]; outputs optional
 int launch_layernorm(int prec, const float* x, const int* row_idx, const float* gamma, const float* beta, float eps,
                      int M, int H, void* y_act, float* y_f32, hipStream_t st);
+// the same on a 2-byte residual stream: x16 = fp16 rows [*,512] (H must be 512, half-precision engines), y_act only
+int launch_layernorm_x16(int prec, const void* x16, const int* row_idx, const float* gamma, const float* beta, float eps, int M,
+                         int H, void* y_act, hipStream_t st);
 // BERT embeddings: word + position + token_type(0) -> LN  (HF:bert/modeling_bert.py:98-106)
 int launch_bert_embed(int prec, const int* ids, int B, int T, int H, const float* word, const float* pos,
                       const float* type0, const float* gamma, const float* beta, float eps, void* y_act, float* y_f32,
@@ -63,7 +73,7 @@ int launch_bert_embed(int prec, const int* ids, int B, int T, int H, const float
 // (HF:clip/modeling_clip.py:250-254)
 int launch_clip_embed(const int* ids, int ids_stride, const int* seg_src, const int* seg_pos0, const int* own_off,
                       const int* own_len, int n_seg, int max_len, int H, const float* tok, const float* pos, float* x,
-                      hipStream_t st);
+                      hipStream_t st, int x16 = 0);  // x16: x is a 2-byte (fp16) residual stream
 // vision: im2col of [B,3,S,S] into patches [B*P, 3*p*p] (act type), then assemble cls/pos
 int launch_im2col(int prec, const float* pixels, int B, int S, int p, void* out, hipStream_t st);
 int launch_vision_assemble(const float* patch_out, int B, int P, int H, const float* cls, const float* pos, float* x,
@@ -203,7 +213,7 @@ int launch_refine_finish(const int* own_off, const int* own_len, const int* coun
 // ---- czc_internal_hooks (include/conzic_hip.h): what libconzic_hip_test.so may reach inside this library -----------
 // The product library has hidden visibility; the hook library (api_test.hip) gets the launchers it wraps and the
 // process-wide kernel-family switches it flips through this table instead of through exported C++ symbols.
-constexpr int HOOKS_ABI = 0x0501;
+constexpr int HOOKS_ABI = 0x0502;
 struct Hooks {
   char* (*err_buf)();  // the calling host thread's g_err [512]
   decltype(&launch_gemm) gemm;
@@ -217,6 +227,7 @@ struct Hooks {
   decltype(&launch_bridge) bridge;
   decltype(&launch_l2_normalize) l2_normalize;
   decltype(&launch_combine) combine;
+  decltype(&launch_layernorm_x16) layernorm_x16;
   int *use_gemm256, *use_skinny, *use_splitk, *gemm_deep, *gemm_small_tiles, *use_wreg, *use_gemm256s, *w_dbg, *ln_lean,
       *rowln_min_m, *wreg_min_m, *gemm256_min_m, *use_mfma_attention, *use_attention_image;
 };

@@ -132,6 +132,61 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const in
   }
 }
 
+// H = 512 rows of a 2-BYTE residual stream (round 5: the bf16 engine's CLIP-text tower keeps x as fp16 rows): a lane owns 8
+// consecutive columns -- one 16-byte load, one 16-byte store -- exact two-pass statistics in fp32, partners 1 .. 16 through
+// ds_swizzle (no address registers: the wave still fits beside the weight-stationary GEMM's two 240-register waves per SIMD).
+// The one LayerNorm of this residual type at every row count, so there is no second kernel to agree with.
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm512_x16_kernel(const f16_t* x, const int* row_idx, const float* gamma,
+                                                               const float* beta, float eps, int M, T* y_act) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const long src = row_idx ? row_idx[m] : m;
+  const uint4 raw = *(const uint4*)(x + src * 512L + lane * 8);
+  float v[8];
+  const unsigned rw[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    v[2 * e] = (float)__builtin_bit_cast(_Float16, (unsigned short)(rw[e] & 0xffffu));
+    v[2 * e + 1] = (float)__builtin_bit_cast(_Float16, (unsigned short)(rw[e] >> 16));
+  }
+  const float mean = wave_sum_rowln_order<true>(((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))) / 512.0f;
+  float q = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; e += 2) {
+    const float a = v[e] - mean, b = v[e + 1] - mean;
+    q += a * a + b * b;
+  }
+  const float rstd = rsqrtf(wave_sum_rowln_order<true>(q) / 512.0f + eps);
+  const float4 g0 = *(const float4*)(gamma + lane * 8), g1 = *(const float4*)(gamma + lane * 8 + 4);
+  const float4 b0 = *(const float4*)(beta + lane * 8), b1 = *(const float4*)(beta + lane * 8 + 4);
+  const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+  const float bt[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+  uint4 o;
+  unsigned* op = (unsigned*)&o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    op[e] = Half<T>::pack2((v[2 * e] - mean) * rstd * gm[2 * e] + bt[2 * e], (v[2 * e + 1] - mean) * rstd * gm[2 * e + 1] + bt[2 * e + 1]);
+  *(uint4*)((unsigned short*)y_act + (long)m * 512 + lane * 8) = o;
+}
+
+int launch_layernorm_x16(int prec, const void* x16, const int* row_idx, const float* gamma, const float* beta, float eps, int M,
+                         int H, void* y_act, hipStream_t st) {
+  if (M <= 0) return 0;
+  if (H != 512 || !prec_is_half(prec) || !y_act) {
+    snprintf(g_err, sizeof(g_err), "layernorm_x16: 512-wide rows of a half-precision engine only (H=%d)", H);
+    return 1;
+  }
+  dim3 grid(cdiv(M, 4)), block(256);
+  if (prec == PREC_BF16)
+    hipLaunchKernelGGL(layernorm512_x16_kernel<bf16_t>, grid, block, 0, st, (const f16_t*)x16, row_idx, gamma, beta, eps, M, (bf16_t*)y_act);
+  else
+    hipLaunchKernelGGL(layernorm512_x16_kernel<f16_t>, grid, block, 0, st, (const f16_t*)x16, row_idx, gamma, beta, eps, M, (f16_t*)y_act);
+  CZC_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
 int g_ln_lean = 1;  // test option ln_lean = 0: the 35-VGPR form of layernorm512_kernel (shuffles through ds_bpermute)
 
 int launch_layernorm(int prec, const float* x, const int* row_idx, const float* gamma, const float* beta, float eps,
@@ -229,7 +284,7 @@ int launch_bert_embed(int prec, const int* ids, int B, int T_, int H, const floa
 __global__ __launch_bounds__(256) void clip_embed_kernel(const int* ids, int ids_stride, const int* seg_src,
                                                          const int* seg_pos0, const int* own_off, const int* own_len,
                                                          int n_seg, int max_len, int H, const float* tok,
-                                                         const float* pos, float* x) {
+                                                         const float* pos, float* x, int x16) {
   const int lane = threadIdx.x & 63;
   const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int s = (int)(w / max_len), i = (int)(w % max_len);
@@ -238,6 +293,14 @@ __global__ __launch_bounds__(256) void clip_embed_kernel(const int* ids, int ids
   const int id = ids[(long)seg_src[s] * ids_stride + p];
   const float* tr = tok + (long)id * H;
   const float* pr = pos + (long)p * H;
+  if (x16) {  // 2-byte residual stream: the same sums, rounded once to fp16
+    f16_t* xh = (f16_t*)x + ((long)own_off[s] + i) * H;
+    for (int c = lane * 4; c < H; c += 256) {
+      const float4 a = *(const float4*)(tr + c), b = *(const float4*)(pr + c);
+      *(uint2*)(xh + c) = make_uint2(pack2_f16(a.x + b.x, a.y + b.y), pack2_f16(a.z + b.z, a.w + b.w));
+    }
+    return;
+  }
   float* xr = x + ((long)own_off[s] + i) * H;
   for (int c = lane * 4; c < H; c += 256) {
     const float4 a = *(const float4*)(tr + c), b = *(const float4*)(pr + c);
@@ -247,11 +310,11 @@ __global__ __launch_bounds__(256) void clip_embed_kernel(const int* ids, int ids
 
 int launch_clip_embed(const int* ids, int ids_stride, const int* seg_src, const int* seg_pos0, const int* own_off,
                       const int* own_len, int n_seg, int max_len, int H, const float* tok, const float* pos, float* x,
-                      hipStream_t st) {
+                      hipStream_t st, int x16) {
   if (n_seg <= 0) return 0;
   dim3 grid(cdiv((long)n_seg * max_len, 4)), block(256);
   hipLaunchKernelGGL(clip_embed_kernel, grid, block, 0, st, ids, ids_stride, seg_src, seg_pos0, own_off, own_len, n_seg,
-                     max_len, H, tok, pos, x);
+                     max_len, H, tok, pos, x, x16);
   CZC_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -534,6 +534,34 @@ def test_gemm(prec, A, W, bias=None, resid=None, act=0, typed_out=False):
     return Cm
 
 
+def test_gemm_x16(prec, A, W, bias, resid):
+    """x = fp16(fp16(resid) + A.W^T + bias) on a 2-byte residual stream (GemmArgs::x16); returned as fp32."""
+    lib = native.load_test()
+    A = np.ascontiguousarray(A, np.float32)
+    W = np.ascontiguousarray(W, np.float32)
+    M, K = A.shape
+    N = W.shape[0]
+    b = None if bias is None else np.ascontiguousarray(bias, np.float32)
+    r = np.ascontiguousarray(resid, np.float32)
+    out = np.empty((M, N), np.float32)
+    native.check(lib.czc_test_gemm_x16(prec, M, N, K, A.ctypes.data, W.ctypes.data, _ptr(b), r.ctypes.data, out.ctypes.data),
+                 None, "czc_test_gemm_x16")
+    return out
+
+
+def test_layernorm_x16(prec, x, gamma, beta, eps):
+    lib = native.load_test()
+    x = np.ascontiguousarray(x, np.float32)
+    M = x.shape[0]
+    assert x.shape[1] == 512
+    g = np.ascontiguousarray(gamma, np.float32)
+    b = np.ascontiguousarray(beta, np.float32)
+    y = np.empty_like(x)
+    native.check(lib.czc_test_layernorm_x16(prec, M, x.ctypes.data, g.ctypes.data, b.ctypes.data, float(eps), y.ctypes.data),
+                 None, "czc_test_layernorm_x16")
+    return y
+
+
 def test_gemm_rowln(prec, A, W, bias, resid, gamma, beta, eps):
     """x = resid + A.W^T + bias and y = LayerNorm(x) from the full-row kernel (W has 512 rows)."""
     lib = native.load_test()

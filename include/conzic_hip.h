@@ -249,6 +249,10 @@ int czc_generate(czc_engine* e, int B, int T, int L, int seed_len, const int32_t
  *   "fuse_ln"         (1) bf16 / fp16 CLIP-text tower at >= 8192 packed rows: the out-projection runs as a full-row
  *                         kernel that also emits LN2 of its result (no LayerNorm pass for it); 2 = fc2 -> the next
  *                         layer's LN1 as well (measured slower), 0 = off
+ *   "resid16"         (1) residual stream of the CLIP-text tower as IEEE fp16 rows in HBM (fp32 accumulate, bias and residual
+ *                         add; one rounding per update): 1 = the bf16 engine (CZC_PREC_BF16), 2 = the single-pass fp16 tower too
+ *                         (outside its validated error budget: experiments), 0 = fp32 rows everywhere.  With it the
+ *                         out-projection runs on the weight-stationary kernel ("fuse_ln" then has nothing to fuse)
  *   "refine_samples" (12), "refine_theta_x1000" (4000): CZC_PREC_REFINE selection -- strata of the mass-stratified sample
  *                         and the softmax_K mass threshold theta = value / 1000 / (beta * exp(logit_scale))
  *   "refine_guard_x1e6" (200): trip point of czc_refine_guard, in units of 1e-6 of cosine

@@ -24,6 +24,13 @@ extern "C" {
  * `precision`, resid must be NULL) instead of the fp32 one -- the path the tower-internal layers use. */
 int czc_test_gemm(int precision, int M, int N, int K, const float* A, const float* W, const float* bias,
                   const float* resid, int act, float* C);
+/* Residual-add layer on a 2-byte residual stream (the bf16 engine's CLIP-text tower, csrc/kernels.h GemmArgs::x16):
+ * x_out[M,N] = fp16(fp16(resid) + A[M,K] * W[N,K]^T + bias), the sum formed in fp32; returned as fp32.  N, K % 8 == 0. */
+int czc_test_gemm_x16(int precision, int M, int N, int K, const float* A, const float* W, const float* bias, const float* resid,
+                      float* x_out);
+/* LayerNorm of fp16 rows, 512 wide: y[M,512] = LN(fp16(x)) rounded to the operand type of `precision` (bf16 / fp16). */
+int czc_test_layernorm_x16(int precision, int M, const float* x, const float* gamma, const float* beta, float eps, float* y);
+
 /* Full-row GEMM with the following LayerNorm in its epilogue (bf16 / fp16 operands, 512 columns, K % 32 == 0):
  *   x_out[M,512] = resid + A[M,K] * W[512,K]^T + bias;  y_out = LayerNorm(x_out; gamma, beta, eps) in the operand type */
 int czc_test_gemm_rowln(int precision, int M, int K, const float* A, const float* W, const float* bias, const float* resid,

@@ -751,3 +751,80 @@ def test_bridge_token_table_equals_the_merge_loop(label):
         lib.czc_test_set_option(b"bridge_no_table", 0)
     np.testing.assert_array_equal(ln0, ln1)
     np.testing.assert_array_equal(ids0, ids1)
+
+
+# ---- round 5: the 2-byte (fp16) residual stream of the bf16 engine's CLIP-text tower ----------------------------------------
+
+def _f16_round(a):
+    return np.ascontiguousarray(a, np.float32).astype(np.float16).astype(np.float32)
+
+
+def _x16_ref(prec, A, W, bias, resid):
+    rnd = _bf16_round if prec == BF16 else _f16_round
+    acc = rnd(A).astype(np.float64) @ rnd(W).astype(np.float64).T
+    return acc + (0 if bias is None else bias.astype(np.float64)) + _f16_round(resid).astype(np.float64)
+
+
+@pytest.mark.parametrize("prec", [BF16, native.PREC_FP16])
+@pytest.mark.parametrize("M,N,K", [(32, 512, 512), (31, 512, 512), (1, 512, 512), (1000, 512, 512), (4097, 512, 512), (20000, 512, 512),
+                                   (40000, 512, 512), (333, 256, 512), (130, 512, 2048), (9000, 512, 2048), (700, 512, 64), (8200, 1024, 512)])
+def test_residual_gemm_on_fp16_rows(prec, M, N, K):
+    """x <- fp16(x + A.W^T + b) for every kernel that serves it: the weight-stationary residual kernel (K = 512: one block,
+    ragged last block, head / steady / tail of the block loop, one or several row sets per column group), the ping-pong ring
+    kernel (>= 8192 rows, K = 2048), the tiled kernel (the rest).  Against fp64 of the rounded operands: within one fp16
+    rounding of the result (the kernels sum in fp32)."""
+    rng = np.random.default_rng(M + 3 * N + K)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
+    W[:, : K // 2] *= 2.0
+    bias = rng.standard_normal(N).astype(np.float32)
+    resid = (rng.standard_normal((M, N)) * 2).astype(np.float32)
+    out = E.test_gemm_x16(prec, A, W, bias, resid)
+    ref = _x16_ref(prec, A, W, bias, resid)
+    tol = np.maximum(np.abs(ref), 1.0) * 2.0 ** -10 + 2e-4 * np.sqrt(K / 64)  # fp16 rounding of the result + fp32 summation order
+    bad = np.abs(out - ref) > tol
+    assert not bad.any(), (int(bad.sum()), float(np.abs(out - ref).max()), np.argwhere(bad)[:4].tolist())
+    out2 = E.test_gemm_x16(prec, A, W, None, resid)  # no bias
+    assert np.abs(out2 - _x16_ref(prec, A, W, None, resid)).max() < float(tol.max())
+
+
+@pytest.mark.parametrize("prec", [BF16, native.PREC_FP16])
+def test_residual_gemm_on_fp16_rows_gives_one_result_per_layer_shape(prec):
+    """fc2 (K = 2048) on the ring kernel and on the tiled kernel (the row-count threshold moved both ways), and the tiled
+    kernel's 64-wide form: bit-identical fp16 rows -- the tower must not change its bits with the batch size.  (The K = 512
+    out-projection runs on the weight-stationary residual kernel at every row count.)"""
+    lib = native.load_test()
+    rng = np.random.default_rng(99)
+    M, N, K = 8200, 512, 2048
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) * 0.03).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    resid = (rng.standard_normal((M, N)) * 2).astype(np.float32)
+    outs = {}
+    try:
+        for name, (mn, small, deep) in {"ring": (1, 4, 1), "tiled": (1 << 30, 0, 1), "tiled64": (1 << 30, 1 << 20, 2)}.items():
+            assert lib.czc_test_set_option(b"gemm256_min_m", mn) == 0 and lib.czc_test_set_option(b"gemm_small_tiles", small) == 0
+            assert lib.czc_test_set_option(b"gemm_deep", deep) == 0
+            outs[name] = E.test_gemm_x16(prec, A, W, bias, resid)
+    finally:
+        lib.czc_test_set_option(b"gemm256_min_m", 8192)
+        lib.czc_test_set_option(b"gemm_small_tiles", 4)
+        lib.czc_test_set_option(b"gemm_deep", 1)
+    np.testing.assert_array_equal(outs["ring"], outs["tiled"])
+    np.testing.assert_array_equal(outs["ring"], outs["tiled64"])
+
+
+@pytest.mark.parametrize("prec", [BF16, native.PREC_FP16])
+def test_layernorm_of_fp16_rows(prec):
+    rng = np.random.default_rng(12)
+    x = (rng.standard_normal((1001, 512)) * 3 + 0.5).astype(np.float32)
+    x[5] *= 40.0   # a row with large entries
+    g = (1 + 0.1 * rng.standard_normal(512)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(512)).astype(np.float32)
+    y = E.test_layernorm_x16(prec, x, g, b, 1e-5)
+    xr = torch.from_numpy(_f16_round(x)).double()
+    ref = torch.nn.functional.layer_norm(xr, (512,), torch.from_numpy(g).double(), torch.from_numpy(b).double(), 1e-5).numpy()
+    rnd = _bf16_round if prec == BF16 else _f16_round
+    tol = np.maximum(np.abs(ref), 1.0) * (2.0 ** -8 if prec == BF16 else 2.0 ** -11) + 1e-5
+    assert (np.abs(y - ref) <= tol).all(), float(np.abs(y - ref).max())
+    assert np.abs(y - rnd(ref.astype(np.float32))).max() <= float(tol.max())
