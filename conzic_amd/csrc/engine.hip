@@ -66,10 +66,14 @@ struct czc_engine {
   // that carry the softmax_K mass (+ a mass-stratified sample of the rest) are re-encoded by the split-fp16 tower
   // (ctext_x / tproj_wx) and the final scores are formed from the mixed cosines (combine.hip)
   bool refine = false;
-  float refine_theta_x = 4.0f;  // mass threshold theta = refine_theta_x / (beta * exp(logit_scale)): 0.02 at beta 2, scale 100
+  // mass threshold theta = refine_theta_x / (beta * exp(logit_scale)): 0.01 at beta 2, scale 100.  A candidate that keeps its
+  // screening cosine moves its fused score by at most theta_x * |d_k - mean|: round 5 lowered theta_x from 4 to 2, so the
+  // largest deviation measured (2.1e-4 over 256 k candidates) gives 4.2e-4 instead of 8.4e-4 of the 1e-3 bar
+  float refine_theta_x = 2.0f;
   int refine_samples = 12;      // strata of the sample among the candidates below the threshold
-  // guard: an image-step whose re-encoded candidates show |screening error - mean| above refine_guard_dev voids the 1e-3
-  // bound for that step (theta_x * dev <= 1e-3 needs dev <= 2.5e-4 at the default theta_x; trip point 0.8 of that)
+  // guard: the ~20 candidates an image re-encodes show their own |screening error - mean|; the candidates that keep their
+  // screening cosine reach at most GUARD_RATIO = 2 times that sample maximum (fitted: 1.75 worst over 1280 image-steps), so
+  // theta_x * 2 * sample_dev <= 1e-3 holds while sample_dev <= 2.5e-4 at theta_x = 2; trip point 0.8 of that
   float refine_guard_dev = 2.0e-4f;
   float guard_max_dev = 0.f; int64_t guard_trips = 0;   // since the last czc_refine_guard(reset = 1)
   // margin gate (czc_generate only; combine.hip refine_select_kernel): an image whose screening winner survives every

@@ -267,19 +267,22 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, 
 // i.e. the out-projection without a 128 x 512 full-row tile that re-streams all of W per 128 rows (gemm_rowln: 10 KB per row
 // through the CU's vector-memory path; here 2 x 1 KB of activations for the two column groups + 1 KB residual in + 1 KB x
 // out).  Differences from gemm_wreg_kernel:
-//   * the epilogue patch is fp32 (32 rows x 128 B per wave: ring 128 KiB + 8 x 4 KiB = the full 160 KiB), so that bias and
-//     residual are added in fp32 and the sum is rounded to fp16 once; the bias lives in registers (8 columns per lane in
-//     the store layout);
-//   * the residual rows of block i (two 16-byte loads per lane, the store layout) are requested in block i's own MFMA
-//     stream and consumed in block i+1's -- a whole block period of latency cover -- into one of two register sets chosen
-//     by the block's PARITY at compile time (a run-time select would read a register with a load in flight);
-//   * VMEM order per block: D0 R0 D1 R1 D2 S0 D3 S1 (DMA pieces of block i+3, residual rows of block i, stores of block
-//     i-1), every one from inline asm, so every wait is an exact count: block i's operands have landed at vmcnt(17)
-//     (S1 + two full periods younger), R0 / R1 of block i-1 at vmcnt(11) in front of S0 / S1;
+//   * every wave owns two 2 KiB LDS tiles (32 rows x 32 columns of fp16, slot = block parity: ring 128 KiB + 8 x 4 KiB = the
+//     full 160 KiB; the bias lives in registers).  The residual rows of block i arrive in tile i & 1 by LDS-DMA (two
+//     instructions: 16 rows x 64 B each, chunk-XOR swizzled in the source address), requested in block i's own MFMA stream
+//     and consumed in block i+1's: a block period of latency cover and NO register with a load in flight across a branch or
+//     a loop edge (a first version kept the rows in registers: hipcc copied such a register at a join before the load had
+//     landed -- correct at 40 k rows, garbage at 64 k);
+//   * the epilogue adds in the accumulator layout: lane (row, 4 columns) reads its four residual values from the tile
+//     (ds_read_b64), forms (acc + bias) + residual in fp32, rounds once to fp16 and writes the result back IN PLACE; the
+//     store pass then reads the tile in 16-byte pieces, 16 rows x 64 B per buffer store as in gemm_wreg_kernel;
+//   * VMEM order per block: D0 R0 D1 R1 D2 D3 S0 S1 (DMA pieces of block i+3, residual tiles of block i, stores of block
+//     i-1), all from inline asm, so the waits are exact counts: block i's operands have landed at vmcnt(18), the residual
+//     tile of block i-1 at vmcnt(7) in front of the first epilogue quad;
 //   * one accumulator chain (gfx950 forwards a dependent same-type MFMA's accumulator): 16 registers less.
 // ================================================================================================
-constexpr int WRR_PATCH = 4096;
-constexpr int WRR_LDS = WR_D * WR_STAGE + 8 * WRR_PATCH;
+constexpr int WRR_TILE = 2048;                    // 32 rows x 64 B
+constexpr int WRR_LDS = WR_D * WR_STAGE + 8 * 2 * WRR_TILE;
 static_assert(WRR_LDS <= 160 * 1024, "LDS budget");
 
 template <bool F16>
@@ -291,8 +294,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_resid_kernel(GemmArgs g, int
   const int half = lane >> 5, l31 = lane & 31;
 
   const int q = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-  // integer division runs on the VALU: pin its (uniform) results to SGPRs here, or hipcc moves every descriptor that
-  // depends on them -- with this many users -- to VGPRs, which an asm "s" operand cannot take
+  // integer division runs on the VALU: pin its (uniform) results to SGPRs
   const int set = __builtin_amdgcn_readfirstlane(q / ncg), cg = q - set * ncg;
   if (set >= nsets) return;
   const int per = __builtin_amdgcn_readfirstlane((nblk + nsets - 1) / nsets);
@@ -307,19 +309,20 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_resid_kernel(GemmArgs g, int
 #pragma unroll
     for (int t = 0; t < 32; ++t) wreg[t] = *(const u32x4_t*)(wp + t * 32);
   }
-  // store layout: lane = 4 * row + slot; the lane owns columns col0 + 8 * slot .. + 7 of rows pass * 16 + (lane >> 2)
-  const int rrow = lane >> 2, rs = lane & 3;
-  const int ccol = col0 + rs * 8;
-  f32x4_t bias_lo = {0.f, 0.f, 0.f, 0.f}, bias_hi = {0.f, 0.f, 0.f, 0.f};
-  if (g.bias) { bias_lo = *(const f32x4_t*)(g.bias + ccol); bias_hi = *(const f32x4_t*)(g.bias + ccol + 4); }
+  // accumulator layout: lane (row l31, half) holds columns col0 + 8 qd + 4 half .. + 3 of quad qd
+  f32x4_t bias4[4];
+#pragma unroll
+  for (int qd = 0; qd < 4; ++qd) {
+    bias4[qd] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (g.bias) bias4[qd] = *(const f32x4_t*)(g.bias + col0 + 8 * qd + 4 * half);
+  }
 #pragma unroll
   for (int t = 0; t < 32; t += 8)
     asm volatile("" ::"v"(wreg[t]), "v"(wreg[t + 1]), "v"(wreg[t + 2]), "v"(wreg[t + 3]), "v"(wreg[t + 4]), "v"(wreg[t + 5]),
                  "v"(wreg[t + 6]), "v"(wreg[t + 7]));
-  asm volatile("" ::"v"(bias_lo), "v"(bias_hi));  // waited for here, once, like the weight panel
-  unsigned char* patch = smem + WR_D * WR_STAGE + wave * WRR_PATCH;
+  asm volatile("" ::"v"(bias4[0]), "v"(bias4[1]), "v"(bias4[2]), "v"(bias4[3]));  // waited for here, once, like the weight panel
+  unsigned char* tiles = smem + WR_D * WR_STAGE + wave * (2 * WRR_TILE);
 
-  // ---- DMA side (as gemm_wreg_kernel) ----
   const unsigned lds0 = __builtin_amdgcn_readfirstlane(
       (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem);
   const int pitch = g.lda * 2;
@@ -329,8 +332,8 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_resid_kernel(GemmArgs g, int
     const int r = wave * 4 + ii;
     voff[ii] = r * pitch + ((lane ^ (r & 15)) << 4);
   }
-  // descriptors are rebuilt from scalars where they are used (a few SALU each; no vector carried around the block loop:
-  // hipcc kept such a loop-carried descriptor in VGPRs here, which an asm "s" operand cannot take)
+  // descriptors are rebuilt from scalars where they are used (a few SALU each): a descriptor carried around the block loop
+  // ended up in VGPRs here, which an asm "s" operand cannot take
   auto desc_rows = [&](const void* base, int j, int row_pitch) __attribute__((always_inline)) {
     const long row0 = (long)(b0 + j) * WR_BLK;
     const unsigned long long pa = (unsigned long long)base + (unsigned long long)row0 * row_pitch;
@@ -356,11 +359,6 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_resid_kernel(GemmArgs g, int
         : "s"(dst), "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "s"(d)
         : "memory", "scc");
   };
-  int va[8];
-#pragma unroll
-  for (int tl = 0; tl < 8; ++tl) va[tl] = l31 * WR_ROWB + ((((2 * tl + half) ^ (l31 & 15)) & 15) << 4);
-  f32x16_t acc0, accP;
-
   auto dma_piece = [&](int ii, int j) __attribute__((always_inline)) {
     const u32x4_t d = desc_rows(g.A, j, pitch);
     const unsigned dst = lds0 + (j & (WR_D - 1)) * WR_STAGE + wave * (4 * WR_ROWB) + ii * WR_ROWB;
@@ -370,50 +368,65 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_resid_kernel(GemmArgs g, int
                  : "s"(dst), "v"(voff[ii]), "s"(d)
                  : "memory");
   };
-
-  // residual rows in / x rows out: fp16, the same lane map for both (a lane reads and later writes the same 16 bytes)
-  const int cpitch = g.ldc * 2, rpitch = g.ldr * 2;
-  const unsigned coff0 = (unsigned)(rrow * cpitch + ccol * 2), coff1 = (unsigned)((16 + rrow) * cpitch + ccol * 2);
-  const unsigned roff0 = (unsigned)(rrow * rpitch + ccol * 2), roff1 = (unsigned)((16 + rrow) * rpitch + ccol * 2);
-  u32x4_t rres[2][2];  // [block parity][pass]; indexed with compile-time constants only
-  auto epi_quad = [&](int qd) __attribute__((always_inline)) {  // accP quad qd (row l31, columns 8 qd + 4 half .. + 3) -> fp32 patch
-    const int slot = (2 * qd + half) ^ (l31 & 7);
-    *(float4*)(patch + l31 * 128 + slot * 16) = make_float4(accP[4 * qd], accP[4 * qd + 1], accP[4 * qd + 2], accP[4 * qd + 3]);
-  };
-  auto epi_store = [&](int pass, int js, u32x4_t& rr, auto wait_c) __attribute__((always_inline)) {  // 16 patch rows + bias + residual -> fp16 -> one buffer store
-    constexpr int WAITN = decltype(wait_c)::value;
-    const int r = pass * 16 + rrow;
-    const float4 t0 = *(const float4*)(patch + r * 128 + (((2 * rs) ^ (r & 7)) << 4));
-    const float4 t1 = *(const float4*)(patch + r * 128 + (((2 * rs + 1) ^ (r & 7)) << 4));
-    if constexpr (WAITN == 11) asm volatile("s_waitcnt vmcnt(11)" : "+v"(rr) : : "memory");
-    else if constexpr (WAITN == 9) asm volatile("s_waitcnt vmcnt(9)" : "+v"(rr) : : "memory");
-    else if constexpr (WAITN == 3) asm volatile("s_waitcnt vmcnt(3)" : "+v"(rr) : : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(rr) : : "memory");
-    const float v[8] = {t0.x + bias_lo[0], t0.y + bias_lo[1], t0.z + bias_lo[2], t0.w + bias_lo[3],
-                        t1.x + bias_hi[0], t1.y + bias_hi[1], t1.z + bias_hi[2], t1.w + bias_hi[3]};
-    u32x4_t o;
+  int va[8];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const unsigned pr = rr[e];
-      const float lo = (float)__builtin_bit_cast(_Float16, (unsigned short)(pr & 0xffffu));
-      const float hi = (float)__builtin_bit_cast(_Float16, (unsigned short)(pr >> 16));
-      o[e] = pack2_f16(v[2 * e] + lo, v[2 * e + 1] + hi);
-    }
-    const unsigned co = pass ? coff1 : coff0;  // (a generic lambda does not capture what only an asm operand names)
-    const u32x4_t rc = desc_rows(g.out_f32, js, cpitch);
+  for (int tl = 0; tl < 8; ++tl) va[tl] = l31 * WR_ROWB + ((((2 * tl + half) ^ (l31 & 15)) & 15) << 4);
+  f32x16_t acc0, accP;
+
+  // residual tile of block j -> slot j & 1: DMA lane = 4 * row + physical chunk; logical chunk = physical ^ ((row >> 2) & 3)
+  const int cpitch = g.ldc * 2, rpitch = g.ldr * 2;
+  const int drow = lane >> 2, dsw = (lane >> 4) & 3;
+  const unsigned roff0 = (unsigned)(drow * rpitch + (col0 + (((lane & 3) ^ dsw) << 3)) * 2);
+  const unsigned roff1 = roff0 + (unsigned)(16 * rpitch);
+  const unsigned tile0 = lds0 + WR_D * WR_STAGE + wave * (2 * WRR_TILE);
+  auto resid_dma = [&](int pass, int j) __attribute__((always_inline)) {
+    const u32x4_t rd = desc_rows(g.resid, j, rpitch);
+    const unsigned dst = tile0 + (j & 1) * WRR_TILE + pass * 1024;
+    const unsigned ro = pass ? roff1 : roff0;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "s"(dst), "v"(ro), "s"(rd)
+                 : "memory");
+  };
+  // store layout: lane = 4 * row + chunk; the lane owns columns col0 + 8 * chunk .. + 7 of rows pass * 16 + (lane >> 2)
+  const int rs = lane & 3;
+  const unsigned coff0 = (unsigned)(drow * cpitch + (col0 + rs * 8) * 2), coff1 = coff0 + (unsigned)(16 * cpitch);
+  const int equad = l31 * 64 + half * 8;             // this lane's 8 bytes inside a 16-byte chunk of tile row l31
+  const int esw = (l31 >> 2) & 3;
+  auto epi_quad = [&](int qd, int j) __attribute__((always_inline)) {  // (accP quad + bias) + residual -> fp16, in place in the tile
+    unsigned char* pq = tiles + (j & 1) * WRR_TILE + equad + ((qd ^ esw) << 4);
+    const uint2 rv = *(const uint2*)pq;
+    const float r0 = (float)__builtin_bit_cast(_Float16, (unsigned short)(rv.x & 0xffffu));
+    const float r1 = (float)__builtin_bit_cast(_Float16, (unsigned short)(rv.x >> 16));
+    const float r2 = (float)__builtin_bit_cast(_Float16, (unsigned short)(rv.y & 0xffffu));
+    const float r3 = (float)__builtin_bit_cast(_Float16, (unsigned short)(rv.y >> 16));
+    const float v0 = (accP[4 * qd] + bias4[qd][0]) + r0, v1 = (accP[4 * qd + 1] + bias4[qd][1]) + r1;
+    const float v2 = (accP[4 * qd + 2] + bias4[qd][2]) + r2, v3 = (accP[4 * qd + 3] + bias4[qd][3]) + r3;
+    *(uint2*)pq = make_uint2(pack2_f16(v0, v1), pack2_f16(v2, v3));
+  };
+  auto epi_store = [&](int pass, int j) __attribute__((always_inline)) {  // 16 tile rows -> one buffer store
+    const int r = pass * 16 + drow;
+    const u32x4_t o = *(const u32x4_t*)(tiles + (j & 1) * WRR_TILE + r * 64 + ((rs ^ ((r >> 2) & 3)) << 4));
+    const unsigned co = pass ? coff1 : coff0;
+    const u32x4_t rc = desc_rows(g.out_f32, j, cpitch);
     asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" : : "v"(o), "v"(co), "s"(rc) : "memory");
   };
-  auto resid_load = [&](int pass, int j, u32x4_t& rr) __attribute__((always_inline)) {
-    const u32x4_t rd = desc_rows(g.resid, j, rpitch);
-    const unsigned ro = pass ? roff1 : roff0;
-    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(rr) : "v"(ro), "s"(rd) : "memory");
+  auto wait_resid = [&](int n) __attribute__((always_inline)) {  // at most n younger VMEM instructions stay in flight
+    switch (n) {
+      case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+      case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    }
   };
 
-  // block i in ring slot `slot`; PAR = i & 1; WAITN = how many younger VMEM instructions may be in flight when the
-  // residual rows of block i-1 are consumed (11 steady; 9 when block i-1 = 0 had no stores yet; 3 = the safe minimum)
-  auto mfma_block = [&](int slot, auto par_c, auto wait_c, bool refill, bool prev, int i, int jd, int js) __attribute__((always_inline)) {
-    constexpr int PAR = decltype(par_c)::value;
-    const unsigned char* sA = smem + slot * WR_STAGE;
+  // block i in ring slot i & 3.  VMEM order: D0 R0 D1 R1 D2 D3 S0 S1; the epilogue of block i-1 (accP) rides in the stream
+  auto mfma_block = [&](auto steady_c, bool refill_rt, bool prev_rt, int rwait, int i) __attribute__((always_inline)) {
+    constexpr bool STEADY = decltype(steady_c)::value;
+    const bool refill = STEADY || refill_rt, prev = STEADY || prev_rt;
+    const unsigned char* sA = smem + (i & (WR_D - 1)) * WR_STAGE;
+    const int jd = i + WR_D - 1, js = i - 1;
     u32x4_t fr[2][4];
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc0[r] = 0.f;
@@ -432,17 +445,17 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_resid_kernel(GemmArgs g, int
       for (int k = 0; k < 4; ++k) acc0 = Half<HT>::mfma(wreg[4 * sgm + k], fr[sgm & 1][k], acc0);
       __builtin_amdgcn_sched_barrier(0);
       if (sgm == 0 && refill) dma_piece(0, jd);
-      if (sgm == 1) resid_load(0, i, rres[PAR][0]);
-      if (sgm == 1 && prev) epi_quad(0);
+      if (sgm == 1) resid_dma(0, i);
       if (sgm == 2 && refill) dma_piece(1, jd);
-      if (sgm == 2 && prev) epi_quad(1);
-      if (sgm == 3) resid_load(1, i, rres[PAR][1]);
-      if (sgm == 3 && prev) epi_quad(2);
+      if (sgm == 2 && prev) { if (STEADY) wait_resid(7); else wait_resid(rwait); epi_quad(0, js); }
+      if (sgm == 3) resid_dma(1, i);
+      if (sgm == 3 && prev) epi_quad(1, js);
       if (sgm == 4 && refill) dma_piece(2, jd);
-      if (sgm == 4 && prev) epi_quad(3);
-      if (sgm == 5 && prev) epi_store(0, js, rres[1 - PAR][0], wait_c);
-      if (sgm == 6 && refill) dma_piece(3, jd);
-      if (sgm == 7 && prev) epi_store(1, js, rres[1 - PAR][1], wait_c);
+      if (sgm == 4 && prev) epi_quad(2, js);
+      if (sgm == 5 && refill) dma_piece(3, jd);
+      if (sgm == 5 && prev) epi_quad(3, js);
+      if (sgm == 6 && prev) epi_store(0, js);
+      if (sgm == 7 && prev) epi_store(1, js);
       __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -450,43 +463,42 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_resid_kernel(GemmArgs g, int
   const int pro = nb < WR_D - 1 ? nb : WR_D - 1;
   for (int j = 0; j < pro; ++j) issue(j);
   {
-    using P0 = std::integral_constant<int, 0>;
-    using P1 = std::integral_constant<int, 1>;
-    using W11 = std::integral_constant<int, 11>;
-    using W9 = std::integral_constant<int, 9>;
-    using W3 = std::integral_constant<int, 3>;
-    // steady block: refill and epilogue unconditional, exact counts
-    auto steady = [&](int i, auto par_c) __attribute__((always_inline)) {
-      asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    // steady block: its operands were requested in block i-3's stream (last piece at position 6 of D0 R0 D1 R1 D2 D3 S0 S1):
+    // S0 S1 + two full periods = 18 younger.  The residual tile of block i-1 (R1 at position 4 of its stream) is waited for
+    // in front of quad 0, in slot 2 behind D0 R0 D1: D2 D3 S0 S1 + D0 R0 D1 = 7 younger
+    auto steady = [&](int i) __attribute__((always_inline)) {
+      asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      mfma_block(i & (WR_D - 1), par_c, W11(), true, true, i, i + WR_D - 1, i - 1);
+      mfma_block(T_(), true, true, 7, i);
 #pragma unroll
       for (int r = 0; r < 16; ++r) accP[r] = acc0[r];
     };
-    // head / tail block: conservative waits (any count <= the number of younger instructions is safe)
-    auto edge = [&](int i, auto par_c) __attribute__((always_inline)) {
-      const bool refill = i + WR_D - 1 < nb;
+    // head / tail block: conservative counts (any count <= the number of younger instructions is safe)
+    auto edge = [&](int i) __attribute__((always_inline)) {
+      const bool refill = i + WR_D - 1 < nb, refill_prev = i + WR_D - 2 < nb;
       if (i + 2 >= nb) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else if (i < 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if (refill && i >= 2) mfma_block(i & (WR_D - 1), par_c, W11(), true, true, i, i + WR_D - 1, i - 1);
-      else if (refill && i == 1) mfma_block(i & (WR_D - 1), par_c, W9(), true, true, i, i + WR_D - 1, i - 1);
-      else mfma_block(i & (WR_D - 1), par_c, W3(), refill, i > 0, i, i + WR_D - 1, i - 1);
+      // younger than R1(i-1) at the wait: [D2 D3 if block i-1 refilled] [S0 S1 if i-1 > 0] of its stream, then of this one
+      // [D0] R0 [D1] (the D's if this block refills)
+      const int rw = (refill_prev ? 2 : 0) + (i > 1 ? 2 : 0) + 1 + (refill ? 2 : 0);  // 1, 3, 5 or 7
+      mfma_block(F_(), refill, i > 0, rw, i);
 #pragma unroll
       for (int r = 0; r < 16; ++r) accP[r] = acc0[r];
     };
     int i = 0;
-    for (; i < nb && i < 4; ++i) { if (i & 1) edge(i, P1()); else edge(i, P0()); }
-    for (; i + WR_D < nb; i += 2) { steady(i, P0()); steady(i + 1, P1()); }  // i is even here
-    for (; i < nb; ++i) { if (i & 1) edge(i, P1()); else edge(i, P0()); }
-    // last block's epilogue: its residual rows were requested in its own stream
-    epi_quad(0); epi_quad(1); epi_quad(2); epi_quad(3);
-    using W0 = std::integral_constant<int, 0>;
-    if ((nb - 1) & 1) { epi_store(0, nb - 1, rres[1][0], W0()); epi_store(1, nb - 1, rres[1][1], W0()); }
-    else { epi_store(0, nb - 1, rres[0][0], W0()); epi_store(1, nb - 1, rres[0][1], W0()); }
+    for (; i < nb && i < 4; ++i) edge(i);
+    for (; i + WR_D - 1 < nb; ++i) steady(i);
+    for (; i < nb; ++i) edge(i);
+    // last block's epilogue: its residual tile was requested in its own stream
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    epi_quad(0, nb - 1); epi_quad(1, nb - 1); epi_quad(2, nb - 1); epi_quad(3, nb - 1);
+    epi_store(0, nb - 1); epi_store(1, nb - 1);
   }
 }
 

@@ -288,11 +288,17 @@ def run_generation(order: str, img_name, model, clip, tokenizer, image_instance,
         # on the validated weights; every step measures that error on the candidates it re-encodes exactly
         g = runner.refine_guard(reset=True)
         if g["tripped"]:
+            trip = float(os.environ.get("CZC_REFINE_GUARD_X1E6", "200")) * 1e-6
             logger.info(f"screen-then-refine guard: |screening error - mean| reached {g['max_dev']:.2e} on {g['tripped']} "
-                        f"image-steps (budget 2.5e-4)" + ("; repeating the call on the all-split engine" if guard_mode == "rerun" else ""))
+                        f"image-steps (trip point {trip:.1e})" + ("; repeating the call on the all-split engine" if guard_mode == "rerun" else ""))
             if guard_mode == "rerun":
                 from clip.clip import ImageEmbeds
                 emb = image_instance.embeds if isinstance(image_instance, ImageEmbeds) else clip.last_image_embeds()
+                # the replicas' workspaces (one per stream) go before the second engine is built on the same GPU
+                grp = getattr(eng, "_group", None)
+                if grp is not None:
+                    grp.close(parent=False)
+                    eng._group = None
                 eng2 = get_engine(model, clip, tokenizer, precision=native.PREC_SPLIT)
                 eng2.set_image_embeds(emb)   # the refine engine's vision tower is the split-fp16 one: same embeddings
                 (ids, cos), _ = polish(eng2)

@@ -26,7 +26,7 @@ from conzic_amd.engine import Engine  # noqa: E402
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 P = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 SAMPLES = [int(v) for v in (sys.argv[3] if len(sys.argv) > 3 else "12").split(",")]
-THETAS = [int(v) for v in (sys.argv[4] if len(sys.argv) > 4 else "4000").split(",")]
+THETAS = [int(v) for v in (sys.argv[4] if len(sys.argv) > 4 else "2000").split(",")]
 L, K, SEED_LEN, SCALE = 10, 200, 4, 4.6052
 hp = Engine.hyper(0.02, 2.0, 0.1)
 rng = np.random.default_rng(2026)
@@ -57,9 +57,14 @@ for th in THETAS:
         su.engine.set_option("refine_theta_x1000", th)
         su.engine.profile_reset()
         su.engine.refine_guard(reset=True)
-        errs, agree, n, margins = [], 0, 0, []
+        errs, agree, n, margins, ratios, true_dev = [], 0, 0, [], [], 0.0
         for p, (before, r) in enumerate(gold):
-            res = su.engine.step(before.copy(), SEED_LEN + (p % L), K, hp, dot_allowed=(p % L == L - 1), want=("idxs", "final_score", "best"))
+            res = su.engine.step(before.copy(), SEED_LEN + (p % L), K, hp, dot_allowed=(p % L == L - 1), want=("idxs", "final_score", "best", "clip_ref"))
+            # a candidate that keeps its screening cosine shows (screening error - estimated mean) in clip_ref; re-encoded ones ~0
+            dev_true = float(np.abs(res["clip_ref"] - r["clip_ref"]).max())
+            gstep = su.engine.refine_guard(reset=False)
+            true_dev = max(true_dev, dev_true)
+            ratios.append(dev_true)
             assert (res["idxs"] == r["idxs"]).all()
             d = np.abs(res["final_score"] - r["final_score"])
             errs.append(d.reshape(-1))
@@ -71,13 +76,13 @@ for th in THETAS:
         e = np.concatenate(errs)
         st = su.engine.stats()
         gd = su.engine.refine_guard(reset=True)
-        print(json.dumps(dict(guard_max_dev=gd["max_dev"], guard_tripped_image_steps=gd["tripped"], images=B, positions=P, K=K, logit_scale=SCALE, refine_samples=m, theta_x=th / 1000.0,
+        print(json.dumps(dict(true_max_dev=true_dev, true_over_sample_dev=round(true_dev / max(gd["max_dev"], 1e-12), 3), guard_max_dev=gd["max_dev"], guard_tripped_image_steps=gd["tripped"], images=B, positions=P, K=K, logit_scale=SCALE, refine_samples=m, theta_x=th / 1000.0,
                               max_abs_dfinal=float(e.max()), p999=float(np.quantile(e, 0.999)), mean=float(e.mean()),
                               image_steps=n, winners_identical=agree, reference_margin_at_flips=margins,
                               re_encoded_seq_frac=round(st["refine_seqs"] / max(st["clip_seqs"], 1), 4),
                               re_encoded_row_frac=round(st["refine_rows"] / max(st["clip_rows"], 1), 4))), flush=True)
 su.engine.set_option("refine_samples", 12)
-su.engine.set_option("refine_theta_x1000", 4000)
+su.engine.set_option("refine_theta_x1000", 2000)
 for gate in (400, 0):
     su.engine.set_option("refine_gate_x1e6", gate)
     su.engine.profile_reset()
