@@ -492,7 +492,7 @@ def main():
         # command (not measurable inside the run); only quoted for the workload and precision they were taken on
         traffic, src = None, None
         key = {native.PREC_BF16: "bf16", native.PREC_REFINE: "refine"}.get(prec_)
-        for tp in ("r04_bench_gemm_traffic.json", "r03_bench_gemm_traffic.json"):
+        for tp in ("r05_bench_gemm_traffic.json", "r04_bench_gemm_traffic.json", "r03_bench_gemm_traffic.json"):
             tp = os.path.join(ROOT, "profiles", tp)
             if key and os.path.exists(tp) and (a.images, L, K, I, a.order, a.gamma, a.total_images) == (256, 10, 200, 10, "sequential", None, None):
                 tj = json.load(open(tp))
@@ -502,11 +502,15 @@ def main():
                            "WRITE_SIZE passes over one caption batch of this workload, gfx950 FETCH_SIZE x2 correction)")
                     break
         fused = not any(kv.replace(" ", "") == "fuse_ln=0" for kv in a.opt)
+        r16 = not any(kv.replace(" ", "") == "resid16=0" for kv in a.opt)  # bf16 engine: fp16 residual stream (engine option resid16)
         half = ("CLIP-text linear layers: czc::gemm_wreg_kernel<%s> (qkv, fc1; weights in registers) + "
                 + ("czc::gemm_rowln_kernel<%s> (out-proj on full 512-wide rows; its launches also do the LayerNorm that follows) + "
                    "czc::gemm256x_kernel<%s> (fc2; 256x256 LDS-DMA ring, two wave groups one phase apart)" if fused else
                    "czc::gemm256x_kernel<%s> (out-proj, fc2; 256x256 LDS-DMA ring, two wave groups one phase apart)"))
-        kern = {native.PREC_BF16: half % (("bf16",) * (3 if fused else 2)),
+        half16 = ("CLIP-text linear layers on a 2-byte (fp16) residual stream: czc::gemm_wreg_kernel<bf16> (qkv, fc1; weights in registers) + "
+                  "czc::gemm_wreg_resid_kernel<bf16> (out-proj; weights in registers, residual rows through per-wave LDS tiles, x updated "
+                  "in place) + czc::gemm256x_kernel<bf16, x16 epilogue> (fc2; 256x256 LDS-DMA ring, two wave groups one phase apart)")
+        kern = {native.PREC_BF16: half16 if r16 else half % (("bf16",) * (3 if fused else 2)),
                 native.PREC_FP16: half % (("fp16",) * (3 if fused else 2)),
                 native.PREC_SPLIT: "CLIP-text linear layers: czc::gemm256sq_kernel (split-fp16 operands, 256x256 LDS-DMA ring, three "
                                    "v_mfma_f32_32x32x16_f16 per product)",

@@ -1244,8 +1244,12 @@ int czc_generate(czc_engine* e, int B, int T, int L, int seed_len, const int32_t
     if (pos < 0 || pos >= L) return fail(e, CZC_ERR_ARG, "generate: position out of range%s");
     const int nm = n_mask_host ? n_mask_host[s] : 1;
     // what this call returns of a step: the ids it leaves in d_inp and, at the snapshot steps, the winner's cosine
-    e->gate_now = e->refine && e->refine_gate_delta > 0.f;
-    e->gate_need_cos = out_cos != nullptr && (s + 1) % snapshot_every == 0;
+    // snapshot steps with a cosine to return take the full selection for every image: the returned cosines come from the
+    // established exact path, and the guard (czc_refine_guard) keeps measuring the screening tower on every image once per
+    // sweep although most of the other steps are gated
+    const bool snap_step = (s + 1) % snapshot_every == 0;
+    e->gate_now = e->refine && e->refine_gate_delta > 0.f && !(snap_step && out_cos);
+    e->gate_need_cos = false;
     E_CHECK(step_device(e, d_inp, B, T, seed_len + pos, nm, pos == L - 1 ? 1 : 0, top_k, hp));
     if ((s + 1) % snapshot_every == 0) {
       if (out_ids)

@@ -915,6 +915,7 @@ def test_fused_layernorm_matches_layernorm_kernel(name, steps, prec):
     outs = []
     try:
         assert lib.czc_test_set_option(b"rowln_min_m", 256) == 0
+        eng.set_option("resid16", 0)   # the fp32 residual stream (what the fp16 / refine engines run; bf16: the option's 0 arm)
         for fuse in (2, 1, 0):
             eng.set_option("fuse_ln", fuse)
             eng.profile(1)
@@ -929,6 +930,7 @@ def test_fused_layernorm_matches_layernorm_kernel(name, steps, prec):
     finally:
         lib.czc_test_set_option(b"rowln_min_m", 8192)
         eng.set_option("fuse_ln", 1)
+        eng.set_option("resid16", 1)
     for fused in outs[:2]:
         for ra, rb in zip(fused[0], outs[2][0]):
             np.testing.assert_array_equal(ra["clip_ids"], rb["clip_ids"])

@@ -10,7 +10,7 @@ import sys
 from collections import defaultdict
 
 FAMILIES = [("gemm_rowln", "gemm_rowln_kernel"), ("gemm256x", "gemm256x_kernel"), ("gemm256q", "gemm256q_kernel"),
-            ("gemm256sq", "gemm256sq_kernel"), ("gemm_wreg", "gemm_wreg_kernel"), ("gemm_128_split", "gemm_kernel<czc::split_t"),
+            ("gemm256sq", "gemm256sq_kernel"), ("gemm_wreg_resid", "gemm_wreg_resid_kernel"), ("gemm_wreg", "gemm_wreg_kernel"), ("gemm_128_split", "gemm_kernel<czc::split_t"),
             ("gemm_128_bf16", "gemm_kernel<unsigned short"), ("gemm_skinny", "gemm_skinny"), ("attention", "attention_")]
 
 
@@ -43,7 +43,7 @@ def main(d):
         out[fam] = dict(launches=launches[fam], mfma_tflop=round(fl / 1e12, 3),
                         mfma_busy_share_of_simd_cycles=None if not gui else round(busy / (1024.0 * gui / 8.0), 4),  # GRBM_GUI_ACTIVE is summed over the 8 XCDs
                         gui_active_cycles=gui)
-    clip = sum(v["mfma_tflop"] for k, v in out.items() if k in ("gemm_rowln", "gemm256x", "gemm256q", "gemm_wreg", "gemm_128_bf16"))
+    clip = sum(v["mfma_tflop"] for k, v in out.items() if k in ("gemm_rowln", "gemm256x", "gemm256q", "gemm_wreg", "gemm_wreg_resid", "gemm_128_bf16"))
     print(json.dumps(dict(per_family=out, total_mfma_tflop=round(tot / 1e12, 3), clip_half_precision_gemm_tflop=round(clip, 3),
                           files=len(files)), indent=1))
 

@@ -9,11 +9,11 @@ import sys
 from collections import defaultdict
 
 FAMILIES = [("gemm_rowln", "gemm_rowln_kernel"), ("gemm256x", "gemm256x_kernel"), ("gemm256q", "gemm256q_kernel"), ("gemm256sq", "gemm256sq_kernel"),
-            ("gemm_wreg", "gemm_wreg_kernel"), ("gemm_split_128", "gemm_kernel<czc::split_t"),
-            ("layernorm", "layernorm_kernel"), ("attention_image", "attention_image_kernel"),
+            ("gemm_wreg_resid", "gemm_wreg_resid_kernel"), ("gemm_wreg", "gemm_wreg_kernel"), ("gemm_split_128", "gemm_kernel<czc::split_t"),
+            ("layernorm", "layernorm"), ("attention_image", "attention_image_kernel"),
             ("attention_branch_split", "attention_branch_split_kernel")]
-GEMM_TEXT = {"bf16": ("gemm_rowln", "gemm256x", "gemm256q", "gemm_wreg"), "fp16": ("gemm_rowln", "gemm256x", "gemm256q", "gemm_wreg"),
-             "refine": ("gemm_rowln", "gemm256x", "gemm256q", "gemm_wreg", "gemm256sq"), "split": ("gemm256sq",)}
+GEMM_TEXT = {"bf16": ("gemm_rowln", "gemm256x", "gemm256q", "gemm_wreg", "gemm_wreg_resid"), "fp16": ("gemm_rowln", "gemm256x", "gemm256q", "gemm_wreg", "gemm_wreg_resid"),
+             "refine": ("gemm_rowln", "gemm256x", "gemm256q", "gemm_wreg", "gemm_wreg_resid", "gemm256sq"), "split": ("gemm256sq",)}
 
 
 def family(name):

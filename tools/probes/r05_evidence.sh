@@ -1,0 +1,26 @@
+# Round-5 evidence (run on the GPU box from the repo root): the driver's bench command, rocprofv3 kernel stats of the bench in
+# its modes, and the MFMA-op / HBM-traffic counters in their own passes.  Summaries land in gpurun_out/r05e/ (copy the ones to
+# keep into profiles/).  usage: r05_evidence.sh [quick]   (quick: no driver-length bench, no PMC passes)
+set -x
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+O=gpurun_out/r05e
+mkdir -p $O
+if [ "$1" != "quick" ]; then
+  python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd.json 2> $O/bench_driver_cmd.err
+fi
+export CZC_NORMAL_EXIT=1
+COMMON="--no-cpu-baseline --no-alt --no-invariance"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/bf16_1s -o p -- python bench.py --streams 1 --steps 2 --warmup 1 $COMMON > $O/bf16_1s.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/bf16_2s -o p -- python bench.py --steps 2 --warmup 1 $COMMON > $O/bf16_2s.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/refine_1s -o p -- python bench.py --precision refine --logit-scale 4.6052 --streams 1 --steps 2 --warmup 1 $COMMON > $O/refine_1s.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/b1 -o p -- python bench.py --images 1 --steps 3 --warmup 1 --no-profile $COMMON > $O/b1.log 2>&1
+for d in bf16_1s bf16_2s refine_1s b1; do f=$(find $O/$d -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/${d}_kernel_stats.csv; done
+if [ "$1" != "quick" ]; then
+  rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_mfma -o p -- python bench.py --streams 1 --steps 1 --warmup 0 --no-profile $COMMON > $O/pmc_mfma.log 2>&1
+  python tools/probes/pmc_mfma_summary.py $O/pmc_mfma > $O/pmc_mfma_summary.json 2> $O/pmc_mfma_summary.err
+  bash tools/probes/pmc_bench_traffic.sh > $O/pmc_traffic.log 2>&1
+  cp gpurun_out/pmc_traffic/summary.json $O/pmc_traffic_summary.json
+fi
+find $O gpurun_out/pmc_traffic -name "*kernel_trace.csv" -delete; find $O gpurun_out/pmc_traffic -name "*counter_collection.csv" -size +4M -delete
+find $O gpurun_out/pmc_traffic -name "*.db" -delete; find $O -name "*agent_info.csv" -delete
+head -c 700 $O/bench_driver_cmd.json; echo; head -8 $O/bf16_1s_kernel_stats.csv | cut -c1-200; tail -1 $O/bf16_1s.log | cut -c1-300; tail -1 $O/bf16_2s.log | cut -c1-300
