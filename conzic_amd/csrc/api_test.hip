@@ -33,6 +33,8 @@ static const Hooks& HK() {
 #define launch_l2_normalize HK().l2_normalize
 #define launch_combine HK().combine
 #define launch_layernorm_x16 HK().layernorm_x16
+#define launch_ln_finalize HK().ln_finalize
+#define launch_fold_ln HK().fold_ln
 #define g_use_gemm256 (*HK().use_gemm256)
 #define g_use_skinny (*HK().use_skinny)
 #define g_use_splitk (*HK().use_splitk)
@@ -140,7 +142,7 @@ int czc_test_gemm(int precision, int M, int N, int K, const float* A, const floa
 // fp16 rows as the engine runs it; which kernel serves it follows the shape and the czc_test_set_option switches (weight-stationary
 // residual kernel at K = 512 / N % 256 == 0, ping-pong ring kernel from gemm256_min_m rows, tiled kernel otherwise).
 int czc_test_gemm_x16(int precision, int M, int N, int K, const float* A, const float* W, const float* bias, const float* resid,
-                      float* x_out) {
+                      float* x_out, float* part_out) {
   if (precision != PREC_BF16 && precision != PREC_F16) { snprintf(TEST_ERR, 512, "gemm_x16: bf16 / fp16 operands only"); return CZC_ERR_ARG; }
   DevPool pool;
   void* dA = up_act(pool, precision, A, (size_t)M * K); T_PTR(dA);
@@ -150,9 +152,46 @@ int czc_test_gemm_x16(int precision, int M, int N, int K, const float* A, const 
   GemmArgs g;
   g.A = dA; g.lda = K; g.W = dW; g.ldw = K; g.bias = dB; g.resid = (const float*)dx; g.ldr = N; g.out_act = nullptr;
   g.out_f32 = (float*)dx; g.ldc = N; g.M = M; g.N = N; g.K = K; g.act = ACT_NONE; g.x16 = 1;
+  float* dpart = nullptr;
+  if (part_out) {  // LayerNorm partials [N / 32][M] float2 of the rows written
+    dpart = (float*)pool.alloc((size_t)(N / 32) * M * 8); T_PTR(dpart);
+    T_HIP(hipMemset(dpart, 0xff, (size_t)(N / 32) * M * 8));
+    g.row_part = dpart; g.part_ld = M;
+  }
   T_CHECK(launch_gemm(precision, g, nullptr));
   T_HIP(hipDeviceSynchronize());
+  if (part_out) T_HIP(hipMemcpy(part_out, dpart, (size_t)(N / 32) * M * 8, hipMemcpyDeviceToHost));
   return down_act(pool, PREC_F16, dx, (size_t)M * N, x_out);
+}
+
+// LayerNorm folded into the weight-stationary K = 512 GEMM: out[M,N] = act( LN(fp16(x); gamma, beta, eps) . W^T + bias ) in the
+// operand type of `precision`, computed as rstd * (x . W'^T - mean * colsum(W')) + b' from x itself: weights prepared by
+// fold_ln_kernel, statistics by ln_finalize_kernel from the partials `part` [16][M] float2 the caller supplies (a producer GEMM
+// would have written them).
+int czc_test_ln_fold_gemm(int precision, int M, int N, const float* x, const float* W, const float* gamma, const float* beta,
+                          const float* bias, const float* part, float eps, int act, float* out) {
+  const int K = 512;
+  if (precision != PREC_BF16 && precision != PREC_F16) { snprintf(TEST_ERR, 512, "ln_fold_gemm: bf16 / fp16 engines only"); return CZC_ERR_ARG; }
+  DevPool pool;
+  void* dx = up_act(pool, PREC_F16, x, (size_t)M * K); T_PTR(dx);
+  float* dW = (float*)pool.up(W, (size_t)N * K * 4); T_PTR(dW);
+  float* dg = (float*)pool.up(gamma, K * 4); T_PTR(dg);
+  float* dbt = (float*)pool.up(beta, K * 4); T_PTR(dbt);
+  float* db = bias ? (float*)pool.up(bias, (size_t)N * 4) : nullptr;
+  float* dpart = (float*)pool.up(part, (size_t)16 * M * 8); T_PTR(dpart);
+  float* dstat = (float*)pool.alloc((size_t)M * 8 + 256); T_PTR(dstat);
+  void* dWf = pool.alloc((size_t)N * K * 2); T_PTR(dWf);
+  float* dcs = (float*)pool.alloc((size_t)N * 4); T_PTR(dcs);
+  float* dbf = (float*)pool.alloc((size_t)N * 4); T_PTR(dbf);
+  void* dout = pool.alloc((size_t)M * N * 2); T_PTR(dout);
+  T_CHECK(launch_ln_finalize(dpart, M, 16, M, eps, dstat, nullptr));
+  T_CHECK(launch_fold_ln(dW, dg, dbt, db, N, K, dWf, dcs, dbf, nullptr));
+  GemmArgs g;
+  g.A = dx; g.lda = K; g.W = dWf; g.ldw = K; g.bias = dbf; g.out_act = dout; g.ldc = N; g.M = M; g.N = N; g.K = K; g.act = act;
+  g.ln_stat = dstat; g.ln_colsum = dcs;
+  T_CHECK(launch_gemm(precision, g, nullptr));
+  T_HIP(hipDeviceSynchronize());
+  return down_act(pool, precision, dout, (size_t)M * N, out);
 }
 
 // LayerNorm of fp16 rows (512 wide) into the operand type: y = LN(fp16(x))

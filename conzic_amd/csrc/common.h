@@ -146,6 +146,15 @@ template <> struct Act<split_t> {
   }
 };
 
+// LayerNorm partials of four stored values (GemmArgs::row_part): fixed association, no fused multiply-adds (HIP compiles with
+// -ffp-contract=fast, and every producer kernel must arrive at the same bits)
+__device__ __forceinline__ float ln_sum4(float a, float b, float c, float d) { return __fadd_rn(__fadd_rn(a, b), __fadd_rn(c, d)); }
+__device__ __forceinline__ float ln_sq4(float a, float b, float c, float d) {
+  return __fadd_rn(__fadd_rn(__fmul_rn(a, a), __fmul_rn(b, b)), __fadd_rn(__fmul_rn(c, c), __fmul_rn(d, d)));
+}
+__device__ __forceinline__ float f16lo(unsigned p) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(p & 0xffffu)); }
+__device__ __forceinline__ float f16hi(unsigned p) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(p >> 16)); }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -34,6 +34,10 @@ struct LayerW {
   void* fc1_w = nullptr; float* fc1_b = nullptr;
   void* fc2_w = nullptr; float* fc2_b = nullptr;
   float *ln2_g = nullptr, *ln2_b = nullptr;
+  // LayerNorm folded into the K = 512 GEMMs (bf16 engine's CLIP-text tower on the 2-byte residual stream): fp16 weights with
+  // the gain folded in, their row sums, bias + W.beta (rowops.hip fold_ln_kernel); null where the fold is not used
+  void *qkv_wf = nullptr, *fc1_wf = nullptr;
+  float *qkv_cs = nullptr, *qkv_bf = nullptr, *fc1_cs = nullptr, *fc1_bf = nullptr;
 };
 
 struct Buf {
@@ -117,6 +121,9 @@ struct czc_engine {
   // screening pass of CZC_PREC_REFINE: outside their validated error budget, experiments only); 0: fp32 residual everywhere.
   // The split-fp16 / f32 towers and the vision tower always keep the fp32 stream.
   int resid16 = 1;
+  // with the 2-byte stream: LayerNorm folded into the q/k/v and fc1 GEMMs (they read x itself; statistics from the producer
+  // GEMMs' partials; no LayerNorm kernel inside the stack).  0: LayerNorm kernels on the fp16 rows
+  int fold_ln = 1;
   int prof = 0;  // 0 off, 1 every kernel class, 2 only the CLIP-text linear layers (the roofline kernel family)
   std::map<std::string, ProfKind> pk;
   int64_t stat_clip_rows = 0, stat_clip_seqs = 0, stat_bert_rows = 0, stat_steps = 0;
@@ -273,11 +280,13 @@ int gemm(czc_engine* e, int prec, const char* kind, const void* A, int lda, cons
 }
 
 // x <- fp16(x + A.W^T + b) on a 2-byte residual stream (GemmArgs::x16): x16 [M,N] fp16 rows, updated in place
+// part (optional): LayerNorm partials of the rows written, [N / 32][part_ld] float2
 int gemm_x16(czc_engine* e, int prec, const char* kind, const void* A, int lda, const void* W, const float* bias, void* x16, int M,
-             int N, int K) {
+             int N, int K, float* part = nullptr, long part_ld = 0) {
   GemmArgs g;
   g.A = A; g.lda = lda; g.W = W; g.ldw = K; g.bias = bias; g.resid = (const float*)x16; g.ldr = N;
   g.out_act = nullptr; g.out_f32 = (float*)x16; g.ldc = N; g.M = M; g.N = N; g.K = K; g.act = ACT_NONE; g.x16 = 1;
+  g.row_part = part; g.part_ld = part_ld;
   ProfScope ps(e, kind, 2.0 * M * (double)N * K);
   E_CHECK(launch_gemm(prec, g, e->st));
   return 0;
@@ -298,7 +307,8 @@ int gemm_ex(czc_engine* e, int prec, const char* kind, const GemmArgs& g) {
 // r16: x (and *pooled) are fp16 rows of a 2-byte residual stream (czc_engine::resid16; H = 512, half-precision P).
 int clip_stack(czc_engine* e, int P, const char* gk, std::vector<LayerW>& L, float* x, int M, int H, int I, int heads,
                float eps, const SegTable& tab, int max_keys, int causal, int plan_B = 0, int plan_K = 0,
-               int plan_max_own = 0, const int* pool_idx = nullptr, int n_pool = 0, float** pooled = nullptr, bool r16 = false) {
+               int plan_max_own = 0, const int* pool_idx = nullptr, int n_pool = 0, float** pooled = nullptr, bool r16 = false,
+               const float* ln_stat0 = nullptr) {  // ln_stat0: (mean, rstd) of the incoming rows (embedding kernel): enables the LayerNorm fold
   const size_t esz = prec_bytes(P);
   void *y, *qkv, *ctx, *hbuf;
   E_CHECK(ensure(e, "cs_y", (size_t)M * H * esz, &y));
@@ -315,6 +325,28 @@ int clip_stack(czc_engine* e, int P, const char* gk, std::vector<LayerW>& L, flo
   // LayerNorm fused into the producer: out-proj (fuse_ln >= 1) and fc2 (fuse_ln >= 2) run on full 512-wide rows and
   // leave y = LN(x) beside the new fp32 x; the LayerNorm kernel then only runs where no such producer exists.
   const bool rowln = !r16 && prec_is_half(P) && e->fuse_ln && H == 512 && M >= g_rowln_min_m && I % 32 == 0;
+  // LayerNorm folded into the q/k/v and fc1 GEMMs: they multiply x itself and correct with the row statistics `stat`, which
+  // come from the producer's partials `part` (out-projection -> LN2, fc2 -> the next layer's LN1, the embedding kernel -> layer 0)
+  const bool fold = r16 && e->fold_ln && !L.empty() && L[0].qkv_wf && ln_stat0;
+  float *part = nullptr, *stat = nullptr;
+  if (fold) {
+    E_CHECK(ensure(e, "cs_part", (size_t)(H / 32) * M * 8, (void**)&part));
+    E_CHECK(ensure(e, "cs_stat", (size_t)M * 8 + 256, (void**)&stat));
+  }
+  auto finalize = [&](int rows) -> int {  // stat <- (mean, rstd) of `rows` rows from part
+    ProfScope ps(e, rk, 0);
+    E_CHECK(launch_ln_finalize(part, M, H / 32, rows, eps, stat, e->st));
+    return 0;
+  };
+  auto folded_gemm = [&](const void* Ax, const void* Wf, const float* bf, const float* cs, const float* st_, void* out, int rows, int N,
+                         int act) -> int {
+    GemmArgs g;
+    g.A = Ax; g.lda = H; g.W = Wf; g.ldw = H; g.bias = bf; g.out_act = out; g.ldc = N; g.M = rows; g.N = N; g.K = H; g.act = act;
+    g.ln_stat = st_; g.ln_colsum = cs;
+    ProfScope ps(e, gk, 2.0 * rows * (double)N * H);
+    E_CHECK(launch_gemm(P, g, e->st));
+    return 0;
+  };
   auto ln = [&](const float* gm, const float* bt, int rows, const void* src, void* dst) -> int {  // dst <- LN(src rows)
     ProfScope ps(e, rk, 0);
     if (r16) E_CHECK(launch_layernorm_x16(P, src, nullptr, gm, bt, eps, rows, H, dst, e->st));
@@ -338,8 +370,12 @@ int clip_stack(czc_engine* e, int P, const char* gk, std::vector<LayerW>& L, flo
   bool have_y = false;  // y already holds this layer's LN1 output (left by the previous layer's fc2)
   for (size_t n = 0; n < L.size(); ++n) {
     LayerW& l = L[n];
-    if (!have_y) E_CHECK(ln(l.ln1_g, l.ln1_b, M, x, y));
-    E_CHECK(gemm(e, P, gk, y, H, l.qkv_w, H, l.qkv_b, nullptr, 0, qkv, nullptr, 3 * H, M, 3 * H, H, ACT_NONE));
+    if (fold) {
+      E_CHECK(folded_gemm(x, l.qkv_wf, l.qkv_bf, l.qkv_cs, n == 0 ? ln_stat0 : stat, qkv, M, 3 * H, ACT_NONE));
+    } else {
+      if (!have_y) E_CHECK(ln(l.ln1_g, l.ln1_b, M, x, y));
+      E_CHECK(gemm(e, P, gk, y, H, l.qkv_w, H, l.qkv_b, nullptr, 0, qkv, nullptr, 3 * H, M, 3 * H, H, ACT_NONE));
+    }
     { ProfScope ps(e, ak, attn_flops);
       int rc = -1;
       if (plan_B > 0 && prec_is_half(P) && g_use_mfma_attention && e->pack_branches)
@@ -358,14 +394,29 @@ int clip_stack(czc_engine* e, int P, const char* gk, std::vector<LayerW>& L, flo
         E_CHECK(launch_gather_rows_bytes(ctx, pool_idx, n_pool, H * (int)esz, ctx_e, e->st));
         if (r16) E_CHECK(launch_gather_rows_bytes(x, pool_idx, n_pool, H * 2, x_e, e->st));
         else E_CHECK(launch_gather_rows_f32(x, pool_idx, n_pool, H, x_e, e->st)); }
-      if (r16) E_CHECK(gemm_x16(e, P, gk, ctx_e, H, l.o_w, l.o_b, x_e, n_pool, H, H));
-      else E_CHECK(gemm(e, P, gk, ctx_e, H, l.o_w, H, l.o_b, x_e, H, nullptr, x_e, H, n_pool, H, H, ACT_NONE));
-      E_CHECK(ln(l.ln2_g, l.ln2_b, n_pool, x_e, y_e));
-      E_CHECK(gemm(e, P, gk, y_e, H, l.fc1_w, H, l.fc1_b, nullptr, 0, h_e, nullptr, I, n_pool, I, H, ACT_QUICK_GELU));
+      if (fold) {
+        E_CHECK(gemm_x16(e, P, gk, ctx_e, H, l.o_w, l.o_b, x_e, n_pool, H, H, part, M));
+        E_CHECK(finalize(n_pool));
+        E_CHECK(folded_gemm(x_e, l.fc1_wf, l.fc1_bf, l.fc1_cs, stat, h_e, n_pool, I, ACT_QUICK_GELU));
+      } else {
+        if (r16) E_CHECK(gemm_x16(e, P, gk, ctx_e, H, l.o_w, l.o_b, x_e, n_pool, H, H));
+        else E_CHECK(gemm(e, P, gk, ctx_e, H, l.o_w, H, l.o_b, x_e, H, nullptr, x_e, H, n_pool, H, H, ACT_NONE));
+        E_CHECK(ln(l.ln2_g, l.ln2_b, n_pool, x_e, y_e));
+        E_CHECK(gemm(e, P, gk, y_e, H, l.fc1_w, H, l.fc1_b, nullptr, 0, h_e, nullptr, I, n_pool, I, H, ACT_QUICK_GELU));
+      }
       if (r16) E_CHECK(gemm_x16(e, P, gk, h_e, I, l.fc2_w, l.fc2_b, x_e, n_pool, H, I));
       else E_CHECK(gemm(e, P, gk, h_e, I, l.fc2_w, I, l.fc2_b, x_e, H, nullptr, x_e, H, n_pool, H, I, ACT_NONE));
       *pooled = x_e;
       return 0;
+    }
+    if (fold) {
+      E_CHECK(gemm_x16(e, P, gk, ctx, H, l.o_w, l.o_b, x, M, H, H, part, M));
+      E_CHECK(finalize(M));
+      E_CHECK(folded_gemm(x, l.fc1_wf, l.fc1_bf, l.fc1_cs, stat, hbuf, M, I, ACT_QUICK_GELU));
+      const bool more = n + 1 < L.size();  // the last layer's rows only feed the final LayerNorm (on the pooled rows)
+      E_CHECK(gemm_x16(e, P, gk, hbuf, I, l.fc2_w, l.fc2_b, x, M, H, I, more ? part : nullptr, M));
+      if (more) E_CHECK(finalize(M));
+      continue;
     }
     if (rowln) E_CHECK(resid_ln_gemm(ctx, H, l.o_w, l.o_b, H, l.ln2_g, l.ln2_b));
     else {
@@ -524,12 +575,15 @@ int clip_tower_on(czc_engine* e, int P, std::vector<LayerW>& L, const void* tpro
   E_CHECK(need(e, "text_model.final_layer_norm.weight", H, &fg));
   E_CHECK(need(e, "text_model.final_layer_norm.bias", H, &fb));
   const bool r16 = H == 512 && ((e->resid16 >= 1 && P == PREC_BF16) || (e->resid16 >= 2 && P == PREC_F16));
+  float* stat0 = nullptr;
+  if (r16 && e->fold_ln && !L.empty() && L[0].qkv_wf) E_CHECK(ensure(e, "c_stat0", (size_t)M * 8 + 256, (void**)&stat0));
   { ProfScope ps(e, "rowops_clip_text", 0);
-    E_CHECK(launch_clip_embed(cids, CZC_CLIP_MAX_LEN, p.src, p.pos0, p.own_off, p.own_len, n_seg, max_len, H, tok, pos, x, e->st, r16 ? 1 : 0)); }
+    E_CHECK(launch_clip_embed(cids, CZC_CLIP_MAX_LEN, p.src, p.pos0, p.own_off, p.own_len, n_seg, max_len, H, tok, pos, x, e->st, r16 ? 1 : 0,
+                              stat0, c.clip_eps)); }
   SegTable tab{p.pre_off, p.pre_len, p.own_off, p.own_len, n_seg, 0, plan_B > 0 ? p.img_max : nullptr};
   float* pooled = nullptr;
   E_CHECK(clip_stack(e, P, gk, L, x, M, H, c.clip_inter, c.clip_heads, c.clip_eps, tab, max_len, 1, plan_B,
-                     plan_K, max_branch, p.eidx, n_pool, &pooled, r16));
+                     plan_K, max_branch, p.eidx, n_pool, &pooled, r16, stat0));
   { ProfScope ps(e, "rowops_clip_text", 0);
     if (r16) {
       if (pooled) E_CHECK(launch_layernorm_x16(P, pooled, nullptr, fg, fb, c.clip_eps, n_pool, H, pa, e->st));
@@ -843,6 +897,7 @@ int czc_destroy(czc_engine* e) {
   auto free_layers = [](std::vector<LayerW>& L) {
     for (auto& l : L) {
       (void)hipFree(l.qkv_w); (void)hipFree(l.qkv_b); (void)hipFree(l.o_w); (void)hipFree(l.fc1_w); (void)hipFree(l.fc2_w);
+      (void)hipFree(l.qkv_wf); (void)hipFree(l.qkv_cs); (void)hipFree(l.qkv_bf); (void)hipFree(l.fc1_wf); (void)hipFree(l.fc1_cs); (void)hipFree(l.fc1_bf);
     }
   };
   free_layers(e->bert); free_layers(e->ctext); free_layers(e->cvis); free_layers(e->ctext_x);
@@ -878,7 +933,7 @@ int czc_replicate(czc_engine* p, czc_engine** out) {
   e->patch_w = p->patch_w; e->tproj_wx = p->tproj_wx;
   e->logit_scale_exp = p->logit_scale_exp;
   e->share_prefix = p->share_prefix; e->pack_branches = p->pack_branches; e->pool_last_layer = p->pool_last_layer;
-  e->fuse_ln = p->fuse_ln; e->bert_prune = p->bert_prune; e->resid16 = p->resid16;
+  e->fuse_ln = p->fuse_ln; e->bert_prune = p->bert_prune; e->resid16 = p->resid16; e->fold_ln = p->fold_ln;
   memset(&e->bd, 0, sizeof(e->bd));
   if (hipSetDevice(e->dev) != hipSuccess || hipStreamCreate(&e->st) != hipSuccess ||
       hipHostMalloc((void**)&e->h_totals, 256) != hipSuccess) {
@@ -914,6 +969,29 @@ int czc_finalize_weights(czc_engine* e) {
   const bool has_bert = c.bert_layers > 0 && c.bert_vocab > 0;
   if (has_bert) E_CHECK(build_layers(e, e->bert, c.bert_layers, c.bert_hidden, c.bert_inter, true, "bert.encoder.layer.", e->pb));
   E_CHECK(build_layers(e, e->ctext, c.clip_layers, c.clip_hidden, c.clip_inter, false, "text_model.encoder.layers.", e->pc));
+  if (prec_is_half(e->pc) && c.clip_hidden == 512) {  // folded-LayerNorm operands of the text tower (used where resid16 + fold_ln apply)
+    const int H = c.clip_hidden, I = c.clip_inter;
+    for (int n = 0; n < c.clip_layers; ++n) {
+      LayerW& l = e->ctext[n];
+      const std::string p = "text_model.encoder.layers." + std::to_string(n);
+      float *qw, *kw, *vw, *f1w;
+      E_CHECK(need(e, p + ".self_attn.q_proj.weight", (size_t)H * H, &qw));
+      E_CHECK(need(e, p + ".self_attn.k_proj.weight", (size_t)H * H, &kw));
+      E_CHECK(need(e, p + ".self_attn.v_proj.weight", (size_t)H * H, &vw));
+      E_CHECK(need(e, p + ".mlp.fc1.weight", (size_t)I * H, &f1w));
+      E_HIP(hipMalloc(&l.qkv_wf, (size_t)3 * H * H * 2));
+      E_HIP(hipMalloc((void**)&l.qkv_cs, (size_t)3 * H * 4));
+      E_HIP(hipMalloc((void**)&l.qkv_bf, (size_t)3 * H * 4));
+      E_HIP(hipMalloc(&l.fc1_wf, (size_t)I * H * 2));
+      E_HIP(hipMalloc((void**)&l.fc1_cs, (size_t)I * 4));
+      E_HIP(hipMalloc((void**)&l.fc1_bf, (size_t)I * 4));
+      const float* srcw[3] = {qw, kw, vw};
+      for (int t = 0; t < 3; ++t)
+        E_CHECK(launch_fold_ln(srcw[t], l.ln1_g, l.ln1_b, l.qkv_b + t * H, H, H, (char*)l.qkv_wf + (size_t)t * H * H * 2, l.qkv_cs + t * H,
+                               l.qkv_bf + t * H, e->st));
+      E_CHECK(launch_fold_ln(f1w, l.ln2_g, l.ln2_b, l.fc1_b, I, H, l.fc1_wf, l.fc1_cs, l.fc1_bf, e->st));
+    }
+  }
   if (e->refine)
     E_CHECK(build_layers(e, e->ctext_x, c.clip_layers, c.clip_hidden, c.clip_inter, false, "text_model.encoder.layers.", PREC_F16X3));
   E_CHECK(build_layers(e, e->cvis, c.vis_layers, c.vis_hidden, c.vis_inter, false, "vision_model.encoder.layers.", e->pv));
@@ -1244,12 +1322,14 @@ int czc_generate(czc_engine* e, int B, int T, int L, int seed_len, const int32_t
     if (pos < 0 || pos >= L) return fail(e, CZC_ERR_ARG, "generate: position out of range%s");
     const int nm = n_mask_host ? n_mask_host[s] : 1;
     // what this call returns of a step: the ids it leaves in d_inp and, at the snapshot steps, the winner's cosine
-    // snapshot steps with a cosine to return take the full selection for every image: the returned cosines come from the
-    // established exact path, and the guard (czc_refine_guard) keeps measuring the screening tower on every image once per
-    // sweep although most of the other steps are gated
-    const bool snap_step = (s + 1) % snapshot_every == 0;
-    e->gate_now = e->refine && e->refine_gate_delta > 0.f && !(snap_step && out_cos);
-    e->gate_need_cos = false;
+    // AUDIT steps -- the snapshot step of every fourth sweep, starting with the first -- take the full selection for every
+    // image: there the guard (czc_refine_guard) measures the screening tower on all images although most other steps are
+    // gated (a checkpoint the fp16 tower carries badly trips it in the first sweep).  At the other snapshot steps a gated
+    // image re-encodes its winner alone, for the cosine this call returns
+    const bool snap_step = (s + 1) % snapshot_every == 0 && out_cos != nullptr;
+    const bool audit = snap_step && (s / snapshot_every) % 4 == 0;
+    e->gate_now = e->refine && e->refine_gate_delta > 0.f && !audit;
+    e->gate_need_cos = snap_step;
     E_CHECK(step_device(e, d_inp, B, T, seed_len + pos, nm, pos == L - 1 ? 1 : 0, top_k, hp));
     if ((s + 1) % snapshot_every == 0) {
       if (out_ids)
@@ -1282,6 +1362,7 @@ int czc_set_option(czc_engine* e, const char* name, int value) {
   if (!strcmp(name, "pool_last_layer")) { e->pool_last_layer = value ? 1 : 0; return CZC_OK; }
   if (!strcmp(name, "fuse_ln")) { e->fuse_ln = value; return CZC_OK; }  // 0 off, 1 out-proj -> LN2, 2 also fc2 -> next LN1
   if (!strcmp(name, "resid16")) { e->resid16 = value < 0 ? 0 : value; return CZC_OK; }
+  if (!strcmp(name, "fold_ln")) { e->fold_ln = value ? 1 : 0; return CZC_OK; }
   if (!strcmp(name, "refine_samples")) { e->refine_samples = value < 0 ? 0 : value; return CZC_OK; }
   if (!strcmp(name, "refine_theta_x1000")) { e->refine_theta_x = (float)value / 1000.f; return CZC_OK; }
   if (!strcmp(name, "refine_guard_x1e6")) { e->refine_guard_dev = (float)value * 1e-6f; return CZC_OK; }
@@ -1401,7 +1482,7 @@ const void* czc_internal_hooks(int abi) {
       []() -> char* { return czc::g_err; },
       &launch_gemm, &launch_gemm_rowln, &launch_layernorm, &launch_convert, &launch_act_to_f32, &launch_attention,
       &launch_softmax_mask_topk, &launch_bridge_precompute, &launch_bridge, &launch_l2_normalize, &launch_combine,
-      &launch_layernorm_x16,
+      &launch_layernorm_x16, &launch_ln_finalize, &launch_fold_ln,
       &g_use_gemm256, &g_use_skinny, &g_use_splitk, &g_gemm_deep, &g_gemm_small_tiles, &g_use_wreg, &g_use_gemm256s, &g_w_dbg,
       &g_ln_lean, &g_rowln_min_m, &g_wreg_min_m, &g_gemm256_min_m, &g_use_mfma_attention, &g_use_attention_image};
   return abi == HOOKS_ABI ? &h : nullptr;

@@ -90,6 +90,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs& g, f32x16_t (&acc)[NB][
     const long rr = (long)row * g.ldr;
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
+      float st_s = 0.f, st_q = 0.f;  // LayerNorm partials of this lane's quads (x16 layers with GemmArgs::row_part)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int col = n0 + wn * (32 * NB) + j * 32 + 8 * q + 4 * half;
@@ -114,7 +115,21 @@ __device__ __forceinline__ void epilogue(const GemmArgs& g, f32x16_t (&acc)[NB][
               v.z += (float)__builtin_bit_cast(_Float16, (unsigned short)(r2.y & 0xffffu));
               v.w += (float)__builtin_bit_cast(_Float16, (unsigned short)(r2.y >> 16));
             }
-            if (oh) *(uint2*)(oh + ro + col) = make_uint2(pack2_f16(v.x, v.y), pack2_f16(v.z, v.w));
+            const uint2 pk = make_uint2(pack2_f16(v.x, v.y), pack2_f16(v.z, v.w));
+            if (oh) *(uint2*)(oh + ro + col) = pk;
+            if (g.row_part) {  // the association order of the weight-stationary residual kernel: quads in order, then half 0 + half 1
+              const float w0 = f16lo(pk.x), w1 = f16hi(pk.x), w2 = f16lo(pk.y), w3 = f16hi(pk.y);
+              const float ps = ln_sum4(w0, w1, w2, w3), pq = ln_sq4(w0, w1, w2, w3);
+              st_s = q == 0 ? ps : __fadd_rn(st_s, ps);
+              st_q = q == 0 ? pq : __fadd_rn(st_q, pq);
+              if (q == 3) {
+                const float os = __shfl_xor(st_s, 32, 64), oq = __shfl_xor(st_q, 32, 64);
+                if (!half) {
+                  const long pcol = (n0 + wn * (32 * NB) + j * 32) / 32;
+                  *(float2*)(g.row_part + (pcol * g.part_ld + row) * 2) = make_float2(__fadd_rn(st_s, os), __fadd_rn(st_q, oq));
+                }
+              }
+            }
             continue;
           }
           if (g.resid) {
@@ -576,8 +591,12 @@ int launch_gemm(int prec, const GemmArgs& g_in, hipStream_t st) {
   }
   if (g.x16) {  // 2-byte residual stream: half-precision engines, vectorisable shapes, no activation-typed second output
     const bool ok = prec_is_half(prec) && g.out_f32 && !g.out_act && g.N % 8 == 0 && g.ldc % 8 == 0 && (!g.resid || g.ldr % 8 == 0);
-    if (!ok) { snprintf(g_err, sizeof(g_err), "gemm: x16 (fp16 residual stream) needs a half-precision engine and N, ldc, ldr %% 8 == 0"); return 1; }
+    if (!ok || (g.row_part && g.N % 32)) { snprintf(g_err, sizeof(g_err), "gemm: x16 (fp16 residual stream) needs a half-precision engine and N, ldc, ldr %% 8 == 0 (N %% 32 with row_part)"); return 1; }
     if (gemm_wreg_resid_eligible(g)) return launch_gemm_wreg_resid(g, st);
+  }
+  if (g.ln_stat && !(prec_is_half(prec) && gemm_wreg_eligible(g))) {
+    snprintf(g_err, sizeof(g_err), "gemm: the folded-LayerNorm form (ln_stat) is served by the weight-stationary K = 512 kernel only");
+    return 1;
   }
   if (prec_is_half(prec) && gemm_wreg_eligible(g)) return launch_gemm_wreg(g, st);
   if (prec_is_half(prec) && g_use_gemm256 && gemm256_eligible(g)) return launch_gemm256(g, st);

@@ -307,6 +307,14 @@ __device__ __forceinline__ void tile_epilogue_x16_asm(const GemmArgs& g, f32x16_
     rsB.z = __builtin_amdgcn_readfirstlane((unsigned)(g.bias ? g.N * 4 : 0));  // no bias: every read returns 0
     rsB.w = 0x00020000u;
   }
+  u32x4_t rsP;  // LayerNorm partials (GemmArgs::row_part, [column block][row] float2); empty without a target
+  {
+    const unsigned long long pp = (unsigned long long)g.row_part;
+    rsP.x = __builtin_amdgcn_readfirstlane((unsigned)pp);
+    rsP.y = __builtin_amdgcn_readfirstlane((unsigned)(pp >> 32) & 0xffffu);
+    rsP.z = __builtin_amdgcn_readfirstlane((unsigned)(g.row_part ? (long)(g.N / 32) * g.part_ld * 8 : 0));
+    rsP.w = 0x00020000u;
+  }
   asm volatile("s_nop 4" ::: "memory");  // descriptors fresh from v_readfirstlane -> buffer_* inside asm strings
   constexpr int NB = 4 * NJ;
   auto colof = [&](int blk) { return n0 + wcol0 + (blk % NJ) * 32 + rs * 8; };
@@ -341,11 +349,14 @@ __device__ __forceinline__ void tile_epilogue_x16_asm(const GemmArgs& g, f32x16_
           make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
     }
     u32x4_t(&r)[2] = rr[blk & 1];
-    // this block's residual rows (and, first time round, the bias) have landed: younger = stores of block blk-1, loads of blk+1
-    if (blk == 0 || blk + 1 == NB)
+    // this block's residual rows (and, first time round, the bias) have landed: younger = the four stores (x, partials) of
+    // block blk-1 and the two loads of blk+1
+    if (blk == 0)
       asm volatile("s_waitcnt vmcnt(2)" : "+v"(r[0]), "+v"(r[1]), "+v"(bias8[j][0]), "+v"(bias8[j][1]) : : "memory");
-    else
+    else if (blk + 1 == NB)
       asm volatile("s_waitcnt vmcnt(4)" : "+v"(r[0]), "+v"(r[1]), "+v"(bias8[j][0]), "+v"(bias8[j][1]) : : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(6)" : "+v"(r[0]), "+v"(r[1]), "+v"(bias8[j][0]), "+v"(bias8[j][1]) : : "memory");
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
       const int rw = pass * 16 + rrow;
@@ -362,6 +373,26 @@ __device__ __forceinline__ void tile_epilogue_x16_asm(const GemmArgs& g, f32x16_
         o[e] = pack2_f16(v[2 * e] + lo, v[2 * e + 1] + hi);
       }
       asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" : : "v"(o), "v"(off(blk, pass, g.ldc)), "s"(rsO) : "memory");
+      // LayerNorm partials of the stored values over this 32-column block, in the association order of the weight-stationary
+      // residual kernel (lane (row, half) there sums its quads 0..3 in order, then half 0 + half 1): lane rs holds quad rs of
+      // both halves, so the four lanes of a row are summed in lane order by quad-broadcast DPP moves
+      const float w0 = f16lo(o[0]), w1 = f16hi(o[0]), w2 = f16lo(o[1]), w3 = f16hi(o[1]);
+      const float w4 = f16lo(o[2]), w5 = f16hi(o[2]), w6 = f16lo(o[3]), w7 = f16hi(o[3]);
+      float part[4] = {ln_sum4(w0, w1, w2, w3), ln_sum4(w4, w5, w6, w7), ln_sq4(w0, w1, w2, w3), ln_sq4(w4, w5, w6, w7)};
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int x = __builtin_bit_cast(int, part[t]);
+        const float q0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0x00, 0xf, 0xf, true));
+        const float q1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0x55, 0xf, 0xf, true));
+        const float q2 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0xAA, 0xf, 0xf, true));
+        const float q3 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0xFF, 0xf, 0xf, true));
+        part[t] = __fadd_rn(__fadd_rn(__fadd_rn(q0, q1), q2), q3);
+      }
+      const uint2 sq = make_uint2(__float_as_uint(__fadd_rn(part[0], part[1])), __float_as_uint(__fadd_rn(part[2], part[3])));
+      const int prow = m0 + wm * 128 + (blk / NJ) * 32 + pass * 16 + rrow;
+      const long pcol = (n0 + wcol0 + (blk % NJ) * 32) / 32;
+      const unsigned po = (rs == 0 && prow < g.M && colof(blk) < g.N) ? (unsigned)((pcol * g.part_ld + prow) * 8) : 0x7ffffff0u;
+      asm volatile("buffer_store_dwordx2 %0, %1, %2, 0 offen\n\ts_nop 1" : : "v"(sq), "v"(po), "s"(rsP) : "memory");
     }
   }
 }

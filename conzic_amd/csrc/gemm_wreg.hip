@@ -43,7 +43,8 @@ constexpr int WR_D = 4;                        // ring depth
 constexpr int WR_PATCH = 2048;                 // per-wave epilogue patch (32 rows x 64 bytes)
 constexpr int WR_BIAS = 128;                   // per-wave bias slice (32 floats)
 constexpr int WR_LDS = WR_D * WR_STAGE + 8 * (WR_PATCH + WR_BIAS);
-static_assert(WR_LDS <= 160 * 1024, "LDS budget");
+constexpr int WR_LDS_LNF = WR_LDS + 8 * (WR_BIAS + WR_D * 256);  // + per wave: colsum slice, ring of (mean, rstd) blocks
+static_assert(WR_LDS_LNF <= 160 * 1024, "LDS budget");
 
 __device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {
   unsigned r;
@@ -57,9 +58,17 @@ __device__ __forceinline__ float wr_act(float v) {
   return v;
 }
 
-template <int ACT, bool F16 = false>
+// LNF (round 5: LayerNorm folded into the GEMM, GemmArgs::ln_stat): A is the raw 2-byte residual stream x (fp16 rows), W the
+// weights with the LayerNorm gain folded in, W' = W * diag(gamma), as fp16, and
+//   C = act( rstd_m * (x . W'^T - mean_m * colsum(W')) + b' ),   b' = b + W . beta,
+// with (mean_m, rstd_m) per row from the producer GEMM's partials (rowops.hip ln_finalize_kernel): no LayerNorm kernel, no
+// normalised copy y of the rows.  The multiply runs on the fp16 MFMA whatever the engine's operand type (x is fp16); the
+// OUTPUT keeps the engine's type (F16 ? fp16 : bf16).  Per block one more LDS-DMA (T: 32 rows x 8 bytes of statistics,
+// every wave its own 256-byte ring slot), VMEM order D0 D1 T D2 S0 D3 S1, the ring wait becomes vmcnt(15).
+template <int ACT, bool F16 = false, bool LNF = false>
 __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, int nsets, int nblk) {
-  using HT = std::conditional_t<F16, f16_t, bf16_t>;  // operand element type: MFMA opcode + converter (common.h Half<>)
+  using OT = std::conditional_t<F16, f16_t, bf16_t>;  // output element type (the engine's activation type)
+  using HT = std::conditional_t<LNF, f16_t, OT>;      // operand element type: MFMA opcode (common.h Half<>)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -92,6 +101,11 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, 
   unsigned char* patch = smem + WR_D * WR_STAGE + wave * WR_PATCH;
   float* bias_s = (float*)(smem + WR_D * WR_STAGE + 8 * WR_PATCH + wave * WR_BIAS);
   if (lane < 32) bias_s[lane] = (g.bias && col0 + lane < g.N) ? g.bias[col0 + lane] : 0.f;
+  float* cs_s = (float*)(smem + WR_LDS + wave * WR_BIAS);                      // LNF: colsum(W') of this wave's 32 columns
+  const unsigned char* stat_s = smem + WR_LDS + 8 * WR_BIAS + wave * (WR_D * 256);  // LNF: this wave's ring of (mean, rstd) blocks
+  if constexpr (LNF) {
+    if (lane < 32) cs_s[lane] = col0 + lane < g.N ? g.ln_colsum[col0 + lane] : 0.f;
+  }
 
   // ---- DMA side: this wave lands rows wave*4 + ii (ii 0..3) of every block ----
   const unsigned lds0 = __builtin_amdgcn_readfirstlane(
@@ -105,6 +119,22 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, 
   }
   u32x4_t rsA;
   rsA.w = 0x00020000u;
+  // LNF: (mean, rstd) of block j's 32 rows -> this wave's slot j % WR_D (64 lanes x 4 bytes = 32 float2)
+  const unsigned stat0 = lds0 + WR_LDS + 8 * WR_BIAS + wave * (WR_D * 256);
+  const unsigned voffT = (unsigned)(lane * 4);
+  auto stat_dma = [&](int j) {
+    const long row0 = (long)(b0 + j) * WR_BLK;
+    const unsigned long long pt = (unsigned long long)g.ln_stat + (unsigned long long)row0 * 8;
+    u32x4_t rsT;
+    rsT.x = __builtin_amdgcn_readfirstlane((unsigned)pt); rsT.y = __builtin_amdgcn_readfirstlane((unsigned)(pt >> 32) & 0xffffu);
+    rsT.z = __builtin_amdgcn_readfirstlane((unsigned)(min((long)WR_BLK, (long)g.M - row0) * 8)); rsT.w = 0x00020000u;
+    const unsigned dst = stat0 + (j & (WR_D - 1)) * 256;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dword %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "s"(dst), "v"(voffT), "s"(rsT)
+                 : "memory");
+  };
   auto issue = [&](int j) {  // block j of this work-group -> ring slot j % WR_D
     const long row0 = (long)(b0 + j) * WR_BLK;
     const unsigned long long pa = (unsigned long long)g.A + (unsigned long long)row0 * pitch;
@@ -122,6 +152,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, 
         : "=&s"(keep)
         : "s"(dst), "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "s"(rsA)
         : "memory", "scc");
+    if constexpr (LNF) stat_dma(j);
   };
 
   // ---- MFMA side ----
@@ -170,12 +201,25 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, 
     rsC.x = (unsigned)pc; rsC.y = (unsigned)(pc >> 32) & 0xffffu;
     rsC.z = (unsigned)(min((long)WR_BLK, (long)g.M - row0) * cpitch);
   };
-  auto epi_quad = [&](int qd) {  // accP quad qd -> bias, activation, bf16 -> patch
+  float ln_rstd = 0.f, ln_t = 0.f;  // LNF: rstd and -mean * rstd of this lane's row of the block whose epilogue is running
+  auto epi_quad = [&](int qd, int js) {  // accP quad qd -> (LayerNorm correction,) bias, activation, 2-byte -> patch
     const float4 b4 = *(const float4*)(bias_s + 8 * qd + 4 * half);
-    float4 v = make_float4(accP[4 * qd] + b4.x, accP[4 * qd + 1] + b4.y, accP[4 * qd + 2] + b4.z, accP[4 * qd + 3] + b4.w);
+    float4 v;
+    if constexpr (LNF) {
+      if (qd == 0) {  // read once per block: the slot is refilled (statistics of block js + WR_D) later in this same stream
+        const float2 st = *(const float2*)(stat_s + (js & (WR_D - 1)) * 256 + l31 * 8);
+        ln_rstd = st.y;
+        ln_t = __fmul_rn(-st.x, st.y);
+      }
+      const float4 c4 = *(const float4*)(cs_s + 8 * qd + 4 * half);
+      v = make_float4(__fmaf_rn(accP[4 * qd], ln_rstd, __fmaf_rn(ln_t, c4.x, b4.x)), __fmaf_rn(accP[4 * qd + 1], ln_rstd, __fmaf_rn(ln_t, c4.y, b4.y)),
+                      __fmaf_rn(accP[4 * qd + 2], ln_rstd, __fmaf_rn(ln_t, c4.z, b4.z)), __fmaf_rn(accP[4 * qd + 3], ln_rstd, __fmaf_rn(ln_t, c4.w, b4.w)));
+    } else {
+      v = make_float4(accP[4 * qd] + b4.x, accP[4 * qd + 1] + b4.y, accP[4 * qd + 2] + b4.z, accP[4 * qd + 3] + b4.w);
+    }
     v.x = wr_act<ACT>(v.x); v.y = wr_act<ACT>(v.y); v.z = wr_act<ACT>(v.z); v.w = wr_act<ACT>(v.w);
     const int slot = (2 * qd + half) ^ ((l31 >> 1) & 7);
-    *(uint2*)(patch + l31 * 64 + slot * 8) = make_uint2(Half<HT>::pack2(v.x, v.y), Half<HT>::pack2(v.z, v.w));
+    *(uint2*)(patch + l31 * 64 + slot * 8) = make_uint2(Half<OT>::pack2(v.x, v.y), Half<OT>::pack2(v.z, v.w));
   };
   auto epi_store = [&](int pass) {  // 16 patch rows -> one buffer store
     const int r = pass * 16 + rrow;
@@ -215,12 +259,13 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, 
       // descriptor arithmetic (a few dozen SALU) rides in the slots too: nothing but the wait and the barrier
       // stands between two blocks' MFMA streams
       if (sgm == 0 && refill) { dma_rebase(jd); dma_piece(0); }
-      if (sgm == 1 && prev) epi_quad(0);
+      if (sgm == 1 && prev) epi_quad(0, js);
       if (sgm == 2 && refill) dma_piece(1);
-      if (sgm == 2 && prev) epi_quad(1);
-      if (sgm == 3 && prev) epi_quad(2);
+      if (sgm == 2 && prev) epi_quad(1, js);
+      if (sgm == 3 && prev) epi_quad(2, js);
+      if constexpr (LNF) { if (sgm == 3 && refill) stat_dma(jd); }
       if (sgm == 4 && refill) dma_piece(2);
-      if (sgm == 4 && prev) { epi_quad(3); store_rebase(js); }
+      if (sgm == 4 && prev) { epi_quad(3, js); store_rebase(js); }
       if (sgm == 5 && prev) epi_store(0);
       if (sgm == 6 && refill) dma_piece(3);
       if (sgm == 7 && prev) epi_store(1);
@@ -237,7 +282,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, 
       // block i landed?  VMEM issued after its last DMA piece: S1 of that block period, then two full periods
       // of 4 DMA + 2 stores (stores start with the second block) -- all in order on vmcnt.
       constexpr bool STEADY = decltype(steady_c)::value;
-      if (STEADY) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+      if (STEADY) { if constexpr (LNF) asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); }
       else if (i + 2 >= nb) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else if (i < 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
@@ -253,7 +298,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, 
     for (; i + WR_D - 1 < nb; ++i) step(i, T_());
     for (; i < nb; ++i) step(i, F_());
     store_rebase(nb - 1);
-    epi_quad(0); epi_quad(1); epi_quad(2); epi_quad(3);
+    epi_quad(0, nb - 1); epi_quad(1, nb - 1); epi_quad(2, nb - 1); epi_quad(3, nb - 1);
     epi_store(0); epi_store(1);
   }
 }
@@ -276,9 +321,11 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, 
 //   * the epilogue adds in the accumulator layout: lane (row, 4 columns) reads its four residual values from the tile
 //     (ds_read_b64), forms (acc + bias) + residual in fp32, rounds once to fp16 and writes the result back IN PLACE; the
 //     store pass then reads the tile in 16-byte pieces, 16 rows x 64 B per buffer store as in gemm_wreg_kernel;
-//   * VMEM order per block: D0 R0 D1 R1 D2 D3 S0 S1 (DMA pieces of block i+3, residual tiles of block i, stores of block
-//     i-1), all from inline asm, so the waits are exact counts: block i's operands have landed at vmcnt(18), the residual
-//     tile of block i-1 at vmcnt(7) in front of the first epilogue quad;
+//   * VMEM order per block: D0 R0 D1 R1 D2 D3 P S0 S1 (DMA pieces of block i+3, residual tiles of block i, LayerNorm partials
+//     and stores of block i-1), all from inline asm, so the waits are exact counts: block i's operands have landed at
+//     vmcnt(21), the residual tile of block i-1 at vmcnt(8) in front of the first epilogue quad;
+//   * GemmArgs::row_part: (sum, sum of squares) of the stored fp16 values per row and 32-column block, for the LayerNorm that
+//     the consumer GEMM folds into its epilogue;
 //   * one accumulator chain (gfx950 forwards a dependent same-type MFMA's accumulator): 16 registers less.
 // ================================================================================================
 constexpr int WRR_TILE = 2048;                    // 32 rows x 64 B
@@ -394,6 +441,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_resid_kernel(GemmArgs g, int
   const unsigned coff0 = (unsigned)(drow * cpitch + (col0 + rs * 8) * 2), coff1 = coff0 + (unsigned)(16 * cpitch);
   const int equad = l31 * 64 + half * 8;             // this lane's 8 bytes inside a 16-byte chunk of tile row l31
   const int esw = (l31 >> 2) & 3;
+  float st_s = 0.f, st_q = 0.f;
   auto epi_quad = [&](int qd, int j) __attribute__((always_inline)) {  // (accP quad + bias) + residual -> fp16, in place in the tile
     unsigned char* pq = tiles + (j & 1) * WRR_TILE + equad + ((qd ^ esw) << 4);
     const uint2 rv = *(const uint2*)pq;
@@ -403,7 +451,25 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_resid_kernel(GemmArgs g, int
     const float r3 = (float)__builtin_bit_cast(_Float16, (unsigned short)(rv.y >> 16));
     const float v0 = (accP[4 * qd] + bias4[qd][0]) + r0, v1 = (accP[4 * qd + 1] + bias4[qd][1]) + r1;
     const float v2 = (accP[4 * qd + 2] + bias4[qd][2]) + r2, v3 = (accP[4 * qd + 3] + bias4[qd][3]) + r3;
-    *(uint2*)pq = make_uint2(pack2_f16(v0, v1), pack2_f16(v2, v3));
+    const uint2 pk = make_uint2(pack2_f16(v0, v1), pack2_f16(v2, v3));
+    *(uint2*)pq = pk;
+    // LayerNorm partials of the stored values: this lane's four quads in order (columns 8 qd + 4 half .. + 3 of the 32-column block)
+    const float w0 = f16lo(pk.x), w1 = f16hi(pk.x), w2 = f16lo(pk.y), w3 = f16hi(pk.y);
+    const float ps = ln_sum4(w0, w1, w2, w3), pq2 = ln_sq4(w0, w1, w2, w3);
+    st_s = qd == 0 ? ps : __fadd_rn(st_s, ps);
+    st_q = qd == 0 ? pq2 : __fadd_rn(st_q, pq2);
+  };
+  // partials of block j's 32 rows over this wave's 32 columns: half 0 + half 1, written by lanes 0..31 (8 bytes per row,
+  // 256 contiguous bytes per wave: row_part is [column block][row]); without a target the descriptor is empty
+  const long pblk = (long)(cg * 8 + wave) * g.part_ld * 8;
+  const unsigned poff = half ? 0x7ffffff0u : (unsigned)(l31 * 8);
+  auto part_store = [&](int j) __attribute__((always_inline)) {
+    const float os = __shfl_xor(st_s, 32, 64), oq = __shfl_xor(st_q, 32, 64);
+    const float S = __fadd_rn(half ? os : st_s, half ? st_s : os), Q = __fadd_rn(half ? oq : st_q, half ? st_q : oq);
+    u32x4_t pd = desc_rows(g.row_part ? (const unsigned char*)g.row_part + pblk : nullptr, j, 8);
+    if (!g.row_part) pd.z = 0;
+    const uint2 sq = make_uint2(__float_as_uint(S), __float_as_uint(Q));
+    asm volatile("buffer_store_dwordx2 %0, %1, %2, 0 offen\n\ts_nop 1" : : "v"(sq), "v"(poff), "s"(pd) : "memory");
   };
   auto epi_store = [&](int pass, int j) __attribute__((always_inline)) {  // 16 tile rows -> one buffer store
     const int r = pass * 16 + drow;
@@ -414,14 +480,16 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_resid_kernel(GemmArgs g, int
   };
   auto wait_resid = [&](int n) __attribute__((always_inline)) {  // at most n younger VMEM instructions stay in flight
     switch (n) {
-      case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+      case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+      case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
       case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
       case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
       default: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
     }
   };
 
-  // block i in ring slot i & 3.  VMEM order: D0 R0 D1 R1 D2 D3 S0 S1; the epilogue of block i-1 (accP) rides in the stream
+  // block i in ring slot i & 3.  VMEM order: D0 R0 D1 R1 D2 D3 P S0 S1; the epilogue of block i-1 (accP) rides in the stream
   auto mfma_block = [&](auto steady_c, bool refill_rt, bool prev_rt, int rwait, int i) __attribute__((always_inline)) {
     constexpr bool STEADY = decltype(steady_c)::value;
     const bool refill = STEADY || refill_rt, prev = STEADY || prev_rt;
@@ -447,14 +515,14 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_resid_kernel(GemmArgs g, int
       if (sgm == 0 && refill) dma_piece(0, jd);
       if (sgm == 1) resid_dma(0, i);
       if (sgm == 2 && refill) dma_piece(1, jd);
-      if (sgm == 2 && prev) { if (STEADY) wait_resid(7); else wait_resid(rwait); epi_quad(0, js); }
+      if (sgm == 2 && prev) { if (STEADY) wait_resid(8); else wait_resid(rwait); epi_quad(0, js); }
       if (sgm == 3) resid_dma(1, i);
       if (sgm == 3 && prev) epi_quad(1, js);
       if (sgm == 4 && refill) dma_piece(2, jd);
       if (sgm == 4 && prev) epi_quad(2, js);
       if (sgm == 5 && refill) dma_piece(3, jd);
       if (sgm == 5 && prev) epi_quad(3, js);
-      if (sgm == 6 && prev) epi_store(0, js);
+      if (sgm == 6 && prev) { part_store(js); epi_store(0, js); }
       if (sgm == 7 && prev) epi_store(1, js);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -465,14 +533,14 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_resid_kernel(GemmArgs g, int
   {
     using T_ = std::true_type;
     using F_ = std::false_type;
-    // steady block: its operands were requested in block i-3's stream (last piece at position 6 of D0 R0 D1 R1 D2 D3 S0 S1):
-    // S0 S1 + two full periods = 18 younger.  The residual tile of block i-1 (R1 at position 4 of its stream) is waited for
-    // in front of quad 0, in slot 2 behind D0 R0 D1: D2 D3 S0 S1 + D0 R0 D1 = 7 younger
+    // steady block: its operands were requested in block i-3's stream (last piece at position 6 of D0 R0 D1 R1 D2 D3 P S0 S1):
+    // P S0 S1 + two full periods = 21 younger.  The residual tile of block i-1 (R1 at position 4 of its stream) is waited for
+    // in front of quad 0, in slot 2 behind D0 R0 D1: D2 D3 P S0 S1 + D0 R0 D1 = 8 younger
     auto steady = [&](int i) __attribute__((always_inline)) {
-      asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(21)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      mfma_block(T_(), true, true, 7, i);
+      mfma_block(T_(), true, true, 8, i);
 #pragma unroll
       for (int r = 0; r < 16; ++r) accP[r] = acc0[r];
     };
@@ -481,12 +549,12 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_resid_kernel(GemmArgs g, int
       const bool refill = i + WR_D - 1 < nb, refill_prev = i + WR_D - 2 < nb;
       if (i + 2 >= nb) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else if (i < 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(21)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      // younger than R1(i-1) at the wait: [D2 D3 if block i-1 refilled] [S0 S1 if i-1 > 0] of its stream, then of this one
+      // younger than R1(i-1) at the wait: [D2 D3 if block i-1 refilled] [P S0 S1 if i-1 > 0] of its stream, then of this one
       // [D0] R0 [D1] (the D's if this block refills)
-      const int rw = (refill_prev ? 2 : 0) + (i > 1 ? 2 : 0) + 1 + (refill ? 2 : 0);  // 1, 3, 5 or 7
+      const int rw = (refill_prev ? 2 : 0) + (i > 1 ? 3 : 0) + 1 + (refill ? 2 : 0);  // 1, 3, 4, 5, 6 or 8
       mfma_block(F_(), refill, i > 0, rw, i);
 #pragma unroll
       for (int r = 0; r < 16; ++r) accP[r] = acc0[r];
@@ -498,6 +566,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_resid_kernel(GemmArgs g, int
     // last block's epilogue: its residual tile was requested in its own stream
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     epi_quad(0, nb - 1); epi_quad(1, nb - 1); epi_quad(2, nb - 1); epi_quad(3, nb - 1);
+    part_store(nb - 1);
     epi_store(0, nb - 1); epi_store(1, nb - 1);
   }
 }
@@ -511,7 +580,8 @@ int g_use_wreg = 1;        // 0: every K = 512 layer goes to the tiled kernels (
 int g_wreg_min_m = 1;
 
 bool gemm_wreg_eligible(const GemmArgs& g) {
-  return g_use_wreg && g.K == WR_K && g.M >= g_wreg_min_m && g.N % 8 == 0 && g.ldc % 8 == 0 && g.lda % 8 == 0 && g.ldw % 8 == 0 &&
+  if (g.ln_stat && !(g.ln_colsum && g.bias)) return false;
+  return (g_use_wreg || g.ln_stat) && g.K == WR_K && g.M >= g_wreg_min_m && g.N % 8 == 0 && g.ldc % 8 == 0 && g.lda % 8 == 0 && g.ldw % 8 == 0 &&
          g.out_act && !g.out_f32 && !g.resid && (g.act == ACT_NONE || g.act == ACT_QUICK_GELU) &&
          (long)g.ldc * 2 * WR_BLK < (1L << 30) && (long)g.lda * 2 * WR_BLK < (1L << 30);
 }
@@ -555,6 +625,12 @@ int launch_gemm_wreg(const GemmArgs& g, hipStream_t st) {
     CZC_ATTR((gemm_wreg_kernel<ACT_NONE, true>));
     CZC_ATTR((gemm_wreg_kernel<ACT_QUICK_GELU, true>));
 #undef CZC_ATTR
+#define CZC_ATTR(K_) CZC_HIP_CHECK(hipFuncSetAttribute((const void*)K_, hipFuncAttributeMaxDynamicSharedMemorySize, WR_LDS_LNF))
+    CZC_ATTR((gemm_wreg_kernel<ACT_NONE, false, true>));
+    CZC_ATTR((gemm_wreg_kernel<ACT_QUICK_GELU, false, true>));
+    CZC_ATTR((gemm_wreg_kernel<ACT_NONE, true, true>));
+    CZC_ATTR((gemm_wreg_kernel<ACT_QUICK_GELU, true, true>));
+#undef CZC_ATTR
     return 0;
   });
   if (init.rc) return launch_init_failed("gemm_wreg");
@@ -568,7 +644,8 @@ int launch_gemm_wreg(const GemmArgs& g, hipStream_t st) {
   }
   if (nsets > nblk) nsets = nblk;
   dim3 grid(n_cu), block(512);
-#define CZC_WR_GO(A_, H_) hipLaunchKernelGGL((gemm_wreg_kernel<A_, H_>), grid, block, WR_LDS, st, g, ncg, nsets, nblk)
+#define CZC_WR_GO(A_, H_) do { if (g.ln_stat) hipLaunchKernelGGL((gemm_wreg_kernel<A_, H_, true>), grid, block, WR_LDS_LNF, st, g, ncg, nsets, nblk); \
+                               else hipLaunchKernelGGL((gemm_wreg_kernel<A_, H_>), grid, block, WR_LDS, st, g, ncg, nsets, nblk); } while (0)
   if (g.f16) { if (g.act == ACT_QUICK_GELU) CZC_WR_GO(ACT_QUICK_GELU, true); else CZC_WR_GO(ACT_NONE, true); }
   else { if (g.act == ACT_QUICK_GELU) CZC_WR_GO(ACT_QUICK_GELU, false); else CZC_WR_GO(ACT_NONE, false); }
 #undef CZC_WR_GO

@@ -22,6 +22,17 @@ struct GemmArgs {
   // elements) instead of fp32 ones -- x <- fp16(x + A.W^T + b), the sum formed in fp32 and rounded once.  Served by the tiled
   // kernel, the ping-pong ring kernel and the weight-stationary kernel's residual form; the others refuse it.
   int x16 = 0;
+  // x16 layers may also leave per-row LayerNorm partials of the rows they write (round 5: LayerNorm folded into the consumer
+  // GEMM): row_part[b * part_ld + m] = float2(sum, sum of squares) of the STORED fp16 values of row m over the 32-column
+  // block b (N / 32 blocks), every producer in the same association order (common.h ln_part4 / the epilogues' comments), so
+  // that the statistics do not depend on which kernel served the layer.  Null: not written.
+  float* row_part = nullptr;
+  long part_ld = 0;
+  // LayerNorm folded into the weight-stationary K = 512 GEMM (gemm_wreg.hip LNF): A = the raw fp16 residual rows, W = fp16
+  // weights with the gain folded in, bias = b + W.beta, ln_colsum [N] = row sums of the stored W', ln_stat = float2 (mean,
+  // rstd) per row of A
+  const float* ln_stat = nullptr;
+  const float* ln_colsum = nullptr;
   // Full-row kernel (gemm_rowln, N = 512): out_f32 <- resid + A.W^T + bias and out_act <- LayerNorm(out_f32; ln_gamma,
   // ln_beta, ln_eps) from one launch.
   const float* ln_gamma = nullptr;
@@ -73,7 +84,11 @@ int launch_bert_embed(int prec, const int* ids, int B, int T, int H, const float
 // (HF:clip/modeling_clip.py:250-254)
 int launch_clip_embed(const int* ids, int ids_stride, const int* seg_src, const int* seg_pos0, const int* own_off,
                       const int* own_len, int n_seg, int max_len, int H, const float* tok, const float* pos, float* x,
-                      hipStream_t st, int x16 = 0);  // x16: x is a 2-byte (fp16) residual stream
+                      hipStream_t st, int x16 = 0, float* stat = nullptr, float eps = 0.f);  // x16: x is a 2-byte (fp16) residual stream; stat: float2 (mean, rstd) per row
+// LayerNorm folded into the consumer GEMM: statistics from the producers' partials, one-time weight preparation
+int launch_ln_finalize(const float* part, long part_ld, int nblk, int M, float eps, float* stat, hipStream_t st);
+int launch_fold_ln(const float* W, const float* gamma, const float* beta, const float* b, int N, int K, void* Wf16, float* colsum, float* bf,
+                   hipStream_t st);
 // vision: im2col of [B,3,S,S] into patches [B*P, 3*p*p] (act type), then assemble cls/pos
 int launch_im2col(int prec, const float* pixels, int B, int S, int p, void* out, hipStream_t st);
 int launch_vision_assemble(const float* patch_out, int B, int P, int H, const float* cls, const float* pos, float* x,
@@ -213,7 +228,7 @@ int launch_refine_finish(const int* own_off, const int* own_len, const int* coun
 // ---- czc_internal_hooks (include/conzic_hip.h): what libconzic_hip_test.so may reach inside this library -----------
 // The product library has hidden visibility; the hook library (api_test.hip) gets the launchers it wraps and the
 // process-wide kernel-family switches it flips through this table instead of through exported C++ symbols.
-constexpr int HOOKS_ABI = 0x0502;
+constexpr int HOOKS_ABI = 0x0503;
 struct Hooks {
   char* (*err_buf)();  // the calling host thread's g_err [512]
   decltype(&launch_gemm) gemm;
@@ -228,6 +243,8 @@ struct Hooks {
   decltype(&launch_l2_normalize) l2_normalize;
   decltype(&launch_combine) combine;
   decltype(&launch_layernorm_x16) layernorm_x16;
+  decltype(&launch_ln_finalize) ln_finalize;
+  decltype(&launch_fold_ln) fold_ln;
   int *use_gemm256, *use_skinny, *use_splitk, *gemm_deep, *gemm_small_tiles, *use_wreg, *use_gemm256s, *w_dbg, *ln_lean,
       *rowln_min_m, *wreg_min_m, *gemm256_min_m, *use_mfma_attention, *use_attention_image;
 };

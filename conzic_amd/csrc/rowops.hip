@@ -187,6 +187,59 @@ int launch_layernorm_x16(int prec, const void* x16, const int* row_idx, const fl
   return 0;
 }
 
+// LayerNorm folded into the consumer GEMM (round 5): (mean, rstd) per row from the producers' partials -- row_part[b * ld + m] =
+// (sum, sum of squares) of row m's stored fp16 values over 32-column block b -- summed over the blocks in order.  One kernel
+// for every row count, so the statistics do not depend on the batch.  var = E[x^2] - mean^2 in fp32 (clamped at 0): the rows of
+// these towers have |mean| of the order of their spread, so the subtraction costs a few ulps, not digits.
+__global__ __launch_bounds__(256) void ln_finalize_kernel(const float2* part, long ld, int nblk, int M, float eps, float2* stat) {
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= M) return;
+  float2 a = part[m];
+  for (int b = 1; b < nblk; ++b) {
+    const float2 p = part[b * ld + m];
+    a.x = __fadd_rn(a.x, p.x);
+    a.y = __fadd_rn(a.y, p.y);
+  }
+  const float n = (float)(nblk * 32);
+  const float mean = a.x / n;
+  const float var = fmaxf(__fsub_rn(a.y / n, __fmul_rn(mean, mean)), 0.f);
+  stat[m] = make_float2(mean, rsqrtf(var + eps));
+}
+
+int launch_ln_finalize(const float* part, long part_ld, int nblk, int M, float eps, float* stat, hipStream_t st) {
+  if (M <= 0) return 0;
+  hipLaunchKernelGGL(ln_finalize_kernel, dim3(cdiv(M, 256)), dim3(256), 0, st, (const float2*)part, part_ld, nblk, M, eps, (float2*)stat);
+  CZC_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// One-time weight preparation of the fold: W' = fp16(W * diag(gamma)) [N,K], colsum[j] = sum_k W'[j,k] (of the STORED values:
+// it multiplies the mean of the stored rows), bf[j] = b[j] + sum_k W[j,k] * beta[k].  One wave per output row.
+__global__ __launch_bounds__(256) void fold_ln_kernel(const float* W, const float* gamma, const float* beta, const float* b, int N, int K,
+                                                      f16_t* Wf, float* colsum, float* bf) {
+  const int lane = threadIdx.x & 63;
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= N) return;
+  float cs = 0.f, wb = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    const float w = W[(long)j * K + k];
+    const unsigned short h = Half<f16_t>::from_f32(w * gamma[k]);
+    Wf[(long)j * K + k].v = h;
+    cs += Half<f16_t>::to_f32(h);
+    wb += w * beta[k];
+  }
+  cs = wave_sum(cs);
+  wb = wave_sum(wb);
+  if (lane == 0) { colsum[j] = cs; bf[j] = (b ? b[j] : 0.f) + wb; }
+}
+
+int launch_fold_ln(const float* W, const float* gamma, const float* beta, const float* b, int N, int K, void* Wf16, float* colsum, float* bf,
+                   hipStream_t st) {
+  hipLaunchKernelGGL(fold_ln_kernel, dim3(cdiv(N, 4)), dim3(256), 0, st, W, gamma, beta, b, N, K, (f16_t*)Wf16, colsum, bf);
+  CZC_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
 int g_ln_lean = 1;  // test option ln_lean = 0: the 35-VGPR form of layernorm512_kernel (shuffles through ds_bpermute)
 
 int launch_layernorm(int prec, const float* x, const int* row_idx, const float* gamma, const float* beta, float eps,
@@ -284,7 +337,7 @@ int launch_bert_embed(int prec, const int* ids, int B, int T_, int H, const floa
 __global__ __launch_bounds__(256) void clip_embed_kernel(const int* ids, int ids_stride, const int* seg_src,
                                                          const int* seg_pos0, const int* own_off, const int* own_len,
                                                          int n_seg, int max_len, int H, const float* tok,
-                                                         const float* pos, float* x, int x16) {
+                                                         const float* pos, float* x, int x16, float* stat, float eps) {
   const int lane = threadIdx.x & 63;
   const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int s = (int)(w / max_len), i = (int)(w % max_len);
@@ -295,9 +348,32 @@ __global__ __launch_bounds__(256) void clip_embed_kernel(const int* ids, int ids
   const float* pr = pos + (long)p * H;
   if (x16) {  // 2-byte residual stream: the same sums, rounded once to fp16
     f16_t* xh = (f16_t*)x + ((long)own_off[s] + i) * H;
-    for (int c = lane * 4; c < H; c += 256) {
-      const float4 a = *(const float4*)(tr + c), b = *(const float4*)(pr + c);
-      *(uint2*)(xh + c) = make_uint2(pack2_f16(a.x + b.x, a.y + b.y), pack2_f16(a.z + b.z, a.w + b.w));
+    float sm = 0.f;
+    float4 keep[LN_MAXV];  // compile-time indices only (H <= 1024)
+#pragma unroll
+    for (int t = 0; t < LN_MAXV; ++t) {
+      const int c = lane * 4 + t * 256;
+      keep[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c < H) {
+        const float4 a = *(const float4*)(tr + c), b = *(const float4*)(pr + c);
+        const uint2 pk = make_uint2(pack2_f16(a.x + b.x, a.y + b.y), pack2_f16(a.z + b.z, a.w + b.w));
+        *(uint2*)(xh + c) = pk;
+        keep[t] = make_float4(f16lo(pk.x), f16hi(pk.x), f16lo(pk.y), f16hi(pk.y));
+        sm += (keep[t].x + keep[t].y) + (keep[t].z + keep[t].w);
+      }
+    }
+    if (stat) {  // (mean, rstd) of the STORED row: layer 0's LayerNorm, folded into its q/k/v GEMM (two-pass, like the LayerNorm kernels)
+      const float mean = wave_sum(sm) / (float)H;
+      float q = 0.f;
+#pragma unroll
+      for (int t = 0; t < LN_MAXV; ++t) {
+        if (lane * 4 + t * 256 < H) {
+          const float a = keep[t].x - mean, b = keep[t].y - mean, c2 = keep[t].z - mean, d = keep[t].w - mean;
+          q += (a * a + b * b) + (c2 * c2 + d * d);
+        }
+      }
+      const float rstd = rsqrtf(wave_sum(q) / (float)H + eps);
+      if (lane == 0) *(float2*)(stat + ((long)own_off[s] + i) * 2) = make_float2(mean, rstd);
     }
     return;
   }
@@ -310,11 +386,11 @@ __global__ __launch_bounds__(256) void clip_embed_kernel(const int* ids, int ids
 
 int launch_clip_embed(const int* ids, int ids_stride, const int* seg_src, const int* seg_pos0, const int* own_off,
                       const int* own_len, int n_seg, int max_len, int H, const float* tok, const float* pos, float* x,
-                      hipStream_t st, int x16) {
+                      hipStream_t st, int x16, float* stat, float eps) {
   if (n_seg <= 0) return 0;
   dim3 grid(cdiv((long)n_seg * max_len, 4)), block(256);
   hipLaunchKernelGGL(clip_embed_kernel, grid, block, 0, st, ids, ids_stride, seg_src, seg_pos0, own_off, own_len, n_seg,
-                     max_len, H, tok, pos, x, x16);
+                     max_len, H, tok, pos, x, x16, stat, eps);
   CZC_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -534,8 +534,26 @@ def test_gemm(prec, A, W, bias=None, resid=None, act=0, typed_out=False):
     return Cm
 
 
-def test_gemm_x16(prec, A, W, bias, resid):
-    """x = fp16(fp16(resid) + A.W^T + bias) on a 2-byte residual stream (GemmArgs::x16); returned as fp32."""
+def test_ln_fold_gemm(prec, x, W, gamma, beta, bias, part, eps, act=0):
+    """act(LN(fp16(x)) . W^T + bias) through the folded-LayerNorm weight-stationary GEMM; part [16, M, 2] = partials of fp16(x)."""
+    lib = native.load_test()
+    x = np.ascontiguousarray(x, np.float32)
+    W = np.ascontiguousarray(W, np.float32)
+    M, N = x.shape[0], W.shape[0]
+    g = np.ascontiguousarray(gamma, np.float32)
+    bt = np.ascontiguousarray(beta, np.float32)
+    b = None if bias is None else np.ascontiguousarray(bias, np.float32)
+    pt = np.ascontiguousarray(part, np.float32)
+    assert pt.shape == (16, M, 2) and x.shape[1] == 512 and W.shape[1] == 512
+    out = np.empty((M, N), np.float32)
+    native.check(lib.czc_test_ln_fold_gemm(prec, M, N, x.ctypes.data, W.ctypes.data, g.ctypes.data, bt.ctypes.data, _ptr(b), pt.ctypes.data,
+                                           float(eps), int(act), out.ctypes.data), None, "czc_test_ln_fold_gemm")
+    return out
+
+
+def test_gemm_x16(prec, A, W, bias, resid, want_part=False):
+    """x = fp16(fp16(resid) + A.W^T + bias) on a 2-byte residual stream (GemmArgs::x16); returned as fp32
+    (with want_part: also the LayerNorm partials [N/32, M, 2])."""
     lib = native.load_test()
     A = np.ascontiguousarray(A, np.float32)
     W = np.ascontiguousarray(W, np.float32)
@@ -544,9 +562,10 @@ def test_gemm_x16(prec, A, W, bias, resid):
     b = None if bias is None else np.ascontiguousarray(bias, np.float32)
     r = np.ascontiguousarray(resid, np.float32)
     out = np.empty((M, N), np.float32)
-    native.check(lib.czc_test_gemm_x16(prec, M, N, K, A.ctypes.data, W.ctypes.data, _ptr(b), r.ctypes.data, out.ctypes.data),
+    part = np.empty((N // 32, M, 2), np.float32) if want_part else None
+    native.check(lib.czc_test_gemm_x16(prec, M, N, K, A.ctypes.data, W.ctypes.data, _ptr(b), r.ctypes.data, out.ctypes.data, _ptr(part)),
                  None, "czc_test_gemm_x16")
-    return out
+    return (out, part) if want_part else out
 
 
 def test_layernorm_x16(prec, x, gamma, beta, eps):

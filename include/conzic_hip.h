@@ -294,9 +294,10 @@ int czc_refine_guard(czc_engine* e, int reset, float* max_dev, int64_t* tripped)
  * the winner's cosine at the snapshot steps (gen_utils.py:78-81, :92), not the K fused scores.  An image-step whose screening
  * (single-pass fp16) winner stays the winner under EVERY assignment of cosine errors |d_k - common| <= delta (delta = option
  * "refine_gate_x1e6" * 1e-6, default 400 = 2x the largest deviation measured over 256 k candidates; the check is the
- * adversarial one: winner's logit down, challenger's up, the rest both ways) needs no second pass for its id.  Image-steps
- * that fail the gate, and every image at the snapshot steps (whose winner cosine is returned, and where the guard above keeps
- * measuring the screening tower), take the full selection.
+ * adversarial one: winner's logit down, challenger's up, the rest both ways) needs no second pass for its id; at a snapshot
+ * step its winner alone is re-encoded, for the cosine the call returns.  Image-steps that fail the gate take the full selection,
+ * and so does every image at the snapshot step of every fourth sweep (the first included): the audit steps on which the guard
+ * above keeps measuring the screening tower.
  * czc_step never gates: all K scores are its output and all of them are refined.  *gated of *image_steps since
  * czc_profile_reset. */
 int czc_refine_gate_stats(czc_engine* e, int64_t* gated, int64_t* image_steps);

@@ -828,3 +828,79 @@ def test_layernorm_of_fp16_rows(prec):
     tol = np.maximum(np.abs(ref), 1.0) * (2.0 ** -8 if prec == BF16 else 2.0 ** -11) + 1e-5
     assert (np.abs(y - ref) <= tol).all(), float(np.abs(y - ref).max())
     assert np.abs(y - rnd(ref.astype(np.float32))).max() <= float(tol.max())
+
+
+def _part_ref(x_out):
+    """(sum, sum of squares) per row and 32-column block of the stored fp16 rows, in fp64."""
+    M, N = x_out.shape
+    blk = x_out.astype(np.float64).reshape(M, N // 32, 32)
+    return np.stack([blk.sum(-1), (blk * blk).sum(-1)], axis=-1).transpose(1, 0, 2)  # [N/32, M, 2]
+
+
+@pytest.mark.parametrize("M,K", [(31, 512), (4097, 512), (40000, 512), (64280, 512), (130, 2048), (9000, 2048), (20000, 2048)])
+def test_residual_gemm_leaves_layernorm_partials(M, K):
+    """GemmArgs::row_part: every producer of the 2-byte residual stream also writes (sum, sum of squares) of the fp16 values it
+    stored, per row and 32-column block.  Against fp64 sums of the returned rows; every slot written (the buffer starts as NaN)."""
+    rng = np.random.default_rng(M + K)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((512, K)) * 0.05).astype(np.float32)
+    bias = rng.standard_normal(512).astype(np.float32)
+    resid = (rng.standard_normal((M, 512)) * 2).astype(np.float32)
+    out, part = E.test_gemm_x16(BF16, A, W, bias, resid, want_part=True)
+    assert np.isfinite(part).all()
+    ref = _part_ref(out)
+    np.testing.assert_allclose(part[..., 0], ref[..., 0], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(part[..., 1], ref[..., 1], rtol=2e-6, atol=1e-4)
+
+
+def test_layernorm_partials_do_not_depend_on_the_kernel():
+    """The same layer on the ring kernel, the tiled kernel (128- and 64-wide tiles) -- fc2 -- and, for K = 512, the
+    weight-stationary residual kernel against the tiled one: bit-identical rows AND bit-identical partials (one association
+    order in every epilogue), so the folded LayerNorm's statistics cannot change with the batch size."""
+    lib = native.load_test()
+    rng = np.random.default_rng(5)
+    bias = rng.standard_normal(512).astype(np.float32)
+    try:
+        M, K = 8200, 2048
+        A = rng.standard_normal((M, K)).astype(np.float32)
+        W = (rng.standard_normal((512, K)) * 0.03).astype(np.float32)
+        resid = (rng.standard_normal((M, 512)) * 2).astype(np.float32)
+        outs = {}
+        for name, (mn, small, deep) in {"ring": (1, 4, 1), "tiled": (1 << 30, 0, 1), "tiled64": (1 << 30, 1 << 20, 2)}.items():
+            assert lib.czc_test_set_option(b"gemm256_min_m", mn) == 0 and lib.czc_test_set_option(b"gemm_small_tiles", small) == 0
+            assert lib.czc_test_set_option(b"gemm_deep", deep) == 0
+            outs[name] = E.test_gemm_x16(BF16, A, W, bias, resid, want_part=True)
+        for name in ("tiled", "tiled64"):
+            np.testing.assert_array_equal(outs["ring"][0], outs[name][0])
+            np.testing.assert_array_equal(outs["ring"][1], outs[name][1])
+    finally:
+        lib.czc_test_set_option(b"gemm256_min_m", 8192)
+        lib.czc_test_set_option(b"gemm_small_tiles", 4)
+        lib.czc_test_set_option(b"gemm_deep", 1)
+
+
+@pytest.mark.parametrize("prec", [BF16, native.PREC_FP16])
+@pytest.mark.parametrize("M,N,act", [(33, 1536, 0), (1000, 2048, 1), (20000, 1536, 0), (50000, 2048, 1)])
+def test_layernorm_folded_into_the_weight_stationary_gemm(prec, M, N, act):
+    """act(LN(x) . W^T + b) computed from x itself: fp16 MFMA on (x, W * gamma), corrected in the epilogue with the row's
+    (mean, rstd) -- against fp64 LayerNorm + GEMM of the fp16-rounded x.  Rows with a large common offset included (the
+    rank-1 correction subtracts mean * colsum from the accumulator: the case that would cancel)."""
+    rng = np.random.default_rng(M + N)
+    x = (rng.standard_normal((M, 512)) * 2).astype(np.float32)
+    x[::7] += 6.0          # |mean| = 3 sigma
+    x[3::11, 17] = 60.0    # an outlier channel
+    W = (rng.standard_normal((N, 512)) * 0.04).astype(np.float32)
+    gamma = (1 + 0.2 * rng.standard_normal(512)).astype(np.float32)
+    beta = (0.1 * rng.standard_normal(512)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    xr = _f16_round(x)
+    part = _part_ref(xr).astype(np.float32)
+    out = E.test_ln_fold_gemm(prec, x, W, gamma, beta, bias, part, 1e-5, act)
+    xd = torch.from_numpy(xr).double()
+    y = torch.nn.functional.layer_norm(xd, (512,), torch.from_numpy(gamma).double(), torch.from_numpy(beta).double(), 1e-5)
+    pre = (y @ torch.from_numpy(W).double().T + torch.from_numpy(bias).double()).numpy()
+    ref = pre * (1.0 / (1.0 + np.exp(-1.702 * pre))) if act == 1 else pre
+    # operand roundings: x is exact (fp16), W * gamma rounded to fp16 (2^-11): ~ 2^-11 * |y| * |W| * sqrt(512); output rounding of `prec`
+    tol = np.maximum(np.abs(ref), 1.0) * (2.0 ** -8 if prec == BF16 else 2.0 ** -10) + 6e-3
+    bad = np.abs(out - ref) > tol
+    assert not bad.any(), (int(bad.sum()), float(np.abs(out - ref).max()), np.argwhere(bad)[:4].tolist())

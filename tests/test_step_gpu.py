@@ -408,7 +408,8 @@ def test_margin_gate_skips_the_second_pass_without_changing_what_generate_return
         np.testing.assert_allclose(cos, np.array(meta["scores"][:-1], dtype=np.float32), atol=2e-5)
     on, off = res[400][2], res[0][2]
     assert off["gated_image_steps"] == 0 and off["gate_image_steps"] == 0
-    assert on["gate_image_steps"] == meta["B"] * len(pos)
+    audits = sum(1 for s_ in range(len(pos)) if (s_ + 1) % every == 0 and (s_ // every) % 4 == 0)  # audit steps never gate
+    assert on["gate_image_steps"] == meta["B"] * (len(pos) - audits)
     frac = on["gated_image_steps"] / on["gate_image_steps"]
     print(f"[margin gate] {on['gated_image_steps']}/{on['gate_image_steps']} image-steps gated; candidates re-encoded "
           f"{on['refine_seqs']} (gate on) vs {off['refine_seqs']} (off)")
@@ -1149,7 +1150,9 @@ def test_large_batch_kernel_families_agree():
             assert np.isfinite(res["final_score"]).all(), name
             # different fp32 summation orders under bf16 roundings: ~1e-4 typical, ~1e-3 in the tail of 12 800 cosines
             np.testing.assert_allclose(res["clip_ref"], ref["clip_ref"], atol=3e-3, err_msg=name)
-            assert np.abs(res["clip_ref"] - ref["clip_ref"]).mean() < 2e-4, name
+            # (3e-4 since round 5: the tower's rows live in fp16, and a different summation order in the out-projection moves
+            # an element across a rounding boundary now and then)
+            assert np.abs(res["clip_ref"] - ref["clip_ref"]).mean() < 3e-4, name
             np.testing.assert_allclose(res["final_score"], ref["final_score"], atol=1e-3, err_msg=name)
         # bit-reproducible from run to run
         again = su.engine.step(inp.copy(), gen_idx, K, hp)
