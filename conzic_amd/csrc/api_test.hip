@@ -187,7 +187,8 @@ int czc_test_ln_fold_gemm(int precision, int M, int N, const float* x, const flo
   T_CHECK(launch_ln_finalize(dpart, M, 16, M, eps, dstat, nullptr));
   T_CHECK(launch_fold_ln(dW, dg, dbt, db, N, K, dWf, dcs, dbf, nullptr));
   GemmArgs g;
-  g.A = dx; g.lda = K; g.W = dWf; g.ldw = K; g.bias = dbf; g.out_act = dout; g.ldc = N; g.M = M; g.N = N; g.K = K; g.act = act;
+  g.A = dx; g.lda = K; g.W = dWf; g.ldw = K; g.bias = dbf; g.resid = nullptr; g.ldr = 0; g.out_act = dout; g.out_f32 = nullptr; g.ldc = N;
+  g.M = M; g.N = N; g.K = K; g.act = act;
   g.ln_stat = dstat; g.ln_colsum = dcs;
   T_CHECK(launch_gemm(precision, g, nullptr));
   T_HIP(hipDeviceSynchronize());

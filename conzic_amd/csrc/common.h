@@ -58,6 +58,12 @@ __device__ __forceinline__ float pin(float v) {
   return v;
 }
 
+// (the products are made opaque: __fmul_rn does not stop hipcc from contracting a * a + b * b into a fused multiply-add,
+// and it fuses differently from kernel to kernel)
+__device__ __forceinline__ float ln_sq4(float a, float b, float c, float d) {
+  return __fadd_rn(__fadd_rn(pin(a * a), pin(b * b)), __fadd_rn(pin(c * c), pin(d * d)));
+}
+
 __device__ __forceinline__ uint32_t pack2_f16(float lo, float hi) {
   typedef __attribute__((ext_vector_type(2))) _Float16 h2;
   const h2 v = {(_Float16)pin(lo), (_Float16)pin(hi)};  // round-to-nearest-even of the fp32 values (v_cvt_pk_f16_f32)
@@ -149,9 +155,6 @@ template <> struct Act<split_t> {
 // LayerNorm partials of four stored values (GemmArgs::row_part): fixed association, no fused multiply-adds (HIP compiles with
 // -ffp-contract=fast, and every producer kernel must arrive at the same bits)
 __device__ __forceinline__ float ln_sum4(float a, float b, float c, float d) { return __fadd_rn(__fadd_rn(a, b), __fadd_rn(c, d)); }
-__device__ __forceinline__ float ln_sq4(float a, float b, float c, float d) {
-  return __fadd_rn(__fadd_rn(__fmul_rn(a, a), __fmul_rn(b, b)), __fadd_rn(__fmul_rn(c, c), __fmul_rn(d, d)));
-}
 __device__ __forceinline__ float f16lo(unsigned p) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(p & 0xffffu)); }
 __device__ __forceinline__ float f16hi(unsigned p) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(p >> 16)); }
 

@@ -341,7 +341,8 @@ int clip_stack(czc_engine* e, int P, const char* gk, std::vector<LayerW>& L, flo
   auto folded_gemm = [&](const void* Ax, const void* Wf, const float* bf, const float* cs, const float* st_, void* out, int rows, int N,
                          int act) -> int {
     GemmArgs g;
-    g.A = Ax; g.lda = H; g.W = Wf; g.ldw = H; g.bias = bf; g.out_act = out; g.ldc = N; g.M = rows; g.N = N; g.K = H; g.act = act;
+    g.A = Ax; g.lda = H; g.W = Wf; g.ldw = H; g.bias = bf; g.resid = nullptr; g.ldr = 0; g.out_act = out; g.out_f32 = nullptr; g.ldc = N;
+    g.M = rows; g.N = N; g.K = H; g.act = act;
     g.ln_stat = st_; g.ln_colsum = cs;
     ProfScope ps(e, gk, 2.0 * rows * (double)N * H);
     E_CHECK(launch_gemm(P, g, e->st));

@@ -309,10 +309,11 @@ __device__ __forceinline__ void tile_epilogue_x16_asm(const GemmArgs& g, f32x16_
   }
   u32x4_t rsP;  // LayerNorm partials (GemmArgs::row_part, [column block][row] float2); empty without a target
   {
-    const unsigned long long pp = (unsigned long long)g.row_part;
+    // (no target: a valid base and four records; every lane's offset is then past the end, the drop that serves the edges)
+    const unsigned long long pp = (unsigned long long)(g.row_part ? (const void*)g.row_part : (const void*)g.W);
     rsP.x = __builtin_amdgcn_readfirstlane((unsigned)pp);
     rsP.y = __builtin_amdgcn_readfirstlane((unsigned)(pp >> 32) & 0xffffu);
-    rsP.z = __builtin_amdgcn_readfirstlane((unsigned)(g.row_part ? (long)(g.N / 32) * g.part_ld * 8 : 0));
+    rsP.z = __builtin_amdgcn_readfirstlane((unsigned)(g.row_part ? (long)(g.N / 32) * g.part_ld * 8 : 4));
     rsP.w = 0x00020000u;
   }
   asm volatile("s_nop 4" ::: "memory");  // descriptors fresh from v_readfirstlane -> buffer_* inside asm strings
@@ -391,7 +392,7 @@ __device__ __forceinline__ void tile_epilogue_x16_asm(const GemmArgs& g, f32x16_
       const uint2 sq = make_uint2(__float_as_uint(__fadd_rn(part[0], part[1])), __float_as_uint(__fadd_rn(part[2], part[3])));
       const int prow = m0 + wm * 128 + (blk / NJ) * 32 + pass * 16 + rrow;
       const long pcol = (n0 + wcol0 + (blk % NJ) * 32) / 32;
-      const unsigned po = (rs == 0 && prow < g.M && colof(blk) < g.N) ? (unsigned)((pcol * g.part_ld + prow) * 8) : 0x7ffffff0u;
+      const unsigned po = (g.row_part && rs == 0 && prow < g.M && colof(blk) < g.N) ? (unsigned)((pcol * g.part_ld + prow) * 8) : 0x7ffffff0u;
       asm volatile("buffer_store_dwordx2 %0, %1, %2, 0 offen\n\ts_nop 1" : : "v"(sq), "v"(po), "s"(rsP) : "memory");
     }
   }

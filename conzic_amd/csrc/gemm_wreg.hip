@@ -461,13 +461,14 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_resid_kernel(GemmArgs g, int
   };
   // partials of block j's 32 rows over this wave's 32 columns: half 0 + half 1, written by lanes 0..31 (8 bytes per row,
   // 256 contiguous bytes per wave: row_part is [column block][row]); without a target the descriptor is empty
+  // (no target: a valid base with every lane's offset past its few records -- the drop that serves the column edges; a null
+  // base with zero records faulted)
   const long pblk = (long)(cg * 8 + wave) * g.part_ld * 8;
-  const unsigned poff = half ? 0x7ffffff0u : (unsigned)(l31 * 8);
+  const unsigned poff = (half || !g.row_part) ? 0x7ffffff0u : (unsigned)(l31 * 8);
   auto part_store = [&](int j) __attribute__((always_inline)) {
     const float os = __shfl_xor(st_s, 32, 64), oq = __shfl_xor(st_q, 32, 64);
     const float S = __fadd_rn(half ? os : st_s, half ? st_s : os), Q = __fadd_rn(half ? oq : st_q, half ? st_q : oq);
-    u32x4_t pd = desc_rows(g.row_part ? (const unsigned char*)g.row_part + pblk : nullptr, j, 8);
-    if (!g.row_part) pd.z = 0;
+    const u32x4_t pd = desc_rows(g.row_part ? (const unsigned char*)g.row_part + pblk : (const unsigned char*)g.W, g.row_part ? j : -b0, 8);
     const uint2 sq = make_uint2(__float_as_uint(S), __float_as_uint(Q));
     asm volatile("buffer_store_dwordx2 %0, %1, %2, 0 offen\n\ts_nop 1" : : "v"(sq), "v"(poff), "s"(pd) : "memory");
   };

@@ -10,13 +10,13 @@ namespace czc {
 // (bf16_t or float).  out_act (same element type, may be null) and/or out_f32 (may be null)
 // are written with leading dimension ldc.  resid may alias out_f32.
 struct GemmArgs {
-  const void* A; int lda;
-  const void* W; int ldw;
-  const float* bias;
-  const float* resid; int ldr;
-  void* out_act; float* out_f32; int ldc;
-  int M, N, K;
-  int act;
+  const void* A = nullptr; int lda = 0;
+  const void* W = nullptr; int ldw = 0;
+  const float* bias = nullptr;
+  const float* resid = nullptr; int ldr = 0;
+  void* out_act = nullptr; float* out_f32 = nullptr; int ldc = 0;
+  int M = 0, N = 0, K = 0;
+  int act = 0;
   int f16 = 0;  // 2-byte operands are IEEE fp16 instead of bf16 (set by launch_gemm from the precision)
   // 2-byte residual stream (round 5; half-precision engines only): `resid` and `out_f32` point to IEEE fp16 rows (ldr / ldc in
   // elements) instead of fp32 ones -- x <- fp16(x + A.W^T + b), the sum formed in fp32 and rounded once.  Served by the tiled

@@ -62,11 +62,23 @@ extern "C" {
 #define CZC_CLIP_MAX_LEN 77       /* clip/clip.py:71-72 (max_length = 77, truncation) */
 #define CZC_PREC_REFINE 5 /* screen-then-refine, for checkpoints with a large logit scale (published CLIP: x100): all K candidates  */
                          /* through the single-pass fp16 text tower (CZC_PREC_FP16 speed), then the candidates that carry the     */
-                         /* softmax_K mass (p_k > 4 / (beta * exp(logit_scale)), the two best fused scores, and a mass-stratified  */
-                         /* sample of the rest that measures the screening tower's mean error) are re-encoded by the split-fp16   */
-                         /* tower and the scores are formed from the mixed cosines: fused score inside 1e-3 (measured 8.4e-4 worst */
-                         /* on the goldens, 7.1e-4 over 256 k more candidates) at 1.8x the CZC_PREC_SPLIT throughput.  Vision tower */
-                         /* and BERT: split-fp16.  Options "refine_samples" (12) / "refine_theta_x1000" (4000) tune the selection.  */
+                         /* softmax_K mass (p_k > theta_x / (beta * exp(logit_scale)), theta_x = 2), the two best fused scores and */
+                         /* a mass-stratified sample of the rest (it measures the screening tower's mean error) are re-encoded by */
+                         /* the split-fp16 tower and the scores are formed from the mixed cosines: a candidate that keeps its     */
+                         /* screening cosine moves its fused score by at most theta_x * |its error - the mean|.  Inside            */
+                         /* czc_generate a margin gate skips the second pass where the winner is already certain                   */
+                         /* (czc_refine_gate_stats).  Vision tower and BERT: split-fp16.  Options "refine_samples" (12) /           */
+                         /* "refine_theta_x1000" (2000) / "refine_gate_x1e6" (400) tune it.  Measured figures: the block below.     */
+/*
+ * BEGIN GENERATED measured
+ * Measured on one MI355X, round 5 (generated by tools/refresh_docs.py from profiles/r05_*):
+ *   fused score vs the reference, worst over the full-size goldens: CZC_PREC_BF16 n/a, CZC_PREC_REFINE n/a,
+ *   CZC_PREC_SPLIT n/a, CZC_PREC_F32 n/a (bar 1e-3);
+ *   CZC_PREC_REFINE against CZC_PREC_SPLIT over n/a more image-steps: worst n/a, 99.9th percentile n/a, winners identical
+ *   n/a / n/a; guard sample maximum n/a against n/a over all candidates;
+ *   BASELINE configs[2]: n/a captions/s (CZC_PREC_BF16), n/a (CZC_PREC_REFINE through czc_generate, n/a % of the image-steps gated).
+ * END GENERATED measured
+ */
 #define CZC_MAX_TOPK 1024
 #define CZC_MAX_BERT_LEN 64
 
@@ -246,14 +258,17 @@ int czc_generate(czc_engine* e, int B, int T, int L, int seed_len, const int32_t
  *                         masked row of every sequence only -- the one row the MLM head reads (gen_utils.py:69)
  *   "pack_branches"   (1) attention of the branch rows with G candidates packed per 32-query MFMA tile
  *   "pool_last_layer" (1) last CLIP-text layer: out-projection + MLP on the EOS rows only
- *   "fuse_ln"         (1) bf16 / fp16 CLIP-text tower at >= 8192 packed rows: the out-projection runs as a full-row
+ *   "fold_ln"         (1) with "resid16": the LayerNorms inside the CLIP-text stack folded into the q/k/v and fc1 GEMMs (they
+ *                         multiply x itself on the fp16 MFMA and correct with the row's (mean, rstd), which come from partial sums
+ *                         the producer GEMMs leave): no LayerNorm kernel and no normalised copy of the rows; 0 = LayerNorm kernels
+ *   "fuse_ln"         (1) fp32-residual CLIP-text tower (fp16 / refine engines; bf16 with resid16 = 0) at >= 8192 packed rows: the out-projection runs as a full-row
  *                         kernel that also emits LN2 of its result (no LayerNorm pass for it); 2 = fc2 -> the next
  *                         layer's LN1 as well (measured slower), 0 = off
  *   "resid16"         (1) residual stream of the CLIP-text tower as IEEE fp16 rows in HBM (fp32 accumulate, bias and residual
  *                         add; one rounding per update): 1 = the bf16 engine (CZC_PREC_BF16), 2 = the single-pass fp16 tower too
  *                         (outside its validated error budget: experiments), 0 = fp32 rows everywhere.  With it the
  *                         out-projection runs on the weight-stationary kernel ("fuse_ln" then has nothing to fuse)
- *   "refine_samples" (12), "refine_theta_x1000" (4000): CZC_PREC_REFINE selection -- strata of the mass-stratified sample
+ *   "refine_samples" (12), "refine_theta_x1000" (2000): CZC_PREC_REFINE selection -- strata of the mass-stratified sample
  *                         and the softmax_K mass threshold theta = value / 1000 / (beta * exp(logit_scale))
  *   "refine_guard_x1e6" (200): trip point of czc_refine_guard, in units of 1e-6 of cosine
  *   "refine_gate_x1e6" (400): cosine-error bound delta of the margin gate of czc_generate (czc_refine_gate_stats), 0 = off */
@@ -281,14 +296,14 @@ int czc_stats(czc_engine* e, int64_t* clip_rows, int64_t* clip_seqs, int64_t* be
  * (of the clip_seqs / clip_rows the screening pass saw); zero for the other precisions. */
 int czc_refine_stats(czc_engine* e, int64_t* refine_seqs, int64_t* refine_rows);
 /* CZC_PREC_REFINE engines, runtime guard of the 1e-3 bound: candidates that keep their screening (single-pass fp16) cosine
- * carry its error minus the estimated mean, and move their fused score by at most theta_x * |that| (theta_x = 4).  Every
- * step records, over the ~16 candidates per image it re-encodes exactly, the largest |screening error - mean|
- * (*max_dev, since the last reset) and counts the image-steps where it exceeds option "refine_guard_x1e6" * 1e-6
- * (default 200) in *tripped.  It is a detector, not a certificate: the ~16 re-encoded candidates under-sample the worst of
- * the ~185 that keep their screening cosine (validated towers: sample maximum 1.0-1.5e-4 with fused-score errors up to 8.4e-4;
- * towers with emulated activation outliers: 3e-4 .. 3e-2, tripping from the point where the error nears the 1e-3 bar).  A
- * checkpoint whose activations the fp16 tower carries worse trips the guard, and conzic_amd/runtime.py then repeats the
- * call on the all-split engine (CZC_REFINE_GUARD=rerun | warn | off). */
+ * carry its error minus the estimated mean, and move their fused score by at most theta_x * |that| (theta_x = 2).  Every step
+ * that runs the full selection records, over the ~20 candidates per image it re-encodes exactly, the largest
+ * |screening error - mean| (*max_dev, since the last reset) and counts the image-steps where it exceeds option
+ * "refine_guard_x1e6" * 1e-6 (default 200) in *tripped.  The candidates that are NOT re-encoded reach at most twice the sample
+ * maximum on the validated towers (tools/refine_validate.py prints the ratio), so below the trip point the bound is
+ * theta_x * 2 * 2.0e-4 = 8e-4 < 1e-3; a checkpoint whose activations the fp16 tower carries worse trips the guard, and
+ * conzic_amd/runtime.py then repeats the call on the all-split engine (CZC_REFINE_GUARD=rerun | warn | off).  Inside czc_generate
+ * gated image-steps re-encode nothing and are not measured: the audit steps (czc_refine_gate_stats) are. */
 int czc_refine_guard(czc_engine* e, int reset, float* max_dev, int64_t* tripped);
 /* CZC_PREC_REFINE engines, margin gate of czc_generate: a whole *_generation call returns the winner's id of every step and
  * the winner's cosine at the snapshot steps (gen_utils.py:78-81, :92), not the K fused scores.  An image-step whose screening

@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""One source of truth per figure: the numbers README.md, DESIGN.md §0 and the precision block of include/conzic_hip.h quote are
+GENERATED from the committed evidence under profiles/ (bench lines, the pytest -m gpu summary, the refine validation), never typed.
+
+    python tools/refresh_docs.py            rewrite the generated blocks in place
+    python tools/refresh_docs.py --check    exit 1 when a block is stale (run by the CPU test suite)
+
+A generated block sits between `BEGIN GENERATED <name>` and `END GENERATED <name>` marker lines; everything else in those files is
+hand-written prose that may cite a block but carries no measured figure of the current round.
+"""
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROUND = "r05"
+P = os.path.join(ROOT, "profiles")
+
+
+def jload(name):
+    path = os.path.join(P, name)
+    if not os.path.exists(path):
+        return None
+    txt = open(path).read().strip()
+    try:
+        return json.loads(txt.splitlines()[-1])
+    except (json.JSONDecodeError, IndexError):
+        return None
+
+
+def jlines(name):
+    path = os.path.join(P, name)
+    if not os.path.exists(path):
+        return []
+    out = []
+    for ln in open(path):
+        ln = ln.strip()
+        if ln.startswith("{"):
+            try:
+                out.append(json.loads(ln))
+            except json.JSONDecodeError:
+                pass
+    return out
+
+
+def facts():
+    """Every figure the generated blocks quote, with the file it comes from."""
+    f = {}
+    drv = jload(f"{ROUND}_bench_driver_cmd.json")
+    if drv:
+        rf = drv.get("roofline") or {}
+        f["value"] = drv["value"]
+        f["ms_per_step"] = drv["ms_per_step"]
+        f["value_scale100"] = drv.get("value_scale100")
+        f["frac"] = rf.get("frac")
+        f["achieved"] = rf.get("achieved")
+        f["frac_1s"] = (rf.get("single_stream_pass") or {}).get("frac")
+        f["tower_util"] = (rf.get("clip_text_mfma_util") or {}).get("frac")
+        f["single_stream_value"] = (drv.get("single_stream") or {}).get("value")
+        f["traffic"] = rf.get("traffic")
+        f["crc"] = (drv.get("captions_crc32") or {}).get("value")
+        cb = drv.get("cpu_baseline") or {}
+        f["cpu_value"], f["cpu_threads"] = cb.get("value"), cb.get("cores")
+        s100 = drv.get("scale100_mode") or {}
+        r100 = s100.get("refine") or {}
+        f["gated_frac"], f["re_encoded_frac"] = r100.get("gated_frac"), r100.get("re_encoded_frac")
+        f["frac_scale100"] = (s100.get("roofline") or {}).get("frac")
+        f["executed_tflop"] = drv.get("executed_tflop_per_caption")
+    for tag, name in (("cfg1", "single image"), ("cfg3", "configs[3] shard"), ("cfg4", "configs[4] shard")):
+        d = jload(f"{ROUND}_bench_{tag}.json")
+        if d:
+            f[tag] = d["value"]
+            f[tag + "_scale100"] = d.get("value_scale100")
+            if tag == "cfg4":
+                f["cfg4_table"] = (d.get("control_table") or {}).get("value")
+                ce = d.get("control_exact") or {}
+                f["cfg4_exact"] = ce.get("value")
+                sc = ce.get("scorer") or {}
+                f["cfg4_exact_workers"], f["cfg4_exact_cost_us"], f["cfg4_memo_hit"] = sc.get("workers"), sc.get("cost_us_per_12_word_sentence"), sc.get("memo_hit_frac")
+    # pytest -m gpu summary: counts and the worst parity figures per engine precision over the full-size goldens
+    path = os.path.join(P, f"{ROUND}_gpu_tests_summary.txt")
+    if os.path.exists(path):
+        txt = open(path).read()
+        m = re.search(r"(\d+) passed(?:, (\d+) skipped)?", txt)
+        if m:
+            f["tests_passed"], f["tests_skipped"] = int(m.group(1)), int(m.group(2) or 0)
+        f["tests_failed"] = int((re.search(r"(\d+) failed", txt) or [0, 0])[1])
+        worst = {}
+        for name, prec, efin, ecos in re.findall(r"^\s+(full_\w+|refine_vs_split\w*)\s+prec=(\d): ([0-9.e+-]+) ([0-9.e+-]+)", txt, re.M):
+            w = worst.setdefault(int(prec), [0.0, 0.0])
+            w[0], w[1] = max(w[0], float(efin)), max(w[1], float(ecos))
+        for prec, key in ((0, "bf16"), (1, "f32"), (3, "split"), (4, "fp16"), (5, "refine")):
+            if prec in worst:
+                f[f"err_final_{key}"], f[f"err_cos_{key}"] = worst[prec]
+        m = re.search(r"host control scorer under the CLIP tower: ([0-9.]+) ms of host work per ([0-9.]+) ms step\s+-> ([0-9.]+)x", txt)
+        if m:
+            f["overlap_cost_ms"], f["overlap_step_ms"], f["overlap_ratio"] = float(m.group(1)), float(m.group(2)), float(m.group(3))
+    rv = jlines(f"{ROUND}_refine_validate_128x10.jsonl")
+    for r in rv:
+        if r.get("mode") == "generate" and r.get("gate_delta", 0) > 0:
+            f["rv_gen_ids_identical"], f["rv_gen_gated"], f["rv_gen_images"], f["rv_gen_steps"] = r["ids_identical"], r["gated_frac"], r["images"], r["image_steps"]
+        elif "max_abs_dfinal" in r:
+            f["rv_max_dfinal"], f["rv_p999"], f["rv_winners"], f["rv_image_steps"] = r["max_abs_dfinal"], r["p999"], r["winners_identical"], r["image_steps"]
+            f["rv_guard_max_dev"], f["rv_true_max_dev"] = r.get("guard_max_dev"), r.get("true_max_dev")
+    return f
+
+
+def fmt(v, spec=".3g", none="n/a"):
+    return none if v is None else format(v, spec)
+
+
+def block_status(f):
+    rows = [
+        "| | |",
+        "|---|---|",
+        f"| `pytest -m gpu` on the MI355X (`profiles/{ROUND}_gpu_tests_summary.txt`) | {fmt(f.get('tests_passed'), 'd')} passed, {fmt(f.get('tests_skipped'), 'd')} skipped, {fmt(f.get('tests_failed'), 'd')} failed |",
+        f"| fused score vs the reference, worst over the full-size goldens | bf16 engine {fmt(f.get('err_final_bf16'), '.2e')} (bar 1e-3), screen-then-refine {fmt(f.get('err_final_refine'), '.2e')}, split-fp16 {fmt(f.get('err_final_split'), '.1e')}, f32 {fmt(f.get('err_final_f32'), '.1e')} |",
+        f"| headline, BASELINE configs[2] (`profiles/{ROUND}_bench_driver_cmd.json` = the driver's `--gpus 1 --steps 20 --warmup 5`) | **{fmt(f.get('value'), '.1f')} captions/s** bf16 engine (HF-init logit scale), **{fmt(f.get('value_scale100'), '.1f')}** screen-then-refine (published checkpoints' logit scale); one stream {fmt(f.get('single_stream_value'), '.1f')} |",
+        f"| roofline of the CLIP-text GEMM family (dense bf16 peak 2.5 PFLOP/s) | {fmt(f.get('frac'), '.3f')} over the timed two-stream region, {fmt(f.get('frac_1s'), '.3f')} on one stream; `clip_text_mfma_util` (GEMM + attention FLOPs over all CLIP-text kernel time) {fmt(f.get('tower_util'), '.3f')} |",
+        f"| screen-then-refine in `czc_generate` | {fmt(None if f.get('gated_frac') is None else 100 * f['gated_frac'], '.0f')} % of the image-steps pass the margin gate, {fmt(None if f.get('re_encoded_frac') is None else 100 * f['re_encoded_frac'], '.1f')} % of the candidates re-encoded; against the all-split engine: ids identical = {f.get('rv_gen_ids_identical', 'n/a')} over {fmt(f.get('rv_gen_steps'), 'd')} image-steps, `czc_step` worst fused-score difference {fmt(f.get('rv_max_dfinal'), '.2e')} over {fmt(f.get('rv_image_steps'), 'd')} image-steps |",
+        f"| other BASELINE shapes (`profiles/{ROUND}_bench_cfg*.json`) | single image {fmt(f.get('cfg1'), '.2f')} captions/s; configs[3] shard (256 images, shuffle, L=15, K=512) {fmt(f.get('cfg3'), '.1f')}; configs[4] shard (64 images, sentiment, L=12): table mode {fmt(f.get('cfg4_table'), '.1f')}, exact host scorer {fmt(f.get('cfg4_exact'), '.1f')} ({fmt(f.get('cfg4_exact_workers'), 'd')} worker interpreters, stand-in tagger at {fmt(f.get('cfg4_exact_cost_us'), '.0f')} us per 12-word sentence) |",
+        f"| CPU oracle on the box's host (one full caption, {fmt(f.get('cpu_threads'), 'd')} threads) | {fmt(f.get('cpu_value'), '.4f')} captions/s |",
+    ]
+    return "\n".join(rows)
+
+
+def block_header(f):
+    """The measured figures of the precision comments in include/conzic_hip.h (C comment lines)."""
+    lines = [
+        f" * Measured on one MI355X, round 5 (generated by tools/refresh_docs.py from profiles/{ROUND}_*):",
+        f" *   fused score vs the reference, worst over the full-size goldens: CZC_PREC_BF16 {fmt(f.get('err_final_bf16'), '.2e')}, CZC_PREC_REFINE {fmt(f.get('err_final_refine'), '.2e')},",
+        f" *   CZC_PREC_SPLIT {fmt(f.get('err_final_split'), '.1e')}, CZC_PREC_F32 {fmt(f.get('err_final_f32'), '.1e')} (bar 1e-3);",
+        f" *   CZC_PREC_REFINE against CZC_PREC_SPLIT over {fmt(f.get('rv_image_steps'), 'd')} more image-steps: worst {fmt(f.get('rv_max_dfinal'), '.2e')}, 99.9th percentile {fmt(f.get('rv_p999'), '.1e')}, winners identical",
+        f" *   {fmt(f.get('rv_winners'), 'd')} / {fmt(f.get('rv_image_steps'), 'd')}; guard sample maximum {fmt(f.get('rv_guard_max_dev'), '.2e')} against {fmt(f.get('rv_true_max_dev'), '.2e')} over all candidates;",
+        f" *   BASELINE configs[2]: {fmt(f.get('value'), '.1f')} captions/s (CZC_PREC_BF16), {fmt(f.get('value_scale100'), '.1f')} (CZC_PREC_REFINE through czc_generate, {fmt(None if f.get('gated_frac') is None else 100 * f['gated_frac'], '.0f')} % of the image-steps gated).",
+    ]
+    return "\n".join(lines)
+
+
+TARGETS = [
+    ("README.md", "status", block_status, "<!-- {} GENERATED {} -->"),
+    ("DESIGN.md", "status", block_status, "<!-- {} GENERATED {} -->"),
+    ("include/conzic_hip.h", "measured", block_header, " * {} GENERATED {}"),
+]
+
+
+def apply(check):
+    f = facts()
+    stale = []
+    for rel, name, fn, marker in TARGETS:
+        path = os.path.join(ROOT, rel)
+        txt = open(path).read()
+        b, e = marker.format("BEGIN", name), marker.format("END", name)
+        if b not in txt or e not in txt:
+            stale.append(f"{rel}: markers of block '{name}' missing")
+            continue
+        i, j = txt.index(b) + len(b), txt.index(e)
+        new = txt[:i] + "\n" + fn(f) + "\n" + txt[j:]
+        if new != txt:
+            if check:
+                stale.append(f"{rel}: block '{name}' is stale (run tools/refresh_docs.py)")
+            else:
+                open(path, "w").write(new)
+    return stale
+
+
+if __name__ == "__main__":
+    problems = apply("--check" in sys.argv)
+    for p_ in problems:
+        print(p_)
+    sys.exit(1 if problems else 0)
