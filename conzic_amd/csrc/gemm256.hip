@@ -298,7 +298,7 @@ __device__ __forceinline__ void tile_epilogue_x16_asm(const GemmArgs& g, f32x16_
     r.w = 0x00020000u;
     return r;
   };
-  const u32x4_t rsR = desc(g.resid, g.ldr, rows), rsO = desc(g.out_f32, g.ldc, rows);
+  u32x4_t rsR = desc(g.resid, g.ldr, rows), rsO = desc(g.out_f32, g.ldc, rows);
   u32x4_t rsB;
   {
     const unsigned long long pb = (unsigned long long)g.bias;
@@ -316,7 +316,10 @@ __device__ __forceinline__ void tile_epilogue_x16_asm(const GemmArgs& g, f32x16_
     rsP.z = __builtin_amdgcn_readfirstlane((unsigned)(g.row_part ? (long)(g.N / 32) * g.part_ld * 8 : 4));
     rsP.w = 0x00020000u;
   }
-  asm volatile("s_nop 4" ::: "memory");  // descriptors fresh from v_readfirstlane -> buffer_* inside asm strings
+  // descriptors fresh from v_readfirstlane -> buffer_* inside asm strings: the wait states hipcc cannot see.  The descriptors
+  // are operands of the nop so that none of their v_readfirstlane can sink below it (the partials' descriptor, first used
+  // late in the first block, did: that block's first store went out with a stale descriptor and was lost)
+  asm volatile("s_nop 4" : "+s"(rsR), "+s"(rsO), "+s"(rsB), "+s"(rsP) : : "memory");
   constexpr int NB = 4 * NJ;
   auto colof = [&](int blk) { return n0 + wcol0 + (blk % NJ) * 32 + rs * 8; };
   auto off = [&](int blk, int pass, int ld) -> unsigned {

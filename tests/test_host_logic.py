@@ -543,3 +543,13 @@ def test_headers_are_plain_c_and_match_the_ctypes_layout(tmp_path):
     want = [C.sizeof(native.Config), C.sizeof(native.Hyper), C.sizeof(native.StepOut), C.sizeof(native.BridgeTables),
             native.Config.precision.offset, native.BridgeTables.merge_out.offset, native.Hyper.negative.offset]
     assert got == want, (got, want)
+
+
+def test_generated_doc_blocks_are_fresh():
+    """README.md, DESIGN.md §0 and the measured-figures comment of include/conzic_hip.h quote the committed evidence under
+    profiles/ through tools/refresh_docs.py (one source of truth per figure): the blocks in the tree must be what the tool
+    generates today."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "refresh_docs.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr

@@ -36,4 +36,4 @@ for B in [int(b) for b in (sys.argv[1] if len(sys.argv) > 1 else "2,8,16,64").sp
         if np.isnan(out[1]["clip_ref"]).any():
             bad = np.argwhere(np.isnan(out[1]["clip_ref"]))
             print("  nan at (image, cand):", bad[:10].tolist(), "count per image", np.isnan(out[1]["clip_ref"]).sum(axis=1).tolist())
-os._exit(0)
+sys.stdout.flush(); os._exit(0)

@@ -22,4 +22,4 @@ for K in (512, 2048):
         bad = err > tol
         rows = np.unique(np.argwhere(bad)[:, 0])
         print(f"K={K} M={M}: max err {err.max():.3e} bad elements {int(bad.sum())} bad rows {len(rows)} first rows {rows[:12].tolist()} blocks {np.unique(rows // 32)[:12].tolist()}", flush=True)
-os._exit(0)
+sys.stdout.flush(); os._exit(0)
