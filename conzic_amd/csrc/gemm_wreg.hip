@@ -43,7 +43,8 @@ constexpr int WR_D = 4;                        // ring depth
 constexpr int WR_PATCH = 2048;                 // per-wave epilogue patch (32 rows x 64 bytes)
 constexpr int WR_BIAS = 128;                   // per-wave bias slice (32 floats)
 constexpr int WR_LDS = WR_D * WR_STAGE + 8 * (WR_PATCH + WR_BIAS);
-constexpr int WR_LDS_LNF = WR_LDS + 8 * (WR_BIAS + WR_D * 256);  // + per wave: colsum slice, ring of (mean, rstd) blocks
+constexpr int WR_TS = 8;                                         // LNF: depth of the shared ring of (mean, rstd) blocks
+constexpr int WR_LDS_LNF = WR_LDS + 8 * WR_BIAS + WR_TS * 256;   // + per wave: colsum slice; + the ring
 static_assert(WR_LDS_LNF <= 160 * 1024, "LDS budget");
 
 __device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {
@@ -63,8 +64,8 @@ __device__ __forceinline__ float wr_act(float v) {
 //   C = act( rstd_m * (x . W'^T - mean_m * colsum(W')) + b' ),   b' = b + W . beta,
 // with (mean_m, rstd_m) per row from the producer GEMM's partials (rowops.hip ln_finalize_kernel): no LayerNorm kernel, no
 // normalised copy y of the rows.  The multiply runs on the fp16 MFMA whatever the engine's operand type (x is fp16); the
-// OUTPUT keeps the engine's type (F16 ? fp16 : bf16).  Per block one more LDS-DMA (T: 32 rows x 8 bytes of statistics,
-// every wave its own 256-byte ring slot), VMEM order D0 D1 T D2 S0 D3 S1, the ring wait becomes vmcnt(15).
+// OUTPUT keeps the engine's type (F16 ? fp16 : bf16).  Per block one more LDS-DMA (T: 32 rows x 8 bytes of statistics, by
+// wave 0 only, into a ring shared by the work-group), VMEM order of wave 0 D0 D1 T D2 S0 D3 S1: its ring wait is vmcnt(15).
 template <int ACT, bool F16 = false, bool LNF = false>
 __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, int nsets, int nblk) {
   using OT = std::conditional_t<F16, f16_t, bf16_t>;  // output element type (the engine's activation type)
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, 
   float* bias_s = (float*)(smem + WR_D * WR_STAGE + 8 * WR_PATCH + wave * WR_BIAS);
   if (lane < 32) bias_s[lane] = (g.bias && col0 + lane < g.N) ? g.bias[col0 + lane] : 0.f;
   float* cs_s = (float*)(smem + WR_LDS + wave * WR_BIAS);                      // LNF: colsum(W') of this wave's 32 columns
-  const unsigned char* stat_s = smem + WR_LDS + 8 * WR_BIAS + wave * (WR_D * 256);  // LNF: this wave's ring of (mean, rstd) blocks
+  const unsigned char* stat_s = smem + WR_LDS + 8 * WR_BIAS;                   // LNF: the work-group's ring of (mean, rstd) blocks
   if constexpr (LNF) {
     if (lane < 32) cs_s[lane] = col0 + lane < g.N ? g.ln_colsum[col0 + lane] : 0.f;
   }
@@ -119,16 +120,21 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, 
   }
   u32x4_t rsA;
   rsA.w = 0x00020000u;
-  // LNF: (mean, rstd) of block j's 32 rows -> this wave's slot j % WR_D (64 lanes x 4 bytes = 32 float2)
-  const unsigned stat0 = lds0 + WR_LDS + 8 * WR_BIAS + wave * (WR_D * 256);
+  // LNF: (mean, rstd) of block j's 32 rows -> slot j % WR_TS of ONE ring shared by the work-group (64 lanes x 4 bytes = 32
+  // float2), requested by wave 0 only: every wave needs the same 32 pairs, and a VMEM instruction per wave and block (a
+  // seventh beside D0 D1 D2 S0 D3 S1) cost the fc1 layer 14 %.  Wave 0's pieces are published like its operand rows (its
+  // counted wait + the block barrier); the ring is 8 deep because the other waves read block i-1's pairs anywhere in
+  // block i's stream while wave 0 already requests block i+3's.
+  const unsigned stat0 = lds0 + WR_LDS + 8 * WR_BIAS;
   const unsigned voffT = (unsigned)(lane * 4);
   auto stat_dma = [&](int j) {
+    if (wave != 0) return;
     const long row0 = (long)(b0 + j) * WR_BLK;
     const unsigned long long pt = (unsigned long long)g.ln_stat + (unsigned long long)row0 * 8;
     u32x4_t rsT;
     rsT.x = __builtin_amdgcn_readfirstlane((unsigned)pt); rsT.y = __builtin_amdgcn_readfirstlane((unsigned)(pt >> 32) & 0xffffu);
     rsT.z = __builtin_amdgcn_readfirstlane((unsigned)(min((long)WR_BLK, (long)g.M - row0) * 8)); rsT.w = 0x00020000u;
-    const unsigned dst = stat0 + (j & (WR_D - 1)) * 256;
+    const unsigned dst = stat0 + (j & (WR_TS - 1)) * 256;
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dword %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
@@ -207,7 +213,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, 
     float4 v;
     if constexpr (LNF) {
       if (qd == 0) {  // read once per block: the slot is refilled (statistics of block js + WR_D) later in this same stream
-        const float2 st = *(const float2*)(stat_s + (js & (WR_D - 1)) * 256 + l31 * 8);
+        const float2 st = *(const float2*)(stat_s + (js & (WR_TS - 1)) * 256 + l31 * 8);
         ln_rstd = st.y;
         ln_t = __fmul_rn(-st.x, st.y);
       }
@@ -282,7 +288,10 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, 
       // block i landed?  VMEM issued after its last DMA piece: S1 of that block period, then two full periods
       // of 4 DMA + 2 stores (stores start with the second block) -- all in order on vmcnt.
       constexpr bool STEADY = decltype(steady_c)::value;
-      if (STEADY) { if constexpr (LNF) asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); }
+      if (STEADY) {  // LNF: wave 0 issues one more instruction per block (T): S1 + two periods of seven
+        if (LNF && wave == 0) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+      }
       else if (i + 2 >= nb) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else if (i < 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
