@@ -353,14 +353,15 @@ __device__ __forceinline__ void tile_epilogue_x16_asm(const GemmArgs& g, f32x16_
           make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
     }
     u32x4_t(&r)[2] = rr[blk & 1];
-    // this block's residual rows (and, first time round, the bias) have landed: younger = the four stores (x, partials) of
+    // this block's residual rows (and, first time round, the bias) have landed: younger = the three stores (x, x, partials) of
     // block blk-1 and the two loads of blk+1
     if (blk == 0)
       asm volatile("s_waitcnt vmcnt(2)" : "+v"(r[0]), "+v"(r[1]), "+v"(bias8[j][0]), "+v"(bias8[j][1]) : : "memory");
     else if (blk + 1 == NB)
-      asm volatile("s_waitcnt vmcnt(4)" : "+v"(r[0]), "+v"(r[1]), "+v"(bias8[j][0]), "+v"(bias8[j][1]) : : "memory");
+      asm volatile("s_waitcnt vmcnt(3)" : "+v"(r[0]), "+v"(r[1]), "+v"(bias8[j][0]), "+v"(bias8[j][1]) : : "memory");
     else
-      asm volatile("s_waitcnt vmcnt(6)" : "+v"(r[0]), "+v"(r[1]), "+v"(bias8[j][0]), "+v"(bias8[j][1]) : : "memory");
+      asm volatile("s_waitcnt vmcnt(5)" : "+v"(r[0]), "+v"(r[1]), "+v"(bias8[j][0]), "+v"(bias8[j][1]) : : "memory");
+    uint2 sq_keep = make_uint2(0u, 0u);
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
       const int rw = pass * 16 + rrow;
@@ -392,11 +393,16 @@ __device__ __forceinline__ void tile_epilogue_x16_asm(const GemmArgs& g, f32x16_
         const float q3 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0xFF, 0xf, 0xf, true));
         part[t] = __fadd_rn(__fadd_rn(__fadd_rn(q0, q1), q2), q3);
       }
+      // one store per block for both passes: lane rs = 0 keeps pass 0's pair (row rrow), lane rs = 1 pass 1's (row 16 + rrow)
       const uint2 sq = make_uint2(__float_as_uint(__fadd_rn(part[0], part[1])), __float_as_uint(__fadd_rn(part[2], part[3])));
-      const int prow = m0 + wm * 128 + (blk / NJ) * 32 + pass * 16 + rrow;
-      const long pcol = (n0 + wcol0 + (blk % NJ) * 32) / 32;
-      const unsigned po = (g.row_part && rs == 0 && prow < g.M && colof(blk) < g.N) ? (unsigned)((pcol * g.part_ld + prow) * 8) : 0x7ffffff0u;
-      asm volatile("buffer_store_dwordx2 %0, %1, %2, 0 offen\n\ts_nop 1" : : "v"(sq), "v"(po), "s"(rsP) : "memory");
+      if (pass == 0) sq_keep = sq;
+      else {
+        const uint2 out = rs == 1 ? sq : sq_keep;
+        const int prow = m0 + wm * 128 + (blk / NJ) * 32 + (rs == 1 ? 16 : 0) + rrow;
+        const long pcol = (n0 + wcol0 + (blk % NJ) * 32) / 32;
+        const unsigned po = (g.row_part && rs < 2 && prow < g.M && n0 + wcol0 + (blk % NJ) * 32 < g.N) ? (unsigned)((pcol * g.part_ld + prow) * 8) : 0x7ffffff0u;
+        asm volatile("buffer_store_dwordx2 %0, %1, %2, 0 offen\n\ts_nop 1" : : "v"(out), "v"(po), "s"(rsP) : "memory");
+      }
     }
   }
 }
