@@ -245,6 +245,15 @@ int czc_bench_gemm(int precision, int M, int N, int K, int act, int out_mode, in
   g.A = dA; g.lda = (int)Kp; g.W = dW; g.ldw = (int)Kp; g.bias = dB; g.resid = dOf; g.ldr = N; g.out_act = dOa; g.out_f32 = dOf;
   g.ldc = N; g.M = M; g.N = N; g.K = K; g.act = act;
   if (out_mode == 6) { g.x16 = 1; }  // 6: fp16 residual stream in place (the fp32 buffer doubles as M x N fp16 rows)
+  if (out_mode == 7) {  // 7: folded-LayerNorm consumer (K = 512): the operands' bytes read as fp16, unit statistics
+    float* dstat = (float*)pool.alloc((size_t)M * 8 + 256); T_PTR(dstat);
+    std::vector<float> hs((size_t)M * 2);
+    for (size_t i = 0; i < hs.size(); i += 2) { hs[i] = 0.1f; hs[i + 1] = 1.0f; }
+    T_HIP(hipMemcpy(dstat, hs.data(), hs.size() * 4, hipMemcpyHostToDevice));
+    g.ln_stat = dstat; g.ln_colsum = dB;
+    g.out_act = pool.alloc((size_t)M * N * es); T_PTR(g.out_act);
+    g.out_f32 = nullptr; g.resid = nullptr;
+  }
   if (out_mode == 4 || out_mode == 5) {  // 4: full-row kernel with the LayerNorm in its epilogue; 5: the pair it replaces
     g.out_act = pool.alloc((size_t)M * N * 2); T_PTR(g.out_act);
     g.ln_gamma = dB; g.ln_beta = dB; g.ln_eps = 1e-5f; g.f16 = precision == PREC_F16;

@@ -35,6 +35,12 @@ namespace czc {
 
 namespace {
 
+// compile-time timing ablations of the folded-LayerNorm form (make ABL=n LIB=...; tools/ab_gemm.py out_mode 7; results are
+// garbage): 1 no statistics DMA, 2 plain bias epilogue, 4 bf16 MFMA opcode on the same bytes
+#ifndef CZC_LNF_ABL
+#define CZC_LNF_ABL 0
+#endif
+constexpr int LNF_ABL = CZC_LNF_ABL;
 constexpr int WR_K = 512;
 constexpr int WR_ROWB = WR_K * 2;              // 1 KiB per activation row
 constexpr int WR_BLK = 32;                     // rows per block
@@ -128,7 +134,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, 
   const unsigned stat0 = lds0 + WR_LDS + 8 * WR_BIAS;
   const unsigned voffT = (unsigned)(lane * 4);
   auto stat_dma = [&](int j) {
-    if (wave != 0) return;
+    if (wave != 0 || (LNF_ABL & 1)) return;
     const long row0 = (long)(b0 + j) * WR_BLK;
     const unsigned long long pt = (unsigned long long)g.ln_stat + (unsigned long long)row0 * 8;
     u32x4_t rsT;
@@ -211,7 +217,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, 
   auto epi_quad = [&](int qd, int js) {  // accP quad qd -> (LayerNorm correction,) bias, activation, 2-byte -> patch
     const float4 b4 = *(const float4*)(bias_s + 8 * qd + 4 * half);
     float4 v;
-    if constexpr (LNF) {
+    if constexpr (LNF && !(LNF_ABL & 2)) {
       if (qd == 0) {  // read once per block: the slot is refilled (statistics of block js + WR_D) later in this same stream
         const float2 st = *(const float2*)(stat_s + (js & (WR_TS - 1)) * 256 + l31 * 8);
         ln_rstd = st.y;
@@ -258,8 +264,13 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, 
 #pragma unroll
       for (int k = 0; k < 4; k += 2) {
         const int t = 4 * sgm + k;
-        acc0 = Half<HT>::mfma(wreg[t], fr[sgm & 1][k], acc0);
-        acc1 = Half<HT>::mfma(wreg[t + 1], fr[sgm & 1][k + 1], acc1);
+        if constexpr (LNF && (LNF_ABL & 4)) {  // timing ablation: the bf16 opcode on the same bytes
+          acc0 = Half<bf16_t>::mfma(wreg[t], fr[sgm & 1][k], acc0);
+          acc1 = Half<bf16_t>::mfma(wreg[t + 1], fr[sgm & 1][k + 1], acc1);
+        } else {
+          acc0 = Half<HT>::mfma(wreg[t], fr[sgm & 1][k], acc0);
+          acc1 = Half<HT>::mfma(wreg[t + 1], fr[sgm & 1][k + 1], acc1);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
       // descriptor arithmetic (a few dozen SALU) rides in the slots too: nothing but the wait and the barrier

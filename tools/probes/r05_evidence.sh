@@ -1,13 +1,20 @@
-# Round-5 evidence (run on the GPU box from the repo root): the driver's bench command, rocprofv3 kernel stats of the bench in
-# its modes, and the MFMA-op / HBM-traffic counters in their own passes.  Summaries land in gpurun_out/r05e/ (copy the ones to
-# keep into profiles/).  usage: r05_evidence.sh [quick]   (quick: no driver-length bench, no PMC passes)
+# Round-5 evidence (run on the GPU box from the repo root): the GPU test suite, the driver's bench command, the other BASELINE
+# shapes, the refine validation, rocprofv3 kernel stats of the bench in its modes, and the MFMA-op / HBM-traffic counters in
+# their own passes.  Summaries land in gpurun_out/r05e/ (the ones to keep are copied into profiles/ as r05_*).
+# usage: r05_evidence.sh [quick]   (quick: no test suite, no driver-length bench, no PMC passes)
 set -x
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r05e
 mkdir -p $O
 if [ "$1" != "quick" ]; then
+  python -m pytest tests -m gpu -q > $O/gpu_tests_summary.txt 2>&1
   python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd.json 2> $O/bench_driver_cmd.err
 fi
+python bench.py > $O/bench_default.json 2> $O/bench_default.err
+python bench.py --config 1 --steps 3 --no-alt > $O/bench_cfg1.json 2> $O/bench_cfg1.err
+python bench.py --config 3 --total-images 256 --steps 1 --warmup 1 --no-cpu-baseline > $O/bench_cfg3.json 2> $O/bench_cfg3.err
+python bench.py --config 4 --total-images 64 --control both --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_cfg4.json 2> $O/bench_cfg4.err
+python tools/refine_validate.py 128 10 12 2000 > $O/refine_validate_128x10.jsonl 2> $O/refine_validate.err
 export CZC_NORMAL_EXIT=1
 COMMON="--no-cpu-baseline --no-alt --no-invariance"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bf16_1s -o p -- python bench.py --streams 1 --steps 2 --warmup 1 $COMMON > $O/bf16_1s.log 2>&1
@@ -23,4 +30,4 @@ if [ "$1" != "quick" ]; then
 fi
 find $O gpurun_out/pmc_traffic -name "*kernel_trace.csv" -delete; find $O gpurun_out/pmc_traffic -name "*counter_collection.csv" -size +4M -delete
 find $O gpurun_out/pmc_traffic -name "*.db" -delete; find $O -name "*agent_info.csv" -delete
-head -c 700 $O/bench_driver_cmd.json; echo; head -8 $O/bf16_1s_kernel_stats.csv | cut -c1-200; tail -1 $O/bf16_1s.log | cut -c1-300; tail -1 $O/bf16_2s.log | cut -c1-300
+head -c 600 $O/bench_driver_cmd.json; echo; head -8 $O/bf16_1s_kernel_stats.csv | cut -c1-200; tail -3 $O/gpu_tests_summary.txt
