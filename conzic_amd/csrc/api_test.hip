@@ -49,6 +49,7 @@ static const Hooks& HK() {
 #define g_gemm256_min_m (*HK().gemm256_min_m)
 #define g_use_mfma_attention (*HK().use_mfma_attention)
 #define g_use_attention_image (*HK().use_attention_image)
+#define g_wreg_resid_min_m (*HK().wreg_resid_min_m)
 #define TEST_ERR (HK().err_buf())
 
 static int g_bench_pad = 0;
@@ -335,6 +336,7 @@ int czc_test_set_option(const char* name, int value) {
   if (!strcmp(name, "gemm256_min_m")) { g_gemm256_min_m = value; return 0; }
   if (!strcmp(name, "mfma_attention")) { g_use_mfma_attention = value; return 0; }
   if (!strcmp(name, "attention_image")) { g_use_attention_image = value; return 0; }
+  if (!strcmp(name, "wreg_resid_min_m")) { g_wreg_resid_min_m = value; return 0; }
   snprintf(TEST_ERR, 512, "unknown option %s", name);
   return CZC_ERR_ARG;
 }

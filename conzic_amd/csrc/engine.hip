@@ -74,6 +74,10 @@ struct czc_engine {
   // screening cosine moves its fused score by at most theta_x * |d_k - mean|: round 5 lowered theta_x from 4 to 2, so the
   // largest deviation measured (2.1e-4 over 256 k candidates) gives 4.2e-4 instead of 8.4e-4 of the 1e-3 bar
   float refine_theta_x = 2.0f;
+  // czc_generate returns ids and winner cosines, not the K scores: its selection keeps round 3's threshold (4.0: fewer mass
+  // carriers to re-encode; winners identical to the all-split engine on every validated image-step), the bound above is czc_step's
+  float refine_theta_gen = 4.0f;
+  bool in_generate = false;
   int refine_samples = 12;      // strata of the sample among the candidates below the threshold
   // guard: the ~20 candidates an image re-encodes show their own |screening error - mean|; the candidates that keep their
   // screening cosine reach at most GUARD_RATIO = 2 times that sample maximum (fitted: 1.75 worst over 1280 image-steps), so
@@ -758,7 +762,7 @@ int step_phase_b(czc_engine* e, const StepArgs& a, int M, int max_len, int max_b
   E_CHECK(plan_bufs(e, a.B, a.K, &sp));
   E_CHECK(plan_bufs(e, a.B, a.K, &rp, "r"));
   const int S = a.B + n_seq;
-  const float theta = e->refine_theta_x / fmaxf(hp->beta * e->logit_scale_exp, 1e-6f);
+  const float theta = (e->in_generate ? e->refine_theta_gen : e->refine_theta_x) / fmaxf(hp->beta * e->logit_scale_exp, 1e-6f);
   { ProfScope ps(e, "combine", 0);
     ca.inp = nullptr;
     E_CHECK(launch_combine(ca, e->st));
@@ -928,7 +932,7 @@ int czc_replicate(czc_engine* p, czc_engine** out) {
   e->cfg = p->cfg; e->dev = p->dev; e->finalized = true; e->shares_weights = true;
   e->esz = p->esz; e->pb = p->pb; e->pc = p->pc; e->pv = p->pv; e->eb = p->eb;
   e->refine = p->refine; e->refine_theta_x = p->refine_theta_x; e->refine_samples = p->refine_samples;
-  e->refine_guard_dev = p->refine_guard_dev; e->refine_gate_delta = p->refine_gate_delta;
+  e->refine_guard_dev = p->refine_guard_dev; e->refine_gate_delta = p->refine_gate_delta; e->refine_theta_gen = p->refine_theta_gen;
   e->w = p->w; e->bert = p->bert; e->ctext = p->ctext; e->cvis = p->cvis; e->ctext_x = p->ctext_x;
   e->mlm_dense_w = p->mlm_dense_w; e->decoder_w = p->decoder_w; e->tproj_w = p->tproj_w; e->vproj_w = p->vproj_w;
   e->patch_w = p->patch_w; e->tproj_wx = p->tproj_wx;
@@ -1277,6 +1281,7 @@ int czc_step(czc_engine* e, int32_t* inp, int B, int T, int gen_idx, int n_mask,
   E_CHECK(ensure(e, "g_inp", (size_t)B * T * 4, (void**)&d_inp));
   E_HIP(hipMemcpyAsync(d_inp, inp, (size_t)B * T * 4, hipMemcpyDefault, e->st));
   e->gate_now = false;  // parity granularity: every one of the K fused scores is an output, all of them are refined
+  e->in_generate = false;
   E_CHECK(step_device(e, d_inp, B, T, gen_idx, n_mask, dot_allowed, top_k, hp));
   const size_t bk = (size_t)B * top_k;
   if (out) {
@@ -1331,6 +1336,7 @@ int czc_generate(czc_engine* e, int B, int T, int L, int seed_len, const int32_t
     const bool audit = snap_step && (s / snapshot_every) % 4 == 0;
     e->gate_now = e->refine && e->refine_gate_delta > 0.f && !audit;
     e->gate_need_cos = snap_step;
+    e->in_generate = true;
     E_CHECK(step_device(e, d_inp, B, T, seed_len + pos, nm, pos == L - 1 ? 1 : 0, top_k, hp));
     if ((s + 1) % snapshot_every == 0) {
       if (out_ids)
@@ -1366,6 +1372,7 @@ int czc_set_option(czc_engine* e, const char* name, int value) {
   if (!strcmp(name, "fold_ln")) { e->fold_ln = value ? 1 : 0; return CZC_OK; }
   if (!strcmp(name, "refine_samples")) { e->refine_samples = value < 0 ? 0 : value; return CZC_OK; }
   if (!strcmp(name, "refine_theta_x1000")) { e->refine_theta_x = (float)value / 1000.f; return CZC_OK; }
+  if (!strcmp(name, "refine_theta_gen_x1000")) { e->refine_theta_gen = (float)value / 1000.f; return CZC_OK; }
   if (!strcmp(name, "refine_guard_x1e6")) { e->refine_guard_dev = (float)value * 1e-6f; return CZC_OK; }
   if (!strcmp(name, "refine_gate_x1e6")) { e->refine_gate_delta = value < 0 ? 0.f : (float)value * 1e-6f; return CZC_OK; }
   return fail(e, CZC_ERR_ARG, "unknown option %s", name);
@@ -1485,7 +1492,7 @@ const void* czc_internal_hooks(int abi) {
       &launch_softmax_mask_topk, &launch_bridge_precompute, &launch_bridge, &launch_l2_normalize, &launch_combine,
       &launch_layernorm_x16, &launch_ln_finalize, &launch_fold_ln,
       &g_use_gemm256, &g_use_skinny, &g_use_splitk, &g_gemm_deep, &g_gemm_small_tiles, &g_use_wreg, &g_use_gemm256s, &g_w_dbg,
-      &g_ln_lean, &g_rowln_min_m, &g_wreg_min_m, &g_gemm256_min_m, &g_use_mfma_attention, &g_use_attention_image};
+      &g_ln_lean, &g_rowln_min_m, &g_wreg_min_m, &g_gemm256_min_m, &g_use_mfma_attention, &g_use_attention_image, &g_wreg_resid_min_m};
   return abi == HOOKS_ABI ? &h : nullptr;
 }
 

@@ -607,8 +607,11 @@ bool gemm_wreg_eligible(const GemmArgs& g) {
          (long)g.ldc * 2 * WR_BLK < (1L << 30) && (long)g.lda * 2 * WR_BLK < (1L << 30);
 }
 
+// below: the tiled kernel's x16 branch serves the layer (same k order, same epilogue arithmetic: bit-identical rows and partials,
+// tests/test_kernels_gpu.py) -- a work-group of this kernel loads its 256 KB weight panel for as little as one 32-row block
+int g_wreg_resid_min_m = 6144;
 bool gemm_wreg_resid_eligible(const GemmArgs& g) {
-  return g_use_wreg && g.x16 && g.K == WR_K && g.N % 256 == 0 && g.resid && g.out_f32 && !g.out_act && g.act == ACT_NONE &&
+  return g_use_wreg && g.M >= g_wreg_resid_min_m && g.x16 && g.K == WR_K && g.N % 256 == 0 && g.resid && g.out_f32 && !g.out_act && g.act == ACT_NONE &&
          g.ldc % 8 == 0 && g.ldr % 8 == 0 && g.lda % 8 == 0 && g.ldw % 8 == 0 && (long)g.ldc * 2 * WR_BLK < (1L << 30) &&
          (long)g.ldr * 2 * WR_BLK < (1L << 30) && (long)g.lda * 2 * WR_BLK < (1L << 30);
 }

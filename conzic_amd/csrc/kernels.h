@@ -61,6 +61,7 @@ int launch_gemm_wreg(const GemmArgs& g, hipStream_t st);  // gemm_wreg.hip: weig
 bool gemm_wreg_resid_eligible(const GemmArgs& g);
 int launch_gemm_wreg_resid(const GemmArgs& g, hipStream_t st);
 extern int g_use_wreg;
+extern int g_wreg_resid_min_m;
 extern int g_wreg_min_m, g_gemm256_min_m;  // row-count thresholds of the two big-batch GEMM families
 
 // ---- imageproc.hip ------------------------------------------------------------------------
@@ -228,7 +229,7 @@ int launch_refine_finish(const int* own_off, const int* own_len, const int* coun
 // ---- czc_internal_hooks (include/conzic_hip.h): what libconzic_hip_test.so may reach inside this library -----------
 // The product library has hidden visibility; the hook library (api_test.hip) gets the launchers it wraps and the
 // process-wide kernel-family switches it flips through this table instead of through exported C++ symbols.
-constexpr int HOOKS_ABI = 0x0503;
+constexpr int HOOKS_ABI = 0x0504;
 struct Hooks {
   char* (*err_buf)();  // the calling host thread's g_err [512]
   decltype(&launch_gemm) gemm;
@@ -246,7 +247,7 @@ struct Hooks {
   decltype(&launch_ln_finalize) ln_finalize;
   decltype(&launch_fold_ln) fold_ln;
   int *use_gemm256, *use_skinny, *use_splitk, *gemm_deep, *gemm_small_tiles, *use_wreg, *use_gemm256s, *w_dbg, *ln_lean,
-      *rowln_min_m, *wreg_min_m, *gemm256_min_m, *use_mfma_attention, *use_attention_image;
+      *rowln_min_m, *wreg_min_m, *gemm256_min_m, *use_mfma_attention, *use_attention_image, *wreg_resid_min_m;
 };
 
 }  // namespace czc

@@ -268,6 +268,7 @@ int czc_generate(czc_engine* e, int B, int T, int L, int seed_len, const int32_t
  *                         add; one rounding per update): 1 = the bf16 engine (CZC_PREC_BF16), 2 = the single-pass fp16 tower too
  *                         (outside its validated error budget: experiments), 0 = fp32 rows everywhere.  With it the
  *                         out-projection runs on the weight-stationary kernel ("fuse_ln" then has nothing to fuse)
+ *   "refine_theta_gen_x1000" (4000): the same threshold inside czc_generate (ids and winner cosines are its output, not the K scores)
  *   "refine_samples" (12), "refine_theta_x1000" (2000): CZC_PREC_REFINE selection -- strata of the mass-stratified sample
  *                         and the softmax_K mass threshold theta = value / 1000 / (beta * exp(logit_scale))
  *   "refine_guard_x1e6" (200): trip point of czc_refine_guard, in units of 1e-6 of cosine

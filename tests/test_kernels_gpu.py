@@ -779,13 +779,19 @@ def test_residual_gemm_on_fp16_rows(prec, M, N, K):
     W[:, : K // 2] *= 2.0
     bias = rng.standard_normal(N).astype(np.float32)
     resid = (rng.standard_normal((M, N)) * 2).astype(np.float32)
-    out = E.test_gemm_x16(prec, A, W, bias, resid)
+    lib = native.load_test()
     ref = _x16_ref(prec, A, W, bias, resid)
     tol = np.maximum(np.abs(ref), 1.0) * 2.0 ** -10 + 2e-4 * np.sqrt(K / 64)  # fp16 rounding of the result + fp32 summation order
-    bad = np.abs(out - ref) > tol
-    assert not bad.any(), (int(bad.sum()), float(np.abs(out - ref).max()), np.argwhere(bad)[:4].tolist())
-    out2 = E.test_gemm_x16(prec, A, W, None, resid)  # no bias
-    assert np.abs(out2 - _x16_ref(prec, A, W, None, resid)).max() < float(tol.max())
+    try:
+        for min_m in (1, 6144):  # the weight-stationary residual kernel at every row count / from its product threshold on
+            assert lib.czc_test_set_option(b"wreg_resid_min_m", min_m) == 0
+            out = E.test_gemm_x16(prec, A, W, bias, resid)
+            bad = np.abs(out - ref) > tol
+            assert not bad.any(), (min_m, int(bad.sum()), float(np.abs(out - ref).max()), np.argwhere(bad)[:4].tolist())
+            out2 = E.test_gemm_x16(prec, A, W, None, resid)  # no bias
+            assert np.abs(out2 - _x16_ref(prec, A, W, None, resid)).max() < float(tol.max())
+    finally:
+        lib.czc_test_set_option(b"wreg_resid_min_m", 6144)
 
 
 @pytest.mark.parametrize("prec", [BF16, native.PREC_FP16])
@@ -873,10 +879,22 @@ def test_layernorm_partials_do_not_depend_on_the_kernel():
         for name in ("tiled", "tiled64"):
             np.testing.assert_array_equal(outs["ring"][0], outs[name][0])
             np.testing.assert_array_equal(outs["ring"][1], outs[name][1])
+        # the out-projection (K = 512): weight-stationary residual kernel vs the tiled kernel that serves it below 6144 rows
+        for M in (100, 8200):
+            A = rng.standard_normal((M, 512)).astype(np.float32)
+            W = (rng.standard_normal((512, 512)) * 0.04).astype(np.float32)
+            resid = (rng.standard_normal((M, 512)) * 2).astype(np.float32)
+            pair = {}
+            for name, min_m in (("wreg_resid", 1), ("tiled", 1 << 30)):
+                assert lib.czc_test_set_option(b"wreg_resid_min_m", min_m) == 0
+                pair[name] = E.test_gemm_x16(BF16, A, W, bias, resid, want_part=True)
+            np.testing.assert_array_equal(pair["wreg_resid"][0], pair["tiled"][0])
+            np.testing.assert_array_equal(pair["wreg_resid"][1], pair["tiled"][1])
     finally:
         lib.czc_test_set_option(b"gemm256_min_m", 8192)
         lib.czc_test_set_option(b"gemm_small_tiles", 4)
         lib.czc_test_set_option(b"gemm_deep", 1)
+        lib.czc_test_set_option(b"wreg_resid_min_m", 6144)
 
 
 @pytest.mark.parametrize("prec", [BF16, native.PREC_FP16])
