@@ -281,7 +281,18 @@ def run_generation(order: str, img_name, model, clip, tokenizer, image_instance,
             eng.set_image_embeds(emb)  # the first engine holds the whole batch again, as after a single-stream call
         return out, runner
 
-    (ids, cos), runner = polish(eng)
+    try:
+        (ids, cos), runner = polish(eng)
+    except native.NativeError as exc:
+        # the bf16 engine keeps the text tower's residual stream as fp16 rows (|x| < 65504): a checkpoint whose rows leave that
+        # range shows up as a non-finite cosine (CZC_ERR_OVERFLOW); its engine then goes back to fp32 rows for good
+        if "non-finite CLIP cosine" not in str(exc) or eng.precision != native.PREC_BF16 or getattr(eng, "_resid16_off", False):
+            raise
+        logger.info("bf16 engine: the fp16 residual stream overflowed on this checkpoint; repeating the call with fp32 rows "
+                    "(engine option resid16 = 0, kept for this engine)")
+        eng.set_option("resid16", 0)
+        eng._resid16_off = True
+        (ids, cos), runner = polish(eng)
     guard_mode = os.environ.get("CZC_REFINE_GUARD", "rerun").lower()
     if eng.precision == native.PREC_REFINE and guard_mode != "off":
         # the screen-then-refine engine's 1e-3 bound rests on the single-pass fp16 tower's error staying near what it is

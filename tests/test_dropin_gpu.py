@@ -285,3 +285,44 @@ def test_refine_guard_trip_repeats_the_call_on_the_split_engine(monkeypatch):
     warned, lines, precs = run("refine", guard_x="1", mode="warn")
     assert precs == [native.PREC_REFINE] and any("screen-then-refine guard" in ln for ln in lines)
     assert warned[0] == plain[0]
+
+
+def test_fp16_residual_overflow_falls_back_to_fp32_rows(monkeypatch):
+    """The bf16 engine's text tower keeps its residual stream as fp16 rows.  A checkpoint whose rows leave the fp16 range (here:
+    token embeddings scaled by 2e6) produces non-finite cosines, which the engine reports (CZC_ERR_OVERFLOW) instead of hiding;
+    `runtime.run_generation` then switches that engine to fp32 rows (option resid16 = 0), repeats the call and says so."""
+    import utils
+    from clip.clip import CLIP
+    from conzic_amd import runtime
+    from conzic_amd.models import SyntheticLM
+    from conzic_amd.text import tokenizers_from_vocab
+    from gen_utils import generate_caption
+    monkeypatch.setenv("CZC_PRECISION", "bf16")
+    sv = synth.make_vocab()
+    bcfg, ccfg = synth.bert_base(), synth.clip_b32()
+    bt, ct = tokenizers_from_vocab(sv)
+    cw = synth.make_clip_weights(ccfg, 12)
+    key = "text_model.embeddings.token_embedding.weight"
+    cw[key] = np.asarray(cw[key], dtype=np.float32) * 2e6
+    lm = SyntheticLM(bcfg, 11)
+    clip = CLIP.from_state(ccfg, cw, ct)
+    from PIL import Image
+    B, L = 2, 4
+    imgs = [Image.fromarray(u) for u in synth.make_images_u8(B, ccfg.v_image)]
+    mask = synth.make_token_mask(sv, regular_only=True)
+
+    class Log:
+        def __init__(self):
+            self.lines = []
+
+        def info(self, s_):
+            self.lines.append(str(s_))
+
+    log = Log()
+    utils.set_seed(42)
+    texts, scores = generate_caption([f"img{j}" for j in range(B)], lm, clip, bt, imgs, mask, log, prompt="Image of a",
+                                     batch_size=B, max_len=L, top_k=50, temperature=0.1, max_iter=2, alpha=0.02, beta=2.0,
+                                     generate_order="sequential")
+    assert any("fp16 residual stream overflowed" in ln for ln in log.lines), log.lines[-5:]
+    assert len(texts) == 3 and all(np.isfinite(np.array(sc, dtype=np.float64)).all() for sc in scores)
+    runtime.evict()
