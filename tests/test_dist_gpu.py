@@ -186,6 +186,34 @@ def test_bench_strong_scaling_two_ranks_reproduce_the_one_rank_captions():
     assert abs(two["value"] - sum(two["ranks"]["per_rank_captions_per_s"])) / two["value"] < 0.2
 
 
+def test_bench_config3_preset_with_samples_reproduces_the_one_rank_captions():
+    """`bench.py --config 3` = BASELINE configs[3] as flags (--total-images 2048 --order shuffle --len 15 --topk 512 --samples 3),
+    here scaled to 64 images and one sweep: three samples per step on image embeddings encoded once, every sample with its own
+    order from the one random.Random(42) stream; two ranks sharing the GPU reproduce the one-rank run's captions (crc32 of the
+    last sample's final ids), and the line names the preset and the sample count."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    common = ["--config", "3", "--total-images", "64", "--steps", "1", "--warmup", "0", "--iters", "1", "--no-cpu-baseline",
+              "--no-invariance", "--no-profile", "--no-alt"]
+
+    def run(extra):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra + common,
+                           capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    one = run(["--gpus", "1"])
+    two = run(["--gpus", "2", "--share-gpu"])
+    for d in (one, two):
+        c = d["config"]
+        assert c["preset"] == 3 and c["samples_num"] == 3 and c["order"] == "shuffle" and c["sentence_len"] == 15 and c["candidate_k"] == 512
+        assert "configs[3]" in c["workload"] and "samples_num=3" in c["workload"]
+        assert d["scaling"] == "strong" and c["total_images"] == 64
+    assert two["ranks"]["per_rank_images"] == [32, 32]
+    assert two["captions_crc32"]["value"] == one["captions_crc32"]["value"] and one["captions_crc32"]["images"] == 64
+    # value counts every sample's captions: 64 images x 3 samples per step
+    assert abs(one["value"] - 64 * 3 / (one["ms_per_step"] * 1e-3)) / one["value"] < 1e-3
+
+
 def test_bench_gpus_2_without_the_flag_fails_on_one_gpu():
     import subprocess
     import torch
