@@ -74,8 +74,8 @@ extern "C" {
  * Measured on one MI355X, round 5 (generated by tools/refresh_docs.py from profiles/r05_*):
  *   fused score vs the reference, worst over the full-size goldens: CZC_PREC_BF16 1.79e-04, CZC_PREC_REFINE 6.03e-04,
  *   CZC_PREC_SPLIT 4.2e-06, CZC_PREC_F32 7.3e-06 (bar 1e-3);
- *   CZC_PREC_REFINE against CZC_PREC_SPLIT over 1280 more image-steps: worst 6.25e-04, 99.9th percentile 1.4e-04, winners identical
- *   1280 / 1280; guard sample maximum 1.53e-04 against 2.11e-04 over all candidates;
+ *   CZC_PREC_REFINE against CZC_PREC_SPLIT over 2560 more image-steps: worst 4.85e-04, 99.9th percentile 1.4e-04, winners identical
+ *   2560 / 2560; guard sample maximum 1.54e-04 against 2.36e-04 over all candidates;
  *   BASELINE configs[2]: 80.3 captions/s (CZC_PREC_BF16), 65.2 (CZC_PREC_REFINE through czc_generate, 85 % of the image-steps gated).
  * END GENERATED measured
  */

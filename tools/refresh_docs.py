@@ -96,7 +96,7 @@ def facts():
         m = re.search(r"host control scorer under the CLIP tower: ([0-9.]+) ms of host work per ([0-9.]+) ms step\s+-> ([0-9.]+)x", txt)
         if m:
             f["overlap_cost_ms"], f["overlap_step_ms"], f["overlap_ratio"] = float(m.group(1)), float(m.group(2)), float(m.group(3))
-    rv = jlines(f"{ROUND}_refine_validate_128x10.jsonl")
+    rv = jlines(f"{ROUND}_refine_validate_256x10_fullcaptions.jsonl") or jlines(f"{ROUND}_refine_validate_128x10.jsonl")
     for r in rv:
         if r.get("mode") == "generate" and r.get("gate_delta", 0) > 0:
             f["rv_gen_ids_identical"], f["rv_gen_gated"], f["rv_gen_images"], f["rv_gen_steps"] = r["ids_identical"], r["gated_frac"], r["images"], r["image_steps"]
