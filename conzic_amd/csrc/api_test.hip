@@ -166,11 +166,11 @@ int czc_test_gemm_x16(int precision, int M, int N, int K, const float* A, const 
 }
 
 // LayerNorm folded into the weight-stationary K = 512 GEMM: out[M,N] = act( LN(fp16(x); gamma, beta, eps) . W^T + bias ) in the
-// operand type of `precision`, computed as rstd * (x . W'^T - mean * colsum(W')) + b' from x itself: weights prepared by
-// fold_ln_kernel, statistics by ln_finalize_kernel from the partials `part` [16][M] float2 the caller supplies (a producer GEMM
-// would have written them).
+// operand type of `precision`, computed as rstd * (x . W"^T) + b' from x itself: centred weights prepared by fold_ln_kernel
+// (rowsum_out, optional [N]: what is left of each stored row's sum), statistics by ln_finalize_kernel from the partials `part`
+// [16][M] float2 the caller supplies (a producer GEMM would have written them).
 int czc_test_ln_fold_gemm(int precision, int M, int N, const float* x, const float* W, const float* gamma, const float* beta,
-                          const float* bias, const float* part, float eps, int act, float* out) {
+                          const float* bias, const float* part, float eps, int act, float* out, float* rowsum_out) {
   const int K = 512;
   if (precision != PREC_BF16 && precision != PREC_F16) { snprintf(TEST_ERR, 512, "ln_fold_gemm: bf16 / fp16 engines only"); return CZC_ERR_ARG; }
   DevPool pool;
@@ -190,9 +190,10 @@ int czc_test_ln_fold_gemm(int precision, int M, int N, const float* x, const flo
   GemmArgs g;
   g.A = dx; g.lda = K; g.W = dWf; g.ldw = K; g.bias = dbf; g.resid = nullptr; g.ldr = 0; g.out_act = dout; g.out_f32 = nullptr; g.ldc = N;
   g.M = M; g.N = N; g.K = K; g.act = act;
-  g.ln_stat = dstat; g.ln_colsum = dcs;
+  g.ln_stat = dstat;
   T_CHECK(launch_gemm(precision, g, nullptr));
   T_HIP(hipDeviceSynchronize());
+  if (rowsum_out) T_HIP(hipMemcpy(rowsum_out, dcs, (size_t)N * 4, hipMemcpyDeviceToHost));
   return down_act(pool, precision, dout, (size_t)M * N, out);
 }
 
@@ -251,7 +252,7 @@ int czc_bench_gemm(int precision, int M, int N, int K, int act, int out_mode, in
     std::vector<float> hs((size_t)M * 2);
     for (size_t i = 0; i < hs.size(); i += 2) { hs[i] = 0.1f; hs[i + 1] = 1.0f; }
     T_HIP(hipMemcpy(dstat, hs.data(), hs.size() * 4, hipMemcpyHostToDevice));
-    g.ln_stat = dstat; g.ln_colsum = dB;
+    g.ln_stat = dstat;
     g.out_act = pool.alloc((size_t)M * N * es); T_PTR(g.out_act);
     g.out_f32 = nullptr; g.resid = nullptr;
   }

@@ -35,9 +35,9 @@ struct LayerW {
   void* fc2_w = nullptr; float* fc2_b = nullptr;
   float *ln2_g = nullptr, *ln2_b = nullptr;
   // LayerNorm folded into the K = 512 GEMMs (bf16 engine's CLIP-text tower on the 2-byte residual stream): fp16 weights with
-  // the gain folded in, their row sums, bias + W.beta (rowops.hip fold_ln_kernel); null where the fold is not used
+  // the gain folded in and their rows centred, bias + W.beta (rowops.hip fold_ln_kernel); null where the fold is not used
   void *qkv_wf = nullptr, *fc1_wf = nullptr;
-  float *qkv_cs = nullptr, *qkv_bf = nullptr, *fc1_cs = nullptr, *fc1_bf = nullptr;
+  float *qkv_bf = nullptr, *fc1_bf = nullptr;
 };
 
 struct Buf {
@@ -342,12 +342,12 @@ int clip_stack(czc_engine* e, int P, const char* gk, std::vector<LayerW>& L, flo
     E_CHECK(launch_ln_finalize(part, M, H / 32, rows, eps, stat, e->st));
     return 0;
   };
-  auto folded_gemm = [&](const void* Ax, const void* Wf, const float* bf, const float* cs, const float* st_, void* out, int rows, int N,
+  auto folded_gemm = [&](const void* Ax, const void* Wf, const float* bf, const float* st_, void* out, int rows, int N,
                          int act) -> int {
     GemmArgs g;
     g.A = Ax; g.lda = H; g.W = Wf; g.ldw = H; g.bias = bf; g.resid = nullptr; g.ldr = 0; g.out_act = out; g.out_f32 = nullptr; g.ldc = N;
     g.M = rows; g.N = N; g.K = H; g.act = act;
-    g.ln_stat = st_; g.ln_colsum = cs;
+    g.ln_stat = st_;
     ProfScope ps(e, gk, 2.0 * rows * (double)N * H);
     E_CHECK(launch_gemm(P, g, e->st));
     return 0;
@@ -376,7 +376,7 @@ int clip_stack(czc_engine* e, int P, const char* gk, std::vector<LayerW>& L, flo
   for (size_t n = 0; n < L.size(); ++n) {
     LayerW& l = L[n];
     if (fold) {
-      E_CHECK(folded_gemm(x, l.qkv_wf, l.qkv_bf, l.qkv_cs, n == 0 ? ln_stat0 : stat, qkv, M, 3 * H, ACT_NONE));
+      E_CHECK(folded_gemm(x, l.qkv_wf, l.qkv_bf, n == 0 ? ln_stat0 : stat, qkv, M, 3 * H, ACT_NONE));
     } else {
       if (!have_y) E_CHECK(ln(l.ln1_g, l.ln1_b, M, x, y));
       E_CHECK(gemm(e, P, gk, y, H, l.qkv_w, H, l.qkv_b, nullptr, 0, qkv, nullptr, 3 * H, M, 3 * H, H, ACT_NONE));
@@ -402,7 +402,7 @@ int clip_stack(czc_engine* e, int P, const char* gk, std::vector<LayerW>& L, flo
       if (fold) {
         E_CHECK(gemm_x16(e, P, gk, ctx_e, H, l.o_w, l.o_b, x_e, n_pool, H, H, part, M));
         E_CHECK(finalize(n_pool));
-        E_CHECK(folded_gemm(x_e, l.fc1_wf, l.fc1_bf, l.fc1_cs, stat, h_e, n_pool, I, ACT_QUICK_GELU));
+        E_CHECK(folded_gemm(x_e, l.fc1_wf, l.fc1_bf, stat, h_e, n_pool, I, ACT_QUICK_GELU));
       } else {
         if (r16) E_CHECK(gemm_x16(e, P, gk, ctx_e, H, l.o_w, l.o_b, x_e, n_pool, H, H));
         else E_CHECK(gemm(e, P, gk, ctx_e, H, l.o_w, H, l.o_b, x_e, H, nullptr, x_e, H, n_pool, H, H, ACT_NONE));
@@ -417,7 +417,7 @@ int clip_stack(czc_engine* e, int P, const char* gk, std::vector<LayerW>& L, flo
     if (fold) {
       E_CHECK(gemm_x16(e, P, gk, ctx, H, l.o_w, l.o_b, x, M, H, H, part, M));
       E_CHECK(finalize(M));
-      E_CHECK(folded_gemm(x, l.fc1_wf, l.fc1_bf, l.fc1_cs, stat, hbuf, M, I, ACT_QUICK_GELU));
+      E_CHECK(folded_gemm(x, l.fc1_wf, l.fc1_bf, stat, hbuf, M, I, ACT_QUICK_GELU));
       const bool more = n + 1 < L.size();  // the last layer's rows only feed the final LayerNorm (on the pooled rows)
       E_CHECK(gemm_x16(e, P, gk, hbuf, I, l.fc2_w, l.fc2_b, x, M, H, I, more ? part : nullptr, M));
       if (more) E_CHECK(finalize(M));
@@ -902,7 +902,7 @@ int czc_destroy(czc_engine* e) {
   auto free_layers = [](std::vector<LayerW>& L) {
     for (auto& l : L) {
       (void)hipFree(l.qkv_w); (void)hipFree(l.qkv_b); (void)hipFree(l.o_w); (void)hipFree(l.fc1_w); (void)hipFree(l.fc2_w);
-      (void)hipFree(l.qkv_wf); (void)hipFree(l.qkv_cs); (void)hipFree(l.qkv_bf); (void)hipFree(l.fc1_wf); (void)hipFree(l.fc1_cs); (void)hipFree(l.fc1_bf);
+      (void)hipFree(l.qkv_wf); (void)hipFree(l.qkv_bf); (void)hipFree(l.fc1_wf); (void)hipFree(l.fc1_bf);
     }
   };
   free_layers(e->bert); free_layers(e->ctext); free_layers(e->cvis); free_layers(e->ctext_x);
@@ -985,16 +985,14 @@ int czc_finalize_weights(czc_engine* e) {
       E_CHECK(need(e, p + ".self_attn.v_proj.weight", (size_t)H * H, &vw));
       E_CHECK(need(e, p + ".mlp.fc1.weight", (size_t)I * H, &f1w));
       E_HIP(hipMalloc(&l.qkv_wf, (size_t)3 * H * H * 2));
-      E_HIP(hipMalloc((void**)&l.qkv_cs, (size_t)3 * H * 4));
       E_HIP(hipMalloc((void**)&l.qkv_bf, (size_t)3 * H * 4));
       E_HIP(hipMalloc(&l.fc1_wf, (size_t)I * H * 2));
-      E_HIP(hipMalloc((void**)&l.fc1_cs, (size_t)I * 4));
       E_HIP(hipMalloc((void**)&l.fc1_bf, (size_t)I * 4));
       const float* srcw[3] = {qw, kw, vw};
       for (int t = 0; t < 3; ++t)
-        E_CHECK(launch_fold_ln(srcw[t], l.ln1_g, l.ln1_b, l.qkv_b + t * H, H, H, (char*)l.qkv_wf + (size_t)t * H * H * 2, l.qkv_cs + t * H,
+        E_CHECK(launch_fold_ln(srcw[t], l.ln1_g, l.ln1_b, l.qkv_b + t * H, H, H, (char*)l.qkv_wf + (size_t)t * H * H * 2, nullptr,
                                l.qkv_bf + t * H, e->st));
-      E_CHECK(launch_fold_ln(f1w, l.ln2_g, l.ln2_b, l.fc1_b, I, H, l.fc1_wf, l.fc1_cs, l.fc1_bf, e->st));
+      E_CHECK(launch_fold_ln(f1w, l.ln2_g, l.ln2_b, l.fc1_b, I, H, l.fc1_wf, nullptr, l.fc1_bf, e->st));
     }
   }
   if (e->refine)

@@ -50,7 +50,7 @@ constexpr int WR_PATCH = 2048;                 // per-wave epilogue patch (32 ro
 constexpr int WR_BIAS = 128;                   // per-wave bias slice (32 floats)
 constexpr int WR_LDS = WR_D * WR_STAGE + 8 * (WR_PATCH + WR_BIAS);
 constexpr int WR_TS = 8;                                         // LNF: depth of the shared ring of (mean, rstd) blocks
-constexpr int WR_LDS_LNF = WR_LDS + 8 * WR_BIAS + WR_TS * 256;   // + per wave: colsum slice; + the ring
+constexpr int WR_LDS_LNF = WR_LDS + WR_TS * 256;                 // + the statistics area
 static_assert(WR_LDS_LNF <= 160 * 1024, "LDS budget");
 
 __device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {
@@ -65,13 +65,31 @@ __device__ __forceinline__ float wr_act(float v) {
   return v;
 }
 
+// The epilogue's VALU work is on the kernel's critical path (quick-GELU on 16 values per lane and block: 96 instructions, a
+// third of them quarter-rate, against 32 MFMAs), so it runs on pairs: v_pk_mul / v_pk_add / v_pk_fma_f32 take two fp32 values
+// per issue.  Same operations on the same values in the same order as wr_act: bit-identical results.
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+template <int ACT>
+__device__ __forceinline__ f32x2_t wr_act2(f32x2_t v) {
+  if (ACT == ACT_QUICK_GELU) {
+    const f32x2_t z = v * -2.4554669595930156f;
+    const f32x2_t e = {__builtin_amdgcn_exp2f(z.x), __builtin_amdgcn_exp2f(z.y)};
+    const f32x2_t d = e + 1.0f;
+    const f32x2_t r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    return v * r;
+  }
+  return v;
+}
+
 // LNF (round 5: LayerNorm folded into the GEMM, GemmArgs::ln_stat): A is the raw 2-byte residual stream x (fp16 rows), W the
-// weights with the LayerNorm gain folded in, W' = W * diag(gamma), as fp16, and
-//   C = act( rstd_m * (x . W'^T - mean_m * colsum(W')) + b' ),   b' = b + W . beta,
-// with (mean_m, rstd_m) per row from the producer GEMM's partials (rowops.hip ln_finalize_kernel): no LayerNorm kernel, no
-// normalised copy y of the rows.  The multiply runs on the fp16 MFMA whatever the engine's operand type (x is fp16); the
-// OUTPUT keeps the engine's type (F16 ? fp16 : bf16).  Per block one more LDS-DMA (T: 32 rows x 8 bytes of statistics, by
-// wave 0 only, into a ring shared by the work-group), VMEM order of wave 0 D0 D1 T D2 S0 D3 S1: its ring wait is vmcnt(15).
+// weights with the LayerNorm gain folded in and every weight row CENTRED, W" = W * diag(gamma) - its row mean, as fp16 whose
+// stored rows sum to zero (rowops.hip fold_ln_kernel), so that x . W"^T = (x - mean_m) . (W * diag(gamma))^T and
+//   C = act( rstd_m * (x . W"^T) + b' ),   b' = b + W . beta,
+// with rstd_m per row from the producer GEMM's partials (rowops.hip ln_finalize_kernel): no LayerNorm kernel, no normalised
+// copy y of the rows, and an epilogue of the plain kernel's size (one FMA where it has an add, one 4-byte LDS read per
+// block).  The multiply runs on the fp16 MFMA whatever the engine's operand type (x is fp16); the
+// OUTPUT keeps the engine's type (F16 ? fp16 : bf16).  Per four blocks one more LDS-DMA (T: 128 rows x 8 bytes of statistics, by
+// wave 0 only, into an area shared by the work-group), VMEM order of wave 0 in such a stream D0 D1 T D2 S0 D3 S1.
 template <int ACT, bool F16 = false, bool LNF = false>
 __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, int nsets, int nblk) {
   using OT = std::conditional_t<F16, f16_t, bf16_t>;  // output element type (the engine's activation type)
@@ -108,11 +126,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, 
   unsigned char* patch = smem + WR_D * WR_STAGE + wave * WR_PATCH;
   float* bias_s = (float*)(smem + WR_D * WR_STAGE + 8 * WR_PATCH + wave * WR_BIAS);
   if (lane < 32) bias_s[lane] = (g.bias && col0 + lane < g.N) ? g.bias[col0 + lane] : 0.f;
-  float* cs_s = (float*)(smem + WR_LDS + wave * WR_BIAS);                      // LNF: colsum(W') of this wave's 32 columns
-  const unsigned char* stat_s = smem + WR_LDS + 8 * WR_BIAS;                   // LNF: the work-group's ring of (mean, rstd) blocks
-  if constexpr (LNF) {
-    if (lane < 32) cs_s[lane] = col0 + lane < g.N ? g.ln_colsum[col0 + lane] : 0.f;
-  }
+  const unsigned char* stat_s = smem + WR_LDS;                                 // LNF: the work-group's (mean, rstd) pairs
 
   // ---- DMA side: this wave lands rows wave*4 + ii (ii 0..3) of every block ----
   const unsigned lds0 = __builtin_amdgcn_readfirstlane(
@@ -126,26 +140,40 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, 
   }
   u32x4_t rsA;
   rsA.w = 0x00020000u;
-  // LNF: (mean, rstd) of block j's 32 rows -> slot j % WR_TS of ONE ring shared by the work-group (64 lanes x 4 bytes = 32
-  // float2), requested by wave 0 only: every wave needs the same 32 pairs, and a VMEM instruction per wave and block (a
-  // seventh beside D0 D1 D2 S0 D3 S1) cost the fc1 layer 14 %.  Wave 0's pieces are published like its operand rows (its
-  // counted wait + the block barrier); the ring is 8 deep because the other waves read block i-1's pairs anywhere in
-  // block i's stream while wave 0 already requests block i+3's.
-  const unsigned stat0 = lds0 + WR_LDS + 8 * WR_BIAS;
-  const unsigned voffT = (unsigned)(lane * 4);
+  // LNF: the (mean, rstd) pairs of FOUR blocks (128 rows x 8 bytes = one 64-lane x 16-byte LDS-DMA) -> half (j / 4) % 2 of a
+  // 2 KiB area shared by the work-group, requested by wave 0 only and only with every fourth block: every wave needs the same
+  // pairs, and what an extra request costs is not its bytes.  Measured on the fc1 shape against the plain kernel (tools/ab_gemm.py
+  // out_mode 7): a seventh VMEM instruction per wave and block +14 %; one per block on wave 0 behind a uniform branch, with the
+  // ring wait chosen per wave, +4..10 % (every TAKEN branch in the block's stream is ~1 %: the compiler laid the skip and the
+  // two waits out as three taken branches for waves 1..7); the same instruction in every wave with EXEC = 0 for waves 1..7
+  // +8..12 % (the hardware still issues it).  Here waves 1..7 fall through an untaken branch, wave 0 leaves the stream once per
+  // four blocks, and the ring wait is the plain kernel's for everybody (see `step`).  Wave 0's pieces are published like its
+  // operand rows (its counted wait + the block barrier).  Two halves suffice: the pairs of blocks 4G..4G+3 are read in the
+  // streams of blocks 4G+1..4G+4, the request that overwrites them (group G+2) is issued in the stream of block 4G+5.
+  const unsigned stat0 = lds0 + WR_LDS;
+  constexpr bool T4 = !(LNF_ABL & 8);  // ablation 8: one dword request per block (ring of WR_TS slots of 256 bytes)
+  const unsigned voffT = (unsigned)(lane * (T4 ? 16 : 4));
   auto stat_dma = [&](int j) {
-    if (wave != 0 || (LNF_ABL & 1)) return;
+    if (LNF_ABL & 1) return;
+    const bool mine = wave == 0 && (!T4 || (j & 3) == 0);
+    if (__builtin_expect(!mine, 1)) return;
     const long row0 = (long)(b0 + j) * WR_BLK;
     const unsigned long long pt = (unsigned long long)g.ln_stat + (unsigned long long)row0 * 8;
     u32x4_t rsT;
     rsT.x = __builtin_amdgcn_readfirstlane((unsigned)pt); rsT.y = __builtin_amdgcn_readfirstlane((unsigned)(pt >> 32) & 0xffffu);
-    rsT.z = __builtin_amdgcn_readfirstlane((unsigned)(min((long)WR_BLK, (long)g.M - row0) * 8)); rsT.w = 0x00020000u;
-    const unsigned dst = stat0 + (j & (WR_TS - 1)) * 256;
+    rsT.z = __builtin_amdgcn_readfirstlane((unsigned)(min((long)(T4 ? 4 * WR_BLK : WR_BLK), (long)g.M - row0) * 8)); rsT.w = 0x00020000u;
+    const unsigned dst = stat0 + (T4 ? ((j >> 2) & 1) * 1024 : (j & (WR_TS - 1)) * 256);
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dword %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "s"(dst), "v"(voffT), "s"(rsT)
-                 : "memory");
+    if constexpr (T4)
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep)
+                   : "s"(dst), "v"(voffT), "s"(rsT)
+                   : "memory");
+    else
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dword %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep)
+                   : "s"(dst), "v"(voffT), "s"(rsT)
+                   : "memory");
   };
   auto issue = [&](int j) {  // block j of this work-group -> ring slot j % WR_D
     const long row0 = (long)(b0 + j) * WR_BLK;
@@ -213,23 +241,25 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, 
     rsC.x = (unsigned)pc; rsC.y = (unsigned)(pc >> 32) & 0xffffu;
     rsC.z = (unsigned)(min((long)WR_BLK, (long)g.M - row0) * cpitch);
   };
-  float ln_rstd = 0.f, ln_t = 0.f;  // LNF: rstd and -mean * rstd of this lane's row of the block whose epilogue is running
+  float ln_rstd = 0.f;  // LNF: rstd of this lane's row of the block whose epilogue is running
   auto epi_quad = [&](int qd, int js) {  // accP quad qd -> (LayerNorm correction,) bias, activation, 2-byte -> patch
     const float4 b4 = *(const float4*)(bias_s + 8 * qd + 4 * half);
-    float4 v;
+    const f32x2_t a01 = {accP[4 * qd], accP[4 * qd + 1]}, a23 = {accP[4 * qd + 2], accP[4 * qd + 3]};
+    const f32x2_t b01 = {b4.x, b4.y}, b23 = {b4.z, b4.w};
+    f32x2_t v01, v23;
     if constexpr (LNF && !(LNF_ABL & 2)) {
-      if (qd == 0) {  // read once per block: the slot is refilled (statistics of block js + WR_D) later in this same stream
-        const float2 st = *(const float2*)(stat_s + (js & (WR_TS - 1)) * 256 + l31 * 8);
-        ln_rstd = st.y;
-        ln_t = __fmul_rn(-st.x, st.y);
-      }
-      const float4 c4 = *(const float4*)(cs_s + 8 * qd + 4 * half);
-      v = make_float4(__fmaf_rn(accP[4 * qd], ln_rstd, __fmaf_rn(ln_t, c4.x, b4.x)), __fmaf_rn(accP[4 * qd + 1], ln_rstd, __fmaf_rn(ln_t, c4.y, b4.y)),
-                      __fmaf_rn(accP[4 * qd + 2], ln_rstd, __fmaf_rn(ln_t, c4.z, b4.z)), __fmaf_rn(accP[4 * qd + 3], ln_rstd, __fmaf_rn(ln_t, c4.w, b4.w)));
+      if (qd == 0)  // read once per block: the area is refilled (statistics of a later group of blocks) in this same stream
+        ln_rstd = *(const float*)(stat_s + (LNF_ABL & 8 ? (js & (WR_TS - 1)) * 256 : ((js >> 2) & 1) * 1024 + (js & 3) * 256) + l31 * 8 + 4);
+      const f32x2_t r2 = {ln_rstd, ln_rstd};
+      v01 = __builtin_elementwise_fma(a01, r2, b01);
+      v23 = __builtin_elementwise_fma(a23, r2, b23);
     } else {
-      v = make_float4(accP[4 * qd] + b4.x, accP[4 * qd + 1] + b4.y, accP[4 * qd + 2] + b4.z, accP[4 * qd + 3] + b4.w);
+      v01 = a01 + b01;
+      v23 = a23 + b23;
     }
-    v.x = wr_act<ACT>(v.x); v.y = wr_act<ACT>(v.y); v.z = wr_act<ACT>(v.z); v.w = wr_act<ACT>(v.w);
+    v01 = wr_act2<ACT>(v01);
+    v23 = wr_act2<ACT>(v23);
+    const float4 v = make_float4(v01.x, v01.y, v23.x, v23.y);
     const int slot = (2 * qd + half) ^ ((l31 >> 1) & 7);
     *(uint2*)(patch + l31 * 64 + slot * 8) = make_uint2(Half<OT>::pack2(v.x, v.y), Half<OT>::pack2(v.z, v.w));
   };
@@ -299,10 +329,11 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, 
       // block i landed?  VMEM issued after its last DMA piece: S1 of that block period, then two full periods
       // of 4 DMA + 2 stores (stores start with the second block) -- all in order on vmcnt.
       constexpr bool STEADY = decltype(steady_c)::value;
-      if (STEADY) {  // LNF: wave 0 issues one more instruction per block (T): S1 + two periods of seven
-        if (LNF && wave == 0) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
-      }
+      // LNF: wave 0 has a seventh instruction (T) in every fourth stream.  The same count stays valid: the thirteen newest
+      // are at least the two previous streams' twelve and one more, so everything up to the last DMA piece of the stream
+      // that requested block i (and its T) has landed -- at most one entry stricter than needed, on a request two block
+      // periods old, and no per-wave choice of the wait (a branch in front of the barrier) as in the first form.
+      if (STEADY) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
       else if (i + 2 >= nb) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else if (i < 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
@@ -601,7 +632,7 @@ int g_use_wreg = 1;        // 0: every K = 512 layer goes to the tiled kernels (
 int g_wreg_min_m = 1;
 
 bool gemm_wreg_eligible(const GemmArgs& g) {
-  if (g.ln_stat && !(g.ln_colsum && g.bias)) return false;
+  if (g.ln_stat && !g.bias) return false;
   return (g_use_wreg || g.ln_stat) && g.K == WR_K && g.M >= g_wreg_min_m && g.N % 8 == 0 && g.ldc % 8 == 0 && g.lda % 8 == 0 && g.ldw % 8 == 0 &&
          g.out_act && !g.out_f32 && !g.resid && (g.act == ACT_NONE || g.act == ACT_QUICK_GELU) &&
          (long)g.ldc * 2 * WR_BLK < (1L << 30) && (long)g.lda * 2 * WR_BLK < (1L << 30);

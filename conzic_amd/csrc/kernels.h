@@ -29,10 +29,9 @@ struct GemmArgs {
   float* row_part = nullptr;
   long part_ld = 0;
   // LayerNorm folded into the weight-stationary K = 512 GEMM (gemm_wreg.hip LNF): A = the raw fp16 residual rows, W = fp16
-  // weights with the gain folded in, bias = b + W.beta, ln_colsum [N] = row sums of the stored W', ln_stat = float2 (mean,
-  // rstd) per row of A
+  // weights with the gain folded in and their rows centred (rowops.hip fold_ln_kernel), bias = b + W.beta, ln_stat = float2
+  // (mean, rstd) per row of A
   const float* ln_stat = nullptr;
-  const float* ln_colsum = nullptr;
   // Full-row kernel (gemm_rowln, N = 512): out_f32 <- resid + A.W^T + bias and out_act <- LayerNorm(out_f32; ln_gamma,
   // ln_beta, ln_eps) from one launch.
   const float* ln_gamma = nullptr;
@@ -88,7 +87,7 @@ int launch_clip_embed(const int* ids, int ids_stride, const int* seg_src, const 
                       hipStream_t st, int x16 = 0, float* stat = nullptr, float eps = 0.f);  // x16: x is a 2-byte (fp16) residual stream; stat: float2 (mean, rstd) per row
 // LayerNorm folded into the consumer GEMM: statistics from the producers' partials, one-time weight preparation
 int launch_ln_finalize(const float* part, long part_ld, int nblk, int M, float eps, float* stat, hipStream_t st);
-int launch_fold_ln(const float* W, const float* gamma, const float* beta, const float* b, int N, int K, void* Wf16, float* colsum, float* bf,
+int launch_fold_ln(const float* W, const float* gamma, const float* beta, const float* b, int N, int K, void* Wf16, float* rowsum, float* bf,
                    hipStream_t st);
 // vision: im2col of [B,3,S,S] into patches [B*P, 3*p*p] (act type), then assemble cls/pos
 int launch_im2col(int prec, const float* pixels, int B, int S, int p, void* out, hipStream_t st);

@@ -213,29 +213,100 @@ int launch_ln_finalize(const float* part, long part_ld, int nblk, int M, float e
   return 0;
 }
 
-// One-time weight preparation of the fold: W' = fp16(W * diag(gamma)) [N,K], colsum[j] = sum_k W'[j,k] (of the STORED values:
-// it multiplies the mean of the stored rows), bf[j] = b[j] + sum_k W[j,k] * beta[k].  One wave per output row.
+// One-time weight preparation of the fold.  LN(x) . W^T + b = rstd * ((x - mean) . W'^T) + b' with W' = W * diag(gamma), b' = b +
+// W . beta, and (x - mean 1) . W'^T = x . W"^T for W"[j,:] = W'[j,:] - rowmean(W'[j,:]): centring the WEIGHT rows once removes
+// the mean from every product, so the consumer's epilogue is rstd * acc + b' and it reads neither the row mean nor a column
+// sum (the first form subtracted mean * colsum(W') there: four more 16-byte LDS reads and eight FMAs per lane and block in a
+// kernel whose LDS is the busiest unit: +5..9 % on the fc1 layer).  What the centring must not leave behind is the rounding:
+// the stored fp16 row sums to eps_j != 0 and the product carries mean * eps_j.  So the row is rounded WITH ITS SUM IN VIEW:
+// after round-to-nearest the row sum r (exact, in fp64) is driven towards zero one fp16 step at a time, each step the single
+// entry whose neighbour in the right direction leaves the smallest |r| -- entries near zero have the finest steps, so a few
+// dozen steps bring |r| from ~6 ulp of the typical entry down to the finest step of the row (< 1e-7 for these weights; an
+// entry moves by at most a few of its own ulps).  One wave per output row; K = 512: eight entries per lane.
 __global__ __launch_bounds__(256) void fold_ln_kernel(const float* W, const float* gamma, const float* beta, const float* b, int N, int K,
-                                                      f16_t* Wf, float* colsum, float* bf) {
+                                                      f16_t* Wf, float* rowsum, float* bf) {
   const int lane = threadIdx.x & 63;
   const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (j >= N) return;
-  float cs = 0.f, wb = 0.f;
-  for (int k = lane; k < K; k += 64) {
-    const float w = W[(long)j * K + k];
-    const unsigned short h = Half<f16_t>::from_f32(w * gamma[k]);
-    Wf[(long)j * K + k].v = h;
-    cs += Half<f16_t>::to_f32(h);
-    wb += w * beta[k];
+  constexpr int PER = 8;  // K <= 512
+  double wg[PER];
+  double sum = 0.0;
+  float wb = 0.f;
+#pragma unroll
+  for (int e = 0; e < PER; ++e) {
+    const int k = lane + 64 * e;
+    wg[e] = 0.0;
+    if (k < K) {
+      const float w = W[(long)j * K + k];
+      wg[e] = (double)w * (double)gamma[k];
+      wb += w * beta[k];
+    }
+    sum += wg[e];
   }
-  cs = wave_sum(cs);
+  auto wave_sum_f64 = [](double v) {
+    for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+  };
+  const double mean = wave_sum_f64(sum) / K;
   wb = wave_sum(wb);
-  if (lane == 0) { colsum[j] = cs; bf[j] = (b ? b[j] : 0.f) + wb; }
+  unsigned short h[PER];
+  double r = 0.0;
+#pragma unroll
+  for (int e = 0; e < PER; ++e) {
+    h[e] = lane + 64 * e < K ? Half<f16_t>::from_f32((float)(wg[e] - mean)) : (unsigned short)0;
+    r += (double)Half<f16_t>::to_f32(h[e]);
+  }
+  r = wave_sum_f64(r);
+  for (int it = 0; it < 96; ++it) {
+    // this lane's best single step: the neighbour (one step of the magnitude, normal numbers only) that leaves the smallest |r|
+    double best = fabs(r), best_err = 0.0;
+    int be = -1;
+    unsigned short bh = 0;
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+      if (lane + 64 * e >= K) continue;
+      const unsigned short cur = h[e];
+      const double v = (double)Half<f16_t>::to_f32(cur);
+      for (int dir = -1; dir <= 1; dir += 2) {
+        const int mag = (cur & 0x7fff) + dir;
+        if (mag < 0x0400 || mag >= 0x7c00) continue;  // stay inside the normal numbers
+        const unsigned short cand = (unsigned short)((cur & 0x8000) | mag);
+        const double cv = (double)Half<f16_t>::to_f32(cand);
+        const double rr = fabs(r + (cv - v)), err = fabs(cv - (wg[e] - mean));
+        // equal |r| (the many entries of one binade): the entry that ends up closest to its exact value, so the steps spread
+        if (rr < best || (be >= 0 && rr == best && err < best_err)) { best = rr; best_err = err; be = e; bh = cand; }
+      }
+    }
+    double wbest = best;
+    for (int o = 32; o; o >>= 1) wbest = fmin(wbest, __shfl_xor(wbest, o, 64));
+    if (!(wbest < fabs(r))) break;  // no single step improves the sum
+    const bool tied = be >= 0 && best == wbest;
+    double werr = tied ? best_err : 1e300;
+    for (int o = 32; o; o >>= 1) werr = fmin(werr, __shfl_xor(werr, o, 64));
+    const unsigned long long who = __ballot(tied && best_err == werr);
+    const int winner = __ffsll((long long)who) - 1;
+    double delta = 0.0;
+    if (lane == winner) {
+#pragma unroll
+      for (int e = 0; e < PER; ++e)
+        if (e == be) { delta = (double)Half<f16_t>::to_f32(bh) - (double)Half<f16_t>::to_f32(h[e]); h[e] = bh; }
+    }
+    r += __shfl(delta, winner, 64);
+  }
+#pragma unroll
+  for (int e = 0; e < PER; ++e)
+    if (lane + 64 * e < K) Wf[(long)j * K + lane + 64 * e].v = h[e];
+  if (lane == 0) {
+    if (rowsum) rowsum[j] = (float)r;
+    bf[j] = (b ? b[j] : 0.f) + wb;
+  }
 }
 
-int launch_fold_ln(const float* W, const float* gamma, const float* beta, const float* b, int N, int K, void* Wf16, float* colsum, float* bf,
+// rowsum (optional, [N]): what is left of each stored row's sum (test output)
+int launch_fold_ln(const float* W, const float* gamma, const float* beta, const float* b, int N, int K, void* Wf16, float* rowsum, float* bf,
                    hipStream_t st) {
-  hipLaunchKernelGGL(fold_ln_kernel, dim3(cdiv(N, 4)), dim3(256), 0, st, W, gamma, beta, b, N, K, (f16_t*)Wf16, colsum, bf);
+  if (K > 512) { snprintf(g_err, sizeof(g_err), "fold_ln: K = %d > 512", K); return 1; }
+  hipLaunchKernelGGL(fold_ln_kernel, dim3(cdiv(N, 4)), dim3(256), 0, st, W, gamma, beta, b, N, K, (f16_t*)Wf16, rowsum, bf);
   CZC_HIP_CHECK(hipGetLastError());
   return 0;
 }

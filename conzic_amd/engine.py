@@ -534,8 +534,9 @@ def test_gemm(prec, A, W, bias=None, resid=None, act=0, typed_out=False):
     return Cm
 
 
-def test_ln_fold_gemm(prec, x, W, gamma, beta, bias, part, eps, act=0):
-    """act(LN(fp16(x)) . W^T + bias) through the folded-LayerNorm weight-stationary GEMM; part [16, M, 2] = partials of fp16(x)."""
+def test_ln_fold_gemm(prec, x, W, gamma, beta, bias, part, eps, act=0, want_rowsum=False):
+    """act(LN(fp16(x)) . W^T + bias) through the folded-LayerNorm weight-stationary GEMM; part [16, M, 2] = partials of fp16(x).
+    want_rowsum: also the sums of the stored (centred, fp16) weight rows."""
     lib = native.load_test()
     x = np.ascontiguousarray(x, np.float32)
     W = np.ascontiguousarray(W, np.float32)
@@ -546,9 +547,10 @@ def test_ln_fold_gemm(prec, x, W, gamma, beta, bias, part, eps, act=0):
     pt = np.ascontiguousarray(part, np.float32)
     assert pt.shape == (16, M, 2) and x.shape[1] == 512 and W.shape[1] == 512
     out = np.empty((M, N), np.float32)
+    rowsum = np.empty(N, np.float32)
     native.check(lib.czc_test_ln_fold_gemm(prec, M, N, x.ctypes.data, W.ctypes.data, g.ctypes.data, bt.ctypes.data, _ptr(b), pt.ctypes.data,
-                                           float(eps), int(act), out.ctypes.data), None, "czc_test_ln_fold_gemm")
-    return out
+                                           float(eps), int(act), out.ctypes.data, rowsum.ctypes.data), None, "czc_test_ln_fold_gemm")
+    return (out, rowsum) if want_rowsum else out
 
 
 def test_gemm_x16(prec, A, W, bias, resid, want_part=False):

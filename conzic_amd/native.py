@@ -117,7 +117,7 @@ SIGNATURES = {
 TEST_SIGNATURES = {
     "czc_test_gemm": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _I, _P]),
     "czc_test_gemm_x16": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
-    "czc_test_ln_fold_gemm": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, C.c_float, _I, _P]),
+    "czc_test_ln_fold_gemm": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, C.c_float, _I, _P, _P]),
     "czc_test_layernorm_x16": (_I, [_I, _I, _P, _P, _P, C.c_float, _P]),
     "czc_test_gemm_rowln": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, C.c_float, _P, _P]),
     "czc_bench_gemm": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(C.c_double)]),

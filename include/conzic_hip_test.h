@@ -29,9 +29,10 @@ int czc_test_gemm(int precision, int M, int N, int K, const float* A, const floa
 int czc_test_gemm_x16(int precision, int M, int N, int K, const float* A, const float* W, const float* bias, const float* resid,
                       float* x_out, float* part_out /* NULL or [N/32][M][2]: (sum, sum of squares) per row and 32-column block */);
 /* LayerNorm folded into the K = 512 GEMM: out[M,N] = act(LN(fp16(x); gamma, beta, eps) . W^T + bias), from x itself, the folded
- * weights and the row statistics derived from `part` [16][M][2] (partials of fp16(x) as a producer GEMM writes them). */
+ * (gain applied, rows centred) fp16 weights and the row statistics derived from `part` [16][M][2] (partials of fp16(x) as a
+ * producer GEMM writes them).  rowsum_out: NULL or [N], what is left of the sum of each stored weight row. */
 int czc_test_ln_fold_gemm(int precision, int M, int N, const float* x, const float* W, const float* gamma, const float* beta,
-                          const float* bias, const float* part, float eps, int act, float* out);
+                          const float* bias, const float* part, float eps, int act, float* out, float* rowsum_out);
 /* LayerNorm of fp16 rows, 512 wide: y[M,512] = LN(fp16(x)) rounded to the operand type of `precision` (bf16 / fp16). */
 int czc_test_layernorm_x16(int precision, int M, const float* x, const float* gamma, const float* beta, float eps, float* y);
 

@@ -900,9 +900,9 @@ def test_layernorm_partials_do_not_depend_on_the_kernel():
 @pytest.mark.parametrize("prec", [BF16, native.PREC_FP16])
 @pytest.mark.parametrize("M,N,act", [(33, 1536, 0), (1000, 2048, 1), (20000, 1536, 0), (50000, 2048, 1)])
 def test_layernorm_folded_into_the_weight_stationary_gemm(prec, M, N, act):
-    """act(LN(x) . W^T + b) computed from x itself: fp16 MFMA on (x, W * gamma), corrected in the epilogue with the row's
-    (mean, rstd) -- against fp64 LayerNorm + GEMM of the fp16-rounded x.  Rows with a large common offset included (the
-    rank-1 correction subtracts mean * colsum from the accumulator: the case that would cancel)."""
+    """act(LN(x) . W^T + b) computed from x itself: fp16 MFMA on (x, W * gamma with every weight row centred), scaled in the
+    epilogue with the row's rstd -- against fp64 LayerNorm + GEMM of the fp16-rounded x.  Rows with a large common offset
+    included: the product carries mean * (sum of the stored weight row), so the stored rows must sum to (almost) nothing."""
     rng = np.random.default_rng(M + N)
     x = (rng.standard_normal((M, 512)) * 2).astype(np.float32)
     x[::7] += 6.0          # |mean| = 3 sigma
@@ -913,7 +913,10 @@ def test_layernorm_folded_into_the_weight_stationary_gemm(prec, M, N, act):
     bias = rng.standard_normal(N).astype(np.float32)
     xr = _f16_round(x)
     part = _part_ref(xr).astype(np.float32)
-    out = E.test_ln_fold_gemm(prec, x, W, gamma, beta, bias, part, 1e-5, act)
+    out, rowsum = E.test_ln_fold_gemm(prec, x, W, gamma, beta, bias, part, 1e-5, act, want_rowsum=True)
+    # round-to-nearest alone leaves ~ sqrt(512) * 2^-12 * |w| ~ 1e-4 per row; the compensated rounding a few of the finest normal
+    # fp16 steps (2^-24 = 6e-8): measured 2.4e-7 worst over these rows
+    assert np.abs(rowsum).max() < 1e-6, float(np.abs(rowsum).max())
     xd = torch.from_numpy(xr).double()
     y = torch.nn.functional.layer_norm(xd, (512,), torch.from_numpy(gamma).double(), torch.from_numpy(beta).double(), 1e-5)
     pre = (y @ torch.from_numpy(W).double().T + torch.from_numpy(bias).double()).numpy()
