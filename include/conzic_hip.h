@@ -272,7 +272,10 @@ int czc_generate(czc_engine* e, int B, int T, int L, int seed_len, const int32_t
  *   "refine_samples" (12), "refine_theta_x1000" (2000): CZC_PREC_REFINE selection -- strata of the mass-stratified sample
  *                         and the softmax_K mass threshold theta = value / 1000 / (beta * exp(logit_scale))
  *   "refine_guard_x1e6" (200): trip point of czc_refine_guard, in units of 1e-6 of cosine
- *   "refine_gate_x1e6" (400): cosine-error bound delta of the margin gate of czc_generate (czc_refine_gate_stats), 0 = off */
+ *   "refine_gate_x1e6" (400): cosine-error bound delta of the margin gate of czc_generate (czc_refine_gate_stats), 0 = off
+ *   "refine_rows16"   (1) CZC_PREC_REFINE inside czc_generate: the screening pass on the 2-byte residual stream with the folded
+ *                         LayerNorms (the "resid16" + "fold_ln" tower form on fp16 operands); gate bound and guard trip point
+ *                         are multiplied by "refine_rows16_x1000" / 1000 (1500) while it is on.  czc_step is not affected */
 int czc_set_option(czc_engine* e, const char* name, int value);
 
 /* ---- measurement ------------------------------------------------------------------------- */

@@ -388,7 +388,8 @@ def test_generate_free_running_full_size_refine(name):
 
 def test_margin_gate_skips_the_second_pass_without_changing_what_generate_returns():
     """czc_generate of the screen-then-refine engine returns ids of every step and the winner's cosine at the snapshot steps.
-    With the margin gate (default: delta = 4e-4) an image-step whose screening winner survives every cosine-error assignment
+    With the margin gate (default: delta = 4e-4, x 1.5 while the screening pass of czc_generate runs on fp16 rows: option
+    refine_rows16, the default) an image-step whose screening winner survives every cosine-error assignment
     within delta does no second pass; `full_scale100` (the published logit scale): same ids and cosines as the reference AND as
     the ungated engine, most image-steps gated, far fewer candidates re-encoded; czc_step never gates."""
     meta, arr = load_case("full_scale100")
@@ -415,6 +416,19 @@ def test_margin_gate_skips_the_second_pass_without_changing_what_generate_return
           f"{on['refine_seqs']} (gate on) vs {off['refine_seqs']} (off)")
     assert frac >= 0.5, frac
     assert on["refine_seqs"] < 0.5 * off["refine_seqs"]
+    # the screening pass on fp32 rows (the form czc_step keeps): the same ids and cosines, a few more image-steps gated
+    try:
+        eng.set_option("refine_gate_x1e6", 400)
+        eng.set_option("refine_rows16", 0)
+        eng.profile_reset()
+        ids32, cos32 = eng.generate(meta["B"], init, meta["L"], SEED_LEN, meta["K"], pos, hp, n_mask=nm, snapshot_every=every)
+        st32 = eng.stats()
+    finally:
+        eng.set_option("refine_rows16", 1)
+    np.testing.assert_array_equal(ids32, res[400][0])
+    np.testing.assert_allclose(cos32, res[400][1], atol=2e-5)
+    print(f"[margin gate] fp32-row screening: {st32['gated_image_steps']}/{st32['gate_image_steps']} image-steps gated")
+    assert st32["gated_image_steps"] >= on["gated_image_steps"]
     # parity granularity is untouched: a czc_step refines the full selection whatever the option says
     eng.set_option("refine_gate_x1e6", 400)
     eng.profile_reset()

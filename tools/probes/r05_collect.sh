@@ -7,6 +7,7 @@ cp $S/bench_driver_cmd.json $D/r05_bench_driver_cmd.json
 cp $S/bench_default.json $D/r05_bench_default.json
 for c in cfg1 cfg3 cfg4; do cp $S/bench_$c.json $D/r05_bench_$c.json; done
 cp $S/refine_validate_128x10.jsonl $D/r05_refine_validate_128x10.jsonl
+[ -s $S/refine_validate_256x10_fullcaptions.jsonl ] && cp $S/refine_validate_256x10_fullcaptions.jsonl $D/r05_refine_validate_256x10_fullcaptions.jsonl
 cp $S/bf16_1s_kernel_stats.csv $D/r05_bench_bf16_kernel_stats.csv
 cp $S/bf16_2s_kernel_stats.csv $D/r05_bench_bf16_2streams_kernel_stats.csv
 cp $S/refine_1s_kernel_stats.csv $D/r05_bench_refine_kernel_stats.csv

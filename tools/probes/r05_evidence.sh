@@ -15,6 +15,7 @@ python bench.py --config 1 --steps 3 --no-alt > $O/bench_cfg1.json 2> $O/bench_c
 python bench.py --config 3 --total-images 256 --steps 1 --warmup 1 --no-cpu-baseline > $O/bench_cfg3.json 2> $O/bench_cfg3.err
 python bench.py --config 4 --total-images 64 --control both --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_cfg4.json 2> $O/bench_cfg4.err
 python tools/refine_validate.py 128 10 12 2000 > $O/refine_validate_128x10.jsonl 2> $O/refine_validate.err
+if [ "$1" != "quick" ]; then GEN_SWEEPS=10 python tools/refine_validate.py 256 10 12 2000 > $O/refine_validate_256x10_fullcaptions.jsonl 2>> $O/refine_validate.err; fi
 export CZC_NORMAL_EXIT=1
 COMMON="--no-cpu-baseline --no-alt --no-invariance"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bf16_1s -o p -- python bench.py --streams 1 --steps 2 --warmup 1 $COMMON > $O/bf16_1s.log 2>&1

@@ -50,6 +50,8 @@ ref_ids, ref_cos = ref.engine.generate(B, init, L, SEED_LEN, K, gpos, hp, n_mask
 ref.engine.close()
 
 su = harness.build_synthetic(False, native.PREC_REFINE, logit_scale=SCALE, regular_only=True)
+for kv in filter(None, os.environ.get("CZC_OPTS", "").split(",")):  # engine options of the refine engine under test, "name=value,..."
+    su.engine.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 su.engine.set_image_embeds(emb)
 for th in THETAS:
     for m in SAMPLES:
@@ -83,7 +85,7 @@ for th in THETAS:
                               re_encoded_row_frac=round(st["refine_rows"] / max(st["clip_rows"], 1), 4))), flush=True)
 su.engine.set_option("refine_samples", 12)
 su.engine.set_option("refine_theta_x1000", 2000)
-for gate in (400, 0):
+for gate in [int(v) for v in os.environ.get("GATES", "400,0").split(",")]:
     su.engine.set_option("refine_gate_x1e6", gate)
     su.engine.profile_reset()
     su.engine.refine_guard(reset=True)
@@ -91,7 +93,9 @@ for gate in (400, 0):
     st = su.engine.stats()
     gd = su.engine.refine_guard(reset=True)
     same_img = (ids == ref_ids).all(axis=(0, 2))
-    print(json.dumps(dict(mode="generate", gate_delta=gate * 1e-6, images=B, sweeps=GEN_SWEEPS, image_steps=B * len(gpos),
+    rows16 = "refine_rows16=0" not in os.environ.get("CZC_OPTS", "")  # the engine default: screening pass of czc_generate on fp16 rows
+    print(json.dumps(dict(mode="generate", gate_delta=gate * 1e-6, screening_rows="fp16" if rows16 else "fp32",
+                          gate_delta_effective=gate * 1e-6 * (1.5 if rows16 else 1.0), images=B, sweeps=GEN_SWEEPS, image_steps=B * len(gpos),
                           images_with_identical_ids=int(same_img.sum()), ids_identical=bool((ids == ref_ids).all()),
                           max_abs_dcos_snapshots=float(np.abs(cos - ref_cos)[:, same_img].max()) if same_img.any() else None,
                           gated_frac=round(st["gated_image_steps"] / max(st["gate_image_steps"], 1), 4),
