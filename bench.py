@@ -450,7 +450,7 @@ def main():
                     image_steps=st_["gate_image_steps"], gated_image_steps=st_["gated_image_steps"],
                     gated_frac=round(st_["gated_image_steps"] / max(st_["gate_image_steps"], 1), 4),
                     gate="czc_generate margin gate (include/conzic_hip.h czc_refine_gate_stats): image-steps whose screening winner "
-                         "survives every cosine-error assignment within delta skip the second pass (delta = 4e-4 x 1.5: the screening pass of czc_generate runs on fp16 rows, option refine_rows16) (winner re-encoded at "
+                         "survives every cosine-error assignment within delta skip the second pass (delta = 4e-4 x 1.75: the screening pass of czc_generate runs on fp16 rows, option refine_rows16) (winner re-encoded at "
                          "snapshot steps only, for the returned cosine); the others take the full selection")
 
     def family_of(prof, passes):

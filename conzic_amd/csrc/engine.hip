@@ -90,12 +90,14 @@ struct czc_engine {
   // over 256 k candidates (2.1e-4), 2.7x the guard's sample maximum (1.5e-4)
   float refine_gate_delta = 4.0e-4f;
   // czc_generate's screening pass on the 2-byte residual stream with the LayerNorms folded into its GEMMs (the bf16 engine's
-  // tower form, fp16 operands): +11 % captions/s; |error - mean| grows from 2.1e-4 to 3.0e-4 and the guard's sample maximum
-  // from 1.5e-4 to 2.3e-4 over the same 256 k candidates, so gate bound and guard trip point are scaled by 1.5 while it is on
-  // (6e-4 / 3e-4: the same 2x and 1.3x margins).  czc_step keeps fp32 rows: all K fused scores are its output and the
-  // candidates that keep their screening cosine carry theta_x times that deviation.
+  // tower form, fp16 operands).  fp16 rows move its cosines: over the validation's candidates the guard's sample maximum
+  // inside czc_generate grows from 1.3-1.6e-4 to 2.3-2.8e-4 (x1.72-1.76; the true maximum over all candidates of the
+  // czc_step series from 2.1e-4 to 3.0e-4), so while it is on the three quantities that are bounds on that deviation move
+  // together by refine_rows16_factor = 1.75: gate bound 7e-4, guard trip point 3.5e-4 (= bound / 2, as before) and the
+  // selection's mass threshold theta_gen / 1.75 (theta * deviation, what a kept screening cosine can move a score by, stays).
+  // czc_step keeps fp32 rows: all K fused scores are its output and fp16 rows would take its worst one from 6.3e-4 to 1.3e-3.
   int refine_rows16 = 1;
-  float refine_rows16_factor = 1.5f;
+  float refine_rows16_factor = 1.75f;
   bool gate_now = false, gate_need_cos = true;  // set per step by czc_generate; czc_step never gates (all K scores are its output)
   int64_t stat_gated = 0, stat_gate_images = 0;
 
@@ -775,7 +777,10 @@ int step_phase_b(czc_engine* e, const StepArgs& a, int M, int max_len, int max_b
   E_CHECK(plan_bufs(e, a.B, a.K, &sp));
   E_CHECK(plan_bufs(e, a.B, a.K, &rp, "r"));
   const int S = a.B + n_seq;
-  const float theta = (e->in_generate ? e->refine_theta_gen : e->refine_theta_x) / fmaxf(hp->beta * e->logit_scale_exp, 1e-6f);
+  // (on fp16 rows the deviation a kept screening cosine carries is refine_rows16_factor times larger: the mass threshold
+  // shrinks by the same factor, so theta * deviation -- what such a candidate can move its score by -- stays what it was)
+  const float theta = (e->in_generate ? e->refine_theta_gen / (refine_rows16_now(e) ? e->refine_rows16_factor : 1.f) : e->refine_theta_x) /
+                      fmaxf(hp->beta * e->logit_scale_exp, 1e-6f);
   { ProfScope ps(e, "combine", 0);
     ca.inp = nullptr;
     E_CHECK(launch_combine(ca, e->st));

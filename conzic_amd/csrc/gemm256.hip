@@ -672,6 +672,14 @@ __global__ __launch_bounds__(768) void gemm256q_kernel(GemmArgs g, int tiles_m, 
 // DBG (timing ablations only, results are garbage): 1 no MFMA, 2 no DMA, 4 no fragment reads, 8 no epilogue;
 // 16 / 32: epilogue A/B forms (tile_epilogue EPI bits 0 / 1; results stay correct); 64 / 128: asm epilogue without its
 // residual loads / without its stores
+// Control flow (round 5, second half): the K loop is branch-free in its steady state.  The first form carried its conditions
+// into every K step -- the `step + ahead < total` guards, the group-dependent choice of the counted waits in front of both
+// barriers, run-time switches of the A/B arms, an integer division for the stage's tile -- which hipcc laid out as ~10 scalar
+// branches per 16 MFMAs, several of them taken and two of them directly in front of a barrier the other seven waves wait at
+// (the weight-stationary kernel showed what that costs: ~1 % per taken branch and 32 MFMAs, gemm_wreg.hip).  Now the two
+// groups run their own copies of the loop (GRP is a compile-time constant in each), every tile but the last three K steps
+// of a work-group runs the STEADY body (all guards true: one DMA issue, twelve fragment reads, one counted wait, two
+// barriers, sixteen MFMAs, one loop branch) and the stage counter of the issue side advances incrementally.
 template <int ACT, bool OUT_F32, bool F16 = false, int DBG = 0>
 __global__ __launch_bounds__(512) void gemm256x_kernel(GemmArgs g, int tiles_m, int tiles_n, int var) {
   using HT = std::conditional_t<F16, f16_t, bf16_t>;
@@ -679,13 +687,16 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(GemmArgs g, int tiles_m, 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = wave >> 2;
   const int nk = g.K >> 5;  // 32-wide K steps
   const int lda_b = g.lda * 2, ldw_b = g.ldw * 2;
   start_stagger(var >> 8, tiles_m * tiles_n, tiles_n);
   const int my_tiles = tile_count(tiles_m, tiles_n);
   const int total = my_tiles * nk;
-  const bool prio = !(var & 1), dma_late = var & 2;
+#ifdef CZC_EXPERIMENTS
+  const bool prio = !(var & 1), dma_late = var & 2;  // A/B arms (w_dbg bits 0 / 1)
+#else
+  constexpr bool prio = true, dma_late = false;
+#endif
 
   // ---- DMA side: pieces ii = 0, 1 land tile rows wave*32 + ii*16 + (lane>>2); physical chunk lane&3 ----
   const unsigned lds0 = __builtin_amdgcn_readfirstlane(
@@ -694,147 +705,164 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(GemmArgs g, int tiles_m, 
   const int cq = ((lane & 3) ^ ((lane >> 4) & 3)) << 4;
   const int a0 = rbase * lda_b + cq, w0 = rbase * ldw_b + cq;
   const int a16 = 16 * lda_b, w16 = 16 * ldw_b;
-  int cur_ti = -1;
   u32x4_t rsA, rsW;
   rsA.x = rsA.y = rsA.z = 0; rsA.w = 0x00020000u;
   rsW = rsA;
-  auto issue = [&](int s) {
-    const int ti = s / nk, kt = s - ti * nk;
-    if (ti != cur_ti) {
-      cur_ti = ti;
+  int is = 0, is_ti = 0, is_kt = 0;  // next stage to issue: number, tile, K step (stages are issued in order)
+  auto issue_rebase = [&]() {
+    int tm, tn;
+    tile_at(is_ti, tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * TM, n0 = tn * TN;
+    const unsigned long long pa = (unsigned long long)g.A + (unsigned long long)m0 * lda_b;
+    const unsigned long long pw = (unsigned long long)g.W + (unsigned long long)n0 * ldw_b;
+    rsA.x = (unsigned)pa; rsA.y = (unsigned)(pa >> 32) & 0xffffu; rsA.z = (unsigned)(min(TM, g.M - m0) * lda_b);
+    rsW.x = (unsigned)pw; rsW.y = (unsigned)(pw >> 32) & 0xffffu; rsW.z = (unsigned)(min(TN, g.N - n0) * ldw_b);
+  };
+  auto issue_next = [&]() {  // stage `is` -> ring slot is % QS
+    const unsigned dstA = lds0 + (is & (QS - 1)) * QSTAGE + wave * (32 * QROWB);
+    const unsigned dstW = dstA + QA_BYTES;
+    const unsigned so = is_kt * QROWB;
+    if (!(DBG & 2)) {
+      unsigned keep;
+      asm volatile(
+          "s_mov_b32 %0, m0\n\t"
+          "s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %7, %9 offen lds\n\t"
+          "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %7, %9 offen lds\n\t"
+          "s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %5, %8, %9 offen lds\n\t"
+          "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %6, %8, %9 offen lds\n\t"
+          "s_mov_b32 m0, %0"
+          : "=&s"(keep)
+          : "s"(dstA), "s"(dstW), "v"(a0), "v"(a0 + a16), "v"(w0), "v"(w0 + w16), "s"(rsA), "s"(rsW), "s"(so)
+          : "memory", "scc");
+    }
+    ++is;
+    if (++is_kt == nk) {  // the next stage opens a tile (once per tile: the only branch of the issue side)
+      is_kt = 0;
+      ++is_ti;
+      if (is < total) issue_rebase();
+    }
+  };
+
+  auto run = [&](auto grp_c) {
+    constexpr int GRP = decltype(grp_c)::value;
+    constexpr int AHEAD = 2 + GRP;  // group 0 issues stage s+2 in L(s), group 1 stage s+3 in its L(s)
+    if (total > 0) issue_rebase();
+    for (int s = 0; s < AHEAD && s < total; ++s) issue_next();
+    {
+      const int later = (total < AHEAD ? total : AHEAD) - 1;  // stages issued behind stage 0
+      if (later >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();  // publishes stage 0
+    asm volatile("" ::: "memory");
+
+    // ---- MFMA side ----
+    const int wn = wave & 3;
+    const int half = lane >> 5;
+    const int arow = GRP * 128 + (lane & 31);
+    const int brow = wn * 64 + (lane & 31);
+    int step = 0;
+    const int steady_end = total - 3;  // steps below it: every guard of the generic body is true
+    for (int ti = 0; ti < my_tiles; ++ti) {
       int tm, tn;
       tile_at(ti, tiles_m, tiles_n, tm, tn);
       const int m0 = tm * TM, n0 = tn * TN;
-      const unsigned long long pa = (unsigned long long)g.A + (unsigned long long)m0 * lda_b;
-      const unsigned long long pw = (unsigned long long)g.W + (unsigned long long)n0 * ldw_b;
-      rsA.x = (unsigned)pa; rsA.y = (unsigned)(pa >> 32) & 0xffffu; rsA.z = (unsigned)(min(TM, g.M - m0) * lda_b);
-      rsW.x = (unsigned)pw; rsW.y = (unsigned)(pw >> 32) & 0xffffu; rsW.z = (unsigned)(min(TN, g.N - n0) * ldw_b);
-    }
-    const unsigned dstA = lds0 + (s & (QS - 1)) * QSTAGE + wave * (32 * QROWB);
-    const unsigned dstW = dstA + QA_BYTES;
-    const unsigned so = kt * QROWB;
-    if (DBG & 2) return;
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %7, %9 offen lds\n\t"
-        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %7, %9 offen lds\n\t"
-        "s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %5, %8, %9 offen lds\n\t"
-        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %6, %8, %9 offen lds\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "s"(dstA), "s"(dstW), "v"(a0), "v"(a0 + a16), "v"(w0), "v"(w0 + w16), "s"(rsA), "s"(rsW), "s"(so)
-        : "memory", "scc");
-  };
-  const int ahead = 2 + grp;  // group 0 issues stage s+2 in L(s), group 1 stage s+3 in its L(s)
-  for (int s = 0; s < ahead && s < total; ++s) issue(s);
-  {
-    const int later = (total < ahead ? total : ahead) - 1;  // stages issued behind stage 0
-    if (later >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  __builtin_amdgcn_s_barrier();  // publishes stage 0
-  asm volatile("" ::: "memory");
-
-  // ---- MFMA side ----
-  const int wn = wave & 3;
-  const int half = lane >> 5;
-  const int arow = grp * 128 + (lane & 31);
-  const int brow = wn * 64 + (lane & 31);
-  int step = 0;
-  for (int ti = 0; ti < my_tiles; ++ti) {
-    int tm, tn;
-    tile_at(ti, tiles_m, tiles_n, tm, tn);
-    const int m0 = tm * TM, n0 = tn * TN;
-    f32x16_t acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    if (grp) {  // group 1 runs one phase behind: this barrier pairs with the one that ends group 0's L of the tile's first stage
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-    }
-    for (int kt = 0; kt < nk; ++kt, ++step) {
-      // ------------------------------- L(step) -------------------------------
-      const unsigned char* sA = smem + (step & (QS - 1)) * QSTAGE;
-      const unsigned char* sB = sA + QA_BYTES;
-      if (!dma_late && step + ahead < total) issue(step + ahead);
-      uint4 fa[2][4], fb[2][2];
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          if (DBG & 4) fb[ks][j] = make_uint4(lane, step, ks, j);
-          else fb[ks][j] = *(const uint4*)(sB + swzq(brow + 32 * j, 2 * ks + half));
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          if (DBG & 4) fa[ks][i] = make_uint4(lane, step, ks, i);
-          else fa[ks][i] = *(const uint4*)(sA + swzq(arow + 32 * i, 2 * ks + half));
-        }
-      }
-      if (dma_late && step + ahead < total) issue(step + ahead);
-      if (grp) {  // stage step+1 is published by the barrier below: this wave's pieces of it must have landed
-        if (step + 3 < total) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (step + 2 < total) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      // ------------------------------- M(step) -------------------------------
-      if (prio) __builtin_amdgcn_s_setprio(1);
-      if (DBG & 1) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {  // keep the fragments (and their LDS reads) alive without the matrix work
-#pragma unroll
-          for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(__builtin_bit_cast(u32x4_t, fb[ks][j])));
-#pragma unroll
-          for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(__builtin_bit_cast(u32x4_t, fa[ks][i])));
-        }
-      } else {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = Half<HT>::mfma(fb[ks][j], fa[ks][i], acc[i][j]);
-      }
-      if (prio) __builtin_amdgcn_s_setprio(0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (!grp) {
-        if (step + 2 < total) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-    }
-    if (!grp) {  // group 1's last M of this tile
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-    }
-    if (DBG & 8) {
+      f32x16_t acc[4][2];
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[i][j]));
-    } else {
-      if constexpr (DBG == 256) {  // 2-byte residual stream (GemmArgs::x16; launch_gemm256 only instantiates it for ACT_NONE, OUT_F32)
-        tile_epilogue_x16_asm<2>(g, acc, smem + QS * QSTAGE + wave * 4096, m0, n0, grp, wn * 64, lane);
-      } else if constexpr (OUT_F32 && ACT == ACT_NONE) {
-        if (!(var & 8) && g.resid && g.out_f32 && !g.out_act)
-          tile_epilogue_f32_asm<2, (DBG >> 6) & 3>(g, acc, smem + QS * QSTAGE + wave * 4096, m0, n0, grp, wn * 64, lane);
-        else
-          tile_epilogue<ACT, OUT_F32, HT, (DBG >> 4) & 3>(g, acc, smem + QS * QSTAGE + wave * 4096, m0, n0, grp, wn, lane);
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      if (GRP) {  // group 1 runs one phase behind: this barrier pairs with the one that ends group 0's L of the tile's first stage
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
+      auto kstep = [&](auto steady_c) __attribute__((always_inline)) {
+        constexpr bool STEADY = decltype(steady_c)::value;
+        // ------------------------------- L(step) -------------------------------
+        const unsigned char* sA = smem + (step & (QS - 1)) * QSTAGE;
+        const unsigned char* sB = sA + QA_BYTES;
+        if (!dma_late && (STEADY || step + AHEAD < total)) issue_next();
+        uint4 fa[2][4], fb[2][2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            if (DBG & 4) fb[ks][j] = make_uint4(lane, step, ks, j);
+            else fb[ks][j] = *(const uint4*)(sB + swzq(brow + 32 * j, 2 * ks + half));
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            if (DBG & 4) fa[ks][i] = make_uint4(lane, step, ks, i);
+            else fa[ks][i] = *(const uint4*)(sA + swzq(arow + 32 * i, 2 * ks + half));
+          }
+        }
+        if (dma_late && (STEADY || step + AHEAD < total)) issue_next();
+        if (GRP) {  // stage step+1 is published by the barrier below: this wave's pieces of it must have landed
+          if (STEADY || step + 3 < total) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+          else if (step + 2 < total) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // ------------------------------- M(step) -------------------------------
+        if (prio) __builtin_amdgcn_s_setprio(1);
+        if (DBG & 1) {
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {  // keep the fragments (and their LDS reads) alive without the matrix work
+#pragma unroll
+            for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(__builtin_bit_cast(u32x4_t, fb[ks][j])));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(__builtin_bit_cast(u32x4_t, fa[ks][i])));
+          }
+        } else {
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+              for (int j = 0; j < 2; ++j) acc[i][j] = Half<HT>::mfma(fb[ks][j], fa[ks][i], acc[i][j]);
+        }
+        if (prio) __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!GRP) {
+          if (STEADY || step + 2 < total) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      };
+      int kt = 0;
+      for (; kt < nk && step < steady_end; ++kt, ++step) kstep(std::true_type());
+      for (; kt < nk; ++kt, ++step) kstep(std::false_type());
+      if (!GRP) {  // group 1's last M of this tile
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
+      if (DBG & 8) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[i][j]));
       } else {
-        tile_epilogue<ACT, OUT_F32, HT, (DBG >> 4) & 3>(g, acc, smem + QS * QSTAGE + wave * 4096, m0, n0, grp, wn, lane);
+        if constexpr (DBG == 256) {  // 2-byte residual stream (GemmArgs::x16; launch_gemm256 only instantiates it for ACT_NONE, OUT_F32)
+          tile_epilogue_x16_asm<2>(g, acc, smem + QS * QSTAGE + wave * 4096, m0, n0, GRP, wn * 64, lane);
+        } else if constexpr (OUT_F32 && ACT == ACT_NONE) {
+          if (!(var & 8) && g.resid && g.out_f32 && !g.out_act)
+            tile_epilogue_f32_asm<2, (DBG >> 6) & 3>(g, acc, smem + QS * QSTAGE + wave * 4096, m0, n0, GRP, wn * 64, lane);
+          else
+            tile_epilogue<ACT, OUT_F32, HT, (DBG >> 4) & 3>(g, acc, smem + QS * QSTAGE + wave * 4096, m0, n0, GRP, wn, lane);
+        } else {
+          tile_epilogue<ACT, OUT_F32, HT, (DBG >> 4) & 3>(g, acc, smem + QS * QSTAGE + wave * 4096, m0, n0, GRP, wn, lane);
+        }
       }
     }
-  }
+  };
+  if (wave >> 2) run(std::integral_constant<int, 1>());
+  else run(std::integral_constant<int, 0>());
 }
 
 // ================================================================================================

@@ -301,8 +301,8 @@ def run_generation(order: str, img_name, model, clip, tokenizer, image_instance,
         # on the validated weights; every step measures that error on the candidates it re-encodes exactly
         g = runner.refine_guard(reset=True)
         if g["tripped"]:
-            # (x 1.5 inside czc_generate while its screening pass runs on fp16 rows: engine option refine_rows16)
-            trip = float(os.environ.get("CZC_REFINE_GUARD_X1E6", "200")) * 1e-6 * (1.0 if getattr(eng, "_resid16_off", False) else 1.5)
+            # (x 1.75 inside czc_generate while its screening pass runs on fp16 rows: engine option refine_rows16)
+            trip = float(os.environ.get("CZC_REFINE_GUARD_X1E6", "200")) * 1e-6 * (1.0 if getattr(eng, "_resid16_off", False) else 1.75)
             logger.info(f"screen-then-refine guard: |screening error - mean| reached {g['max_dev']:.2e} on {g['tripped']} "
                         f"image-steps (trip point {trip:.1e})" + ("; repeating the call on the all-split engine" if guard_mode == "rerun" else ""))
             if guard_mode == "rerun":

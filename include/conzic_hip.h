@@ -72,11 +72,11 @@ extern "C" {
 /*
  * BEGIN GENERATED measured
  * Measured on one MI355X, round 5 (generated by tools/refresh_docs.py from profiles/r05_*):
- *   fused score vs the reference, worst over the full-size goldens: CZC_PREC_BF16 1.79e-04, CZC_PREC_REFINE 6.03e-04,
+ *   fused score vs the reference, worst over the full-size goldens: CZC_PREC_BF16 2.46e-04, CZC_PREC_REFINE 6.03e-04,
  *   CZC_PREC_SPLIT 4.2e-06, CZC_PREC_F32 7.3e-06 (bar 1e-3);
  *   CZC_PREC_REFINE against CZC_PREC_SPLIT over 2560 more image-steps: worst 4.85e-04, 99.9th percentile 1.4e-04, winners identical
  *   2560 / 2560; guard sample maximum 1.54e-04 against 2.36e-04 over all candidates;
- *   BASELINE configs[2]: 80.3 captions/s (CZC_PREC_BF16), 65.2 (CZC_PREC_REFINE through czc_generate, 85 % of the image-steps gated).
+ *   BASELINE configs[2]: 79.4 captions/s (CZC_PREC_BF16), 70.2 (CZC_PREC_REFINE through czc_generate, 79 % of the image-steps gated).
  * END GENERATED measured
  */
 #define CZC_MAX_TOPK 1024
@@ -275,7 +275,8 @@ int czc_generate(czc_engine* e, int B, int T, int L, int seed_len, const int32_t
  *   "refine_gate_x1e6" (400): cosine-error bound delta of the margin gate of czc_generate (czc_refine_gate_stats), 0 = off
  *   "refine_rows16"   (1) CZC_PREC_REFINE inside czc_generate: the screening pass on the 2-byte residual stream with the folded
  *                         LayerNorms (the "resid16" + "fold_ln" tower form on fp16 operands); gate bound and guard trip point
- *                         are multiplied by "refine_rows16_x1000" / 1000 (1500) while it is on.  czc_step is not affected */
+ *                         are multiplied by "refine_rows16_x1000" / 1000 (1750) while it is on and the selection's mass threshold
+ *                         divided by it.  czc_step is not affected */
 int czc_set_option(czc_engine* e, const char* name, int value);
 
 /* ---- measurement ------------------------------------------------------------------------- */

@@ -388,7 +388,7 @@ def test_generate_free_running_full_size_refine(name):
 
 def test_margin_gate_skips_the_second_pass_without_changing_what_generate_returns():
     """czc_generate of the screen-then-refine engine returns ids of every step and the winner's cosine at the snapshot steps.
-    With the margin gate (default: delta = 4e-4, x 1.5 while the screening pass of czc_generate runs on fp16 rows: option
+    With the margin gate (default: delta = 4e-4, x 1.75 while the screening pass of czc_generate runs on fp16 rows: option
     refine_rows16, the default) an image-step whose screening winner survives every cosine-error assignment
     within delta does no second pass; `full_scale100` (the published logit scale): same ids and cosines as the reference AND as
     the ungated engine, most image-steps gated, far fewer candidates re-encoded; czc_step never gates."""

@@ -93,9 +93,10 @@ for gate in [int(v) for v in os.environ.get("GATES", "400,0").split(",")]:
     st = su.engine.stats()
     gd = su.engine.refine_guard(reset=True)
     same_img = (ids == ref_ids).all(axis=(0, 2))
+    ROWS16_FACTOR = next((int(kv.split("=")[1]) / 1000 for kv in os.environ.get("CZC_OPTS", "").split(",") if kv.startswith("refine_rows16_x1000=")), 1.75)
     rows16 = "refine_rows16=0" not in os.environ.get("CZC_OPTS", "")  # the engine default: screening pass of czc_generate on fp16 rows
     print(json.dumps(dict(mode="generate", gate_delta=gate * 1e-6, screening_rows="fp16" if rows16 else "fp32",
-                          gate_delta_effective=gate * 1e-6 * (1.5 if rows16 else 1.0), images=B, sweeps=GEN_SWEEPS, image_steps=B * len(gpos),
+                          gate_delta_effective=gate * 1e-6 * (ROWS16_FACTOR if rows16 else 1.0), images=B, sweeps=GEN_SWEEPS, image_steps=B * len(gpos),
                           images_with_identical_ids=int(same_img.sum()), ids_identical=bool((ids == ref_ids).all()),
                           max_abs_dcos_snapshots=float(np.abs(cos - ref_cos)[:, same_img].max()) if same_img.any() else None,
                           gated_frac=round(st["gated_image_steps"] / max(st["gate_image_steps"], 1), 4),
