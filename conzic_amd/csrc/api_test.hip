@@ -35,6 +35,7 @@ static const Hooks& HK() {
 #define launch_layernorm_x16 HK().layernorm_x16
 #define launch_ln_finalize HK().ln_finalize
 #define launch_fold_ln HK().fold_ln
+#define gemm_wreg_stats_in_kernel HK().wreg_stats_ok
 #define g_use_gemm256 (*HK().use_gemm256)
 #define g_use_skinny (*HK().use_skinny)
 #define g_use_splitk (*HK().use_splitk)
@@ -50,6 +51,7 @@ static const Hooks& HK() {
 #define g_use_mfma_attention (*HK().use_mfma_attention)
 #define g_use_attention_image (*HK().use_attention_image)
 #define g_wreg_resid_min_m (*HK().wreg_resid_min_m)
+#define g_wreg_stats_in_kernel (*HK().wreg_stats_in_kernel)
 #define TEST_ERR (HK().err_buf())
 
 static int g_bench_pad = 0;
@@ -185,12 +187,14 @@ int czc_test_ln_fold_gemm(int precision, int M, int N, const float* x, const flo
   float* dcs = (float*)pool.alloc((size_t)N * 4); T_PTR(dcs);
   float* dbf = (float*)pool.alloc((size_t)N * 4); T_PTR(dbf);
   void* dout = pool.alloc((size_t)M * N * 2); T_PTR(dout);
-  T_CHECK(launch_ln_finalize(dpart, M, 16, M, eps, dstat, nullptr));
+  const bool in_kernel = gemm_wreg_stats_in_kernel(M, N);  // small launches: the consumer sums the partials itself (option wreg_stats_in_kernel)
+  if (!in_kernel) T_CHECK(launch_ln_finalize(dpart, M, 16, M, eps, dstat, nullptr));
   T_CHECK(launch_fold_ln(dW, dg, dbt, db, N, K, dWf, dcs, dbf, nullptr));
   GemmArgs g;
   g.A = dx; g.lda = K; g.W = dWf; g.ldw = K; g.bias = dbf; g.resid = nullptr; g.ldr = 0; g.out_act = dout; g.out_f32 = nullptr; g.ldc = N;
   g.M = M; g.N = N; g.K = K; g.act = act;
   g.ln_stat = dstat;
+  if (in_kernel) { g.ln_part = dpart; g.ln_part_ld = M; g.ln_eps = eps; }
   T_CHECK(launch_gemm(precision, g, nullptr));
   T_HIP(hipDeviceSynchronize());
   if (rowsum_out) T_HIP(hipMemcpy(rowsum_out, dcs, (size_t)N * 4, hipMemcpyDeviceToHost));
@@ -338,6 +342,7 @@ int czc_test_set_option(const char* name, int value) {
   if (!strcmp(name, "mfma_attention")) { g_use_mfma_attention = value; return 0; }
   if (!strcmp(name, "attention_image")) { g_use_attention_image = value; return 0; }
   if (!strcmp(name, "wreg_resid_min_m")) { g_wreg_resid_min_m = value; return 0; }
+  if (!strcmp(name, "wreg_stats_in_kernel")) { g_wreg_stats_in_kernel = value; return 0; }
   snprintf(TEST_ERR, 512, "unknown option %s", name);
   return CZC_ERR_ARG;
 }

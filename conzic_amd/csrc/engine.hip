@@ -346,17 +346,22 @@ int clip_stack(czc_engine* e, int P, const char* gk, std::vector<LayerW>& L, flo
     E_CHECK(ensure(e, "cs_part", (size_t)(H / 32) * M * 8, (void**)&part));
     E_CHECK(ensure(e, "cs_stat", (size_t)M * 8 + 256, (void**)&stat));
   }
-  auto finalize = [&](int rows) -> int {  // stat <- (mean, rstd) of `rows` rows from part
+  // the statistics of `rows` rows for a folded consumer with N columns: stat <- (mean, rstd) from part -- unless the consumer is
+  // small enough to form them itself (gemm_wreg_stats_in_kernel: one or two images), which saves this launch
+  auto finalize = [&](int rows, int N) -> int {
+    if (gemm_wreg_stats_in_kernel(rows, N)) return 0;
     ProfScope ps(e, rk, 0);
     E_CHECK(launch_ln_finalize(part, M, H / 32, rows, eps, stat, e->st));
     return 0;
   };
+  // st_: the rows' statistics; nullptr = what finalize(rows, N) left (in `stat`, or still in `part` for the consumer to sum)
   auto folded_gemm = [&](const void* Ax, const void* Wf, const float* bf, const float* st_, void* out, int rows, int N,
                          int act) -> int {
     GemmArgs g;
     g.A = Ax; g.lda = H; g.W = Wf; g.ldw = H; g.bias = bf; g.resid = nullptr; g.ldr = 0; g.out_act = out; g.out_f32 = nullptr; g.ldc = N;
     g.M = rows; g.N = N; g.K = H; g.act = act;
-    g.ln_stat = st_;
+    g.ln_stat = st_ ? st_ : stat;
+    if (!st_ && gemm_wreg_stats_in_kernel(rows, N)) { g.ln_part = part; g.ln_part_ld = M; g.ln_eps = eps; }
     ProfScope ps(e, gk, 2.0 * rows * (double)N * H);
     E_CHECK(launch_gemm(P, g, e->st));
     return 0;
@@ -385,7 +390,7 @@ int clip_stack(czc_engine* e, int P, const char* gk, std::vector<LayerW>& L, flo
   for (size_t n = 0; n < L.size(); ++n) {
     LayerW& l = L[n];
     if (fold) {
-      E_CHECK(folded_gemm(x, l.qkv_wf, l.qkv_bf, n == 0 ? ln_stat0 : stat, qkv, M, 3 * H, ACT_NONE));
+      E_CHECK(folded_gemm(x, l.qkv_wf, l.qkv_bf, n == 0 ? ln_stat0 : nullptr, qkv, M, 3 * H, ACT_NONE));
     } else {
       if (!have_y) E_CHECK(ln(l.ln1_g, l.ln1_b, M, x, y));
       E_CHECK(gemm(e, P, gk, y, H, l.qkv_w, H, l.qkv_b, nullptr, 0, qkv, nullptr, 3 * H, M, 3 * H, H, ACT_NONE));
@@ -410,8 +415,8 @@ int clip_stack(czc_engine* e, int P, const char* gk, std::vector<LayerW>& L, flo
         else E_CHECK(launch_gather_rows_f32(x, pool_idx, n_pool, H, x_e, e->st)); }
       if (fold) {
         E_CHECK(gemm_x16(e, P, gk, ctx_e, H, l.o_w, l.o_b, x_e, n_pool, H, H, part, M));
-        E_CHECK(finalize(n_pool));
-        E_CHECK(folded_gemm(x_e, l.fc1_wf, l.fc1_bf, stat, h_e, n_pool, I, ACT_QUICK_GELU));
+        E_CHECK(finalize(n_pool, I));
+        E_CHECK(folded_gemm(x_e, l.fc1_wf, l.fc1_bf, nullptr, h_e, n_pool, I, ACT_QUICK_GELU));
       } else {
         if (r16) E_CHECK(gemm_x16(e, P, gk, ctx_e, H, l.o_w, l.o_b, x_e, n_pool, H, H));
         else E_CHECK(gemm(e, P, gk, ctx_e, H, l.o_w, H, l.o_b, x_e, H, nullptr, x_e, H, n_pool, H, H, ACT_NONE));
@@ -425,11 +430,11 @@ int clip_stack(czc_engine* e, int P, const char* gk, std::vector<LayerW>& L, flo
     }
     if (fold) {
       E_CHECK(gemm_x16(e, P, gk, ctx, H, l.o_w, l.o_b, x, M, H, H, part, M));
-      E_CHECK(finalize(M));
-      E_CHECK(folded_gemm(x, l.fc1_wf, l.fc1_bf, stat, hbuf, M, I, ACT_QUICK_GELU));
+      E_CHECK(finalize(M, I));
+      E_CHECK(folded_gemm(x, l.fc1_wf, l.fc1_bf, nullptr, hbuf, M, I, ACT_QUICK_GELU));
       const bool more = n + 1 < L.size();  // the last layer's rows only feed the final LayerNorm (on the pooled rows)
       E_CHECK(gemm_x16(e, P, gk, hbuf, I, l.fc2_w, l.fc2_b, x, M, H, I, more ? part : nullptr, M));
-      if (more) E_CHECK(finalize(M));
+      if (more) E_CHECK(finalize(M, 3 * H));
       continue;
     }
     if (rowln) E_CHECK(resid_ln_gemm(ctx, H, l.o_w, l.o_b, H, l.ln2_g, l.ln2_b));
@@ -1510,9 +1515,10 @@ const void* czc_internal_hooks(int abi) {
       []() -> char* { return czc::g_err; },
       &launch_gemm, &launch_gemm_rowln, &launch_layernorm, &launch_convert, &launch_act_to_f32, &launch_attention,
       &launch_softmax_mask_topk, &launch_bridge_precompute, &launch_bridge, &launch_l2_normalize, &launch_combine,
-      &launch_layernorm_x16, &launch_ln_finalize, &launch_fold_ln,
+      &launch_layernorm_x16, &launch_ln_finalize, &launch_fold_ln, &gemm_wreg_stats_in_kernel,
       &g_use_gemm256, &g_use_skinny, &g_use_splitk, &g_gemm_deep, &g_gemm_small_tiles, &g_use_wreg, &g_use_gemm256s, &g_w_dbg,
-      &g_ln_lean, &g_rowln_min_m, &g_wreg_min_m, &g_gemm256_min_m, &g_use_mfma_attention, &g_use_attention_image, &g_wreg_resid_min_m};
+      &g_ln_lean, &g_rowln_min_m, &g_wreg_min_m, &g_gemm256_min_m, &g_use_mfma_attention, &g_use_attention_image, &g_wreg_resid_min_m,
+      &g_wreg_stats_in_kernel};
   return abi == HOOKS_ABI ? &h : nullptr;
 }
 

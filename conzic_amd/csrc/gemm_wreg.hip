@@ -126,7 +126,31 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, 
   unsigned char* patch = smem + WR_D * WR_STAGE + wave * WR_PATCH;
   float* bias_s = (float*)(smem + WR_D * WR_STAGE + 8 * WR_PATCH + wave * WR_BIAS);
   if (lane < 32) bias_s[lane] = (g.bias && col0 + lane < g.N) ? g.bias[col0 + lane] : 0.f;
-  const unsigned char* stat_s = smem + WR_LDS;                                 // LNF: the work-group's (mean, rstd) pairs
+  unsigned char* stat_s = smem + WR_LDS;                                       // LNF: the work-group's (mean, rstd) pairs
+  // LNF, small launches (GemmArgs::ln_part; the launcher guarantees nb <= 8 = the area's 256 rows): the statistics of all of
+  // this work-group's rows up front, from the producer's partials -- ln_finalize_kernel's arithmetic to the letter (sums in
+  // block order, var = E[x^2] - mean^2 clamped), so the two routes give the same bits -- and no statistics request in the loop.
+  // Saves a 5 us launch in front of every folded GEMM where that is a third of the GEMM (one or two images).
+  const bool stats_here = LNF && g.ln_part != nullptr;
+  if constexpr (LNF) {
+    if (stats_here) {
+      const int rows = min(nb * WR_BLK, g.M - b0 * WR_BLK);
+      const float2* part = (const float2*)g.ln_part + (long)b0 * WR_BLK;
+      for (int r = threadIdx.x; r < rows; r += 512) {
+        float2 a = part[r];
+        for (int b = 1; b < WR_K / 32; ++b) {
+          const float2 p2 = part[b * g.ln_part_ld + r];
+          a.x = __fadd_rn(a.x, p2.x);
+          a.y = __fadd_rn(a.y, p2.y);
+        }
+        const float n = (float)WR_K;
+        const float mean = a.x / n;
+        const float var = fmaxf(__fsub_rn(a.y / n, __fmul_rn(mean, mean)), 0.f);
+        *(float2*)(stat_s + r * 8) = make_float2(mean, rsqrtf(var + g.ln_eps));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // published by the first block barrier
+    }
+  }
 
   // ---- DMA side: this wave lands rows wave*4 + ii (ii 0..3) of every block ----
   const unsigned lds0 = __builtin_amdgcn_readfirstlane(
@@ -155,7 +179,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, 
   const unsigned voffT = (unsigned)(lane * (T4 ? 16 : 4));
   auto stat_dma = [&](int j) {
     if (LNF_ABL & 1) return;
-    const bool mine = wave == 0 && (!T4 || (j & 3) == 0);
+    const bool mine = wave == 0 && (!T4 || (j & 3) == 0) && !stats_here;
     if (__builtin_expect(!mine, 1)) return;
     const long row0 = (long)(b0 + j) * WR_BLK;
     const unsigned long long pt = (unsigned long long)g.ln_stat + (unsigned long long)row0 * 8;
@@ -630,6 +654,26 @@ int g_use_wreg = 1;        // 0: every K = 512 layer goes to the tiled kernels (
 // last bits than the tiled kernels, so choosing by M would make an image's caption depend on its batch; measured at one
 // image (M ~ 1-3 k rows) it is also the faster kernel (4.21 vs 4.10 captions/s), at 8 images equal
 int g_wreg_min_m = 1;
+int g_wreg_stats_in_kernel = 1;
+
+// mirrors launch_gemm_wreg's split of the row blocks over the work-groups: at most WR_TS blocks (the statistics area) per work-group
+bool gemm_wreg_stats_in_kernel(int M, int N) {
+  if (!g_wreg_stats_in_kernel || M <= 0 || N <= 0) return false;
+  static int cu_of[64];  // per device, filled on first use (racing host threads write the same value)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  if (!cu_of[dev]) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+    cu_of[dev] = n;
+  }
+  const int n_cu = cu_of[dev] & ~7;
+  const int ncg = cdiv(N, 256), nblk = cdiv(M, WR_BLK);
+  int nsets = n_cu / ncg;
+  if (nsets < 1) return false;
+  if (nsets > nblk) nsets = nblk;
+  return cdiv(nblk, nsets) <= WR_TS;
+}
 
 bool gemm_wreg_eligible(const GemmArgs& g) {
   if (g.ln_stat && !g.bias) return false;
@@ -698,6 +742,10 @@ int launch_gemm_wreg(const GemmArgs& g, hipStream_t st) {
     return 1;
   }
   if (nsets > nblk) nsets = nblk;
+  if (g.ln_part && (!g.ln_stat || cdiv(nblk, nsets) > WR_TS)) {
+    snprintf(g_err, sizeof(g_err), "gemm_wreg: statistics in the kernel need at most %d row blocks per work-group (M=%d N=%d): gemm_wreg_stats_in_kernel()", WR_TS, g.M, g.N);
+    return 1;
+  }
   dim3 grid(n_cu), block(512);
 #define CZC_WR_GO(A_, H_) do { if (g.ln_stat) hipLaunchKernelGGL((gemm_wreg_kernel<A_, H_, true>), grid, block, WR_LDS_LNF, st, g, ncg, nsets, nblk); \
                                else hipLaunchKernelGGL((gemm_wreg_kernel<A_, H_>), grid, block, WR_LDS, st, g, ncg, nsets, nblk); } while (0)

@@ -32,6 +32,11 @@ struct GemmArgs {
   // weights with the gain folded in and their rows centred (rowops.hip fold_ln_kernel), bias = b + W.beta, ln_stat = float2
   // (mean, rstd) per row of A
   const float* ln_stat = nullptr;
+  // small launches: the statistics are formed inside the consumer from the producer's partials ([16][ln_part_ld] float2, what
+  // ln_finalize_kernel would read; same arithmetic, bit-identical) -- only where gemm_wreg_stats_in_kernel(M, N) says so;
+  // ln_stat must still be non-null (it selects the folded kernel) but is not read
+  const float* ln_part = nullptr;
+  long ln_part_ld = 0;
   // Full-row kernel (gemm_rowln, N = 512): out_f32 <- resid + A.W^T + bias and out_act <- LayerNorm(out_f32; ln_gamma,
   // ln_beta, ln_eps) from one launch.
   const float* ln_gamma = nullptr;
@@ -61,6 +66,8 @@ bool gemm_wreg_resid_eligible(const GemmArgs& g);
 int launch_gemm_wreg_resid(const GemmArgs& g, hipStream_t st);
 extern int g_use_wreg;
 extern int g_wreg_resid_min_m;
+extern int g_wreg_stats_in_kernel;  // 0: the folded consumer always takes its statistics from ln_finalize_kernel
+bool gemm_wreg_stats_in_kernel(int M, int N);  // a folded launch of this shape can form its rows' statistics itself (GemmArgs::ln_part)
 extern int g_wreg_min_m, g_gemm256_min_m;  // row-count thresholds of the two big-batch GEMM families
 
 // ---- imageproc.hip ------------------------------------------------------------------------
@@ -228,7 +235,7 @@ int launch_refine_finish(const int* own_off, const int* own_len, const int* coun
 // ---- czc_internal_hooks (include/conzic_hip.h): what libconzic_hip_test.so may reach inside this library -----------
 // The product library has hidden visibility; the hook library (api_test.hip) gets the launchers it wraps and the
 // process-wide kernel-family switches it flips through this table instead of through exported C++ symbols.
-constexpr int HOOKS_ABI = 0x0504;
+constexpr int HOOKS_ABI = 0x0505;
 struct Hooks {
   char* (*err_buf)();  // the calling host thread's g_err [512]
   decltype(&launch_gemm) gemm;
@@ -245,8 +252,9 @@ struct Hooks {
   decltype(&launch_layernorm_x16) layernorm_x16;
   decltype(&launch_ln_finalize) ln_finalize;
   decltype(&launch_fold_ln) fold_ln;
+  decltype(&gemm_wreg_stats_in_kernel) wreg_stats_ok;
   int *use_gemm256, *use_skinny, *use_splitk, *gemm_deep, *gemm_small_tiles, *use_wreg, *use_gemm256s, *w_dbg, *ln_lean,
-      *rowln_min_m, *wreg_min_m, *gemm256_min_m, *use_mfma_attention, *use_attention_image, *wreg_resid_min_m;
+      *rowln_min_m, *wreg_min_m, *gemm256_min_m, *use_mfma_attention, *use_attention_image, *wreg_resid_min_m, *wreg_stats_in_kernel;
 };
 
 }  // namespace czc

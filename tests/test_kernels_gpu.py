@@ -925,3 +925,11 @@ def test_layernorm_folded_into_the_weight_stationary_gemm(prec, M, N, act):
     tol = np.maximum(np.abs(ref), 1.0) * (2.0 ** -8 if prec == BF16 else 2.0 ** -10) + 6e-3
     bad = np.abs(out - ref) > tol
     assert not bad.any(), (int(bad.sum()), float(np.abs(out - ref).max()), np.argwhere(bad)[:4].tolist())
+    # small launches form the rows' statistics inside the GEMM (no ln_finalize launch): the same bits as the two-kernel route
+    lib = native.load_test()
+    try:
+        assert lib.czc_test_set_option(b"wreg_stats_in_kernel", 0) == 0
+        two = E.test_ln_fold_gemm(prec, x, W, gamma, beta, bias, part, 1e-5, act)
+    finally:
+        lib.czc_test_set_option(b"wreg_stats_in_kernel", 1)
+    np.testing.assert_array_equal(out, two)
