@@ -61,6 +61,29 @@ def physical_cores():
 CPU_BASELINE_THREADS = 16
 
 
+def box_calibration():
+    """How fast THIS box is, with nothing of this repo in it: a dense bf16 torch.matmul (hipBLASLt) of 8192^3, TFLOP/s.  The boxes of
+    the pool differ by several per cent on identical code (clocks under load, host); lines from different boxes compare through it."""
+    import torch
+    try:
+        a = torch.randn(8192, 8192, device="cuda", dtype=torch.bfloat16)
+        b = torch.randn(8192, 8192, device="cuda", dtype=torch.bfloat16)
+        for _ in range(3):
+            a @ b
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(20):
+            a @ b
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 20
+        return dict(what="torch.matmul bf16 8192 x 8192 x 8192 (vendor library), mean of 20 after 3", ms=round(ms, 4),
+                    tflops=round(2.0 * 8192 ** 3 / (ms * 1e-3) / 1e12, 1))
+    except Exception as exc:  # the measurement is a courtesy figure, never a reason to lose the line
+        return dict(what="torch.matmul bf16 8192^3", error=str(exc)[:200])
+
+
 def cpu_baseline(L, K, I=10, threads=None):
     """The oracle (CPU restatement of the reference, oracle/) timed on this host: B=1, config-1 shape, ONE FULL caption
     (image encode + I sweeps x L position-steps, nothing extrapolated).  Thread count: fixed at
@@ -647,6 +670,7 @@ def main():
         if split_res is not None:
             out["scale100_all_split"] = alt_block(split_res, native.PREC_SPLIT,
                                                   "the same with every tower on split-fp16 MFMA (the round-2 product mode)")
+        out["box_calibration"] = box_calibration()  # after the timed legs: it shares nothing with them
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(L, K, I, a.cpu_threads)
         else:

@@ -67,6 +67,7 @@ def facts():
         f["gated_frac"], f["re_encoded_frac"] = r100.get("gated_frac"), r100.get("re_encoded_frac")
         f["frac_scale100"] = (s100.get("roofline") or {}).get("frac")
         f["executed_tflop"] = drv.get("executed_tflop_per_caption")
+        f["calib"] = (drv.get("box_calibration") or {}).get("tflops")
     for tag, name in (("cfg1", "single image"), ("cfg3", "configs[3] shard"), ("cfg4", "configs[4] shard")):
         d = jload(f"{ROUND}_bench_{tag}.json")
         if d:
@@ -116,7 +117,7 @@ def block_status(f):
         "|---|---|",
         f"| `pytest -m gpu` on the MI355X (`profiles/{ROUND}_gpu_tests_summary.txt`) | {fmt(f.get('tests_passed'), 'd')} passed, {fmt(f.get('tests_skipped'), 'd')} skipped, {fmt(f.get('tests_failed'), 'd')} failed |",
         f"| fused score vs the reference, worst over the full-size goldens | bf16 engine {fmt(f.get('err_final_bf16'), '.2e')} (bar 1e-3), screen-then-refine {fmt(f.get('err_final_refine'), '.2e')}, split-fp16 {fmt(f.get('err_final_split'), '.1e')}, f32 {fmt(f.get('err_final_f32'), '.1e')} |",
-        f"| headline, BASELINE configs[2] (`profiles/{ROUND}_bench_driver_cmd.json` = the driver's `--gpus 1 --steps 20 --warmup 5`) | **{fmt(f.get('value'), '.1f')} captions/s** bf16 engine (HF-init logit scale), **{fmt(f.get('value_scale100'), '.1f')}** screen-then-refine (published checkpoints' logit scale); one stream {fmt(f.get('single_stream_value'), '.1f')} |",
+        f"| headline, BASELINE configs[2] (`profiles/{ROUND}_bench_driver_cmd.json` = the driver's `--gpus 1 --steps 20 --warmup 5`) | **{fmt(f.get('value'), '.1f')} captions/s** bf16 engine (HF-init logit scale), **{fmt(f.get('value_scale100'), '.1f')}** screen-then-refine (published checkpoints' logit scale); one stream {fmt(f.get('single_stream_value'), '.1f')}; this box ran the vendor library's dense bf16 8192^3 matmul at {fmt(f.get('calib'), '.0f')} TFLOP/s (`box_calibration`: the pool's boxes differ by several per cent on identical code, `profiles/r05_tower_ab.txt` holds the same-box A/Bs) |",
         f"| roofline of the CLIP-text GEMM family (dense bf16 peak 2.5 PFLOP/s) | {fmt(f.get('frac'), '.3f')} over the timed two-stream region, {fmt(f.get('frac_1s'), '.3f')} on one stream; `clip_text_mfma_util` (GEMM + attention FLOPs over all CLIP-text kernel time) {fmt(f.get('tower_util'), '.3f')} |",
         f"| screen-then-refine in `czc_generate` | {fmt(None if f.get('gated_frac') is None else 100 * f['gated_frac'], '.0f')} % of the image-steps pass the margin gate, {fmt(None if f.get('re_encoded_frac') is None else 100 * f['re_encoded_frac'], '.1f')} % of the candidates re-encoded; against the all-split engine: ids identical = {f.get('rv_gen_ids_identical', 'n/a')} over {fmt(f.get('rv_gen_steps'), 'd')} image-steps, `czc_step` worst fused-score difference {fmt(f.get('rv_max_dfinal'), '.2e')} over {fmt(f.get('rv_image_steps'), 'd')} image-steps |",
         f"| other BASELINE shapes (`profiles/{ROUND}_bench_cfg*.json`) | single image {fmt(f.get('cfg1'), '.2f')} captions/s; configs[3] shard (256 images, shuffle, L=15, K=512) {fmt(f.get('cfg3'), '.1f')}; configs[4] shard (64 images, sentiment, L=12): table mode {fmt(f.get('cfg4_table'), '.1f')}, exact host scorer {fmt(f.get('cfg4_exact'), '.1f')} ({fmt(f.get('cfg4_exact_workers'), 'd')} worker interpreters, stand-in tagger at {fmt(f.get('cfg4_exact_cost_us'), '.0f')} us per 12-word sentence) |",
