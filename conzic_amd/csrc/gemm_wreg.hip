@@ -49,7 +49,7 @@ constexpr int WR_D = 4;                        // ring depth
 constexpr int WR_PATCH = 2048;                 // per-wave epilogue patch (32 rows x 64 bytes)
 constexpr int WR_BIAS = 128;                   // per-wave bias slice (32 floats)
 constexpr int WR_LDS = WR_D * WR_STAGE + 8 * (WR_PATCH + WR_BIAS);
-constexpr int WR_TS = 8;                                         // LNF: depth of the shared ring of (mean, rstd) blocks
+constexpr int WR_TS = 8;                                         // LNF: row blocks of (mean, rstd) pairs the work-group's statistics area holds (2 x 4)
 constexpr int WR_LDS_LNF = WR_LDS + WR_TS * 256;                 // + the statistics area
 static_assert(WR_LDS_LNF <= 160 * 1024, "LDS budget");
 
@@ -59,15 +59,10 @@ __device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {
   return r;
 }
 
-template <int ACT>
-__device__ __forceinline__ float wr_act(float v) {
-  if (ACT == ACT_QUICK_GELU) return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930156f * v));
-  return v;
-}
-
-// The epilogue's VALU work is on the kernel's critical path (quick-GELU on 16 values per lane and block: 96 instructions, a
-// third of them quarter-rate, against 32 MFMAs), so it runs on pairs: v_pk_mul / v_pk_add / v_pk_fma_f32 take two fp32 values
-// per issue.  Same operations on the same values in the same order as wr_act: bit-identical results.
+// The epilogue's VALU work (quick-GELU on 16 values per lane and block: 96 instructions, a third of them quarter-rate,
+// against 32 MFMAs) runs on pairs: v_pk_mul / v_pk_add / v_pk_fma_f32 take two fp32 values per issue, 130 -> 103 VALU
+// instructions per block (measured neutral on the big launches -- profiles/r05_tower_ab.txt --, kept for the issue slots).  The same operations on the same values in the same order as the scalar form
+// v * rcp(1 + exp2(-2.4554669595930156 * v)) it replaced: bit-identical results.
 typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 template <int ACT>
 __device__ __forceinline__ f32x2_t wr_act2(f32x2_t v) {
