@@ -59,20 +59,13 @@ __device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {
   return r;
 }
 
-// The epilogue's VALU work (quick-GELU on 16 values per lane and block: 96 instructions, a third of them quarter-rate,
-// against 32 MFMAs) runs on pairs: v_pk_mul / v_pk_add / v_pk_fma_f32 take two fp32 values per issue, 130 -> 103 VALU
-// instructions per block (measured neutral on the big launches -- profiles/r05_tower_ab.txt --, kept for the issue slots).  The same operations on the same values in the same order as the scalar form
-// v * rcp(1 + exp2(-2.4554669595930156 * v)) it replaced: bit-identical results.
-typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+// Scalar fp32 on purpose.  The same epilogue on pairs (v_pk_mul / v_pk_add / v_pk_fma_f32: 130 -> 103 VALU instructions per
+// block) made the quick-GELU kernels ~10 % SLOWER inside the engine (fc1: 586 -> 646 us per launch, the activation-free q/k/v
+// launches unchanged: profiles/r05_tower_ab.txt) -- the packed fp32 forms do not slide under the MFMA stream the way the
+// scalar ones do.
 template <int ACT>
-__device__ __forceinline__ f32x2_t wr_act2(f32x2_t v) {
-  if (ACT == ACT_QUICK_GELU) {
-    const f32x2_t z = v * -2.4554669595930156f;
-    const f32x2_t e = {__builtin_amdgcn_exp2f(z.x), __builtin_amdgcn_exp2f(z.y)};
-    const f32x2_t d = e + 1.0f;
-    const f32x2_t r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
-    return v * r;
-  }
+__device__ __forceinline__ float wr_act(float v) {
+  if (ACT == ACT_QUICK_GELU) return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930156f * v));
   return v;
 }
 
@@ -263,22 +256,16 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(GemmArgs g, int ncg, 
   float ln_rstd = 0.f;  // LNF: rstd of this lane's row of the block whose epilogue is running
   auto epi_quad = [&](int qd, int js) {  // accP quad qd -> (LayerNorm correction,) bias, activation, 2-byte -> patch
     const float4 b4 = *(const float4*)(bias_s + 8 * qd + 4 * half);
-    const f32x2_t a01 = {accP[4 * qd], accP[4 * qd + 1]}, a23 = {accP[4 * qd + 2], accP[4 * qd + 3]};
-    const f32x2_t b01 = {b4.x, b4.y}, b23 = {b4.z, b4.w};
-    f32x2_t v01, v23;
+    float4 v;
     if constexpr (LNF && !(LNF_ABL & 2)) {
       if (qd == 0)  // read once per block: the area is refilled (statistics of a later group of blocks) in this same stream
         ln_rstd = *(const float*)(stat_s + (LNF_ABL & 8 ? (js & (WR_TS - 1)) * 256 : ((js >> 2) & 1) * 1024 + (js & 3) * 256) + l31 * 8 + 4);
-      const f32x2_t r2 = {ln_rstd, ln_rstd};
-      v01 = __builtin_elementwise_fma(a01, r2, b01);
-      v23 = __builtin_elementwise_fma(a23, r2, b23);
+      v = make_float4(__fmaf_rn(accP[4 * qd], ln_rstd, b4.x), __fmaf_rn(accP[4 * qd + 1], ln_rstd, b4.y),
+                      __fmaf_rn(accP[4 * qd + 2], ln_rstd, b4.z), __fmaf_rn(accP[4 * qd + 3], ln_rstd, b4.w));
     } else {
-      v01 = a01 + b01;
-      v23 = a23 + b23;
+      v = make_float4(accP[4 * qd] + b4.x, accP[4 * qd + 1] + b4.y, accP[4 * qd + 2] + b4.z, accP[4 * qd + 3] + b4.w);
     }
-    v01 = wr_act2<ACT>(v01);
-    v23 = wr_act2<ACT>(v23);
-    const float4 v = make_float4(v01.x, v01.y, v23.x, v23.y);
+    v.x = wr_act<ACT>(v.x); v.y = wr_act<ACT>(v.y); v.z = wr_act<ACT>(v.z); v.w = wr_act<ACT>(v.w);
     const int slot = (2 * qd + half) ^ ((l31 >> 1) & 7);
     *(uint2*)(patch + l31 * 64 + slot * 8) = make_uint2(Half<OT>::pack2(v.x, v.y), Half<OT>::pack2(v.z, v.w));
   };

@@ -2,6 +2,7 @@
 arms and compare medians).  usage: ab_gemm.py M N K act out_mode arm[,arm...] [rounds]; arm = use256[:w_dbg[:out_mode[:row_pad]]]
 (out_mode 4 = full-row kernel with the LayerNorm in its epilogue, 5 = the GEMM + LayerNorm pair it replaces)"""
 import ctypes as C
+import os
 import statistics
 import sys
 
@@ -17,13 +18,14 @@ def _arm(text):
 
 arms = [_arm(a) for a in sys.argv[6].split(',')]
 rounds = int(sys.argv[7]) if len(sys.argv) > 7 else 12
+ITERS = int(os.environ.get("AB_ITERS", "5"))  # launches per timing: 5 = a burst from a cool chip; hundreds = the sustained (power-limited) rate
 t = {a: [] for a in arms}
 for r in range(rounds):
     for a in (arms if r % 2 == 0 else arms[::-1]):
         ms = C.c_double()
         lib.czc_test_set_option(b'w_dbg', a[1])
         lib.czc_test_set_option(b'bench_pad', a[3])
-        native.check(lib.czc_bench_gemm(0, M, N, K, act, a[2], 5, a[0], C.byref(ms)), None, "bench")
+        native.check(lib.czc_bench_gemm(0, M, N, K, act, a[2], ITERS, a[0], C.byref(ms)), None, "bench")
         t[a].append(ms.value)
 for a in arms:
     med = statistics.median(t[a])

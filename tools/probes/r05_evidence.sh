@@ -1,7 +1,9 @@
 # Round-5 evidence (run on the GPU box from the repo root): the GPU test suite, the driver's bench command, the other BASELINE
 # shapes, the refine validation, rocprofv3 kernel stats of the bench in its modes, and the MFMA-op / HBM-traffic counters in
 # their own passes.  Summaries land in gpurun_out/r05e/ (the ones to keep are copied into profiles/ as r05_*).
-# usage: r05_evidence.sh [quick]   (quick: no test suite, no driver-length bench, no PMC passes)
+# usage: r05_evidence.sh [quick|kernels]   (quick: no test suite, no driver-length bench, no PMC passes; kernels: what a timing-only
+# kernel change moves -- test suite, driver bench, default / single-image bench, kernel stats, MFMA counters -- and not the other
+# BASELINE shapes, the refine validations or the HBM-traffic passes)
 set -x
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r05e
@@ -12,10 +14,12 @@ if [ "$1" != "quick" ]; then
 fi
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 python bench.py --config 1 --steps 3 --no-alt > $O/bench_cfg1.json 2> $O/bench_cfg1.err
+if [ "$1" != "kernels" ]; then
 python bench.py --config 3 --total-images 256 --steps 1 --warmup 1 --no-cpu-baseline > $O/bench_cfg3.json 2> $O/bench_cfg3.err
 python bench.py --config 4 --total-images 64 --control both --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_cfg4.json 2> $O/bench_cfg4.err
 python tools/refine_validate.py 128 10 12 2000 > $O/refine_validate_128x10.jsonl 2> $O/refine_validate.err
 if [ "$1" != "quick" ]; then GEN_SWEEPS=10 python tools/refine_validate.py 256 10 12 2000 > $O/refine_validate_256x10_fullcaptions.jsonl 2>> $O/refine_validate.err; fi
+fi
 export CZC_NORMAL_EXIT=1
 COMMON="--no-cpu-baseline --no-alt --no-invariance"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bf16_1s -o p -- python bench.py --streams 1 --steps 2 --warmup 1 $COMMON > $O/bf16_1s.log 2>&1
@@ -26,8 +30,10 @@ for d in bf16_1s bf16_2s refine_1s b1; do f=$(find $O/$d -name "*kernel_stats.cs
 if [ "$1" != "quick" ]; then
   rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_mfma -o p -- python bench.py --streams 1 --steps 1 --warmup 0 --no-profile $COMMON > $O/pmc_mfma.log 2>&1
   python tools/probes/pmc_mfma_summary.py $O/pmc_mfma > $O/pmc_mfma_summary.json 2> $O/pmc_mfma_summary.err
-  bash tools/probes/pmc_bench_traffic.sh > $O/pmc_traffic.log 2>&1
-  cp gpurun_out/pmc_traffic/summary.json $O/pmc_traffic_summary.json
+  if [ "$1" != "kernels" ]; then
+    bash tools/probes/pmc_bench_traffic.sh > $O/pmc_traffic.log 2>&1
+    cp gpurun_out/pmc_traffic/summary.json $O/pmc_traffic_summary.json
+  fi
 fi
 find $O gpurun_out/pmc_traffic -name "*kernel_trace.csv" -delete; find $O gpurun_out/pmc_traffic -name "*counter_collection.csv" -size +4M -delete
 find $O gpurun_out/pmc_traffic -name "*.db" -delete; find $O -name "*agent_info.csv" -delete
