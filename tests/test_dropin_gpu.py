@@ -287,17 +287,19 @@ def test_refine_guard_trip_repeats_the_call_on_the_split_engine(monkeypatch):
     assert warned[0] == plain[0]
 
 
-def test_fp16_residual_overflow_falls_back_to_fp32_rows(monkeypatch):
-    """The bf16 engine's text tower keeps its residual stream as fp16 rows.  A checkpoint whose rows leave the fp16 range (here:
-    token embeddings scaled by 2e6) produces non-finite cosines, which the engine reports (CZC_ERR_OVERFLOW) instead of hiding;
-    `runtime.run_generation` then switches that engine to fp32 rows (option resid16 = 0), repeats the call and says so."""
+@pytest.mark.parametrize("precision", ["bf16", "refine"])
+def test_fp16_residual_overflow_falls_back_to_fp32_rows(monkeypatch, precision):
+    """The bf16 engine's text tower -- and the screening pass of the screen-then-refine engine inside a whole generation call --
+    keep the residual stream as fp16 rows.  A checkpoint whose rows leave the fp16 range (here: token embeddings scaled by 2e6)
+    produces non-finite cosines, which the engine reports (CZC_ERR_OVERFLOW) instead of hiding; `runtime.run_generation` then
+    switches that engine to fp32 rows (option resid16 = 0 / refine_rows16 = 0), repeats the call and says so."""
     import utils
     from clip.clip import CLIP
     from conzic_amd import runtime
     from conzic_amd.models import SyntheticLM
     from conzic_amd.text import tokenizers_from_vocab
     from gen_utils import generate_caption
-    monkeypatch.setenv("CZC_PRECISION", "bf16")
+    monkeypatch.setenv("CZC_PRECISION", precision)
     sv = synth.make_vocab()
     bcfg, ccfg = synth.bert_base(), synth.clip_b32()
     bt, ct = tokenizers_from_vocab(sv)
