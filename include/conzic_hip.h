@@ -259,8 +259,9 @@ int czc_generate(czc_engine* e, int B, int T, int L, int seed_len, const int32_t
  *   "pack_branches"   (1) attention of the branch rows with G candidates packed per 32-query MFMA tile
  *   "pool_last_layer" (1) last CLIP-text layer: out-projection + MLP on the EOS rows only
  *   "fold_ln"         (1) with "resid16": the LayerNorms inside the CLIP-text stack folded into the q/k/v and fc1 GEMMs (they
- *                         multiply x itself on the fp16 MFMA and correct with the row's (mean, rstd), which come from partial sums
- *                         the producer GEMMs leave): no LayerNorm kernel and no normalised copy of the rows; 0 = LayerNorm kernels
+ *                         multiply x itself on the fp16 MFMA by weights whose rows carry the gain and are centred, and scale with
+ *                         the row's rstd, which comes from partial sums the producer GEMMs leave): no LayerNorm kernel and no
+ *                         normalised copy of the rows; 0 = LayerNorm kernels
  *   "fuse_ln"         (1) fp32-residual CLIP-text tower (fp16 / refine engines; bf16 with resid16 = 0) at >= 8192 packed rows: the out-projection runs as a full-row
  *                         kernel that also emits LN2 of its result (no LayerNorm pass for it); 2 = fc2 -> the next
  *                         layer's LN1 as well (measured slower), 0 = off
