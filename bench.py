@@ -44,6 +44,19 @@ def caption_flops(L, K, I, P=3):
     return tot + 8.7e9
 
 
+def metric_name(L, K, order, gamma=None, samples=1):
+    """BASELINE.json's metric, spelled with the shape this line was actually measured on (the default is its own
+    "captions/sec (L=10, K=200, seq order)"; --config 3 is L=15, K=512, shuffle order, 3 samples)."""
+    o = {"sequential": "seq", "shuffle": "shuffle"}.get(order, order)
+    extra = ("" if gamma is None else f", sentiment gamma={gamma:g}") + ("" if samples <= 1 else f", samples_num={samples}")
+    return f"captions/sec (L={L}, K={K}, {o} order{extra})"
+
+
+def per_caption(total, images, samples=1):
+    """A per-step total (FLOPs, ...) of one rank divided by the captions that step produced: images x samples_num."""
+    return total / (images * max(1, samples))
+
+
 def physical_cores():
     """Physical cores of this host (distinct (package, core) pairs of /proc/cpuinfo), or None."""
     try:
@@ -100,7 +113,8 @@ def cpu_baseline(L, K, I=10, threads=None):
     mask = torch.from_numpy(synth.make_token_mask(sv, regular_only=True))
     pix = synth.pixels_from_u8(synth.make_images_u8(1))
     ncpu, phys = os.cpu_count() or 8, physical_cores()
-    threads = int(threads) if threads else min(CPU_BASELINE_THREADS, phys or ncpu)
+    from conzic_amd.dist import local_world_size
+    threads = int(threads) if threads else max(1, min(CPU_BASELINE_THREADS, (phys or ncpu) // local_world_size()))
     torch.set_num_threads(threads)
     with torch.no_grad():
         # warm the thread pool and the allocator on one full-length step (untimed)
@@ -242,6 +256,8 @@ def main():
     if shared_gpu and os.environ.get("CZC_SHARE_GPU") != "1":
         sys.exit(f"bench.py: {world} ranks but {torch.cuda.device_count()} visible GPUs (one rank per GPU; --share-gpu is for tests)")
     local = local % torch.cuda.device_count()
+    # host resources per rank: CPU affinity = this rank's slice of its GPU's NUMA node, torch threads to match (no-op at one rank)
+    host_info = czd.pin_rank(int(os.environ.get("LOCAL_RANK", 0)), device_index=local)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     backend = os.environ.get("CZC_DIST_BACKEND", "nccl")  # "nccl" == RCCL on ROCm
@@ -302,10 +318,17 @@ def main():
         ccfg.logit_scale = logit_scale  # make_clip_weights writes it into the "logit_scale" tensor
         # frozen weights: generated on rank 0, broadcast once over RCCL (xGMI), consumed in place
         t0 = time.time()
+        broadcast_s = None
         if world > 1:
-            bw = czd.broadcast_state(synth.make_bert_weights(bcfg, 11) if rank == 0 else None, dev)
-            cw = czd.broadcast_state(synth.make_clip_weights(ccfg, 12) if rank == 0 else None, dev)
-            torch.cuda.synchronize()
+            bw_src = synth.make_bert_weights(bcfg, 11) if rank == 0 else None
+            cw_src = synth.make_clip_weights(ccfg, 12) if rank == 0 else None
+            barrier()
+            tb = time.perf_counter()
+            bw = czd.broadcast_state(bw_src, dev)
+            cw = czd.broadcast_state(cw_src, dev)
+            barrier()
+            broadcast_s = round(time.perf_counter() - tb, 4)   # both towers' buckets, rank 0's host arrays -> every GPU
+            del bw_src, cw_src
         else:
             bw, cw = synth.make_bert_weights(bcfg, 11), synth.make_clip_weights(ccfg, 12)
         su = harness.build_synthetic(False, prec_, logit_scale=logit_scale, regular_only=True, device=local, bert_w=bw,
@@ -342,10 +365,22 @@ def main():
 
         last = {}
 
+        per_step_scoring = []
+
         def step():
+            if scorer is not None:
+                # every step polishes the SAME resident images: a memo kept across steps would hand the timed steps the
+                # strings the warm-up (or the previous step) already scored.  A real run sees new images per batch, so each
+                # step starts cold; what remains is the reuse INSIDE one generate call (same candidates at a position whose
+                # context did not change between sweeps)
+                with scorer._lock:
+                    scorer.sent_memo.clear()
+                a0, s0 = scorer.asked, scorer.scored
             last["embeds"] = grp.encode_images(pixels)  # once per image and step; every sample re-uses the resident embeddings
             for sp, sn, se in sample_plans:
                 out_ = grp.generate(B, init, L, seed_len, K, sp, hp, n_mask=sn, snapshot_every=se)
+            if scorer is not None:
+                per_step_scoring.append((scorer.asked - a0, scorer.scored - s0))
             return out_
 
         for _ in range(warmup):
@@ -359,11 +394,15 @@ def main():
         events_in_region = profile and B >= 128
         grp.profile(2 if events_in_region else 0)
         barrier()
+        del per_step_scoring[:]
+        host_s0 = scorer.host_seconds if scorer is not None else 0.0
         t0 = time.perf_counter()
         for _ in range(steps):
             ids, cos = step()
         barrier()
         dt = time.perf_counter() - t0
+        timed_scoring = list(per_step_scoring)
+        host_s_timed = (scorer.host_seconds - host_s0) if scorer is not None else 0.0
         grp.profile(False)
         stats = grp.stats()
         prof_steps = steps
@@ -420,20 +459,26 @@ def main():
         # the captions of the last timed step over ALL ranks (image order = rank order = shard order), as a checksum: an N-rank
         # strong-scaling run must reproduce the 1-rank run's ids exactly (tests/test_dist_gpu.py)
         import zlib
+        tg = time.perf_counter()
         all_ids = czd.gather_along(ids, world, axis=1) if world > 1 else ids
+        gather_s = round(time.perf_counter() - tg, 4) if world > 1 else None
         ids_crc = zlib.crc32(np.ascontiguousarray(all_ids, dtype=np.int32).tobytes()) & 0xFFFFFFFF
         ctl = None
         if scorer is not None:
             ctl = dict(scorer="conzic_amd.control.HostScorer over tests/nltk_standin.py installed as nltk (a stand-in: nltk and its "
                               "corpora exist on neither box); context-dependent tagger, the reference's arithmetic",
                        cost_us_per_12_word_sentence=float(os.environ.get("CZC_STANDIN_COST_US", "0")),
-                       workers=scorer.workers, host_cpus=os.cpu_count(), callbacks=scorer.calls, sentences_asked=scorer.asked,
-                       sentences_scored=scorer.scored, memo_hit_frac=round(1.0 - scorer.scored / max(scorer.asked, 1), 4),
-                       host_seconds_in_scorer=round(scorer.host_seconds, 2),
+                       workers=scorer.workers, host_cpus=os.cpu_count(), callbacks=scorer.calls,
+                       timed_steps=[dict(sentences_asked=a_, sentences_scored=s_) for a_, s_ in timed_scoring],
+                       sentences_asked=sum(a_ for a_, _ in timed_scoring), sentences_scored=sum(s_ for _, s_ in timed_scoring),
+                       memo_hit_frac=round(1.0 - sum(s_ for _, s_ in timed_scoring) / max(sum(a_ for a_, _ in timed_scoring), 1), 4),
+                       memo="sentence memo EMPTIED at the start of every step (warm-up and timed): the hit fraction is reuse inside one "
+                            "generate call only, what a run over new images per batch sees",
+                       host_seconds_in_scorer=round(host_s_timed, 2),
                        note="the callback runs on the host while the same step's CLIP tower runs on the GPU (csrc/engine.hip "
-                            "control_score); host_seconds_in_scorer sums over the streams' threads and all steps incl. warm-up")
+                            "control_score); counts and host_seconds_in_scorer cover the TIMED steps only (summed over the streams' threads)")
             scorer.close()
-        res = dict(dt=dt, prof=prof, prof_timed=prof_timed, breakdown=breakdown, stats=stats, setup_s=t_setup, invariance=None, control=ctl,
+        res = dict(host=host_info, broadcast_s=broadcast_s, gather_s=gather_s, dt=dt, prof=prof, prof_timed=prof_timed, breakdown=breakdown, stats=stats, setup_s=t_setup, invariance=None, control=ctl,
                    streams=n_streams, single_ms=single_ms, per_rank=per_rank, steps=prof_steps, events_in_region=events_in_region, ids_crc=ids_crc,
                    n_ids=int(all_ids.shape[1]))
         if invariance and rank == 0 and B > 2:
@@ -590,7 +635,7 @@ def main():
         f_cap = caption_flops(L, K, I)
         bd = main_res["breakdown"]
         gemm_fl = sum(v["flops"] for k, v in bd.items() if k.startswith("gemm")) if bd else None
-        out = dict(metric="captions/sec (L=10, K=200, seq order)", value=round(value, 4), unit="captions/s",
+        out = dict(metric=metric_name(L, K, a.order, a.gamma, a.samples), value=round(value, 4), unit="captions/s",
                    n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(main_res["dt"] / a.steps * 1e3, 2),
                    higher_is_better=True, scaling="strong" if a.total_images is not None else "weak", vs_baseline=None,
                    dtype=DT[prec], data="synthetic",
@@ -609,10 +654,11 @@ def main():
                    ranks=dict(world_size=world, backend=("rccl (torch 'nccl')" if backend == "nccl" else backend) if world > 1 else None,
                               reported_by_backend=dist_world, devices_visible=torch.cuda.device_count(), shared_gpu=shared_gpu,
                               per_rank_images=[n for n, _ in main_res["per_rank"]],
-                              per_rank_captions_per_s=[round(n * a.steps / d, 3) for n, d in main_res["per_rank"]]),
+                              per_rank_captions_per_s=[round(n * max(1, a.samples) * a.steps / d, 3) for n, d in main_res["per_rank"]],
+                              host=main_res["host"], broadcast_s=main_res["broadcast_s"], gather_s=main_res["gather_s"]),
                    image_position_steps_per_s=round(value * L * I, 2),
                    algorithmic_tflop_per_caption=round(f_cap / 1e12, 3),
-                   executed_tflop_per_caption=None if not gemm_fl else round(gemm_fl / B / 1e12, 3),
+                   executed_tflop_per_caption=None if not gemm_fl else round(per_caption(gemm_fl, B, a.samples) / 1e12, 3),
                    roofline=roofline_of(main_res, prec),
                    kernel_ms_one_step={k: round(v["ms"], 1) for k, v in bd.items()},
                    kernel_ms_note="one extra untimed single-stream step with an event pair around every kernel class; the timed "

@@ -33,6 +33,7 @@ from typing import Callable, Optional, Sequence
 import numpy as np
 
 from . import sentiment, synth
+from .dist import local_world_size
 
 NLTK_HELP = ("the controllable path scores candidates with nltk (sentiments_classifer.py:1-3, POS_classifier.py:1-2): "
              "install nltk with the punkt / averaged_perceptron_tagger / wordnet / sentiwordnet data (app.py:280-283), "
@@ -68,13 +69,24 @@ def import_nltk():
     return nltk if ok else None
 
 
+def host_cpus() -> int:
+    """CPUs THIS process may run on (its affinity mask: conzic_amd.dist.pin_to_gpu_numa_node narrows it per rank)."""
+    try:
+        return len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        return os.cpu_count() or 1
+
+
 def default_workers(n_texts: int) -> int:
     """Interpreters a step's strings are spread over when CZC_CONTROL_WORKERS is unset: the reference's serial loop for a
-    demo.py-sized step, min(32, cores / 2) from 2048 strings per step on (run.py-sized batches: B * K = 10^4..10^5 sentences
-    through a Python tagger per step would leave the GPU waiting for the host)."""
+    demo.py-sized step; from 2048 strings per step on (run.py-sized batches: B * K = 10^4..10^5 sentences through a Python
+    tagger per step would leave the GPU waiting for the host) min(32, this rank's share of the host / 2) -- the share is the
+    smaller of the process's affinity mask and cores / ranks on the host, so that 8 ranks on a 128-core box spawn 8 x 8
+    interpreters, not 8 x 32."""
     if n_texts < 2048:
         return 0
-    return max(2, min(32, (os.cpu_count() or 2) // 2))
+    share = min(host_cpus(), max(1, (os.cpu_count() or 2) // local_world_size()))
+    return max(2, min(32, share // 2))
 
 
 def control_mode() -> str:
@@ -188,6 +200,7 @@ class HostScorer:
         self.memo = {}
         self.sent_memo = {}       # sentence string -> score
         self.calls = self.asked = self.scored = 0   # callbacks, sentences asked for, sentences actually scored
+        self.memo_evictions = 0   # times the sentence memo was emptied because it had reached SENT_MEMO_MAX
         self.host_seconds = 0.0   # wall time spent inside __call__ (decode + scoring), all calling threads
         self._pool = None
         # one scorer serves the parent engine AND its replicas (EngineGroup forwards set_control_callback), i.e. two host
@@ -217,18 +230,29 @@ class HostScorer:
     def score_texts(self, texts):
         """Scores of `texts`.  A sentence's score is a pure function of its string (tokenise -> tag -> look-ups), so a
         string already scored in an earlier step is not scored again: from the second sweep on most of a step's K candidate
-        sentences per image were candidates of that position before (same context wherever the caption did not change)."""
-        memo = self.sent_memo
-        todo = [t for t in dict.fromkeys(texts) if t not in memo]
+        sentences per image were candidates of that position before (same context wherever the caption did not change).
+
+        The result is built from a dict LOCAL to the call (memo hits captured up front + the freshly scored strings): a full
+        memo is emptied without touching what this call -- or a call running on the other stream's host thread -- returns.
+        The shared memo is only read and written under the lock; scoring itself (the slow part, pool.map) runs outside it."""
+        uniq = list(dict.fromkeys(texts))
+        with self._lock:
+            memo = self.sent_memo
+            got = {t: memo[t] for t in uniq if t in memo}
+        todo = [t for t in uniq if t not in got]
         if todo:
-            if len(memo) + len(todo) > self.SENT_MEMO_MAX:
-                memo.clear()
-            for t, v in zip(todo, self._score_new(todo)):
-                memo[t] = v
+            fresh = dict(zip(todo, self._score_new(todo)))
+            got.update(fresh)
+            with self._lock:
+                if len(self.sent_memo) + len(fresh) > self.SENT_MEMO_MAX:
+                    self.sent_memo.clear()          # (a batch larger than the cap simply is not remembered)
+                    self.memo_evictions += 1
+                if len(fresh) <= self.SENT_MEMO_MAX:
+                    self.sent_memo.update(fresh)
         with self._lock:
             self.scored += len(todo)
             self.asked += len(texts)
-        return [memo[t] for t in texts]
+        return [got[t] for t in texts]
 
     def _score_new(self, texts):
         pool = self._get_pool(len(texts))

@@ -14,6 +14,109 @@ def env_rank_world() -> Tuple[int, int, int]:
     return int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
 
 
+def local_world_size() -> int:
+    """Ranks sharing this host: LOCAL_WORLD_SIZE (torchrun exports it), else WORLD_SIZE, else 1."""
+    for k in ("LOCAL_WORLD_SIZE", "WORLD_SIZE"):
+        v = os.environ.get(k, "").strip()
+        if v.isdigit() and int(v) > 0:
+            return int(v)
+    return 1
+
+
+def _parse_cpulist(text: str) -> List[int]:
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11] (the format of /sys/devices/system/node/nodeN/cpulist)."""
+    out: List[int] = []
+    for part in text.strip().split(","):
+        part = part.strip()
+        if not part:
+            continue
+        if "-" in part:
+            a, b = part.split("-", 1)
+            out.extend(range(int(a), int(b) + 1))
+        else:
+            out.append(int(part))
+    return out
+
+
+def gpu_numa_node(device_index: int, sysfs: str = "/sys") -> Optional[int]:
+    """NUMA node of GPU `device_index` (HIP device order) from sysfs, or None where the kernel does not say.  The PCI
+    address comes from torch (`cuda.get_device_properties(i).pci_bus_id` etc.) when a GPU is visible; the node from
+    /sys/bus/pci/devices/<addr>/numa_node (what `rocm-smi --showtoponuma` prints)."""
+    addr = None
+    try:
+        import torch
+        if torch.cuda.is_available() and device_index < torch.cuda.device_count():
+            pr = torch.cuda.get_device_properties(device_index)
+            dom = getattr(pr, "pci_domain_id", 0)
+            addr = "%04x:%02x:%02x.0" % (dom, pr.pci_bus_id, pr.pci_device_id)
+    except Exception:  # noqa: BLE001 -- pinning is an optimisation, never a reason to fail a run
+        addr = None
+    if addr is None:
+        return None
+    try:
+        node = int(open(os.path.join(sysfs, "bus/pci/devices", addr, "numa_node")).read().strip())
+    except (OSError, ValueError):
+        return None
+    return node if node >= 0 else None
+
+
+def rank_cpu_share(local_rank: int, local_world: int, node: Optional[int] = None, sysfs: str = "/sys",
+                   allowed: Optional[List[int]] = None) -> List[int]:
+    """CPUs rank `local_rank` of `local_world` ranks on this host should run on.  With the NUMA node of its GPU known: the
+    CPUs of that node, cut into ceil(local_world / nodes) slices and indexed by local_rank modulo that count (GPUs are spread
+    evenly over the nodes on the 8-GPU boxes: 4 per socket).  Without NUMA information: slice local_rank of local_world equal
+    slices of the allowed CPUs.  Always at least one CPU; always a subset of `allowed` (the current affinity mask)."""
+    if allowed is None:
+        try:
+            allowed = sorted(os.sched_getaffinity(0))
+        except (AttributeError, OSError):
+            allowed = list(range(os.cpu_count() or 1))
+    cpus = allowed
+    slices, idx = max(1, local_world), local_rank % max(1, local_world)
+    if node is not None:
+        try:
+            on_node = set(_parse_cpulist(open(os.path.join(sysfs, "devices/system/node/node%d/cpulist" % node)).read()))
+            nodes = len([d for d in os.listdir(os.path.join(sysfs, "devices/system/node")) if d.startswith("node") and d[4:].isdigit()])
+            mine = [c for c in allowed if c in on_node]
+            if mine:
+                cpus = mine
+                per_node = max(1, -(-local_world // max(1, nodes)))   # ranks per node, rounded up
+                slices, idx = per_node, local_rank % per_node
+        except OSError:
+            pass
+    q, r = divmod(len(cpus), slices)
+    if q == 0:
+        return [cpus[idx % len(cpus)]]
+    lo = idx * q + min(idx, r)
+    return cpus[lo: lo + q + (1 if idx < r else 0)]
+
+
+def pin_rank(local_rank: int, device_index: Optional[int] = None, set_torch_threads: bool = True) -> Dict[str, object]:
+    """Per-rank host resources of a multi-GPU run (one process per GPU on ONE host): CPU affinity = this rank's share of
+    the CPUs of its GPU's NUMA node (`rank_cpu_share`), torch's intra-op threads = the size of that share.  A single-rank
+    run (local world 1) is left alone.  `CZC_PIN=0` disables it.  Returns what was done (bench.py prints it)."""
+    lw = local_world_size()
+    info: Dict[str, object] = dict(local_world=lw, pinned=False)
+    if lw <= 1 or os.environ.get("CZC_PIN", "1") == "0":
+        return info
+    node = gpu_numa_node(local_rank if device_index is None else device_index)
+    cpus = rank_cpu_share(local_rank, lw, node)
+    try:
+        os.sched_setaffinity(0, cpus)
+        info.update(pinned=True)
+    except (AttributeError, OSError):
+        pass
+    info.update(numa_node=node, cpus=len(cpus), first_cpu=cpus[0], last_cpu=cpus[-1])
+    if set_torch_threads:
+        try:
+            import torch
+            torch.set_num_threads(max(1, min(len(cpus), 16)))
+            info.update(torch_threads=torch.get_num_threads())
+        except Exception:  # noqa: BLE001
+            pass
+    return info
+
+
 def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
     """Block partition: rank r owns [r*n/world, (r+1)*n/world) (remainder spread over the first ranks)."""
     q, r = divmod(n_items, world)

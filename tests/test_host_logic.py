@@ -316,6 +316,34 @@ def test_bench_gpus_n_never_falls_back_to_fewer_gpus():
     assert r.returncode != 0 and "WORLD_SIZE=4 but --gpus 2" in r.stderr
 
 
+def test_bench_line_bookkeeping_follows_the_shape_it_ran():
+    """bench.py's `metric` names the L / K / order (/ gamma / samples_num) the line was measured on -- BASELINE.json's own
+    string only for configs[2] -- and per-caption figures divide by images x samples_num.  Every committed bench line of this
+    round executes at most the algorithmic FLOPs (prefix sharing and row pruning only REMOVE work)."""
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    base = json.load(open(os.path.join(root, "BASELINE.json")))["metric"]
+    assert base.startswith(bench.metric_name(10, 200, "sequential"))
+    presets = {n: dict(dict(L=10, topk=200, order="sequential", gamma=None, samples=1), **p) for n, p in bench.CONFIG_PRESETS.items()}
+    names = {n: bench.metric_name(p["L"], p["topk"], p["order"], p["gamma"], p["samples"]) for n, p in presets.items()}
+    assert names[1] == names[2] == "captions/sec (L=10, K=200, seq order)"
+    assert names[3] == "captions/sec (L=15, K=512, shuffle order, samples_num=3)"
+    assert names[4] == "captions/sec (L=12, K=200, seq order, sentiment gamma=5)"
+    assert bench.per_caption(12.0, 4, 3) == 1.0 and bench.per_caption(12.0, 4) == 3.0 and bench.per_caption(8.0, 4, 0) == 2.0
+    for n, p in presets.items():   # the work-skipping engine can only execute less than the reference's full towers
+        assert bench.caption_flops(p["L"], p["topk"], 10) > 0
+    lines = sorted(glob.glob(os.path.join(root, "profiles", "r06_bench_*.json")))
+    for path in lines:
+        j = json.load(open(path))
+        if not isinstance(j, dict) or j.get("executed_tflop_per_caption") is None:
+            continue
+        assert j["executed_tflop_per_caption"] <= j["algorithmic_tflop_per_caption"], path
+        c = j["config"]
+        assert j["metric"] == bench.metric_name(c["sentence_len"], c["candidate_k"], c["order"], c["gamma"], c["samples_num"]), path
+
+
 def test_image_cache_key_follows_the_pixels_not_only_the_object():
     """The drop-in CLIP caches the last batch's embeddings per image OBJECT (demo.py:83 polishes one image samples_num
     times); a caller that refills the same buffer in place must not get the old embeddings back."""
@@ -514,6 +542,68 @@ def test_host_control_scorer_worker_pool_gives_the_serial_scores():
                 pooled.close()
     finally:
         nltk_standin.uninstall()
+
+
+def test_host_control_scorer_survives_a_full_sentence_memo():
+    """The sentence memo of the exact-mode scorer is bounded (SENT_MEMO_MAX).  Reaching the bound empties it -- without
+    losing strings the running call still has to return (hits captured before the eviction), from either of the two host
+    threads that share one scorer (one per stream).  Scores stay those of an unbounded memo."""
+    import threading
+    from conzic_amd import control
+
+    class Fake(control.HostScorer):
+        def __init__(self, cap):
+            super().__init__(None, "sentiment", "positive", None)
+            self.SENT_MEMO_MAX = cap
+
+        def _score_new(self, texts):
+            return [float(len(t)) + sum(map(ord, t)) * 1e-3 for t in texts]
+
+    s = Fake(4)
+    assert s.score_texts(["a", "bb", "ccc"]) == Fake(1 << 20).score_texts(["a", "bb", "ccc"])
+    # 'a' is a memo hit, 'dddd' + 'e' overflow the 4-entry memo: the call used to raise KeyError('a')
+    got = s.score_texts(["a", "dddd", "e", "a"])
+    assert got == Fake(1 << 20).score_texts(["a", "dddd", "e", "a"])
+    assert s.memo_evictions == 1 and len(s.sent_memo) <= 4
+    big = [str(i) for i in range(64)]                # one call larger than the cap: scored, not remembered, no error
+    assert s.score_texts(big) == Fake(1 << 20).score_texts(big)
+    assert s.asked == 3 + 4 + 64 and s.scored == 3 + 2 + 64
+
+    # two threads on one scorer with a tiny cap: every call returns the unbounded-memo scores
+    s2, ref, errs = Fake(8), Fake(1 << 20), []
+
+    def run(seed):
+        rng = np.random.default_rng(seed)
+        try:
+            for _ in range(300):
+                texts = ["w%d" % v for v in rng.integers(0, 40, size=12)]
+                if s2.score_texts(texts) != [float(len(t)) + sum(map(ord, t)) * 1e-3 for t in texts]:
+                    errs.append("mismatch")
+        except Exception as ex:  # noqa: BLE001
+            errs.append(repr(ex))
+    th = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs[:3]
+    assert s2.memo_evictions > 0
+    del ref
+
+
+def test_control_workers_divide_the_host_between_the_ranks(monkeypatch):
+    """CZC_CONTROL_WORKERS unset: a rank spawns min(32, its share of the host / 2) interpreters, the share being cores /
+    ranks on this host (LOCAL_WORLD_SIZE, else WORLD_SIZE) or the process's affinity mask, whichever is smaller."""
+    from conzic_amd import control
+    monkeypatch.setattr(control.os, "cpu_count", lambda: 128)
+    monkeypatch.setattr(control, "host_cpus", lambda: 128)
+    monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    assert control.default_workers(100) == 0 and control.default_workers(51200) == 32
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    assert control.default_workers(51200) == 8            # 8 ranks x 8 interpreters = 64 = cores / 2
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "2")           # two ranks on this host of an 8-rank job
+    assert control.default_workers(51200) == 32
+    monkeypatch.setattr(control, "host_cpus", lambda: 16)  # pinned to a 16-CPU NUMA node
+    assert control.default_workers(51200) == 8
 
 
 def test_headers_are_plain_c_and_match_the_ctypes_layout(tmp_path):
