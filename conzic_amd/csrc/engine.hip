@@ -636,7 +636,7 @@ int read_totals(czc_engine* e, int* M, int* max_len, int* max_branch, int* n_tru
   const czc_config& c = e->cfg;
   *M = e->h_totals[0]; *max_len = e->h_totals[3]; *max_branch = e->h_totals[4]; *n_trunk = e->h_totals[6];
   e->plan_pairs = (double)e->h_totals[7];
-  if (e->h_totals[8]) return fail(e, CZC_ERR_OVERFLOW, "non-finite CLIP cosine (fp16 operand overflow in a tower? use CZC_PREC_SPLIT)%s");
+  if (e->h_totals[8]) return fail(e, CZC_ERR_OVERFLOW, "non-finite CLIP cosine: an fp16 quantity overflowed in a tower (fp16 residual rows: set option resid16 = 0 on the bf16 engine, refine_rows16 = 0 on the refine engine; fp16 operands: use CZC_PREC_SPLIT)%s");
   if (e->h_totals[2]) return fail(e, CZC_ERR_OVERFLOW, "text bridge overflow (row text > CZC_BRIDGE_MAX_BYTES)%s");
   if (*max_len > c.clip_max_pos || *max_len > CZC_CLIP_MAX_LEN)
     return fail(e, CZC_ERR_ARG, "CLIP sequence longer than max_position_embeddings%s");
@@ -858,6 +858,23 @@ int copy_out(czc_engine* e, void* dst, const char* ws_name, size_t bytes) {
   return 0;
 }
 
+// Does any option setting of this engine run the text tower on fp16 rows with the LayerNorms folded into its GEMMs?  The folded
+// operands (44 MB for 12 layers) are built by czc_finalize_weights only then: the bf16 engine (resid16 >= 1, its default), the
+// refine engine whose czc_generate screens on fp16 rows (refine_rows16, default), a single-pass fp16 engine asked for resid16 = 2.
+bool wants_folded_ln(const czc_engine* e) {
+  if (!prec_is_half(e->pc) || e->cfg.clip_hidden != 512 || !e->fold_ln) return false;
+  if (e->pc == PREC_BF16) return e->resid16 >= 1;
+  return e->resid16 >= 2 || (e->refine && e->refine_rows16);
+}
+
+void free_layer_set(std::vector<LayerW>& L) {
+  for (auto& l : L) {
+    (void)hipFree(l.qkv_w); (void)hipFree(l.qkv_b); (void)hipFree(l.o_w); (void)hipFree(l.fc1_w); (void)hipFree(l.fc2_w);
+    (void)hipFree(l.qkv_wf); (void)hipFree(l.qkv_bf); (void)hipFree(l.fc1_wf); (void)hipFree(l.fc1_bf);
+  }
+  L.clear();
+}
+
 }  // namespace
 
 // =================================================================================================
@@ -923,13 +940,7 @@ int czc_destroy(czc_engine* e) {
   if (e->shares_weights) { e->w.clear(); e->bert.clear(); e->ctext.clear(); e->cvis.clear(); e->ctext_x.clear();
                            e->mlm_dense_w = e->decoder_w = e->tproj_w = e->vproj_w = e->patch_w = e->tproj_wx = nullptr; }
   for (auto& kv : e->w) if (kv.second.p) (void)hipFree(kv.second.p);
-  auto free_layers = [](std::vector<LayerW>& L) {
-    for (auto& l : L) {
-      (void)hipFree(l.qkv_w); (void)hipFree(l.qkv_b); (void)hipFree(l.o_w); (void)hipFree(l.fc1_w); (void)hipFree(l.fc2_w);
-      (void)hipFree(l.qkv_wf); (void)hipFree(l.qkv_bf); (void)hipFree(l.fc1_wf); (void)hipFree(l.fc1_bf);
-    }
-  };
-  free_layers(e->bert); free_layers(e->ctext); free_layers(e->cvis); free_layers(e->ctext_x);
+  free_layer_set(e->bert); free_layer_set(e->ctext); free_layer_set(e->cvis); free_layer_set(e->ctext_x);
   (void)hipFree(e->mlm_dense_w); (void)hipFree(e->decoder_w); (void)hipFree(e->tproj_w); (void)hipFree(e->vproj_w);
   (void)hipFree(e->patch_w); (void)hipFree(e->tproj_wx);
   for (auto& kv : e->ws) if (kv.second.p) (void)hipFree(kv.second.p);
@@ -997,9 +1008,14 @@ int czc_finalize_weights(czc_engine* e) {
   E_HIP(hipSetDevice(e->dev));
   const czc_config& c = e->cfg;
   const bool has_bert = c.bert_layers > 0 && c.bert_vocab > 0;
+  if (e->shares_weights) return fail(e, CZC_ERR_STATE, "czc_finalize_weights: a replica shares its parent's weights%s");
+  if (e->finalized) return CZC_OK;  // nothing loaded since the last call (czc_load_tensor clears the flag)
+  E_HIP(hipStreamSynchronize(e->st));
+  free_layer_set(e->bert); free_layer_set(e->ctext); free_layer_set(e->cvis); free_layer_set(e->ctext_x);
+  for (void** p : {&e->mlm_dense_w, &e->decoder_w, &e->tproj_w, &e->vproj_w, &e->patch_w, &e->tproj_wx}) { (void)hipFree(*p); *p = nullptr; }
   if (has_bert) E_CHECK(build_layers(e, e->bert, c.bert_layers, c.bert_hidden, c.bert_inter, true, "bert.encoder.layer.", e->pb));
   E_CHECK(build_layers(e, e->ctext, c.clip_layers, c.clip_hidden, c.clip_inter, false, "text_model.encoder.layers.", e->pc));
-  if (prec_is_half(e->pc) && c.clip_hidden == 512) {  // folded-LayerNorm operands of the text tower (used where resid16 + fold_ln apply)
+  if (wants_folded_ln(e)) {  // folded-LayerNorm operands of the text tower (used where resid16 + fold_ln apply)
     const int H = c.clip_hidden, I = c.clip_inter;
     for (int n = 0; n < c.clip_layers; ++n) {
       LayerW& l = e->ctext[n];
@@ -1009,6 +1025,8 @@ int czc_finalize_weights(czc_engine* e) {
       E_CHECK(need(e, p + ".self_attn.k_proj.weight", (size_t)H * H, &kw));
       E_CHECK(need(e, p + ".self_attn.v_proj.weight", (size_t)H * H, &vw));
       E_CHECK(need(e, p + ".mlp.fc1.weight", (size_t)I * H, &f1w));
+      // (each pointer lands in the LayerW the moment it exists: czc_destroy / the next czc_finalize_weights frees whatever an
+      // early return leaves behind)
       E_HIP(hipMalloc(&l.qkv_wf, (size_t)3 * H * H * 2));
       E_HIP(hipMalloc((void**)&l.qkv_bf, (size_t)3 * H * 4));
       E_HIP(hipMalloc(&l.fc1_wf, (size_t)I * H * 2));
@@ -1325,7 +1343,7 @@ int czc_step(czc_engine* e, int32_t* inp, int B, int T, int gen_idx, int n_mask,
   E_HIP(hipMemcpyAsync(inp, d_inp, (size_t)B * T * 4, hipMemcpyDefault, e->st));
   E_HIP(hipMemcpyAsync(e->h_totals + 9, e->ws["s_nonfinite"].p, 24, hipMemcpyDeviceToHost, e->st));
   E_HIP(hipStreamSynchronize(e->st));
-  if (e->h_totals[9]) return fail(e, CZC_ERR_OVERFLOW, "non-finite CLIP cosine (fp16 operand overflow in a tower? use CZC_PREC_SPLIT)%s");
+  if (e->h_totals[9]) return fail(e, CZC_ERR_OVERFLOW, "non-finite CLIP cosine: an fp16 quantity overflowed in a tower (fp16 residual rows: set option resid16 = 0 on the bf16 engine, refine_rows16 = 0 on the refine engine; fp16 operands: use CZC_PREC_SPLIT)%s");
   { float dev; memcpy(&dev, e->h_totals + 10, 4); e->guard_max_dev = fmaxf(e->guard_max_dev, dev); e->guard_trips += e->h_totals[11];
     e->stat_gated += e->h_totals[13]; e->stat_gate_images += e->h_totals[14]; }
   return CZC_OK;
@@ -1346,6 +1364,7 @@ int czc_generate(czc_engine* e, int B, int T, int L, int seed_len, const int32_t
   E_HIP(hipMemcpyAsync(d_row, init_ids_host, (size_t)T * 4, hipMemcpyHostToDevice, e->st));
   E_CHECK(launch_broadcast_rows_i32(d_row, T, B, d_inp, e->st));
   int snap = 0;
+  bool audited = false;
   for (int s = 0; s < n_steps; ++s) {
     const int pos = positions_host[s];
     if (pos < 0 || pos >= L) return fail(e, CZC_ERR_ARG, "generate: position out of range%s");
@@ -1354,10 +1373,15 @@ int czc_generate(czc_engine* e, int B, int T, int L, int seed_len, const int32_t
     // AUDIT steps -- the snapshot step of every fourth sweep, starting with the first -- take the full selection for every
     // image: there the guard (czc_refine_guard) measures the screening tower on all images although most other steps are
     // gated (a checkpoint the fp16 tower carries badly trips it in the first sweep).  At the other snapshot steps a gated
-    // image re-encodes its winner alone, for the cosine this call returns
-    const bool snap_step = (s + 1) % snapshot_every == 0 && out_cos != nullptr;
-    const bool audit = snap_step && (s / snapshot_every) % 4 == 0;
-    e->gate_now = e->refine && e->refine_gate_delta > 0.f && !audit;
+    // image re-encodes its winner alone, for the cosine this call returns.  The gate is the guard's dependant: with the guard
+    // switched off (refine_guard_x1e6 = 0) nothing polices the bound the gate rests on, so nothing is gated
+    const bool snap_idx = (s + 1) % snapshot_every == 0;
+    const bool snap_step = snap_idx && out_cos != nullptr;
+    // (whether or not the caller reads cosines: the guard must see the screening tower on every call -- and a call too short
+    // to reach a snapshot step is audited at its last step)
+    const bool audit = (snap_idx && (s / snapshot_every) % 4 == 0) || (s + 1 == n_steps && !audited);
+    audited = audited || audit;
+    e->gate_now = e->refine && e->refine_gate_delta > 0.f && e->refine_guard_dev > 0.f && !audit;
     e->gate_need_cos = snap_step;
     e->in_generate = true;
     E_CHECK(step_device(e, d_inp, B, T, seed_len + pos, nm, pos == L - 1 ? 1 : 0, top_k, hp));
@@ -1371,7 +1395,7 @@ int czc_generate(czc_engine* e, int B, int T, int L, int seed_len, const int32_t
   }
   E_HIP(hipMemcpyAsync(e->h_totals + 9, e->ws["s_nonfinite"].p, 24, hipMemcpyDeviceToHost, e->st));
   E_HIP(hipStreamSynchronize(e->st));
-  if (e->h_totals[9]) return fail(e, CZC_ERR_OVERFLOW, "non-finite CLIP cosine (fp16 operand overflow in a tower? use CZC_PREC_SPLIT)%s");
+  if (e->h_totals[9]) return fail(e, CZC_ERR_OVERFLOW, "non-finite CLIP cosine: an fp16 quantity overflowed in a tower (fp16 residual rows: set option resid16 = 0 on the bf16 engine, refine_rows16 = 0 on the refine engine; fp16 operands: use CZC_PREC_SPLIT)%s");
   { float dev; memcpy(&dev, e->h_totals + 10, 4); e->guard_max_dev = fmaxf(e->guard_max_dev, dev); e->guard_trips += e->h_totals[11];
     e->stat_gated += e->h_totals[13]; e->stat_gate_images += e->h_totals[14]; }
   return CZC_OK;
@@ -1391,15 +1415,40 @@ int czc_set_option(czc_engine* e, const char* name, int value) {
   if (!strcmp(name, "pack_branches")) { e->pack_branches = value ? 1 : 0; return CZC_OK; }
   if (!strcmp(name, "pool_last_layer")) { e->pool_last_layer = value ? 1 : 0; return CZC_OK; }
   if (!strcmp(name, "fuse_ln")) { e->fuse_ln = value; return CZC_OK; }  // 0 off, 1 out-proj -> LN2, 2 also fc2 -> next LN1
-  if (!strcmp(name, "resid16")) { e->resid16 = value < 0 ? 0 : value; return CZC_OK; }
-  if (!strcmp(name, "fold_ln")) { e->fold_ln = value ? 1 : 0; return CZC_OK; }
+  const auto fold_ready = [&]() -> int {  // an option that turns the folded form on after the weights were finalized without it
+    if (e->finalized && wants_folded_ln(e) && (e->ctext.empty() || !e->ctext[0].qkv_wf))
+      return fail(e, CZC_ERR_STATE, "option %s: this engine was finalized without the folded-LayerNorm operands (set it before czc_finalize_weights)", name);
+    return CZC_OK;
+  };
+  if (!strcmp(name, "resid16")) { const int old = e->resid16; e->resid16 = value < 0 ? 0 : value; const int rc = fold_ready(); if (rc) e->resid16 = old; return rc; }
+  if (!strcmp(name, "fold_ln")) { const int old = e->fold_ln; e->fold_ln = value ? 1 : 0; const int rc = fold_ready(); if (rc) e->fold_ln = old; return rc; }
   if (!strcmp(name, "refine_samples")) { e->refine_samples = value < 0 ? 0 : value; return CZC_OK; }
   if (!strcmp(name, "refine_theta_x1000")) { e->refine_theta_x = (float)value / 1000.f; return CZC_OK; }
   if (!strcmp(name, "refine_theta_gen_x1000")) { e->refine_theta_gen = (float)value / 1000.f; return CZC_OK; }
   if (!strcmp(name, "refine_guard_x1e6")) { e->refine_guard_dev = (float)value * 1e-6f; return CZC_OK; }
   if (!strcmp(name, "refine_gate_x1e6")) { e->refine_gate_delta = value < 0 ? 0.f : (float)value * 1e-6f; return CZC_OK; }
-  if (!strcmp(name, "refine_rows16")) { e->refine_rows16 = value ? 1 : 0; return CZC_OK; }
+  if (!strcmp(name, "refine_rows16")) { const int old = e->refine_rows16; e->refine_rows16 = value ? 1 : 0; const int rc = fold_ready(); if (rc) e->refine_rows16 = old; return rc; }
   if (!strcmp(name, "refine_rows16_x1000")) { e->refine_rows16_factor = value < 1000 ? 1.f : (float)value / 1000.f; return CZC_OK; }
+  return fail(e, CZC_ERR_ARG, "unknown option %s", name);
+}
+
+int czc_get_option(czc_engine* e, const char* name, int* value) {
+  if (!e || !name || !value) return CZC_ERR_ARG;
+  const bool r16 = e->refine && e->refine_rows16 && e->cfg.clip_hidden == 512;  // what czc_generate's screening pass runs on
+  const float f16x = r16 ? e->refine_rows16_factor : 1.f;
+  struct { const char* n; int v; } tab[] = {
+      {"share_prefix", e->share_prefix}, {"bert_prune", e->bert_prune}, {"pack_branches", e->pack_branches},
+      {"pool_last_layer", e->pool_last_layer}, {"fuse_ln", e->fuse_ln}, {"resid16", e->resid16}, {"fold_ln", e->fold_ln},
+      {"refine_samples", e->refine_samples}, {"refine_theta_x1000", (int)lrintf(e->refine_theta_x * 1000.f)},
+      {"refine_theta_gen_x1000", (int)lrintf(e->refine_theta_gen * 1000.f)},
+      {"refine_guard_x1e6", (int)lrintf(e->refine_guard_dev * 1e6f)}, {"refine_gate_x1e6", (int)lrintf(e->refine_gate_delta * 1e6f)},
+      {"refine_rows16", e->refine_rows16}, {"refine_rows16_x1000", (int)lrintf(e->refine_rows16_factor * 1000.f)},
+      // read-only, derived: the trip point / gate bound in force inside czc_generate (x refine_rows16_factor on fp16 rows)
+      {"refine_guard_generate_x1e6", (int)lrintf(e->refine_guard_dev * f16x * 1e6f)},
+      {"refine_gate_generate_x1e6", (int)lrintf(e->refine_gate_delta * f16x * 1e6f)},
+      {"has_folded_ln_weights", !e->ctext.empty() && e->ctext[0].qkv_wf ? 1 : 0},
+  };
+  for (auto& t : tab) if (!strcmp(name, t.n)) { *value = t.v; return CZC_OK; }
   return fail(e, CZC_ERR_ARG, "unknown option %s", name);
 }
 

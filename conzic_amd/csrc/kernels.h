@@ -232,7 +232,7 @@ int launch_refine_plan(const int* clip_len, const int* trunk_len, const int* lis
 int launch_refine_finish(const int* own_off, const int* own_len, const int* count, const int* count_off, const int* kr_dev, int B, int K,
                          int* pre_off, int* eos_idx, hipStream_t st);
 
-// ---- czc_internal_hooks (include/conzic_hip.h): what libconzic_hip_test.so may reach inside this library -----------
+// ---- czc_internal_hooks (declared below, private to the build): what libconzic_hip_test.so may reach inside this library -----------
 // The product library has hidden visibility; the hook library (api_test.hip) gets the launchers it wraps and the
 // process-wide kernel-family switches it flips through this table instead of through exported C++ symbols.
 constexpr int HOOKS_ABI = 0x0505;
@@ -258,3 +258,10 @@ struct Hooks {
 };
 
 }  // namespace czc
+
+// The one door through which libconzic_hip_test.so (include/conzic_hip_test.h: kernel-level parity hooks for tests/ and the GEMM
+// microbenchmark for tools/) reaches this library's kernel launchers and process-wide kernel-family switches.  NOT part of the
+// drop-in boundary and not in include/conzic_hip.h: the symbol is exported (the hook library links against it), its table layout
+// is private to the build.  Returns NULL when `abi` is not this build's tag.  Nothing on the product path calls it.
+extern "C" __attribute__((visibility("default"))) const void* czc_internal_hooks(int abi);
+

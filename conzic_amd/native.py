@@ -28,8 +28,15 @@ PREC_REFINE = 5
 CLIP_MAX_LEN = 77
 
 
+ERR_ARG, ERR_HIP, ERR_STATE, ERR_OVERFLOW = 1, 2, 3, 4   # include/conzic_hip.h CZC_ERR_*
+
+
 class NativeError(RuntimeError):
-    pass
+    """A non-zero status of the C ABI; `code` is that status (CZC_ERR_*), None where no call was made."""
+
+    def __init__(self, msg, code=None):
+        super().__init__(msg)
+        self.code = code
 
 
 class Config(C.Structure):
@@ -100,6 +107,7 @@ SIGNATURES = {
     "czc_step": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, C.POINTER(Hyper), C.POINTER(StepOut)]),
     "czc_generate": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _P, _P, _I, C.POINTER(Hyper), _P, _P]),
     "czc_set_option": (_I, [_P, C.c_char_p, _I]),
+    "czc_get_option": (_I, [_P, C.c_char_p, C.POINTER(_I)]),
     "czc_profile_enable": (_I, [_P, _I]),
     "czc_profile_reset": (_I, [_P]),
     "czc_profile_get": (_I, [_P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
@@ -110,9 +118,10 @@ SIGNATURES = {
     "czc_refine_stats": (_I, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "czc_refine_guard": (_I, [_P, _I, C.POINTER(C.c_float), C.POINTER(C.c_int64)]),
     "czc_refine_gate_stats": (_I, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
-    # not part of the boundary: the hook library's door into this one (nothing in conzic_amd/ calls it)
-    "czc_internal_hooks": (_P, [_I]),
 }
+# exported, but not part of the boundary and not in the public header: the hook library's door into this one (declared in
+# csrc/kernels.h; nothing in conzic_amd/ calls it)
+PRIVATE_SIGNATURES = {"czc_internal_hooks": (_P, [_I])}
 # every entry point include/conzic_hip_test.h declares (libconzic_hip_test.so)
 TEST_SIGNATURES = {
     "czc_test_gemm": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _I, _P]),
@@ -142,7 +151,7 @@ def load() -> C.CDLL:
         raise NativeError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(there is no CPU fallback)")
     lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
-    for name, (res, args) in SIGNATURES.items():
+    for name, (res, args) in list(SIGNATURES.items()) + list(PRIVATE_SIGNATURES.items()):
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
@@ -171,4 +180,4 @@ def check(rc: int, handle=None, what: str = ""):
     if rc != 0:
         lib = load()
         msg = lib.czc_last_error(handle)
-        raise NativeError(f"{what} failed (status {rc}): {msg.decode() if msg else '?'}")
+        raise NativeError(f"{what} failed (status {rc}): {msg.decode() if msg else '?'}", code=rc)

@@ -288,8 +288,9 @@ def run_generation(order: str, img_name, model, clip, tokenizer, image_instance,
         # residual stream as fp16 rows (|x| < 65504): a checkpoint whose rows leave that range shows up as a non-finite cosine
         # (CZC_ERR_OVERFLOW); its engine then goes back to fp32 rows for good
         opt = {native.PREC_BF16: "resid16", native.PREC_REFINE: "refine_rows16"}.get(eng.precision)
-        if "non-finite CLIP cosine" not in str(exc) or opt is None or getattr(eng, "_resid16_off", False):
-            raise
+        if getattr(exc, "code", None) != native.ERR_OVERFLOW or "non-finite" not in str(exc) or opt is None \
+                or getattr(eng, "_resid16_off", False):
+            raise   # (CZC_ERR_OVERFLOW also names the text bridge's scratch overflow: no other rows would help there)
         logger.info(f"the fp16 residual stream overflowed on this checkpoint; repeating the call with fp32 rows "
                     f"(engine option {opt} = 0, kept for this engine)")
         eng.set_option(opt, 0)
@@ -301,8 +302,7 @@ def run_generation(order: str, img_name, model, clip, tokenizer, image_instance,
         # on the validated weights; every step measures that error on the candidates it re-encodes exactly
         g = runner.refine_guard(reset=True)
         if g["tripped"]:
-            # (x 1.75 inside czc_generate while its screening pass runs on fp16 rows: engine option refine_rows16)
-            trip = float(os.environ.get("CZC_REFINE_GUARD_X1E6", "200")) * 1e-6 * (1.0 if getattr(eng, "_resid16_off", False) else 1.75)
+            trip = eng.get_option("refine_guard_generate_x1e6") * 1e-6   # the trip point the engine applied inside czc_generate
             logger.info(f"screen-then-refine guard: |screening error - mean| reached {g['max_dev']:.2e} on {g['tripped']} "
                         f"image-steps (trip point {trip:.1e})" + ("; repeating the call on the all-split engine" if guard_mode == "rerun" else ""))
             if guard_mode == "rerun":

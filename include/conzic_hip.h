@@ -38,7 +38,8 @@ extern "C" {
 #define CZC_ERR_ARG 1
 #define CZC_ERR_HIP 2
 #define CZC_ERR_STATE 3
-#define CZC_ERR_OVERFLOW 4 /* text bridge scratch overflow (row text > CZC_BRIDGE_MAX_BYTES) */
+#define CZC_ERR_OVERFLOW 4 /* text bridge scratch overflow (row text > CZC_BRIDGE_MAX_BYTES), or a non-finite CLIP cosine: an fp16
+                              quantity overflowed in a tower (options resid16 / refine_rows16 = 0 keep fp32 rows; CZC_PREC_SPLIT) */
 
 #define CZC_PREC_BF16 0 /* throughput mode: CLIP towers on bf16 MFMA operands (fp32 accumulate, residual, LN, */
                         /* softmax); the BERT tower runs on split-fp16 MFMA (hi+lo planes, 3 passes, ~22  */
@@ -279,6 +280,13 @@ int czc_generate(czc_engine* e, int B, int T, int L, int seed_len, const int32_t
  *                         are multiplied by "refine_rows16_x1000" / 1000 (1750) while it is on and the selection's mass threshold
  *                         divided by it.  czc_step is not affected */
 int czc_set_option(czc_engine* e, const char* name, int value);
+/* Reads an option back (same names and units as czc_set_option), plus three read-only derived values:
+ *   "refine_guard_generate_x1e6" / "refine_gate_generate_x1e6": the guard's trip point / the margin gate's bound in force inside
+ *       czc_generate (the base values x "refine_rows16_x1000" / 1000 while its screening pass runs on fp16 rows);
+ *   "has_folded_ln_weights": 1 when czc_finalize_weights built the folded-LayerNorm operands (it does where an option can use
+ *       them: bf16 engine with resid16 >= 1, refine engine with refine_rows16, fp16 engine with resid16 = 2; turning such an
+ *       option on afterwards returns CZC_ERR_STATE). */
+int czc_get_option(czc_engine* e, const char* name, int* value);
 
 /* ---- measurement ------------------------------------------------------------------------- */
 /* HIP-event timing of kernel classes on the engine's own stream (bench.py roofline leg).  on: 0 off, 1 an event pair
@@ -322,13 +330,6 @@ int czc_refine_guard(czc_engine* e, int reset, float* max_dev, int64_t* tripped)
  * czc_step never gates: all K scores are its output and all of them are refined.  *gated of *image_steps since
  * czc_profile_reset. */
 int czc_refine_gate_stats(czc_engine* e, int64_t* gated, int64_t* image_steps);
-
-/* ---- not part of the drop-in boundary ------------------------------------------------------ */
-/* The one door through which libconzic_hip_test.so (include/conzic_hip_test.h: kernel-level parity hooks for tests/ and
- * the GEMM microbenchmark for tools/) reaches this library's kernel launchers and its process-wide kernel-family
- * switches; everything else inside the library has hidden visibility.  Returns a table whose layout is private to the
- * build (csrc/kernels.h `czc::Hooks`), or NULL when `abi` is not that build's tag.  Nothing on the product path calls it. */
-const void* czc_internal_hooks(int abi);
 
 #if defined(__GNUC__)
 #pragma GCC visibility pop

@@ -210,8 +210,37 @@ def test_bench_config3_preset_with_samples_reproduces_the_one_rank_captions():
         assert d["scaling"] == "strong" and c["total_images"] == 64
     assert two["ranks"]["per_rank_images"] == [32, 32]
     assert two["captions_crc32"]["value"] == one["captions_crc32"]["value"] and one["captions_crc32"]["images"] == 64
-    # value counts every sample's captions: 64 images x 3 samples per step
+    # value counts every sample's captions: 64 images x 3 samples per step -- and so do the per-rank rates and the per-caption work
     assert abs(one["value"] - 64 * 3 / (one["ms_per_step"] * 1e-3)) / one["value"] < 1e-3
+    assert abs(one["value"] - one["ranks"]["per_rank_captions_per_s"][0]) / one["value"] < 1e-3
+    assert abs(two["value"] - sum(two["ranks"]["per_rank_captions_per_s"])) / two["value"] < 0.25
+    assert one["metric"] == "captions/sec (L=15, K=512, shuffle order, samples_num=3)"
+
+
+def test_bench_eight_ranks_on_a_shared_gpu_reproduce_the_one_rank_captions():
+    """The rank count of the 8-GPU node, on this one-GPU box under the explicit test flag: `bench.py --gpus 8 --share-gpu
+    --total-images 16` starts eight ranks (gloo rendezvous), every rank receives the weights through the start-up broadcast,
+    polishes its two images, the gather restores image order: n_gpus 8, eight ranks reported by the backend, the 1-rank run's
+    captions (crc32), and the line carries what the first real SCALE run needs to explain itself (broadcast_s, gather_s, the
+    host share of each rank)."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE")}
+    common = ["--steps", "1", "--warmup", "0", "--iters", "1", "--no-cpu-baseline", "--no-invariance", "--no-profile", "--no-alt"]
+
+    def run(extra):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra + common,
+                           capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    one = run(["--gpus", "1", "--images", "16"])
+    eight = run(["--gpus", "8", "--share-gpu", "--total-images", "16"])
+    assert eight["n_gpus"] == 8 and eight["ranks"]["world_size"] == 8 and eight["ranks"]["reported_by_backend"] == 8
+    assert eight["ranks"]["per_rank_images"] == [2] * 8 and eight["scaling"] == "strong"
+    assert eight["captions_crc32"]["images"] == 16 and eight["captions_crc32"]["value"] == one["captions_crc32"]["value"]
+    assert eight["ranks"]["broadcast_s"] > 0 and eight["ranks"]["gather_s"] is not None
+    assert one["ranks"]["broadcast_s"] is None and one["ranks"]["gather_s"] is None
+    h = eight["ranks"]["host"]
+    assert h["local_world"] == 8 and (not h["pinned"] or h["cpus"] >= 1)
 
 
 def test_bench_gpus_2_without_the_flag_fails_on_one_gpu():

@@ -8,6 +8,7 @@ import pytest
 import torch
 
 from conzic_amd import engine as E
+import kernel_hooks as KH
 from conzic_amd import harness, native, synth
 from conzic_amd.bridge import tables_from_tokenizers
 from conzic_amd.text import tokenizers_from_vocab
@@ -41,7 +42,7 @@ def test_gemm_asymmetric(prec, M, N, K):
     A = rng.standard_normal((M, K)).astype(np.float32)
     W = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
     W[:, : K // 2] *= 3.0  # asymmetric along K too
-    C = E.test_gemm(prec, A, W)
+    C = KH.gemm(prec, A, W)
     if prec == BF16:
         ref = _bf16_round(A).astype(np.float64) @ _bf16_round(W).astype(np.float64).T
         tol = 2e-3 * np.sqrt(K / 64)
@@ -61,7 +62,7 @@ def test_gemm_epilogues(prec, act):
     W = (rng.standard_normal((N, K)) * 0.1).astype(np.float32)
     bias = rng.standard_normal(N).astype(np.float32)
     resid = rng.standard_normal((M, N)).astype(np.float32)
-    C = E.test_gemm(prec, A, W, bias=bias, resid=resid, act=act)
+    C = KH.gemm(prec, A, W, bias=bias, resid=resid, act=act)
     a, w = (A, W) if prec == F32 else (_bf16_round(A), _bf16_round(W))
     pre = (a.astype(np.float64) @ w.astype(np.float64).T + bias).astype(np.float32)
     ref = _act(pre, act) + resid
@@ -76,7 +77,7 @@ def test_layernorm(prec, H):
     g = (1 + 0.1 * rng.standard_normal(H)).astype(np.float32)
     b = (0.1 * rng.standard_normal(H)).astype(np.float32)
     for eps in (1e-5, 1e-12):
-        y = E.test_layernorm(prec, x, g, b, eps)
+        y = KH.layernorm(prec, x, g, b, eps)
         ref = torch.nn.functional.layer_norm(torch.from_numpy(x), (H,), torch.from_numpy(g), torch.from_numpy(b), eps).numpy()
         tol = 3e-6 * 10 if prec == F32 else 2e-2
         assert np.abs(y - ref).max() < tol
@@ -110,7 +111,7 @@ def test_attention_packed_sequences(prec, causal):
     qkv = rng.standard_normal((M, 3 * heads * 64)).astype(np.float32)
     if prec == BF16:
         qkv = _bf16_round(qkv)
-    out = E.test_attention(prec, qkv, lens, heads, causal, 0.125)
+    out = KH.attention(prec, qkv, lens, heads, causal, 0.125)
     ref = _attn_ref(qkv, lens, heads, causal, 0.125)
     assert np.abs(out - ref).max() < (2e-5 if prec == F32 else 1.5e-2)
 
@@ -120,7 +121,7 @@ def test_attention_other_head_counts(heads):
     rng = np.random.default_rng(4)
     lens = [17, 17, 50]
     qkv = rng.standard_normal((sum(lens), 3 * heads * 64)).astype(np.float32)
-    out = E.test_attention(F32, qkv, lens, heads, False, 0.125)
+    out = KH.attention(F32, qkv, lens, heads, False, 0.125)
     assert np.abs(out - _attn_ref(qkv, lens, heads, False, 0.125)).max() < 2e-5
 
 
@@ -132,7 +133,7 @@ def test_softmax_mask_topk(V, K):
     mask = (rng.random(V) > 0.1).astype(np.float32)
     dot_id = 17
     for dot_allowed in (False, True):
-        p, i, c = E.test_topk(logits, mask, K, 0.1, dot_id, dot_allowed)
+        p, i, c = KH.topk(logits, mask, K, 0.1, dot_id, dot_allowed)
         m = torch.from_numpy(mask.copy())
         m[dot_id] = 1.0 if dot_allowed else 0.0
         probs = torch.softmax(torch.from_numpy(logits) / 0.1, -1) * m
@@ -164,7 +165,7 @@ def test_topk_with_a_trained_models_logit_range(K):
         logits[b, hot[b]] = np.linspace(16.0, 5.6, 300).astype(np.float32) + rng.uniform(-0.01, 0.01, 300).astype(np.float32)
     mask = np.ones(V, np.float32)
     mask[:999] = 0.0
-    p, i, c = E.test_topk(logits, mask, K, 0.1, 1012, False)
+    p, i, c = KH.topk(logits, mask, K, 0.1, 1012, False)
     m = torch.from_numpy(mask.copy())
     m[1012] = 0.0
     probs = (torch.softmax(torch.from_numpy(logits) / 0.1, -1) * m).numpy()
@@ -194,7 +195,7 @@ def test_topk_ties_and_all_masked():
     logits[1, :] = np.linspace(0, 1, V)
     mask = np.zeros(V, np.float32)
     mask[[5, 33, 900]] = 1
-    p, i, c = E.test_topk(logits, mask, K, 1.0, 0, False)
+    p, i, c = KH.topk(logits, mask, K, 1.0, 0, False)
     assert i[0, :3].tolist() == [5, 900, 33]
     assert i[0, 3:].tolist() == [j for j in range(V) if j not in (5, 33, 900)][: K - 3]
     assert (p[0, 3:] == 0).all() and (c[0, 3:] == 0).all()
@@ -214,7 +215,7 @@ def test_device_bridge_matches_hf_golden(label):
     n = 0
     for T, items in by_len.items():
         rows = np.array([it[0] for it in items], np.int32)
-        ids, ln = E.test_bridge(t, rows)
+        ids, ln = KH.bridge(t, rows)
         for r, (_, c) in enumerate(items):
             assert ln[r] == len(c)
             assert ids[r, : ln[r]].tolist() == c
@@ -231,7 +232,7 @@ def test_device_bridge_overflow_fails_loudly():
     rows = np.full((1, 64), longest, np.int32)
     if 64 * (len(sv.bert_tokens[longest].encode()) + 1) > 512:
         with pytest.raises(native.NativeError, match="overflow"):
-            E.test_bridge(t, rows)
+            KH.bridge(t, rows)
 
 
 @pytest.mark.parametrize("senti", [False, True])
@@ -245,7 +246,7 @@ def test_fused_score_combine(senti):
     reps = rng.integers(0, 3, (B, K)).astype(np.float32)
     for ls in (2.6592, 4.6052):
         hp = E.Engine.hyper(0.02, 2.0, 0.1, gamma=5.0 if senti else None)
-        cs, cr, fs, best = E.test_combine(tf, ie, ls, probs, hp, sraw if senti else None, reps if senti else None)
+        cs, cr, fs, best = KH.combine(tf, ie, ls, probs, hp, sraw if senti else None, reps if senti else None)
         t = torch.from_numpy(tf).view(B, K, D)
         i = torch.from_numpy(ie)
         t = t / t.norm(dim=-1, keepdim=True)
@@ -268,7 +269,7 @@ def test_combine_first_argmax_on_ties():
     ie = np.ones((B, D), np.float32)
     probs = np.zeros((B, K), np.float32)
     hp = E.Engine.hyper(0.02, 2.0, 0.1)
-    _, _, fs, best = E.test_combine(tf, ie, 2.0, probs, hp)
+    _, _, fs, best = KH.combine(tf, ie, 2.0, probs, hp)
     assert best[0] == 0 and np.allclose(fs, fs[0, 0])
 
 
@@ -287,7 +288,7 @@ def test_gemm256_variants(variant, M, N, K, act, resid):
     R = rng.standard_normal((M, N)).astype(np.float32) if resid else None
     try:
         assert lib.czc_test_set_option(b"gemm256", variant) == 0
-        C = E.test_gemm(BF16, A, W, bias=bias, resid=R, act=act)
+        C = KH.gemm(BF16, A, W, bias=bias, resid=R, act=act)
     finally:
         lib.czc_test_set_option(b"gemm256", 1)
     pre = (_bf16_round(A).astype(np.float64) @ _bf16_round(W).astype(np.float64).T + bias).astype(np.float32)
@@ -314,7 +315,7 @@ def test_register_staged_four_wave_gemm_equals_the_ring_kernel_bitwise(M, N, K):
         assert lib.czc_test_set_option(b"gemm256_min_m", 1) == 0
         for v in (5, 9):
             assert lib.czc_test_set_option(b"gemm256", v) == 0
-            out[v] = E.test_gemm(BF16, A, W, bias=bias, resid=R)
+            out[v] = KH.gemm(BF16, A, W, bias=bias, resid=R)
     finally:
         lib.czc_test_set_option(b"gemm256", 1)
         lib.czc_test_set_option(b"gemm256_min_m", 8192)
@@ -338,9 +339,9 @@ def test_gemm_weight_stationary(M, N, act):
     bias = rng.standard_normal(N).astype(np.float32)
     try:
         assert lib.czc_test_set_option(b"wreg", 1) == 0
-        C = E.test_gemm(BF16, A, W, bias=bias, act=act, typed_out=True)
+        C = KH.gemm(BF16, A, W, bias=bias, act=act, typed_out=True)
         assert lib.czc_test_set_option(b"wreg", 0) == 0
-        C2 = E.test_gemm(BF16, A, W, bias=bias, act=act, typed_out=True)
+        C2 = KH.gemm(BF16, A, W, bias=bias, act=act, typed_out=True)
     finally:
         lib.czc_test_set_option(b"wreg", WREG_DEFAULT)
     pre = (_bf16_round(A).astype(np.float64) @ _bf16_round(W).astype(np.float64).T + bias).astype(np.float32)
@@ -360,7 +361,7 @@ def test_split_fp16_gemm_is_fp32_class(M, N, K, act):
     A = (rng.standard_normal((M, K)) * 2).astype(np.float32)
     W = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
     bias = rng.standard_normal(N).astype(np.float32)
-    C = E.test_gemm(F16X3, A, W, bias=bias, act=act)
+    C = KH.gemm(F16X3, A, W, bias=bias, act=act)
     ref = _act((A.astype(np.float64) @ W.astype(np.float64).T + bias).astype(np.float32), act)
     err = np.abs(C - ref).max()
     assert err < 1e-5 * np.sqrt(K / 64) * 4, err
@@ -378,14 +379,14 @@ def test_split_fp16_skinny_gemm(M, N, K, act, resid):
     W[:, : K // 2] *= 3.0
     bias = rng.standard_normal(N).astype(np.float32)
     R = rng.standard_normal((M, N)).astype(np.float32) if resid else None
-    C = E.test_gemm(F16X3, A, W, bias=bias, resid=R, act=act)
+    C = KH.gemm(F16X3, A, W, bias=bias, resid=R, act=act)
     ref = _act((A.astype(np.float64) @ W.astype(np.float64).T + bias).astype(np.float32), act) + (R if resid else 0)
     tol = 1e-5 * np.sqrt(K / 64) * 4
     assert np.abs(C - ref).max() < tol
     lib = native.load_test()
     try:
         assert lib.czc_test_set_option(b"skinny", 0) == 0
-        C2 = E.test_gemm(F16X3, A, W, bias=bias, resid=R, act=act)
+        C2 = KH.gemm(F16X3, A, W, bias=bias, resid=R, act=act)
     finally:
         lib.czc_test_set_option(b"skinny", 1)
     assert np.abs(C - C2).max() < tol
@@ -403,15 +404,15 @@ def test_split_fp16_gemm_split_k(M, N, K, resid):
     W = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
     bias = rng.standard_normal(N).astype(np.float32)
     R = rng.standard_normal((M, N)).astype(np.float32) if resid else None
-    C = E.test_gemm(F16X3, A, W, bias=bias, resid=R)
-    C_again = E.test_gemm(F16X3, A, W, bias=bias, resid=R)
+    C = KH.gemm(F16X3, A, W, bias=bias, resid=R)
+    C_again = KH.gemm(F16X3, A, W, bias=bias, resid=R)
     np.testing.assert_array_equal(C, C_again)
     ref = (A.astype(np.float64) @ W.astype(np.float64).T + bias).astype(np.float32) + (R if resid else 0)
     tol = 1e-5 * np.sqrt(K / 64) * 4
     assert np.abs(C - ref).max() < tol
     try:
         assert lib.czc_test_set_option(b"splitk", 0) == 0
-        C1 = E.test_gemm(F16X3, A, W, bias=bias, resid=R)
+        C1 = KH.gemm(F16X3, A, W, bias=bias, resid=R)
     finally:
         lib.czc_test_set_option(b"splitk", 1)
     assert np.abs(C - C1).max() < tol
@@ -422,12 +423,12 @@ def test_split_fp16_layernorm_and_attention():
     x = (rng.standard_normal((33, 768)) * 2).astype(np.float32)
     g = (1 + 0.1 * rng.standard_normal(768)).astype(np.float32)
     b = (0.1 * rng.standard_normal(768)).astype(np.float32)
-    y = E.test_layernorm(F16X3, x, g, b, 1e-12)
+    y = KH.layernorm(F16X3, x, g, b, 1e-12)
     ref = torch.nn.functional.layer_norm(torch.from_numpy(x), (768,), torch.from_numpy(g), torch.from_numpy(b), 1e-12).numpy()
     assert np.abs(y - ref).max() < 2e-5
     lens = [15, 17, 64]
     qkv = rng.standard_normal((sum(lens), 3 * 12 * 64)).astype(np.float32)
-    out = E.test_attention(F16X3, qkv, lens, 12, False, 0.125)
+    out = KH.attention(F16X3, qkv, lens, 12, False, 0.125)
     assert np.abs(out - _attn_ref(qkv, lens, 12, False, 0.125)).max() < 3e-5
 
 
@@ -447,7 +448,7 @@ def test_full_row_gemm_with_layernorm_epilogue(prec, M, K, mean_shift):
     resid = (rng.standard_normal((M, 512)) * 1.5 + mean_shift).astype(np.float32)
     gamma = (1.0 + 0.3 * rng.standard_normal(512)).astype(np.float32)
     beta = (0.2 * rng.standard_normal(512)).astype(np.float32)
-    x, y = E.test_gemm_rowln(prec, A, W, b, resid, gamma, beta, 1e-5)
+    x, y = KH.gemm_rowln(prec, A, W, b, resid, gamma, beta, 1e-5)
     dt = torch.bfloat16 if prec == 0 else torch.float16
     rd = lambda a: torch.from_numpy(a).to(dt).to(torch.float64).numpy()
     x_ref = resid.astype(np.float64) + rd(A) @ rd(W).T + b
@@ -459,7 +460,7 @@ def test_full_row_gemm_with_layernorm_epilogue(prec, M, K, mean_shift):
     err = np.abs(y - y_ref)
     assert (err <= ulp * np.abs(y_ref) + 2e-5 * (1.0 + abs(mean_shift))).all(), err.max()
     # and the stand-alone LayerNorm kernel on the same x gives the same rounded rows (a few last-place flips at most)
-    y_k = E.test_layernorm(prec, x, gamma, beta, 1e-5) if prec == 0 else None
+    y_k = KH.layernorm(prec, x, gamma, beta, 1e-5) if prec == 0 else None
     if y_k is not None:
         assert (y_k != y).mean() < 2e-3 and np.abs(y_k - y).max() <= 2 * ulp * np.abs(y_ref).max()
 
@@ -476,7 +477,7 @@ def test_split_fp16_gemm_256_tile_kernel(M, N, K, act, mode):
     W = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
     bias = rng.standard_normal(N).astype(np.float32)
     R = rng.standard_normal((M, N)).astype(np.float32) if mode == "resid" else None
-    C = E.test_gemm(F16X3, A, W, bias=bias, resid=R, act=act, typed_out=(mode == "typed"))
+    C = KH.gemm(F16X3, A, W, bias=bias, resid=R, act=act, typed_out=(mode == "typed"))
     ref = _act((A.astype(np.float64) @ W.astype(np.float64).T + bias).astype(np.float32), act) + (R if R is not None else 0)
     tol = 1e-5 * np.sqrt(K / 64) * 4 + (2e-6 * np.abs(ref).max() if mode == "typed" else 0)  # typed: hi+lo storage ~2^-22
     assert np.abs(C - ref).max() < tol, np.abs(C - ref).max()
@@ -484,7 +485,7 @@ def test_split_fp16_gemm_256_tile_kernel(M, N, K, act, mode):
     for variant in (0,):  # 0: the 128x128 kernel (default 1: the four-stage ring kernel)
         try:
             assert lib.czc_test_set_option(b"gemm256s", variant) == 0
-            C2 = E.test_gemm(F16X3, A, W, bias=bias, resid=R, act=act, typed_out=(mode == "typed"))
+            C2 = KH.gemm(F16X3, A, W, bias=bias, resid=R, act=act, typed_out=(mode == "typed"))
         finally:
             lib.czc_test_set_option(b"gemm256s", 1)
         assert np.abs(C - C2).max() < tol, variant
@@ -497,7 +498,7 @@ def test_split_fp16_store_has_one_value_behind_hi_and_lo():
     rng = np.random.default_rng(1)
     heads, lens = 12, [64]
     qkv = rng.standard_normal((64, 3 * heads * 64)).astype(np.float32)
-    out = E.test_attention(F16X3, qkv, lens, heads, False, 0.125)
+    out = KH.attention(F16X3, qkv, lens, heads, False, 0.125)
     assert np.abs(out - _attn_ref(qkv, lens, heads, False, 0.125)).max() < 5e-6
 
 
@@ -509,13 +510,13 @@ def test_split_fp16_mfma_attention(causal):
     for heads in (8, 12):
         lens = [15, 1, 7, 16, 20, 77, 50, 64, 65, 2, 33]
         qkv = rng.standard_normal((sum(lens), 3 * heads * 64)).astype(np.float32)
-        out = E.test_attention(F16X3, qkv, lens, heads, causal, 0.125)
+        out = KH.attention(F16X3, qkv, lens, heads, causal, 0.125)
         ref = _attn_ref(qkv, lens, heads, causal, 0.125)
         assert np.abs(out - ref).max() < 3e-5, np.abs(out - ref).max()
         lib = native.load_test()
         try:
             assert lib.czc_test_set_option(b"mfma_attention", 0) == 0
-            out2 = E.test_attention(F16X3, qkv, lens, heads, causal, 0.125)
+            out2 = KH.attention(F16X3, qkv, lens, heads, causal, 0.125)
         finally:
             lib.czc_test_set_option(b"mfma_attention", 1)
         assert np.abs(out - out2).max() < 3e-5
@@ -538,7 +539,7 @@ def test_fp16_gemm_kernel_families(M, N, K, act, mode):
     W = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
     bias = rng.standard_normal(N).astype(np.float32)
     R = rng.standard_normal((M, N)).astype(np.float32) if mode == "resid" else None
-    C = E.test_gemm(FP16, A, W, bias=bias, resid=R, act=act, typed_out=(mode == "typed"))
+    C = KH.gemm(FP16, A, W, bias=bias, resid=R, act=act, typed_out=(mode == "typed"))
     pre = (_f16_round(A).astype(np.float64) @ _f16_round(W).astype(np.float64).T + bias).astype(np.float32)
     ref = _act(pre, act) + (R if R is not None else 0)
     tol = 3e-4 * np.sqrt(K / 64) + (2 ** -10 * np.abs(ref).max() if mode == "typed" else 0)
@@ -551,7 +552,7 @@ def test_fp16_attention(causal):
     heads = 8
     lens = [15, 1, 7, 16, 20, 77, 50, 64, 65, 2]
     qkv = _f16_round(rng.standard_normal((sum(lens), 3 * heads * 64)).astype(np.float32))
-    out = E.test_attention(FP16, qkv, lens, heads, causal, 0.125)
+    out = KH.attention(FP16, qkv, lens, heads, causal, 0.125)
     assert np.abs(out - _attn_ref(qkv, lens, heads, causal, 0.125)).max() < 2e-3
 
 
@@ -576,13 +577,13 @@ def test_tiled_and_ring_gemms_agree_bitwise_on_fp32_residual_layers(prec, N, K):
     try:
         for variant in (0, 3, 5):
             assert lib.czc_test_set_option(b"gemm256", variant) == 0
-            outs.append(E.test_gemm(prec, A, W, bias=bias, resid=R))
+            outs.append(KH.gemm(prec, A, W, bias=bias, resid=R))
     finally:
         lib.czc_test_set_option(b"gemm256", 1)
     np.testing.assert_array_equal(outs[0], outs[1])
     np.testing.assert_array_equal(outs[0], outs[2])
     # and a row's result does not depend on how many rows ride with it
-    np.testing.assert_array_equal(E.test_gemm(prec, A[:100], W, bias=bias, resid=R[:100]), outs[0][:100])
+    np.testing.assert_array_equal(KH.gemm(prec, A[:100], W, bias=bias, resid=R[:100]), outs[0][:100])
 
 
 @pytest.mark.parametrize("prec", [0, 4])
@@ -598,16 +599,16 @@ def test_full_row_kernel_and_gemm_plus_layernorm_agree_bitwise(prec):
     resid = (rng.standard_normal((M, 512)) * 1.5 + 0.7).astype(np.float32)
     gamma = (1.0 + 0.3 * rng.standard_normal(512)).astype(np.float32)
     beta = (0.2 * rng.standard_normal(512)).astype(np.float32)
-    x, y = E.test_gemm_rowln(prec, A, W, b, resid, gamma, beta, 1e-5)
-    x2 = E.test_gemm(prec, A, W, bias=b, resid=resid)
+    x, y = KH.gemm_rowln(prec, A, W, b, resid, gamma, beta, 1e-5)
+    x2 = KH.gemm(prec, A, W, bias=b, resid=resid)
     np.testing.assert_array_equal(x, x2)
-    y2 = E.test_layernorm(prec, x2, gamma, beta, 1e-5)
+    y2 = KH.layernorm(prec, x2, gamma, beta, 1e-5)
     np.testing.assert_array_equal(y, y2)
     # the 30-VGPR LayerNorm kernel (ds_swizzle partners, default) against the ds_bpermute form: same tree, same bits
     lib = native.load_test()
     try:
         assert lib.czc_test_set_option(b"ln_lean", 0) == 0
-        np.testing.assert_array_equal(E.test_layernorm(prec, x2, gamma, beta, 1e-5), y2)
+        np.testing.assert_array_equal(KH.layernorm(prec, x2, gamma, beta, 1e-5), y2)
     finally:
         lib.czc_test_set_option(b"ln_lean", 1)
     # the asm-counted x phase of the epilogue (default) against the compiler-scheduled one it replaces, twice (a mis-counted
@@ -618,13 +619,13 @@ def test_full_row_kernel_and_gemm_plus_layernorm_agree_bitwise(prec):
         try:
             for dbg in (0, 8, 0):
                 assert lib.czc_test_set_option(b"w_dbg", dbg) == 0
-                outs.append(E.test_gemm_rowln(prec, A, W, bias, resid, gamma, beta, 1e-5))
+                outs.append(KH.gemm_rowln(prec, A, W, bias, resid, gamma, beta, 1e-5))
         finally:
             lib.czc_test_set_option(b"w_dbg", 0)
         for xo, yo in outs[1:]:
             np.testing.assert_array_equal(xo, outs[0][0])
             np.testing.assert_array_equal(yo, outs[0][1])
-    np.testing.assert_array_equal(outs[0][0], E.test_gemm(prec, A, W, resid=resid))
+    np.testing.assert_array_equal(outs[0][0], KH.gemm(prec, A, W, resid=resid))
 
 
 @pytest.mark.parametrize("act", [0, 1])
@@ -636,9 +637,9 @@ def test_weight_stationary_gemm_serves_every_row_count(act):
     A = rng.standard_normal((M, K)).astype(np.float32)
     W = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
     bias = rng.standard_normal(N).astype(np.float32)
-    C = E.test_gemm(BF16, A, W, bias=bias, act=act, typed_out=True)
+    C = KH.gemm(BF16, A, W, bias=bias, act=act, typed_out=True)
     for m in (1, 31, 100, 2047):
-        np.testing.assert_array_equal(E.test_gemm(BF16, A[:m], W, bias=bias, act=act, typed_out=True), C[:m])
+        np.testing.assert_array_equal(KH.gemm(BF16, A[:m], W, bias=bias, act=act, typed_out=True), C[:m])
 
 
 def test_kernel_families_agree_bitwise_on_random_shapes():
@@ -661,7 +662,7 @@ def test_kernel_families_agree_bitwise_on_random_shapes():
             ref = None
             for variant in (0, 3, 5, 5):
                 assert lib.czc_test_set_option(b"gemm256", variant) == 0
-                out = E.test_gemm(BF16, A, W, bias=bias, resid=R)
+                out = KH.gemm(BF16, A, W, bias=bias, resid=R)
                 if ref is None:
                     ref = out
                 else:
@@ -689,7 +690,7 @@ def test_tiled_gemm_prefetch_depth_does_not_change_results(prec):
             outs = []
             for deep in (0, 2):
                 assert lib.czc_test_set_option(b"gemm_deep", deep) == 0
-                outs.append(E.test_gemm(prec, A, W, bias=bias, resid=R))
+                outs.append(KH.gemm(prec, A, W, bias=bias, resid=R))
             np.testing.assert_array_equal(outs[0], outs[1], err_msg=f"M={M} N={N} K={K}")
     finally:
         lib.czc_test_set_option(b"gemm_deep", 1)
@@ -716,7 +717,7 @@ def test_tiled_gemm_small_tiles_do_not_change_results(prec):
             outs = []
             for small in (0, 1):
                 assert lib.czc_test_set_option(b"gemm_small_tiles", small) == 0
-                outs.append(E.test_gemm(prec, A, W, bias=bias, resid=R, act=act))
+                outs.append(KH.gemm(prec, A, W, bias=bias, resid=R, act=act))
             np.testing.assert_array_equal(outs[0], outs[1], err_msg=f"M={M} N={N} K={K}")
     finally:
         lib.czc_test_set_option(b"gemm_small_tiles", 4)
@@ -744,9 +745,9 @@ def test_bridge_token_table_equals_the_merge_loop(label):
     rows[100:200, 1:] = rng.integers(sv.regular_lo, sv.regular_hi, size=(100, 15))  # captions of whole words
     try:
         assert lib.czc_test_set_option(b"bridge_no_table", 1) == 0
-        ids0, ln0 = E.test_bridge(t, rows)
+        ids0, ln0 = KH.bridge(t, rows)
         assert lib.czc_test_set_option(b"bridge_no_table", 0) == 0
-        ids1, ln1 = E.test_bridge(t, rows)
+        ids1, ln1 = KH.bridge(t, rows)
     finally:
         lib.czc_test_set_option(b"bridge_no_table", 0)
     np.testing.assert_array_equal(ln0, ln1)
@@ -785,10 +786,10 @@ def test_residual_gemm_on_fp16_rows(prec, M, N, K):
     try:
         for min_m in (1, 6144):  # the weight-stationary residual kernel at every row count / from its product threshold on
             assert lib.czc_test_set_option(b"wreg_resid_min_m", min_m) == 0
-            out = E.test_gemm_x16(prec, A, W, bias, resid)
+            out = KH.gemm_x16(prec, A, W, bias, resid)
             bad = np.abs(out - ref) > tol
             assert not bad.any(), (min_m, int(bad.sum()), float(np.abs(out - ref).max()), np.argwhere(bad)[:4].tolist())
-            out2 = E.test_gemm_x16(prec, A, W, None, resid)  # no bias
+            out2 = KH.gemm_x16(prec, A, W, None, resid)  # no bias
             assert np.abs(out2 - _x16_ref(prec, A, W, None, resid)).max() < float(tol.max())
     finally:
         lib.czc_test_set_option(b"wreg_resid_min_m", 6144)
@@ -811,7 +812,7 @@ def test_residual_gemm_on_fp16_rows_gives_one_result_per_layer_shape(prec):
         for name, (mn, small, deep) in {"ring": (1, 4, 1), "tiled": (1 << 30, 0, 1), "tiled64": (1 << 30, 1 << 20, 2)}.items():
             assert lib.czc_test_set_option(b"gemm256_min_m", mn) == 0 and lib.czc_test_set_option(b"gemm_small_tiles", small) == 0
             assert lib.czc_test_set_option(b"gemm_deep", deep) == 0
-            outs[name] = E.test_gemm_x16(prec, A, W, bias, resid)
+            outs[name] = KH.gemm_x16(prec, A, W, bias, resid)
     finally:
         lib.czc_test_set_option(b"gemm256_min_m", 8192)
         lib.czc_test_set_option(b"gemm_small_tiles", 4)
@@ -827,7 +828,7 @@ def test_layernorm_of_fp16_rows(prec):
     x[5] *= 40.0   # a row with large entries
     g = (1 + 0.1 * rng.standard_normal(512)).astype(np.float32)
     b = (0.1 * rng.standard_normal(512)).astype(np.float32)
-    y = E.test_layernorm_x16(prec, x, g, b, 1e-5)
+    y = KH.layernorm_x16(prec, x, g, b, 1e-5)
     xr = torch.from_numpy(_f16_round(x)).double()
     ref = torch.nn.functional.layer_norm(xr, (512,), torch.from_numpy(g).double(), torch.from_numpy(b).double(), 1e-5).numpy()
     rnd = _bf16_round if prec == BF16 else _f16_round
@@ -852,7 +853,7 @@ def test_residual_gemm_leaves_layernorm_partials(M, K):
     W = (rng.standard_normal((512, K)) * 0.05).astype(np.float32)
     bias = rng.standard_normal(512).astype(np.float32)
     resid = (rng.standard_normal((M, 512)) * 2).astype(np.float32)
-    out, part = E.test_gemm_x16(BF16, A, W, bias, resid, want_part=True)
+    out, part = KH.gemm_x16(BF16, A, W, bias, resid, want_part=True)
     assert np.isfinite(part).all()
     ref = _part_ref(out)
     np.testing.assert_allclose(part[..., 0], ref[..., 0], rtol=0, atol=2e-4)
@@ -875,7 +876,7 @@ def test_layernorm_partials_do_not_depend_on_the_kernel():
         for name, (mn, small, deep) in {"ring": (1, 4, 1), "tiled": (1 << 30, 0, 1), "tiled64": (1 << 30, 1 << 20, 2)}.items():
             assert lib.czc_test_set_option(b"gemm256_min_m", mn) == 0 and lib.czc_test_set_option(b"gemm_small_tiles", small) == 0
             assert lib.czc_test_set_option(b"gemm_deep", deep) == 0
-            outs[name] = E.test_gemm_x16(BF16, A, W, bias, resid, want_part=True)
+            outs[name] = KH.gemm_x16(BF16, A, W, bias, resid, want_part=True)
         for name in ("tiled", "tiled64"):
             np.testing.assert_array_equal(outs["ring"][0], outs[name][0])
             np.testing.assert_array_equal(outs["ring"][1], outs[name][1])
@@ -887,7 +888,7 @@ def test_layernorm_partials_do_not_depend_on_the_kernel():
             pair = {}
             for name, min_m in (("wreg_resid", 1), ("tiled", 1 << 30)):
                 assert lib.czc_test_set_option(b"wreg_resid_min_m", min_m) == 0
-                pair[name] = E.test_gemm_x16(BF16, A, W, bias, resid, want_part=True)
+                pair[name] = KH.gemm_x16(BF16, A, W, bias, resid, want_part=True)
             np.testing.assert_array_equal(pair["wreg_resid"][0], pair["tiled"][0])
             np.testing.assert_array_equal(pair["wreg_resid"][1], pair["tiled"][1])
     finally:
@@ -913,7 +914,7 @@ def test_layernorm_folded_into_the_weight_stationary_gemm(prec, M, N, act):
     bias = rng.standard_normal(N).astype(np.float32)
     xr = _f16_round(x)
     part = _part_ref(xr).astype(np.float32)
-    out, rowsum = E.test_ln_fold_gemm(prec, x, W, gamma, beta, bias, part, 1e-5, act, want_rowsum=True)
+    out, rowsum = KH.ln_fold_gemm(prec, x, W, gamma, beta, bias, part, 1e-5, act, want_rowsum=True)
     # round-to-nearest alone leaves ~ sqrt(512) * 2^-12 * |w| ~ 1e-4 per row; the compensated rounding a few of the finest normal
     # fp16 steps (2^-24 = 6e-8): measured 2.4e-7 worst over these rows
     assert np.abs(rowsum).max() < 1e-6, float(np.abs(rowsum).max())
@@ -929,7 +930,7 @@ def test_layernorm_folded_into_the_weight_stationary_gemm(prec, M, N, act):
     lib = native.load_test()
     try:
         assert lib.czc_test_set_option(b"wreg_stats_in_kernel", 0) == 0
-        two = E.test_ln_fold_gemm(prec, x, W, gamma, beta, bias, part, 1e-5, act)
+        two = KH.ln_fold_gemm(prec, x, W, gamma, beta, bias, part, 1e-5, act)
     finally:
         lib.czc_test_set_option(b"wreg_stats_in_kernel", 1)
     np.testing.assert_array_equal(out, two)

@@ -438,6 +438,52 @@ def test_margin_gate_skips_the_second_pass_without_changing_what_generate_return
     assert st["gate_image_steps"] == 0 and st["refine_seqs"] >= 2 * meta["B"]
 
 
+def test_refine_guard_audits_every_generate_call_whether_or_not_cosines_are_read():
+    """The margin gate rests on a bound only the guard polices, and gated image-steps never feed the guard: the audit steps do.
+    They used to exist only where the caller asked for cosines (out_cos != NULL).  Now: the snapshot step of every fourth
+    sweep is an audit step whatever the caller reads, a call too short to reach one audits its last step, and with the guard
+    switched off nothing is gated.  The trip point the engine applies is readable (czc_get_option)."""
+    meta, arr = load_case("full_scale100")
+    su = setup_for(meta, REFINE)
+    eng = su.engine
+    eng.set_image_embeds(arr["image_embeds"])
+    hp = Engine.hyper(meta["alpha"], meta["beta"], meta["temperature"], meta["gamma"])
+    init = su.bert_tok.encode(meta["prompt"] + su.bert_tok.mask_token * meta["L"])
+    pos, nm, every = harness.order_positions(meta["order"], meta["L"], meta["I"], order_list=meta["order_list"])
+    B = meta["B"]
+    assert eng.get_option("refine_guard_x1e6") == 200 and eng.get_option("refine_rows16") == 1
+    assert eng.get_option("refine_guard_generate_x1e6") == 350 and eng.get_option("refine_gate_generate_x1e6") == 700
+    assert eng.get_option("has_folded_ln_weights") == 1
+    with pytest.raises(native.NativeError) as ei:
+        eng.get_option("no_such_option")
+    assert ei.value.code == native.ERR_ARG
+    # without cosines: same ids, the guard has measured something, the audit steps were not gated
+    eng.refine_guard(reset=True)
+    eng.profile_reset()
+    ids, cos = eng.generate(B, init, meta["L"], SEED_LEN, meta["K"], pos, hp, n_mask=nm, snapshot_every=every, want_cos=False)
+    assert cos is None
+    np.testing.assert_array_equal(ids, arr["snaps"])
+    g = eng.refine_guard(reset=True)
+    st = eng.stats()
+    audits = sum(1 for s_ in range(len(pos)) if (s_ + 1) % every == 0 and (s_ // every) % 4 == 0)
+    assert audits >= 1 and st["gate_image_steps"] == B * (len(pos) - audits)
+    assert 0.0 < g["max_dev"] < 3.5e-4 and g["tripped"] == 0
+    # a call shorter than one sweep (no snapshot step at all): its last step is the audit
+    short = pos[:3]
+    eng.profile_reset()
+    eng.generate(B, init, meta["L"], SEED_LEN, meta["K"], short, hp, n_mask=nm[:3], snapshot_every=every, want_cos=False)
+    g = eng.refine_guard(reset=True)
+    assert eng.stats()["gate_image_steps"] == B * 2 and g["max_dev"] > 0.0
+    # guard off -> gate off (nothing would police the bound)
+    try:
+        eng.set_option("refine_guard_x1e6", 0)
+        eng.profile_reset()
+        eng.generate(B, init, meta["L"], SEED_LEN, meta["K"], short, hp, n_mask=nm[:3], snapshot_every=every)
+        assert eng.stats()["gate_image_steps"] == 0
+    finally:
+        eng.set_option("refine_guard_x1e6", 200)
+
+
 def test_refine_engine_vs_split_engine_many_image_steps():
     """The goldens hold ~20 image-steps per case; this holds the screen-then-refine engine to the all-split-fp16 engine
     (pinned to the reference within 8e-6) on 32 images x 6 positions at the published logit scale: same candidate lists,

@@ -1,6 +1,7 @@
 import numpy as np, sys, torch
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
 from conzic_amd import engine as E, native
+import kernel_hooks as KH
 from test_kernels_gpu import _attn_ref
 lib = native.load_test()
 heads = 12
@@ -8,9 +9,9 @@ lens = [64]
 for seed in range(6):
     rng = np.random.default_rng(seed)
     qkv = rng.standard_normal((sum(lens), 3 * heads * 64)).astype(np.float32)
-    out = E.test_attention(3, qkv, lens, heads, False, 0.125)
+    out = KH.attention(3, qkv, lens, heads, False, 0.125)
     lib.czc_test_set_option(b"mfma_attention", 0)
-    out2 = E.test_attention(3, qkv, lens, heads, False, 0.125)
+    out2 = KH.attention(3, qkv, lens, heads, False, 0.125)
     lib.czc_test_set_option(b"mfma_attention", 1)
     ref = _attn_ref(qkv, lens, heads, False, 0.125)
     err = np.abs(out - ref)

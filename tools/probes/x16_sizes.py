@@ -4,6 +4,8 @@ import sys, os
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import kernel_hooks as KH
 import torch
 from conzic_amd import engine as E, native
 def bf(a): return torch.from_numpy(np.ascontiguousarray(a)).to(torch.bfloat16).to(torch.float32).numpy()
@@ -15,7 +17,7 @@ for K in (512, 2048):
     for M in [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "12856,25712,28672,40000,64280,102848").split(",")]:
         A = rng.standard_normal((M, K)).astype(np.float32)
         resid = (rng.standard_normal((M, 512)) * 2).astype(np.float32)
-        out = E.test_gemm_x16(native.PREC_BF16, A, W, bias, resid)
+        out = KH.gemm_x16(native.PREC_BF16, A, W, bias, resid)
         ref = bf(A).astype(np.float64) @ bf(W).astype(np.float64).T + bias + f16(resid)
         err = np.abs(out - ref)
         tol = np.maximum(np.abs(ref), 1.0) * 2.0 ** -10 + 2e-4 * np.sqrt(K / 64)
