@@ -413,6 +413,10 @@ CASES = dict(
     full_scale100=dict(tiny=False, B=2, L=10, K=200, I=1, order="sequential", image="synthetic", logit_scale=4.6052),
     # BASELINE configs[3] shape: shuffle order, L=15, K=512 (gen_utils.py:98-146)
     full_shuffle_k512=dict(tiny=False, B=2, L=15, K=512, I=1, order="shuffle", image="synthetic"),
+    # the two remaining visiting orders on full-size towers, one sweep: span (two positions per BERT forward, gen_utils.py:148-195)
+    # and random (positions from np.random, snapshots every max_len steps, gen_utils.py:197-242, :307-312)
+    full_span=dict(tiny=False, B=2, L=10, K=200, I=1, order="span", image="synthetic"),
+    full_random=dict(tiny=False, B=2, L=10, K=200, I=1, order="random", image="synthetic"),
     # BASELINE configs[4] shape: sentiment control, gamma=5, L=12, K=200 (control_gen_utils.py:30-80)
     full_senti=dict(tiny=False, B=2, L=12, K=200, I=1, order="sequential", image="synthetic", gamma=5.0, style="positive"),
     # POS control on full-size towers (control_gen_utils.py:136-195), the template demo.py:40-45 ships

@@ -110,7 +110,7 @@ def test_oracle_imageproc_matches_reference_processor(label, S):
 
 
 @pytest.mark.parametrize("name,step", [("full_scale100", 6), ("full_senti", 7), ("full_shuffle_k512", 3), ("full_pos", 5),
-                                       ("full_senti_ctx", 6), ("full_pos_ctx", 4)])
+                                       ("full_senti_ctx", 6), ("full_pos_ctx", 4), ("full_span", 4), ("full_random", 5)])
 def test_oracle_full_size_mid_trajectory_step(name, step):
     """The oracle on the full-size goldens added for the published logit scale (x100, clip/clip.py:95-98), the
     sentiment control path at configs[4] shape (gamma=5, L=12; control_gen_utils.py:53-63) and configs[3] shape
@@ -130,5 +130,8 @@ def test_oracle_full_size_mid_trajectory_step(name, step):
     np.testing.assert_allclose(r["clip_score"].numpy(), arr["clip_score"][step], atol=2e-6, rtol=2e-4)
     if "ctl_raw" in arr:
         np.testing.assert_allclose(r["senti_raw"].numpy(), arr["ctl_raw"][step], atol=1e-6, rtol=0)
-    if step + 1 < arr["inp_before"].shape[0]:
-        np.testing.assert_array_equal(r["inp_after"].numpy()[:, gen_idx], arr["inp_before"][step + 1][:, gen_idx])
+    nxt = step + 1
+    while nxt < len(meta["reuse"]) and meta["reuse"][nxt]:
+        nxt += 1   # the second position of a span re-uses the forward: its `inp_before` is the forward's input, not the state
+    if nxt < arr["inp_before"].shape[0]:
+        np.testing.assert_array_equal(r["inp_after"].numpy()[:, gen_idx], arr["inp_before"][nxt][:, gen_idx])

@@ -202,7 +202,8 @@ def teacher_forced(meta, arr, prec, n_steps=None):
 
 TINY = ["tiny_seq", "tiny_shuffle", "tiny_span", "tiny_random", "tiny_senti_seq", "tiny_senti_shuffle", "tiny_scale100",
         "tiny_pos_seq"]
-FULL = ["full_cfg1", "full_synth_b2", "full_regular", "full_scale100", "full_shuffle_k512", "full_senti", "full_pos"]
+FULL = ["full_cfg1", "full_synth_b2", "full_regular", "full_scale100", "full_shuffle_k512", "full_senti", "full_pos",
+        "full_span", "full_random"]
 
 
 @pytest.mark.parametrize("name", TINY)
@@ -217,7 +218,11 @@ def test_step_parity_tiny_bf16(name):
     meta, arr = load_case(name)
     assert bf16_in_budget(meta)
     soft, n = teacher_forced(meta, arr, BF16)
-    assert soft <= n  # near-tie winners may flip in bf16; hard asserts are inside check_step
+    # near-tie winners may flip in bf16 on the tiny towers (64-wide rows: cosines quantise coarsely; the bar there is 2.5e-2);
+    # the hard asserts are inside check_step.  A flip at more than half of the steps would mean the tolerance rule, not the
+    # arithmetic, is carrying the test (measured: see the [soft] lines of the GPU run)
+    print(f"[soft] {name} bf16: {soft}/{n} steps with a near-tie winner flip")
+    assert soft <= (n + 1) // 2
 
 
 @pytest.mark.parametrize("name", TINY)
@@ -368,7 +373,7 @@ def test_step_parity_tiny_refine(name):
     assert soft <= max(1, n // 10)
 
 
-@pytest.mark.parametrize("name", ["full_scale100", "full_senti", "full_pos"])
+@pytest.mark.parametrize("name", ["full_scale100", "full_senti", "full_pos", "full_span", "full_random"])
 def test_generate_free_running_full_size_refine(name):
     """czc_generate through the screen-then-refine engine reproduces the reference's trajectory id for id at the
     published-checkpoint logit scale (and with the sentiment / POS control scores fused in)."""
@@ -379,7 +384,8 @@ def test_generate_free_running_full_size_refine(name):
     hp = Engine.hyper(meta["alpha"], meta["beta"], meta["temperature"], meta["gamma"], meta["style"] == "negative",
                       control="pos" if meta.get("pos") else None)
     init = su.bert_tok.encode(meta["prompt"] + su.bert_tok.mask_token * meta["L"])
-    pos, nm, every = harness.order_positions(meta["order"], meta["L"], meta["I"], order_list=meta["order_list"])
+    pos, nm, every = harness.order_positions(meta["order"], meta["L"], meta["I"], order_list=meta["order_list"],
+                                             random_positions=meta["positions"] if meta["order"] == "random" else None)
     assert pos == meta["positions"]
     ids, cos = eng.generate(meta["B"], init, meta["L"], SEED_LEN, meta["K"], pos, hp, n_mask=nm, snapshot_every=every)
     np.testing.assert_array_equal(ids, arr["snaps"])
@@ -646,7 +652,8 @@ def test_refine_engine_encode_text_and_images_are_exact():
 def test_step_parity_tiny_fp16(name):
     meta, arr = load_case(name)
     soft, n = teacher_forced(meta, arr, FP16)
-    assert soft <= n
+    print(f"[soft] {name} fp16: {soft}/{n} steps with a near-tie winner flip")
+    assert soft <= max(1, n // 4)
 
 
 def test_precision_selected_from_logit_scale():
@@ -703,7 +710,7 @@ def test_generate_free_running_tiny_f32(name):
     assert texts == meta["texts"][:-1]
 
 
-@pytest.mark.parametrize("name", ["full_scale100", "full_senti", "full_shuffle_k512", "full_pos"])
+@pytest.mark.parametrize("name", ["full_scale100", "full_senti", "full_shuffle_k512", "full_pos", "full_span", "full_random"])
 def test_generate_free_running_full_size_split(name):
     """czc_generate on full-size towers in the split-fp16 precision reproduces the reference's trajectory
     id-for-id (published-checkpoint logit scale; sentiment control at configs[4] shape; K=512 shuffle at
@@ -715,7 +722,8 @@ def test_generate_free_running_full_size_split(name):
     hp = Engine.hyper(meta["alpha"], meta["beta"], meta["temperature"], meta["gamma"], meta["style"] == "negative",
                       control="pos" if meta.get("pos") else None)
     init = su.bert_tok.encode(meta["prompt"] + su.bert_tok.mask_token * meta["L"])
-    pos, nm, every = harness.order_positions(meta["order"], meta["L"], meta["I"], order_list=meta["order_list"])
+    pos, nm, every = harness.order_positions(meta["order"], meta["L"], meta["I"], order_list=meta["order_list"],
+                                             random_positions=meta["positions"] if meta["order"] == "random" else None)
     assert pos == meta["positions"]
     ids, cos = eng.generate(meta["B"], init, meta["L"], SEED_LEN, meta["K"], pos, hp, n_mask=nm, snapshot_every=every)
     np.testing.assert_array_equal(ids, arr["snaps"])
