@@ -664,6 +664,13 @@ def main():
                    kernel_ms_note="one extra untimed single-stream step with an event pair around every kernel class; the timed "
                                   "region only carries events around the roofline family",
                    clip_rows_per_step=st["clip_rows"] // max(1, a.steps), setup_s=round(main_res["setup_s"], 1),
+                   dedup=dict(option="dedup=1 (default)" if not any(kv.replace(" ", "") == "dedup=0" for kv in a.opt) else "dedup=0",
+                              candidate_seqs=st["clip_seqs"], deduplicated_seqs=st["dedup_seqs"],
+                              note="exact de-duplication of identical candidate sentences (czc_dedup_stats): on these random-init towers "
+                                   "softmax(logits / 0.1) is flat -- all K probabilities non-zero, no candidate masked to [PAD], no two "
+                                   "decode to the same string -- so nothing is removed and `value` is unaffected; with a trained MLM head "
+                                   "the zero-probability tail of the K candidates collapses to one caption "
+                                   "(tests/test_step_gpu.py::test_dedup_is_exact: 25 % of the candidates, 20 % of the rows)"),
                    single_stream=None if main_res["single_ms"] is None else dict(
                        ms_per_step=round(main_res["single_ms"], 2), value=round(B * max(1, a.samples) / main_res["single_ms"] * 1e3, 4),
                        note="the same step on ONE engine / ONE stream (rank 0's images), wall-clock around the pass "

@@ -183,13 +183,10 @@ class CLIP:
     # ---- clip/clip.py:86-98 ------------------------------------------------------------------
     def compute_image_text_similarity_via_embeddings(self, image_embeds, text_embeds):
         """-> (softmax over the text list of cos*exp(logit_scale), cos), both [batch, len(text_list)]"""
-        from conzic_amd.engine import Engine, test_combine
         ie = np.asarray(image_embeds, dtype=np.float32)
         te = np.asarray(text_embeds, dtype=np.float32).reshape(ie.shape[0], -1, ie.shape[1])
         B, K, D = te.shape
-        ls = float(np.asarray(self.clip_state_dict()["logit_scale"], dtype=np.float32))
-        cs, cr, _, _ = test_combine(te.reshape(B * K, D), ie, ls, np.zeros((B, K), np.float32),
-                                    Engine.hyper(0.0, 1.0, 1.0))
+        cs, cr = self._eng().similarity(ie, te.reshape(B * K, D), K)   # czc_similarity: the product library, not a test hook
         return _wrap(cs), _wrap(cr)
 
     def compute_image_text_similarity_via_raw_text(self, image_embeds, text_list):

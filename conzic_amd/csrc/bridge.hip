@@ -263,12 +263,23 @@ int launch_scan(const int* len, int n, int* off, int* totals, hipStream_t st) {
 // ---- shared-prefix plan ---------------------------------------------------------------------------
 // Causal attention + EOS pooling make every hidden state in front of the first differing CLIP token
 // identical across the K candidates of an image, so that prefix is encoded once.
+//
+// Exact de-duplication (rep != nullptr): candidates of one image whose CLIP id rows are identical -- every candidate the
+// token mask turned into [PAD] decodes to the SAME caption without the word (gen_utils.py:72-75; with a real stop-word
+// mask at tau = 0.1 that is most of the tail of the K candidates), and different word pieces can decode to the same string --
+// have identical hidden states in every row.  The first of them (lowest k) keeps its rows; the others get NO rows
+// (own_len = 0) and point their EOS index at the representative's EOS row (prefix_finish_kernel), so the pooled feature,
+// the cosine and everything behind it are the representative's, bit for bit what their own rows would have produced
+// (a row's arithmetic does not depend on its place in a launch: tests/test_step_gpu.py::test_dedup_is_exact).
+// Detection: 64-bit FNV-1a of (length, ids) per candidate in LDS, K^2 / 256 hash compares per thread, every hash match
+// confirmed id by id (no false merges).
 __global__ __launch_bounds__(256) void prefix_plan_kernel(const int* cids, const int* clen, int B, int K, int share,
                                                           int* own_len, int* pre_len, int* seg_src, int* seg_pos0,
-                                                          int* max_len_out, int* img_max) {
-  __shared__ int s_p, s_max, s_keys;
+                                                          int* max_len_out, int* img_max, int* rep, int* n_dup_out) {
+  __shared__ int s_p, s_max, s_keys, s_dup;
+  __shared__ unsigned long long s_hash[1024];  // K <= CZC_MAX_TOPK
   const int b = blockIdx.x, tid = threadIdx.x;
-  if (tid == 0) { s_p = 1 << 30; s_max = 0; s_keys = 0; }
+  if (tid == 0) { s_p = 1 << 30; s_max = 0; s_keys = 0; s_dup = 0; }
   __syncthreads();
   const int* r0 = cids + (long)b * K * BR_LEN;
   const int l0 = clen[b * K];
@@ -281,6 +292,11 @@ __global__ __launch_bounds__(256) void prefix_plan_kernel(const int* cids, const
     while (c < lim && rk[c] == r0[c]) ++c;
     p = min(p, min(c, lk - 1));
     mx = max(mx, lk);
+    if (rep) {
+      unsigned long long h = 1469598103934665603ull ^ (unsigned)lk;
+      for (int c2 = 0; c2 < lk; ++c2) { h ^= (unsigned)rk[c2]; h *= 1099511628211ull; }
+      s_hash[k] = h;
+    }
   }
   atomicMin(&s_p, p);
   atomicMax(&s_max, mx);
@@ -293,9 +309,25 @@ __global__ __launch_bounds__(256) void prefix_plan_kernel(const int* cids, const
     if (img_max) img_max[b] = s_max - pb;
   }
   int keys = 0;  // causal (query, key) pairs of this image's segments: what the attention of one layer and head multiplies
+  int dups = 0;
   for (int k = tid; k < K; k += blockDim.x) {
     const int s = B + b * K + k;
-    const int own = clen[b * K + k] - pb;
+    int own = clen[b * K + k] - pb;
+    if (rep) {
+      int r = k;
+      const unsigned long long hk = s_hash[k];
+      const int lk = clen[b * K + k];
+      const int* rk = r0 + (long)k * BR_LEN;
+      for (int j = 0; j < k; ++j) {
+        if (s_hash[j] != hk || clen[b * K + j] != lk) continue;
+        const int* rj = r0 + (long)j * BR_LEN;
+        int c = 0;
+        while (c < lk && rj[c] == rk[c]) ++c;
+        if (c == lk) { r = j; break; }  // the lowest identical candidate is the representative (it is its own: rep[j] == j)
+      }
+      rep[b * K + k] = r;
+      if (r != k) { own = 0; ++dups; }
+    }
     own_len[s] = own;
     pre_len[s] = pb;
     seg_src[s] = b * K + k;
@@ -303,34 +335,41 @@ __global__ __launch_bounds__(256) void prefix_plan_kernel(const int* cids, const
     keys += own * pb + own * (own + 1) / 2;
   }
   atomicAdd(&s_keys, keys);
+  if (dups) atomicAdd(&s_dup, dups);
   __syncthreads();
-  if (tid == 0) atomicAdd(max_len_out + 4, s_keys + pb * (pb + 1) / 2);  // totals[7] (profiling: attention FLOPs)
+  if (tid == 0) {
+    atomicAdd(max_len_out + 4, s_keys + pb * (pb + 1) / 2);  // totals[7] (profiling: attention FLOPs)
+    if (n_dup_out && s_dup) atomicAdd(n_dup_out, s_dup);     // totals[5]: candidates that ride on another one's rows
+  }
 }
 
 int launch_prefix_plan(const int* clip_ids, const int* clip_len, int B, int K, int share, int* own_len, int* pre_len,
-                       int* seg_src, int* seg_pos0, int* max_len_out, int* img_max, hipStream_t st) {
+                       int* seg_src, int* seg_pos0, int* max_len_out, int* img_max, hipStream_t st, int* rep, int* n_dup_out) {
+  if (rep && K > 1024) { snprintf(g_err, sizeof(g_err), "prefix plan: de-duplication needs K <= 1024"); return 1; }
   hipLaunchKernelGGL(prefix_plan_kernel, dim3(B), dim3(256), 0, st, clip_ids, clip_len, B, K, share, own_len, pre_len,
-                     seg_src, seg_pos0, max_len_out, img_max);
+                     seg_src, seg_pos0, max_len_out, img_max, rep, n_dup_out);
   CZC_HIP_CHECK(hipGetLastError());
   return 0;
 }
 
+// rep (optional, [B*K]): candidate i pools the EOS row of candidate rep[i] of the same image (its own when rep[i] == i % K)
 __global__ void prefix_finish_kernel(const int* own_off, const int* own_len, int B, int K, int* pre_off, int* eos_idx,
-                                     int* n_trunk_rows) {
+                                     int* n_trunk_rows, const int* rep) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i == 0 && n_trunk_rows) *n_trunk_rows = own_off[B];  // the B trunk segments come first
   if (i < B) pre_off[i] = 0;
   if (i < B * K) {
     const int s = B + i;
     pre_off[s] = own_off[i / K];
-    eos_idx[i] = own_off[s] + own_len[s] - 1;
+    const int sr = rep ? B + (i / K) * K + rep[i] : s;
+    eos_idx[i] = own_off[sr] + own_len[sr] - 1;
   }
 }
 
 int launch_prefix_finish(const int* own_off, const int* own_len, int B, int K, int* pre_off, int* eos_idx,
-                         int* n_trunk_rows, hipStream_t st) {
+                         int* n_trunk_rows, hipStream_t st, const int* rep) {
   hipLaunchKernelGGL(prefix_finish_kernel, dim3(cdiv((long)B * K, 256)), dim3(256), 0, st, own_off, own_len, B, K,
-                     pre_off, eos_idx, n_trunk_rows);
+                     pre_off, eos_idx, n_trunk_rows, rep);
   CZC_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -122,6 +122,7 @@ struct czc_engine {
   int bert_prune = 1;       // last BERT layer behind the attention on the one row per sequence the MLM head reads (n_mask == 1 steps)
   int bert_pruned_idx = -1; // row the previous forward kept (-1: all rows of b_x are valid)
   int share_prefix = 1;  // encode the candidates' common causal prefix once per image
+  int dedup = 1;         // candidates of one image with identical CLIP id rows are encoded once (bridge.hip prefix_plan_kernel; exact)
   float* d_staged = nullptr; int staged_cap = 0, staged_n = 0;  // czc_preprocess_u8 output slots [cap][3][S][S]
   int pack_branches = 1; // pack several candidates' rows into one attention MFMA tile
   int pool_last_layer = 1; // last CLIP-text layer: out-proj + MLP on the EOS rows only
@@ -141,6 +142,7 @@ struct czc_engine {
   std::map<std::string, ProfKind> pk;
   int64_t stat_clip_rows = 0, stat_clip_seqs = 0, stat_bert_rows = 0, stat_steps = 0;
   int64_t stat_refine_rows = 0, stat_refine_seqs = 0;
+  int64_t stat_dedup_seqs = 0;  // candidate sequences that rode on an identical one's rows (of stat_clip_seqs)
   // czc_set_control_callback: the host scores the K candidate sentences of every image itself (the reference's own
   // nltk scorer where it is installed) between the two halves of a step; replaces the table look-ups of the bridge kernel
   czc_control_fn ctl_fn = nullptr; void* ctl_user = nullptr;
@@ -546,7 +548,7 @@ int mlm_head(czc_engine* e, int B, int T, int gen_idx, float** logits_out) {
 // (trunk segment) and every candidate only carries the rows from its first differing token on.
 // Two halves around the step's single host round trip (32 bytes of totals: rows, longest sequence, overflow):
 // clip_plan builds the segment table on the device and starts the read, clip_tower runs on the sizes it returned.
-struct PlanBufs { int *own_len, *pre_len, *src, *pos0, *own_off, *pre_off, *eidx, *img_max; };
+struct PlanBufs { int *own_len, *pre_len, *src, *pos0, *own_off, *pre_off, *eidx, *img_max, *rep; };
 
 // the refine engine inside czc_generate: screening pass on fp16 rows (czc_engine::refine_rows16)
 static inline bool refine_rows16_now(const czc_engine* e) {
@@ -565,6 +567,7 @@ int plan_bufs(czc_engine* e, int B, int K, PlanBufs* p, const char* pfx = "p") {
   E_CHECK(ensure(e, (q + "_pre_off").c_str(), (size_t)S * 4, (void**)&p->pre_off));
   E_CHECK(ensure(e, (q + "_eidx").c_str(), (size_t)n_seq * 4, (void**)&p->eidx));
   E_CHECK(ensure(e, (q + "_img_max").c_str(), (size_t)B * 4, (void**)&p->img_max));
+  E_CHECK(ensure(e, (q + "_rep").c_str(), (size_t)n_seq * 4, (void**)&p->rep));
   return 0;
 }
 
@@ -573,9 +576,11 @@ int clip_plan(czc_engine* e, const int* cids, const int* clen, int B, int K, int
   E_CHECK(plan_bufs(e, B, K, &p));
   const int S = B + B * K;
   { ProfScope ps(e, "bridge", 0);
-    E_CHECK(launch_prefix_plan(cids, clen, B, K, share, p.own_len, p.pre_len, p.src, p.pos0, totals + 3, p.img_max, e->st));
+    // de-duplication rides on the shared-prefix plan (K > 1 candidates per image; czc_encode_text's independent sequences have none)
+    int* rep = e->dedup && share && K > 1 ? p.rep : nullptr;
+    E_CHECK(launch_prefix_plan(cids, clen, B, K, share, p.own_len, p.pre_len, p.src, p.pos0, totals + 3, p.img_max, e->st, rep, totals + 5));
     E_CHECK(launch_scan(p.own_len, S, p.own_off, totals, e->st));
-    E_CHECK(launch_prefix_finish(p.own_off, p.own_len, B, K, p.pre_off, p.eidx, totals + 6, e->st)); }
+    E_CHECK(launch_prefix_finish(p.own_off, p.own_len, B, K, p.pre_off, p.eidx, totals + 6, e->st, rep)); }
   E_HIP(hipMemcpyAsync(e->h_totals, totals, 32, hipMemcpyDeviceToHost, e->st));
   int* flag;
   E_CHECK(ensure(e, "s_nonfinite", 32, (void**)&flag));
@@ -848,6 +853,7 @@ int step_device(czc_engine* e, int* d_inp, int B, int T, int gen_idx, int n_mask
   E_CHECK(step_phase_b(e, a, M, max_len, max_branch, n_trunk));
   e->stat_clip_rows += M;
   e->stat_clip_seqs += B * K;
+  e->stat_dedup_seqs += e->h_totals[5];
   e->stat_steps += 1;
   return 0;
 }
@@ -973,7 +979,7 @@ int czc_replicate(czc_engine* p, czc_engine** out) {
   e->mlm_dense_w = p->mlm_dense_w; e->decoder_w = p->decoder_w; e->tproj_w = p->tproj_w; e->vproj_w = p->vproj_w;
   e->patch_w = p->patch_w; e->tproj_wx = p->tproj_wx;
   e->logit_scale_exp = p->logit_scale_exp;
-  e->share_prefix = p->share_prefix; e->pack_branches = p->pack_branches; e->pool_last_layer = p->pool_last_layer;
+  e->share_prefix = p->share_prefix; e->dedup = p->dedup; e->pack_branches = p->pack_branches; e->pool_last_layer = p->pool_last_layer;
   e->fuse_ln = p->fuse_ln; e->bert_prune = p->bert_prune; e->resid16 = p->resid16; e->fold_ln = p->fold_ln;
   memset(&e->bd, 0, sizeof(e->bd));
   if (hipSetDevice(e->dev) != hipSuccess || hipStreamCreate(&e->st) != hipSuccess ||
@@ -1312,6 +1318,47 @@ int czc_encode_text(czc_engine* e, const int32_t* clip_ids, const int32_t* clip_
   return CZC_OK;
 }
 
+// clip/clip.py:86-98 `compute_image_text_similarity_via_embeddings` as a call of its own (the per-step path never needs it:
+// czc_step / czc_generate fuse it into the score-combine kernel; this is the drop-in CLIP wrapper's public method): both sides
+// L2-normalised, cos = t . i, logits = cos * exp(logit_scale) of the loaded checkpoint, softmax over the K texts of an image.
+int czc_similarity(czc_engine* e, const float* image_embeds, const float* text_embeds, int B, int K, float* clip_score,
+                   float* clip_ref) {
+  if (!e || !image_embeds || !text_embeds || B <= 0 || K <= 0 || K > CZC_MAX_TOPK) return e ? fail(e, CZC_ERR_ARG, "similarity: bad B / K%s") : CZC_ERR_ARG;
+  if (!e->finalized) return fail(e, CZC_ERR_STATE, "weights not finalized%s");
+  E_HIP(hipSetDevice(e->dev));
+  e->err[0] = 0;
+  const int D = e->cfg.clip_proj;
+  const size_t bk = (size_t)B * K;
+  float *tf, *ie, *in_, *zero, *cs, *cr, *fin, *bc; int *cand, *best, *flag;
+  E_CHECK(ensure(e, "sim_tf", bk * D * 4, (void**)&tf));
+  E_CHECK(ensure(e, "sim_ie", (size_t)B * D * 4, (void**)&ie));
+  E_CHECK(ensure(e, "sim_in", (size_t)B * D * 4, (void**)&in_));
+  E_CHECK(ensure(e, "sim_zero", bk * 4, (void**)&zero));
+  E_CHECK(ensure(e, "sim_cand", bk * 4, (void**)&cand));
+  E_CHECK(ensure(e, "sim_cs", bk * 4, (void**)&cs));
+  E_CHECK(ensure(e, "sim_cr", bk * 4, (void**)&cr));
+  E_CHECK(ensure(e, "sim_fin", bk * 4, (void**)&fin));
+  E_CHECK(ensure(e, "sim_best", (size_t)B * 4, (void**)&best));
+  E_CHECK(ensure(e, "sim_bc", (size_t)B * 4, (void**)&bc));
+  E_CHECK(ensure(e, "sim_flag", 32, (void**)&flag));
+  E_HIP(hipMemcpyAsync(tf, text_embeds, bk * D * 4, hipMemcpyDefault, e->st));
+  E_HIP(hipMemcpyAsync(ie, image_embeds, (size_t)B * D * 4, hipMemcpyDefault, e->st));
+  E_HIP(hipMemsetAsync(zero, 0, bk * 4, e->st));
+  E_HIP(hipMemsetAsync(cand, 0, bk * 4, e->st));
+  E_HIP(hipMemsetAsync(flag, 0, 32, e->st));
+  E_CHECK(launch_l2_normalize(ie, B, D, in_, e->st));
+  CombineArgs a;
+  a.text_feat = tf; a.img_n = in_; a.logit_scale_exp = e->logit_scale_exp; a.probs = zero; a.cand = cand;
+  a.senti_raw = nullptr; a.repeats = nullptr; a.alpha = 0.f; a.beta = 1.f; a.gamma = 0.f; a.use_senti = 0;
+  a.B = B; a.K = K; a.D = D; a.clip_score = cs; a.clip_ref = cr; a.final_score = fin; a.best = best; a.best_cos = bc;
+  a.inp = nullptr; a.T = 0; a.gen_idx = 0; a.nonfinite = flag;
+  E_CHECK(launch_combine(a, e->st));
+  if (clip_score) E_HIP(hipMemcpyAsync(clip_score, cs, bk * 4, hipMemcpyDefault, e->st));
+  if (clip_ref) E_HIP(hipMemcpyAsync(clip_ref, cr, bk * 4, hipMemcpyDefault, e->st));
+  E_HIP(hipStreamSynchronize(e->st));
+  return CZC_OK;
+}
+
 int czc_step(czc_engine* e, int32_t* inp, int B, int T, int gen_idx, int n_mask, int dot_allowed, int top_k,
              const czc_hyper* hp, const czc_step_out* out) {
   if (!e || !inp || !hp || B <= 0) return CZC_ERR_ARG;
@@ -1411,6 +1458,7 @@ int czc_set_control_callback(czc_engine* e, czc_control_fn fn, void* user) {
 int czc_set_option(czc_engine* e, const char* name, int value) {
   if (!e || !name) return CZC_ERR_ARG;
   if (!strcmp(name, "share_prefix")) { e->share_prefix = value ? 1 : 0; return CZC_OK; }
+  if (!strcmp(name, "dedup")) { e->dedup = value ? 1 : 0; return CZC_OK; }
   if (!strcmp(name, "bert_prune")) { e->bert_prune = value ? 1 : 0; return CZC_OK; }
   if (!strcmp(name, "pack_branches")) { e->pack_branches = value ? 1 : 0; return CZC_OK; }
   if (!strcmp(name, "pool_last_layer")) { e->pool_last_layer = value ? 1 : 0; return CZC_OK; }
@@ -1438,7 +1486,7 @@ int czc_get_option(czc_engine* e, const char* name, int* value) {
   const float f16x = r16 ? e->refine_rows16_factor : 1.f;
   struct { const char* n; int v; } tab[] = {
       {"share_prefix", e->share_prefix}, {"bert_prune", e->bert_prune}, {"pack_branches", e->pack_branches},
-      {"pool_last_layer", e->pool_last_layer}, {"fuse_ln", e->fuse_ln}, {"resid16", e->resid16}, {"fold_ln", e->fold_ln},
+      {"dedup", e->dedup}, {"pool_last_layer", e->pool_last_layer}, {"fuse_ln", e->fuse_ln}, {"resid16", e->resid16}, {"fold_ln", e->fold_ln},
       {"refine_samples", e->refine_samples}, {"refine_theta_x1000", (int)lrintf(e->refine_theta_x * 1000.f)},
       {"refine_theta_gen_x1000", (int)lrintf(e->refine_theta_gen * 1000.f)},
       {"refine_guard_x1e6", (int)lrintf(e->refine_guard_dev * 1e6f)}, {"refine_gate_x1e6", (int)lrintf(e->refine_gate_delta * 1e6f)},
@@ -1474,6 +1522,7 @@ int czc_profile_reset(czc_engine* e) {
   for (auto& kv : e->pk) { kv.second.used = 0; kv.second.flops = 0; kv.second.launches = 0; }
   e->stat_clip_rows = e->stat_clip_seqs = e->stat_bert_rows = e->stat_steps = 0;
   e->stat_refine_rows = e->stat_refine_seqs = 0;
+  e->stat_dedup_seqs = 0;
   e->stat_gated = e->stat_gate_images = 0;
   return CZC_OK;
 }
@@ -1534,6 +1583,13 @@ int czc_stats(czc_engine* e, int64_t* clip_rows, int64_t* clip_seqs, int64_t* be
   if (clip_seqs) *clip_seqs = e->stat_clip_seqs;
   if (bert_rows) *bert_rows = e->stat_bert_rows;
   if (steps) *steps = e->stat_steps;
+  return CZC_OK;
+}
+
+int czc_dedup_stats(czc_engine* e, int64_t* dedup_seqs, int64_t* clip_seqs) {
+  if (!e) return CZC_ERR_ARG;
+  if (dedup_seqs) *dedup_seqs = e->stat_dedup_seqs;
+  if (clip_seqs) *clip_seqs = e->stat_clip_seqs;
   return CZC_OK;
 }
 

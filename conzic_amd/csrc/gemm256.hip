@@ -865,6 +865,7 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(GemmArgs g, int tiles_m, 
   else run(std::integral_constant<int, 0>());
 }
 
+#ifdef CZC_EXPERIMENTS  // an A/B arm that lost (profiles/r04_gemm256r_ablations.txt): `make EXPERIMENTS=1` builds only, not in the product library
 // ================================================================================================
 // gemm256r (round 4, A/B arm: test option gemm256 = 9): the vendor library's structure for the fp32-residual layers --
 // FOUR waves, each 128 x 128 of C (16 v_mfma_f32_32x32x16 accumulators = 256 registers, one wave per SIMD), operands
@@ -1052,6 +1053,8 @@ __global__ __launch_bounds__(256) void gemm256r_kernel(GemmArgs g, int tiles_m, 
 #undef CZC_R_PIN
 #undef CZC_R_HALF
 }
+
+#endif  // CZC_EXPERIMENTS (gemm256r)
 
 // ================================================================================================
 // gemm256sq: gemm256q's 4-deep ring of 32 KiB stages for the SPLIT-fp16 precision.  A 64-byte tile row holds 16
@@ -1636,8 +1639,10 @@ int launch_gemm256(const GemmArgs& g, hipStream_t st) {
                       CZC_ATTR((K_<ACT_QUICK_GELU, false, true>)); CZC_ATTR((K_<ACT_QUICK_GELU, true, true>))
     CZC_ATTR4(gemm256q_kernel);
     CZC_ATTR4(gemm256x_kernel);
+#ifdef CZC_EXPERIMENTS
     CZC_ATTR((gemm256r_kernel<false>));
     CZC_ATTR((gemm256r_kernel<true>));
+#endif
     CZC_ATTR((gemm256x_kernel<ACT_NONE, true, false, 256>));
     CZC_ATTR((gemm256x_kernel<ACT_NONE, true, true, 256>));
 #undef CZC_ATTR4
@@ -1703,9 +1708,12 @@ int launch_gemm256(const GemmArgs& g, hipStream_t st) {
       CZC_HIP_CHECK(hipGetLastError());
       return 0;
     }
-#endif
     if (g.f16) hipLaunchKernelGGL((gemm256r_kernel<true>), gq, dim3(256), shp, st, g, tiles_m, tiles_n, stagger256 << 8);
     else hipLaunchKernelGGL((gemm256r_kernel<false>), gq, dim3(256), shp, st, g, tiles_m, tiles_n, stagger256 << 8);
+#else
+    snprintf(g_err, sizeof(g_err), "gemm256 = 9 (gemm256r, the register-staged A/B arm) exists in EXPERIMENTS=1 builds only");
+    return 1;
+#endif
   } else if (pp) CZC_DISPATCH(gemm256x_kernel, 512, (g_w_dbg & 15) | stagger256 << 8);
   else CZC_DISPATCH(gemm256q_kernel, 768);
 #undef CZC_DISPATCH

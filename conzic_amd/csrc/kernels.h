@@ -186,11 +186,14 @@ int launch_scan(const int* len, int n, int* off, int* totals, hipStream_t st);
 //   trunk b: own_len p_b, src row b*K, pos0 0, pre_len 0;  branch (b,k): own_len len-p_b, src b*K+k, pos0 p_b, pre_len p_b
 // max_len_out (two device ints, pre-zeroed) receive max len and max branch own_len via atomicMax.
 int launch_prefix_plan(const int* clip_ids, const int* clip_len, int B, int K, int share, int* own_len, int* pre_len,
-                       int* seg_src, int* seg_pos0, int* max_len_out, int* img_max, hipStream_t st);  // img_max [B]: longest branch per image
+                       int* seg_src, int* seg_pos0, int* max_len_out, int* img_max, hipStream_t st,  // img_max [B]: longest branch per image
+                       int* rep = nullptr, int* n_dup_out = nullptr);
+// rep (optional, [B*K]): exact de-duplication -- rep[b*K+k] = lowest k' with an identical CLIP id row in image b (k itself for a
+// first occurrence); the others get own_len 0 and pool their representative's EOS row; *n_dup_out += their number
 // after the scan of own_len: pre_off[trunk] = 0, pre_off[branch (b,k)] = own_off[b];
 // eos_idx[b*K+k] = own_off[B+b*K+k] + own_len[B+b*K+k] - 1
 int launch_prefix_finish(const int* own_off, const int* own_len, int B, int K, int* pre_off, int* eos_idx,
-                         int* n_trunk_rows, hipStream_t st);
+                         int* n_trunk_rows, hipStream_t st, const int* rep = nullptr);
 
 // ---- combine.hip --------------------------------------------------------------------------
 struct CombineArgs {

@@ -348,6 +348,16 @@ class Engine:
         self._ck(rc, "czc_generate")
         return ids, cos
 
+    def similarity(self, image_embeds, text_embeds, K: int):
+        """clip/clip.py:86-98: (softmax_K(cos * exp(logit_scale)), cos), both [B, K], from un-normalised embeddings."""
+        ie = np.ascontiguousarray(image_embeds, np.float32)
+        te = np.ascontiguousarray(text_embeds, np.float32)
+        B = ie.shape[0]
+        assert te.shape == (B * K, ie.shape[1]), (te.shape, ie.shape, K)
+        cs, cr = np.empty((B, K), np.float32), np.empty((B, K), np.float32)
+        self._ck(self.lib.czc_similarity(self.h, ie.ctypes.data, te.ctypes.data, B, K, cs.ctypes.data, cr.ctypes.data), "czc_similarity")
+        return cs, cr
+
     def set_option(self, name: str, value: int):
         self._ck(self.lib.czc_set_option(self.h, name.encode(), int(value)), f"czc_set_option({name})")
         self._record("option:" + name, "set_option", name, int(value))
@@ -379,8 +389,10 @@ class Engine:
         self._ck(self.lib.czc_refine_stats(self.h, C.byref(rs), C.byref(rr)), "czc_refine_stats")
         g, gi = C.c_int64(), C.c_int64()
         self._ck(self.lib.czc_refine_gate_stats(self.h, C.byref(g), C.byref(gi)), "czc_refine_gate_stats")
+        dd = C.c_int64()
+        self._ck(self.lib.czc_dedup_stats(self.h, C.byref(dd), None), "czc_dedup_stats")
         return dict(clip_rows=a.value, clip_seqs=b.value, bert_rows=c_.value, steps=d.value, refine_seqs=rs.value,
-                    refine_rows=rr.value, gated_image_steps=g.value, gate_image_steps=gi.value)
+                    refine_rows=rr.value, gated_image_steps=g.value, gate_image_steps=gi.value, dedup_seqs=dd.value)
 
     def refine_guard(self, reset: bool = True):
         """(max |screening error - mean| seen on re-encoded candidates, image-steps above the trip point) of a

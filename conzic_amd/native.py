@@ -104,6 +104,7 @@ SIGNATURES = {
     "czc_encode_staged": (_I, [_P, _I, _P]),
     "czc_set_image_embeds": (_I, [_P, _P, _I]),
     "czc_encode_text": (_I, [_P, _P, _P, _I, _P]),
+    "czc_similarity": (_I, [_P, _P, _P, _I, _I, _P, _P]),
     "czc_step": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, C.POINTER(Hyper), C.POINTER(StepOut)]),
     "czc_generate": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _P, _P, _I, C.POINTER(Hyper), _P, _P]),
     "czc_set_option": (_I, [_P, C.c_char_p, _I]),
@@ -116,6 +117,7 @@ SIGNATURES = {
     "czc_sync": (_I, [_P]),
     "czc_stats": (_I, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "czc_refine_stats": (_I, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "czc_dedup_stats": (_I, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "czc_refine_guard": (_I, [_P, _I, C.POINTER(C.c_float), C.POINTER(C.c_int64)]),
     "czc_refine_gate_stats": (_I, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
 }

@@ -229,6 +229,12 @@ int czc_set_image_embeds(czc_engine* e, const float* embeds, int B);
 /* clip/clip.py:64-84 after tokenisation: CLIP ids int32 [n, CZC_CLIP_MAX_LEN] (right-padded) and
  * lengths (tokens incl. BOS/EOS) -> un-normalised text_embeds fp32 [n, proj]. */
 int czc_encode_text(czc_engine* e, const int32_t* clip_ids, const int32_t* clip_len, int n, float* out_embeds);
+/* clip/clip.py:86-98 `compute_image_text_similarity_via_embeddings`: image_embeds [B, proj] and text_embeds [B*K, proj]
+ * (both as returned by czc_encode_images / czc_encode_text, un-normalised) -> clip_score [B, K] = softmax over an image's K
+ * texts of cos * exp(logit_scale of the loaded checkpoint), clip_ref [B, K] = the cosines.  K <= CZC_MAX_TOPK.  (czc_step /
+ * czc_generate never call it: the same arithmetic runs fused inside their score-combine kernel.) */
+int czc_similarity(czc_engine* e, const float* image_embeds, const float* text_embeds, int B, int K, float* clip_score,
+                   float* clip_ref);
 
 /* ---- the hot path ------------------------------------------------------------------------ */
 /* Parity granularity: one position-step (gen_utils.py:66-81) on `inp` int32 [B,T] (in/out, host
@@ -255,6 +261,9 @@ int czc_generate(czc_engine* e, int B, int T, int L, int seed_len, const int32_t
 /* Engine options (all are exact work reductions / kernel choices; results agree within the engine precision):
  *   "share_prefix"    (1) encode the causal prefix common to an image's K candidates once per step instead of K
  *                         times
+ *   "dedup"           (1) with "share_prefix": candidates of one image whose CLIP id rows are identical (all the candidates the
+ *                         token mask turned into [PAD], gen_utils.py:72-75) are encoded once; bit-identical outputs
+ *                         (czc_dedup_stats)
  *   "bert_prune"      (1) n_mask == 1 steps: the last BERT layer behind its attention (out-projection, LayerNorms, MLP) on the
  *                         masked row of every sequence only -- the one row the MLM head reads (gen_utils.py:69)
  *   "pack_branches"   (1) attention of the branch rows with G candidates packed per 32-query MFMA tile
@@ -306,6 +315,11 @@ int czc_profile_intervals(czc_engine* e, czc_engine* ref, const char* kind, doub
 int czc_sync(czc_engine* e);
 /* counters of the last generate/step: rows pushed through the CLIP text tower etc. */
 int czc_stats(czc_engine* e, int64_t* clip_rows, int64_t* clip_seqs, int64_t* bert_rows, int64_t* steps);
+/* Exact de-duplication (option "dedup", default 1): of the *clip_seqs candidate sequences the text tower was asked for since
+ * czc_profile_reset, *dedup_seqs had a CLIP id row identical to an earlier candidate of the same image (every candidate the
+ * token mask turned into [PAD] decodes to the same caption without the word, gen_utils.py:72-75) and were not encoded
+ * again: they take their representative's feature, bit for bit what their own rows would have produced. */
+int czc_dedup_stats(czc_engine* e, int64_t* dedup_seqs, int64_t* clip_seqs);
 /* CZC_PREC_REFINE engines: candidate sequences / packed rows re-encoded by the split-fp16 tower since czc_profile_reset
  * (of the clip_seqs / clip_rows the screening pass saw); zero for the other precisions. */
 int czc_refine_stats(czc_engine* e, int64_t* refine_seqs, int64_t* refine_rows);

@@ -67,6 +67,23 @@ def test_test_hooks_live_in_their_own_library():
     assert not re.search(r"czc_(test|bench)_", open(native.HEADER_PATH).read())
 
 
+def test_product_modules_never_touch_the_test_library():
+    """The drop-in modules and conzic_amd/ reach the GPU through libconzic_hip.so only: none of them loads the hook library
+    (native.load_test), names a czc_test_* / czc_bench_* symbol, imports tests/kernel_hooks.py or the oracle."""
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = [os.path.join(root, f) for f in ("gen_utils.py", "control_gen_utils.py", "utils.py", "clip/clip.py")]
+    files += sorted(glob.glob(os.path.join(root, "conzic_amd", "*.py")))
+    for f in files:
+        src = open(f).read()
+        if f.endswith(os.path.join("conzic_amd", "native.py")):
+            src = src[:src.index("# every entry point include/conzic_hip_test.h declares")] + src[src.index("_lib: Optional"):]
+            src = src.replace("def load_test()", "def _lt()")
+        for needle in ("load_test(", "czc_test_", "czc_bench_", "kernel_hooks"):
+            assert needle not in src, (f, needle)
+        assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
+
+
 def test_struct_sizes_match_header_layout():
     assert native.ctypes_sizeof_ok() if hasattr(native, "ctypes_sizeof_ok") else True
     import ctypes as C

@@ -315,7 +315,12 @@ def test_register_staged_four_wave_gemm_equals_the_ring_kernel_bitwise(M, N, K):
         assert lib.czc_test_set_option(b"gemm256_min_m", 1) == 0
         for v in (5, 9):
             assert lib.czc_test_set_option(b"gemm256", v) == 0
-            out[v] = KH.gemm(BF16, A, W, bias=bias, resid=R)
+            try:
+                out[v] = KH.gemm(BF16, A, W, bias=bias, resid=R)
+            except native.NativeError as exc:
+                if v == 9 and "EXPERIMENTS=1 builds only" in str(exc):
+                    pytest.skip("gemm256r is an A/B arm: built by `make EXPERIMENTS=1` only, not into the product library")
+                raise
     finally:
         lib.czc_test_set_option(b"gemm256", 1)
         lib.czc_test_set_option(b"gemm256_min_m", 8192)

@@ -878,6 +878,97 @@ def test_prefix_sharing_is_exact(prec, name, one_gemm_family):
             np.testing.assert_array_equal(ia, ib)
 
 
+def _peaky_bert_weights(bcfg, n_hot, seed=5):
+    """BERT weights whose MLM head behaves like a TRAINED model's at tau = 0.1 (tests/test_kernels_gpu.py::
+    test_topk_with_a_trained_models_logit_range): `n_hot` regular tokens sit 5.6..16 logit units above a bulk that underflows
+    to exactly zero in softmax(logits / 0.1), so fewer than K probabilities are non-zero and the tail of the top-K is
+    zero-probability fill-ins -- which gen_utils.py:72 (`idxs * mask[idxs]`) turns into [PAD], i.e. K - n_hot copies of the same
+    caption without the word."""
+    w = synth.make_bert_weights(bcfg, 11)
+    sv = harness.cached_vocab(False)
+    regular = np.nonzero(synth.make_token_mask(sv, regular_only=True)[0] > 0)[0]
+    hot = np.random.default_rng(seed).choice(regular, size=n_hot, replace=False)
+    bias = w["cls.predictions.bias"].copy()
+    bias[hot] += np.linspace(16.0, 5.6, n_hot).astype(np.float32)
+    w["cls.predictions.bias"] = bias
+    if "cls.predictions.decoder.bias" in w:
+        w["cls.predictions.decoder.bias"] = bias
+    return w
+
+
+@pytest.mark.parametrize("prec,B", [(F32, 2), (BF16, 2), (BF16, 64), (SPLIT, 2), (REFINE, 64)])
+def test_dedup_is_exact(prec, B):
+    """Exact de-duplication of identical candidate sentences (option "dedup", bridge.hip prefix_plan_kernel): with a
+    trained-like MLM head 150 of the K = 200 probabilities are non-zero, the other 50 candidates all decode to the caption
+    without the word -- one CLIP id row.  49 of them per image ride on the first one's rows: fewer rows through the text
+    tower, the SAME outputs bit for bit (ids, cosines, fused scores, winner, write-back), czc_dedup_stats says how many; both
+    attention forms (B = 2: one wave per candidate group; B = 64: the per-image kernel) and the two-pass engine."""
+    L, K, n_hot = 10, 200, 150
+    bcfg = synth.bert_base()
+    scale = 4.6052 if prec == REFINE else 2.6592
+    su = harness.build_synthetic(False, prec, logit_scale=scale, regular_only=True, bert_w=_peaky_bert_weights(bcfg, n_hot), bert_cfg=bcfg)
+    eng = su.engine
+    try:
+        rng = np.random.default_rng(B)
+        eng.set_image_embeds(rng.standard_normal((B, 512)).astype(np.float32))
+        hp = Engine.hyper(0.02, 2.0, 0.1)
+        inp0 = np.array([su.bert_tok.encode("Image of a" + su.bert_tok.mask_token * L)] * B, dtype=np.int32)
+        regular = np.nonzero(su.token_mask[0] > 0)[0]
+        inp0[:, SEED_LEN:SEED_LEN + L] = rng.choice(regular, size=(B, L))
+        want = ("probs", "idxs", "cand_ids", "clip_ids", "clip_len", "clip_score", "clip_ref", "final_score", "best", "best_cos")
+        outs = {}
+        for dd in (1, 0):
+            eng.set_option("dedup", dd)
+            assert eng.get_option("dedup") == dd
+            eng.profile_reset()
+            rows = []
+            for pos in (0, 4, L - 1):
+                inp = inp0.copy()
+                r = eng.step(inp, SEED_LEN + pos, K, hp, dot_allowed=(pos == L - 1), want=want)
+                rows.append((r, inp))
+            outs[dd] = (rows, eng.stats())
+        (a, sa), (b, sb) = outs[1], outs[0]
+        pads = [int((r["cand_ids"] == 0).sum()) for r, _ in a]
+        assert all(p_ >= B * (K - n_hot - 2) for p_ in pads), pads            # the construction: ~50 [PAD] candidates per image
+        assert sb["dedup_seqs"] == 0 and sa["dedup_seqs"] >= sum(p_ - B for p_ in pads)
+        assert sa["clip_seqs"] == sb["clip_seqs"] == 3 * B * K
+        assert sa["clip_rows"] < sb["clip_rows"]
+        print(f"[dedup] prec {prec} B {B}: {sa['dedup_seqs']} of {sa['clip_seqs']} candidates ride on an identical one; "
+              f"text-tower rows {sa['clip_rows']} vs {sb['clip_rows']} ({sa['clip_rows'] / sb['clip_rows']:.3f})")
+        for (ra, ia), (rb, ib) in zip(a, b):
+            for k in want:
+                np.testing.assert_array_equal(ra[k], rb[k], err_msg=k)
+            np.testing.assert_array_equal(ia, ib)
+            # and the duplicates really carry ONE value: all [PAD] candidates of an image share cosine and clip score
+            for j in range(B):
+                pad = ra["cand_ids"][j] == 0
+                assert pad.sum() >= K - n_hot - 2 and len(set(ra["clip_ref"][j][pad].tolist())) == 1
+    finally:
+        eng.set_option("dedup", 1)
+        eng.close()
+
+
+def test_dedup_leaves_the_flat_softmax_goldens_alone():
+    """On the random-weight towers of the goldens every one of the K probabilities is non-zero and no two candidates decode
+    to the same string: nothing is de-duplicated (the headline bench is unaffected) and the reference's trajectory is
+    reproduced with the option on (every other test) and off (here)."""
+    meta, arr = load_case("full_regular")
+    su = setup_for(meta, F32)
+    eng = su.engine
+    eng.set_image_embeds(arr["image_embeds"])
+    hp = Engine.hyper(meta["alpha"], meta["beta"], meta["temperature"])
+    try:
+        for dd in (1, 0):
+            eng.set_option("dedup", dd)
+            eng.profile_reset()
+            inp = np.ascontiguousarray(arr["inp_before"][3], dtype=np.int32)
+            r = eng.step(inp, SEED_LEN + meta["positions"][3], meta["K"], hp, want=("clip_ref", "best"))
+            assert eng.stats()["dedup_seqs"] == 0
+            np.testing.assert_allclose(r["clip_ref"], arr["clip_ref"][3], atol=5e-6)
+    finally:
+        eng.set_option("dedup", 1)
+
+
 @pytest.mark.parametrize("prec", [F32, BF16])
 @pytest.mark.parametrize("name", ["tiny_shuffle", "full_synth_b2", "full_senti"])
 def test_last_bert_layer_on_the_masked_row_only_is_exact(prec, name):
