@@ -64,6 +64,25 @@ def build_synthetic(tiny: bool, precision: int = native.PREC_BF16, bseed: int = 
     return SynthSetup(eng, sv, bert_cfg, clip_cfg, bt, ct, tables, mask)
 
 
+OUTLIER_CHANNELS = (7, 93, 200, 301, 402, 499)
+
+
+def outlier_clip_weights(clip_cfg, cseed: int = 12, gain: float = 1.0):
+    """CLIP weights of seed `cseed` with six channels of every TEXT-tower LayerNorm gain multiplied by `gain`: the activation
+    outlier channels trained checkpoints have (a few LayerNorm gains tens of times the rest), which a single-pass fp16 tower
+    rounds more coarsely (tests/test_step_gpu.py, tools/refine_validate.py; gain 1 = the plain draw)."""
+    cw = synth.make_clip_weights(clip_cfg, cseed)
+    if gain != 1.0:
+        ch = np.array(OUTLIER_CHANNELS)
+        for n in range(clip_cfg.layers):
+            for ln in ("layer_norm1", "layer_norm2"):
+                k = f"text_model.encoder.layers.{n}.{ln}.weight"
+                g = np.array(cw[k], dtype=np.float32, copy=True)
+                g[ch] *= gain
+                cw[k] = g
+    return cw
+
+
 def order_positions(order: str, L: int, iters: int, order_list=None, random_positions=None):
     """(positions, n_mask, snapshot_every) for czc_generate from the reference's visiting orders
     (gen_utils.py:64-65 sequential, :110-115 shuffle, :160-166 span, :209-210 random)."""

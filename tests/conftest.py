@@ -72,6 +72,12 @@ def pytest_terminal_summary(terminalreporter):
                                     "engine, guard max_dev, tripped / image-steps):")
         for f_, worst, dev, trips, n in olog:
             terminalreporter.write_line(f"  x{f_:<5g} {worst:.3e}  {dev:.3e}  {trips}/{n}")
+    wlog = getattr(mod, "DRAW_LOG", None)
+    if wlog:
+        terminalreporter.write_line("screen-then-refine heuristics on other weight draws, against the all-split engine (draw: czc_step worst "
+                                    "|d final_score| over untripped image-steps, czc_generate guard max_dev, images with identical ids, guard trips):")
+        for name, worst, dev, same, n, trips in wlog:
+            terminalreporter.write_line(f"  {name:34s} {worst:.3e}  {dev:.3e}  {same}/{n}  tripped {trips}")
     rlog = getattr(mod, "REFINE_LOG", None)
     if rlog:
         terminalreporter.write_line("screen-then-refine engine: candidate sequences re-encoded by the split-fp16 tower (case: seqs, rows):")

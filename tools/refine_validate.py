@@ -11,7 +11,12 @@ and the share of candidates / rows the refine pass re-encodes.
 
 Last line (`mode: generate`): the same two engines through czc_generate (GEN_SWEEPS sweeps from the initial [MASK] row) --
 the refine engine with its margin gate on (the product default): ids of every snapshot must be IDENTICAL to the split
-engine's, the returned winner cosines equal to fp32 class, and the share of image-steps the gate let skip the second pass."""
+engine's, the returned winner cosines equal to fp32 class, and the share of image-steps the gate let skip the second pass.
+
+Weight draws (round 6: every constant of the engine -- gate delta, guard trip point, theta_gen, the x1.75 of fp16 rows -- was fitted on
+seeds 11 / 12): env BSEED / CSEED pick the BERT / CLIP weight seeds, EMB_SEED the image embeddings and the sentences, OUTLIER=F
+multiplies six channels of every text-tower LayerNorm gain by F (activation outliers as trained checkpoints have them; F = 12 is
+the tower tests/test_step_gpu.py::test_refine_guard_catches_towers... calls x12).  Every output line carries them."""
 import json
 import os
 import sys
@@ -29,10 +34,23 @@ SAMPLES = [int(v) for v in (sys.argv[3] if len(sys.argv) > 3 else "12").split(",
 THETAS = [int(v) for v in (sys.argv[4] if len(sys.argv) > 4 else "2000").split(",")]
 L, K, SEED_LEN, SCALE = 10, 200, 4, 4.6052
 hp = Engine.hyper(0.02, 2.0, 0.1)
-rng = np.random.default_rng(2026)
+BSEED, CSEED = int(os.environ.get("BSEED", "11")), int(os.environ.get("CSEED", "12"))
+EMB_SEED, OUTLIER = int(os.environ.get("EMB_SEED", "2026")), float(os.environ.get("OUTLIER", "1"))
+DRAW = dict(bseed=BSEED, cseed=CSEED, emb_seed=EMB_SEED, outlier_gain=OUTLIER)
+rng = np.random.default_rng(EMB_SEED)
 emb = rng.standard_normal((B, 512)).astype(np.float32)
 
-ref = harness.build_synthetic(False, native.PREC_SPLIT, logit_scale=SCALE, regular_only=True)
+
+def build(prec):
+    """The towers of this draw in precision `prec` (harness.outlier_clip_weights: six LayerNorm gain channels x OUTLIER)."""
+    from conzic_amd import synth
+    ccfg = synth.clip_b32()
+    ccfg.logit_scale = SCALE
+    cw = harness.outlier_clip_weights(ccfg, CSEED, OUTLIER)
+    return harness.build_synthetic(False, prec, bseed=BSEED, cseed=CSEED, logit_scale=SCALE, regular_only=True, clip_w=cw, clip_cfg=ccfg)
+
+
+ref = build(native.PREC_SPLIT)
 inp0 = np.array([ref.bert_tok.encode("Image of a" + ref.bert_tok.mask_token * L)] * B, dtype=np.int32)
 regular = np.nonzero(ref.token_mask[0] > 0)[0]
 inp0[:, SEED_LEN:SEED_LEN + L] = rng.choice(regular, size=(B, L))
@@ -49,7 +67,7 @@ gpos, gnm, gevery = harness.order_positions("sequential", L, GEN_SWEEPS)
 ref_ids, ref_cos = ref.engine.generate(B, init, L, SEED_LEN, K, gpos, hp, n_mask=gnm, snapshot_every=gevery)
 ref.engine.close()
 
-su = harness.build_synthetic(False, native.PREC_REFINE, logit_scale=SCALE, regular_only=True)
+su = build(native.PREC_REFINE)
 for kv in filter(None, os.environ.get("CZC_OPTS", "").split(",")):  # engine options of the refine engine under test, "name=value,..."
     su.engine.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 su.engine.set_image_embeds(emb)
@@ -78,7 +96,7 @@ for th in THETAS:
         e = np.concatenate(errs)
         st = su.engine.stats()
         gd = su.engine.refine_guard(reset=True)
-        print(json.dumps(dict(true_max_dev=true_dev, true_over_sample_dev=round(true_dev / max(gd["max_dev"], 1e-12), 3), guard_max_dev=gd["max_dev"], guard_tripped_image_steps=gd["tripped"], images=B, positions=P, K=K, logit_scale=SCALE, refine_samples=m, theta_x=th / 1000.0,
+        print(json.dumps(dict(draw=DRAW, true_max_dev=true_dev, true_over_sample_dev=round(true_dev / max(gd["max_dev"], 1e-12), 3), guard_max_dev=gd["max_dev"], guard_tripped_image_steps=gd["tripped"], images=B, positions=P, K=K, logit_scale=SCALE, refine_samples=m, theta_x=th / 1000.0,
                               max_abs_dfinal=float(e.max()), p999=float(np.quantile(e, 0.999)), mean=float(e.mean()),
                               image_steps=n, winners_identical=agree, reference_margin_at_flips=margins,
                               re_encoded_seq_frac=round(st["refine_seqs"] / max(st["clip_seqs"], 1), 4),
@@ -95,7 +113,7 @@ for gate in [int(v) for v in os.environ.get("GATES", "400,0").split(",")]:
     same_img = (ids == ref_ids).all(axis=(0, 2))
     ROWS16_FACTOR = next((int(kv.split("=")[1]) / 1000 for kv in os.environ.get("CZC_OPTS", "").split(",") if kv.startswith("refine_rows16_x1000=")), 1.75)
     rows16 = "refine_rows16=0" not in os.environ.get("CZC_OPTS", "")  # the engine default: screening pass of czc_generate on fp16 rows
-    print(json.dumps(dict(mode="generate", gate_delta=gate * 1e-6, screening_rows="fp16" if rows16 else "fp32",
+    print(json.dumps(dict(mode="generate", draw=DRAW, gate_delta=gate * 1e-6, screening_rows="fp16" if rows16 else "fp32",
                           gate_delta_effective=gate * 1e-6 * (ROWS16_FACTOR if rows16 else 1.0), images=B, sweeps=GEN_SWEEPS, image_steps=B * len(gpos),
                           images_with_identical_ids=int(same_img.sum()), ids_identical=bool((ids == ref_ids).all()),
                           max_abs_dcos_snapshots=float(np.abs(cos - ref_cos)[:, same_img].max()) if same_img.any() else None,
