@@ -48,6 +48,7 @@ static const Hooks& HK() {
 #define g_rowln_min_m (*HK().rowln_min_m)
 #define g_wreg_min_m (*HK().wreg_min_m)
 #define g_gemm256_min_m (*HK().gemm256_min_m)
+#define g_gemm256s_min_m (*HK().gemm256s_min_m)
 #define g_use_mfma_attention (*HK().use_mfma_attention)
 #define g_use_attention_image (*HK().use_attention_image)
 #define g_wreg_resid_min_m (*HK().wreg_resid_min_m)
@@ -339,6 +340,7 @@ int czc_test_set_option(const char* name, int value) {
   if (!strcmp(name, "rowln_min_m")) { g_rowln_min_m = value; return 0; }
   if (!strcmp(name, "wreg_min_m")) { g_wreg_min_m = value; return 0; }
   if (!strcmp(name, "gemm256_min_m")) { g_gemm256_min_m = value; return 0; }
+  if (!strcmp(name, "gemm256s_min_m")) { g_gemm256s_min_m = value; return 0; }
   if (!strcmp(name, "mfma_attention")) { g_use_mfma_attention = value; return 0; }
   if (!strcmp(name, "attention_image")) { g_use_attention_image = value; return 0; }
   if (!strcmp(name, "wreg_resid_min_m")) { g_wreg_resid_min_m = value; return 0; }

@@ -269,8 +269,10 @@ int launch_scan(const int* len, int n, int* off, int* totals, hipStream_t st) {
 // mask at tau = 0.1 that is most of the tail of the K candidates), and different word pieces can decode to the same string --
 // have identical hidden states in every row.  The first of them (lowest k) keeps its rows; the others get NO rows
 // (own_len = 0) and point their EOS index at the representative's EOS row (prefix_finish_kernel), so the pooled feature,
-// the cosine and everything behind it are the representative's, bit for bit what their own rows would have produced
-// (a row's arithmetic does not depend on its place in a launch: tests/test_step_gpu.py::test_dedup_is_exact).
+// the cosine and everything behind it are the representative's, bit for bit.  In the f32 engine that is exactly what their
+// own rows would have produced; in the MFMA engines the copies of one sentence never agreed among themselves to the last bit
+// (a candidate's softmax sum is associated by its slot inside the 32-query attention tile), they now share one of those
+// values (tests/test_step_gpu.py::test_dedup_is_exact spells out what is asserted per precision).
 // Detection: 64-bit FNV-1a of (length, ids) per candidate in LDS, K^2 / 256 hash compares per thread, every hash match
 // confirmed id by id (no false merges).
 __global__ __launch_bounds__(256) void prefix_plan_kernel(const int* cids, const int* clen, int B, int K, int share,

@@ -1623,7 +1623,7 @@ const void* czc_internal_hooks(int abi) {
       &launch_layernorm_x16, &launch_ln_finalize, &launch_fold_ln, &gemm_wreg_stats_in_kernel,
       &g_use_gemm256, &g_use_skinny, &g_use_splitk, &g_gemm_deep, &g_gemm_small_tiles, &g_use_wreg, &g_use_gemm256s, &g_w_dbg,
       &g_ln_lean, &g_rowln_min_m, &g_wreg_min_m, &g_gemm256_min_m, &g_use_mfma_attention, &g_use_attention_image, &g_wreg_resid_min_m,
-      &g_wreg_stats_in_kernel};
+      &g_wreg_stats_in_kernel, &g_gemm256s_min_m};
   return abi == HOOKS_ABI ? &h : nullptr;
 }
 

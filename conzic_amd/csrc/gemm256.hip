@@ -1723,10 +1723,11 @@ int launch_gemm256(const GemmArgs& g, hipStream_t st) {
 }
 
 int g_use_gemm256s = 1;  // 0: split-fp16 layers stay on the 128x128 kernel
+int g_gemm256s_min_m = 16384;  // rows from which a split-fp16 layer takes the 256 x 256 ring (test option gemm256s_min_m)
 
 // split-fp16 operands; big-M layers only (BERT at a few thousand rows stays on the 128x128 + split-K path)
 bool gemm256s_eligible(const GemmArgs& g) {
-  return g_use_gemm256s && g.M >= 16384 && g.N % 8 == 0 && g.K % 32 == 0 && g.ldc % 8 == 0 && g.lda % 8 == 0 && g.ldw % 8 == 0 &&
+  return g_use_gemm256s && g.M >= g_gemm256s_min_m && g.N % 8 == 0 && g.K % 32 == 0 && g.ldc % 8 == 0 && g.lda % 8 == 0 && g.ldw % 8 == 0 &&
          (!g.resid || g.ldr % 4 == 0) && (g.act == ACT_NONE || g.act == ACT_QUICK_GELU) &&
          !(g.out_act && g.out_f32) && (long)256 * g.lda * 4 < (1L << 31) && (long)256 * g.ldw * 4 < (1L << 31);
 }

@@ -49,7 +49,7 @@ int launch_gemm256(const GemmArgs& g, hipStream_t st);  // gemm256.hip: 256x256 
 extern int g_use_gemm256;  // 0 off, 1 default (ping-pong kernel for fp32 outputs, loader-wave kernel otherwise), 3 / 5 pin one of them
 bool gemm256s_eligible(const GemmArgs& g);  // split-fp16 operands, same 256x256 persistent structure
 int launch_gemm256s(const GemmArgs& g, hipStream_t st);
-extern int g_use_gemm256s;
+extern int g_use_gemm256s, g_gemm256s_min_m;
 extern int g_w_dbg;
 extern int g_ln_lean;
 bool gemm_rowln_eligible(const GemmArgs& g);  // gemm256.hip: 128 x 512 full-row kernel, LayerNorm in the epilogue
@@ -238,7 +238,7 @@ int launch_refine_finish(const int* own_off, const int* own_len, const int* coun
 // ---- czc_internal_hooks (declared below, private to the build): what libconzic_hip_test.so may reach inside this library -----------
 // The product library has hidden visibility; the hook library (api_test.hip) gets the launchers it wraps and the
 // process-wide kernel-family switches it flips through this table instead of through exported C++ symbols.
-constexpr int HOOKS_ABI = 0x0505;
+constexpr int HOOKS_ABI = 0x0601;
 struct Hooks {
   char* (*err_buf)();  // the calling host thread's g_err [512]
   decltype(&launch_gemm) gemm;
@@ -257,7 +257,8 @@ struct Hooks {
   decltype(&launch_fold_ln) fold_ln;
   decltype(&gemm_wreg_stats_in_kernel) wreg_stats_ok;
   int *use_gemm256, *use_skinny, *use_splitk, *gemm_deep, *gemm_small_tiles, *use_wreg, *use_gemm256s, *w_dbg, *ln_lean,
-      *rowln_min_m, *wreg_min_m, *gemm256_min_m, *use_mfma_attention, *use_attention_image, *wreg_resid_min_m, *wreg_stats_in_kernel;
+      *rowln_min_m, *wreg_min_m, *gemm256_min_m, *use_mfma_attention, *use_attention_image, *wreg_resid_min_m, *wreg_stats_in_kernel,
+      *gemm256s_min_m;
 };
 
 }  // namespace czc

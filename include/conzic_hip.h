@@ -262,7 +262,7 @@ int czc_generate(czc_engine* e, int B, int T, int L, int seed_len, const int32_t
  *   "share_prefix"    (1) encode the causal prefix common to an image's K candidates once per step instead of K
  *                         times
  *   "dedup"           (1) with "share_prefix": candidates of one image whose CLIP id rows are identical (all the candidates the
- *                         token mask turned into [PAD], gen_utils.py:72-75) are encoded once; bit-identical outputs
+ *                         token mask turned into [PAD], gen_utils.py:72-75) are encoded once and share one feature
  *                         (czc_dedup_stats)
  *   "bert_prune"      (1) n_mask == 1 steps: the last BERT layer behind its attention (out-projection, LayerNorms, MLP) on the
  *                         masked row of every sequence only -- the one row the MLM head reads (gen_utils.py:69)
@@ -318,7 +318,8 @@ int czc_stats(czc_engine* e, int64_t* clip_rows, int64_t* clip_seqs, int64_t* be
 /* Exact de-duplication (option "dedup", default 1): of the *clip_seqs candidate sequences the text tower was asked for since
  * czc_profile_reset, *dedup_seqs had a CLIP id row identical to an earlier candidate of the same image (every candidate the
  * token mask turned into [PAD] decodes to the same caption without the word, gen_utils.py:72-75) and were not encoded
- * again: they take their representative's feature, bit for bit what their own rows would have produced. */
+ * again: they take their representative's feature bit for bit (f32 engine: exactly what their own rows would have produced;
+ * MFMA engines: within the attention tile's packing noise of it, tests/test_step_gpu.py::test_dedup_is_exact). */
 int czc_dedup_stats(czc_engine* e, int64_t* dedup_seqs, int64_t* clip_seqs);
 /* CZC_PREC_REFINE engines: candidate sequences / packed rows re-encoded by the split-fp16 tower since czc_profile_reset
  * (of the clip_seqs / clip_rows the screening pass saw); zero for the other precisions. */
