@@ -108,3 +108,34 @@ def order_positions(order: str, L: int, iters: int, order_list=None, random_posi
         assert len(pos) == L * iters
         return pos, [1] * len(pos), L
     raise ValueError(order)
+
+
+def first_divergence(engine, emb_row, init_row, ref_snaps, got_snaps, L, seed_len, K, hp, positions_per_sweep=None):
+    """Where and how closely one image left a reference trajectory.  `ref_snaps` / `got_snaps`: int32 [S, T] per-sweep snapshots
+    of that image from the reference engine (`engine`, e.g. the all-split one) and from the engine under test, sequential
+    (or `positions_per_sweep`) order.  Replays `engine` ALONE on the image from the last common snapshot up to the first
+    position whose token differs and returns what the reference engine saw there: its top-2 margin and the gap between its
+    winner and the token the other engine wrote -- a gap inside the fused-score bar is a near-tie, i.e. inside the stated
+    tolerance ("identical argmax ids" can only hold where the margin exceeds the error bound).  None if the snapshots agree."""
+    ref_snaps, got_snaps = np.asarray(ref_snaps), np.asarray(got_snaps)
+    diff = np.nonzero((ref_snaps != got_snaps).any(axis=1))[0]
+    if diff.size == 0:
+        return None
+    s = int(diff[0])
+    order = list(positions_per_sweep) if positions_per_sweep is not None else list(range(L))
+    p_idx = next(i for i, p in enumerate(order) if ref_snaps[s][seed_len + p] != got_snaps[s][seed_len + p])
+    cur = np.ascontiguousarray((ref_snaps[s - 1] if s > 0 else np.asarray(init_row))[None, :], dtype=np.int32).copy()
+    engine.set_image_embeds(np.ascontiguousarray(emb_row[None, :], dtype=np.float32))
+    r = None
+    for i in range(p_idx + 1):
+        p = order[i]
+        r = engine.step(cur, seed_len + p, K, hp, dot_allowed=(p == L - 1), want=("cand_ids", "final_score", "best"))
+        if i < p_idx and cur[0, seed_len + p] != ref_snaps[s][seed_len + p]:
+            return dict(sweep=s, position=int(p), replay_mismatch=True)  # the single-image replay left the batch's trajectory itself
+    fin, cand = r["final_score"][0], r["cand_ids"][0]
+    srt = np.sort(fin)[::-1]
+    other = int(got_snaps[s][seed_len + order[p_idx]])
+    where = np.nonzero(cand == other)[0]
+    gap = float(srt[0] - fin[where].max()) if where.size else None
+    return dict(sweep=s, position=int(order[p_idx]), reference_top2_margin=float(srt[0] - srt[1]),
+                gap_to_other_engines_choice=gap, other_choice_rank=(int((fin > fin[where].max()).sum()) if where.size else None))

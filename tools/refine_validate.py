@@ -65,7 +65,7 @@ GEN_SWEEPS = int(os.environ.get("GEN_SWEEPS", "3"))
 init = ref.bert_tok.encode("Image of a" + ref.bert_tok.mask_token * L)
 gpos, gnm, gevery = harness.order_positions("sequential", L, GEN_SWEEPS)
 ref_ids, ref_cos = ref.engine.generate(B, init, L, SEED_LEN, K, gpos, hp, n_mask=gnm, snapshot_every=gevery)
-ref.engine.close()
+# (the split engine stays open: images that leave its trajectory below are replayed on it alone)
 
 su = build(native.PREC_REFINE)
 for kv in filter(None, os.environ.get("CZC_OPTS", "").split(",")):  # engine options of the refine engine under test, "name=value,..."
@@ -111,16 +111,21 @@ for gate in [int(v) for v in os.environ.get("GATES", "400,0").split(",")]:
     st = su.engine.stats()
     gd = su.engine.refine_guard(reset=True)
     same_img = (ids == ref_ids).all(axis=(0, 2))
+    # every image that left the split engine's trajectory: where, and how close the split engine's own decision was there
+    divergences = [dict(image=int(b_), **harness.first_divergence(ref.engine, emb[b_], init, ref_ids[:, b_], ids[:, b_], L, SEED_LEN, K, hp))
+                   for b_ in np.nonzero(~same_img)[0]]
     ROWS16_FACTOR = next((int(kv.split("=")[1]) / 1000 for kv in os.environ.get("CZC_OPTS", "").split(",") if kv.startswith("refine_rows16_x1000=")), 1.75)
     rows16 = "refine_rows16=0" not in os.environ.get("CZC_OPTS", "")  # the engine default: screening pass of czc_generate on fp16 rows
     print(json.dumps(dict(mode="generate", draw=DRAW, gate_delta=gate * 1e-6, screening_rows="fp16" if rows16 else "fp32",
                           gate_delta_effective=gate * 1e-6 * (ROWS16_FACTOR if rows16 else 1.0), images=B, sweeps=GEN_SWEEPS, image_steps=B * len(gpos),
                           images_with_identical_ids=int(same_img.sum()), ids_identical=bool((ids == ref_ids).all()),
+                          divergences=divergences,
                           max_abs_dcos_snapshots=float(np.abs(cos - ref_cos)[:, same_img].max()) if same_img.any() else None,
                           gated_frac=round(st["gated_image_steps"] / max(st["gate_image_steps"], 1), 4),
                           re_encoded_seq_frac=round(st["refine_seqs"] / max(st["clip_seqs"], 1), 4),
                           re_encoded_row_frac=round(st["refine_rows"] / max(st["clip_rows"], 1), 4),
                           guard_max_dev=gd["max_dev"], guard_tripped_image_steps=gd["tripped"])), flush=True)
 su.engine.close()
+ref.engine.close()
 sys.stdout.flush()
 os._exit(0)
