@@ -560,7 +560,7 @@ def main():
         # command (not measurable inside the run); only quoted for the workload and precision they were taken on
         traffic, src = None, None
         key = {native.PREC_BF16: "bf16", native.PREC_REFINE: "refine"}.get(prec_)
-        for tp in ("r05_bench_gemm_traffic.json", "r04_bench_gemm_traffic.json", "r03_bench_gemm_traffic.json"):
+        for tp in ("r06_bench_gemm_traffic.json", "r05_bench_gemm_traffic.json", "r04_bench_gemm_traffic.json", "r03_bench_gemm_traffic.json"):
             tp = os.path.join(ROOT, "profiles", tp)
             if key and os.path.exists(tp) and (a.images, L, K, I, a.order, a.gamma, a.total_images) == (256, 10, 200, 10, "sequential", None, None):
                 tj = json.load(open(tp))

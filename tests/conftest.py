@@ -72,6 +72,16 @@ def pytest_terminal_summary(terminalreporter):
                                     "engine, guard max_dev, tripped / image-steps):")
         for f_, worst, dev, trips, n in olog:
             terminalreporter.write_line(f"  x{f_:<5g} {worst:.3e}  {dev:.3e}  {trips}/{n}")
+    slog = getattr(mod, "SOFT_LOG", None)
+    if slog:
+        terminalreporter.write_line("tiny towers, half-precision engines: steps whose winner flipped at a near-tie (case precision: flips / steps): "
+                                    + ", ".join(f"{n_} {p_} {s_}/{t_}" for n_, p_, s_, t_ in slog))
+    ddlog = getattr(mod, "DEDUP_LOG", None)
+    if ddlog:
+        terminalreporter.write_line("exact de-duplication on a trained-like MLM head (precision, images: candidates riding on an identical one / all, "
+                                    "text-tower rows with / without the option):")
+        for prec, B_, dd, seqs, ra_, rb_ in ddlog:
+            terminalreporter.write_line(f"  prec={prec} B={B_:<3d} {dd}/{seqs} = {dd / max(seqs, 1):.3f}   rows {ra_}/{rb_} = {ra_ / max(rb_, 1):.3f}")
     wlog = getattr(mod, "DRAW_LOG", None)
     if wlog:
         terminalreporter.write_line("screen-then-refine heuristics on other weight draws, against the all-split engine (draw: czc_step worst "

@@ -221,6 +221,7 @@ def test_step_parity_tiny_bf16(name):
     # near-tie winners may flip in bf16 on the tiny towers (64-wide rows: cosines quantise coarsely; the bar there is 2.5e-2);
     # the hard asserts are inside check_step.  A flip at more than half of the steps would mean the tolerance rule, not the
     # arithmetic, is carrying the test (measured: see the [soft] lines of the GPU run)
+    SOFT_LOG.append((name, "bf16", soft, n))
     print(f"[soft] {name} bf16: {soft}/{n} steps with a near-tie winner flip")
     assert soft <= (n + 1) // 2
 
@@ -626,6 +627,8 @@ def test_refine_guard_catches_towers_the_fp16_screening_pass_does_not_carry():
     assert seen_trip, OUTLIER_LOG  # the emulated outliers are strong enough to exercise the guard at all
 
 
+DEDUP_LOG = []  # (precision, images, de-duplicated candidate sequences, candidate sequences, rows with / without the option)
+SOFT_LOG = []   # (case, precision, steps with a near-tie winner flip, steps)
 DRAW_LOG = []  # (draw, worst |d final| czc_step, guard max_dev in czc_generate, images with identical ids, images, tripped)
 
 
@@ -731,6 +734,7 @@ def test_refine_engine_encode_text_and_images_are_exact():
 def test_step_parity_tiny_fp16(name):
     meta, arr = load_case(name)
     soft, n = teacher_forced(meta, arr, FP16)
+    SOFT_LOG.append((name, "fp16", soft, n))
     print(f"[soft] {name} fp16: {soft}/{n} steps with a near-tie winner flip")
     assert soft <= max(1, n // 4)
 
@@ -1016,6 +1020,7 @@ def test_dedup_is_exact(prec, B):
         assert sb["dedup_seqs"] == 0 and sa["dedup_seqs"] >= sum(p_ - B for p_ in pads)
         assert sa["clip_seqs"] == sb["clip_seqs"] == 3 * B * K
         assert sa["clip_rows"] < sb["clip_rows"]
+        DEDUP_LOG.append((prec, B, sa["dedup_seqs"], sa["clip_seqs"], sa["clip_rows"], sb["clip_rows"]))
         print(f"[dedup] prec {prec} B {B}: {sa['dedup_seqs']} of {sa['clip_seqs']} candidates ride on an identical one; "
               f"text-tower rows {sa['clip_rows']} vs {sb['clip_rows']} ({sa['clip_rows'] / sb['clip_rows']:.3f})")
         cos_tol = {F32: 0.0, SPLIT: 2e-6, BF16: 1e-3, REFINE: 4e-4}[prec]      # packing noise of the precision (test_prefix_sharing_is_exact's bars)
