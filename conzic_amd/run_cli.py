@@ -107,6 +107,8 @@ def main(argv=None):
         import torch.distributed as tdist
         if torch.cuda.is_available():
             torch.cuda.set_device(local % torch.cuda.device_count())
+            # host resources of this rank: the CPUs of its GPU's NUMA node, torch threads and scorer workers to match
+            logger.info(f"rank {rank}: host share {czd.pin_rank(local, device_index=local % torch.cuda.device_count())}")
         if not tdist.is_initialized():
             tdist.init_process_group(os.environ.get("CZC_DIST_BACKEND", "nccl"))
     all_batches = list(batches(names, args.batch_size))

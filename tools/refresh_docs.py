@@ -14,7 +14,7 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = "r05"
+ROUND = "r06"
 P = os.path.join(ROOT, "profiles")
 
 
@@ -155,6 +155,73 @@ def block_status(f):
     return "\n".join(rows)
 
 
+# kernel-name pattern -> (what it is in the step, what bounds it, work model)
+#   work model: ("gemm", N, Kdim, which rows) FLOPs = 2 * rows * N * Kdim per pass;  ("bytes", bytes per row, which rows);  None
+KERNELS = [
+    (r"gemm_wreg_kernel<1,", "fc1 512->2048 + quick-GELU, LayerNorm folded in (weights in registers, `gemm_wreg.hip`)", "MFMA", ("gemm", 2048, 512, "mlp")),
+    (r"gemm256x_kernel<0, true, (false|true), 256>", "fc2 2048->512 + residual on fp16 rows (256x256 ping-pong ring, `gemm256.hip`)", "MFMA", ("gemm", 512, 2048, "mlp")),
+    (r"gemm_wreg_kernel<0,", "q/k/v 512->1536, LayerNorm folded in (weights in registers)", "MFMA", ("gemm", 1536, 512, "all")),
+    (r"attention_image_kernel", "branch attention, one work-group per (image, 4 heads) (`attention.hip`)", "HBM: 4 KB per row (q, k, v in, context out)", ("bytes", 4096, "all")),
+    (r"gemm_wreg_resid_kernel", "out-projection 512->512 + residual, x updated in place, LayerNorm partials out", "HBM: 3 KB per row (context, x in, x out; the second column group's context read hits L2)", ("gemmbytes", 512, 512, "mlp", 3072)),
+    (r"gemm_kernel<czc::split_t, 0, true, false, 128>", "BERT q/k/v and fc2 slices (split-fp16, 3 MFMA passes, 128x128 tiles, `gemm.hip`)", "latency / tile count (180-540 tiles)", None),
+    (r"gemm_kernel<czc::split_t, 2, true, false, 128>", "BERT fc1 + GELU", "latency / tile count", None),
+    (r"gemm_kernel<czc::split_t, 0, true, true, 64>", "BERT out-projection (64-wide tiles), pruned last layer", "latency", None),
+    (r"attention_mfma_split_kernel", "BERT attention (split-fp16)", "latency", None),
+    (r"ln_finalize_kernel", "(mean, rstd) per row from the producers' 16 partial sums", "HBM: 136 B per row", ("bytes", 136, "all2")),
+    (r"layernorm_kernel<czc::split_t>", "BERT residual + LayerNorm", "HBM", None),
+    (r"clip_embed_kernel", "token + position embedding -> fp16 rows + LayerNorm statistics of layer 0", "HBM (fp32 table rows in, fp16 rows out)", None),
+    (r"bridge_kernel", "WordPiece decode -> CLIP BPE ids, control scores (`bridge.hip`)", "latency", None),
+    (r"attention_mfma_kernel", "trunk attention (one wave per image and head)", "latency", None),
+    (r"splitk_reduce_kernel", "BERT fc2: sum of the K slices + bias + residual", "HBM", None),
+    (r"softmax_mask_topk_kernel", "softmax(logits / tau) * mask -> top-K (`topk.hip`)", "HBM: 122 KB per image", None),
+    (r"scan_kernel", "exclusive scan of the segment lengths", "latency (one work-group)", None),
+    (r"gemm_kernel<czc::split_t, 0, false, false, 128>", "MLM decoder 768->30522 on the masked rows", "weight streaming", None),
+    (r"cosine_kernel", "cosine of every candidate with its image", "HBM", None),
+    (r"combine_kernel", "softmax_K, fusion, first argmax, write-back (`combine.hip`)", "latency", None),
+    (r"prefix_plan_kernel", "shared-prefix plan + exact de-duplication", "latency", None),
+]
+
+
+def block_kernels(f):
+    """what runs in one caption batch of configs[2] on ONE stream, from the rocprofv3 kernel stats of
+    `bench.py --streams 1 --steps 2 --warmup 1` (4 caption batches in the process) and the workload's row counts."""
+    import csv
+    path = os.path.join(P, f"{ROUND}_bench_bf16_kernel_stats.csv")
+    dflt = jload(f"{ROUND}_bench_default.json") or jload(f"{ROUND}_bench_driver_cmd.json")
+    if not os.path.exists(path) or not dflt:
+        return "(no kernel stats collected for this round yet)"
+    rows = list(csv.DictReader(open(path)))
+    total_ns = sum(float(r["TotalDurationNs"]) for r in rows)
+    batches = 4
+    R = dflt["clip_rows_per_step"]                        # packed text-tower rows of one caption batch (sum over its 100 position-steps)
+    S = dflt["config"]["images_per_gpu"] * dflt["config"]["candidate_k"] * dflt["config"]["sentence_len"] * dflt["config"]["num_iterations"]
+    which = {"all": 12 * R, "mlp": 11 * R + S, "all2": 23 * R}   # rows a kernel class sees per caption batch (last layer: EOS rows only)
+    out = ["| kernel | role | launches per caption batch | mean us | share of GPU time | achieved | bound |", "|---|---|---|---|---|---|---|"]
+    shown = 0.0
+    for pat, role, bound, work in KERNELS:
+        hit = [r for r in rows if re.search(pat, r["Name"])]
+        if not hit:
+            continue
+        ns = sum(float(r["TotalDurationNs"]) for r in hit)
+        calls = sum(int(r["Calls"]) for r in hit)
+        ach = ""
+        if work and work[0] in ("gemm", "gemmbytes"):
+            fl = 2.0 * which[work[3]] * work[1] * work[2] * batches
+            ach = f"{fl / ns / 1e3:.0f} TFLOP/s = {fl / ns / 1e3 / 2500:.2f} of peak"
+            if work[0] == "gemmbytes":
+                ach += f"; {which[work[3]] * work[4] * batches / ns / 1e3:.1f} TB/s"
+        elif work and work[0] == "bytes":
+            ach = f"{which[work[2]] * work[1] * batches / ns / 1e3:.1f} TB/s"
+        name = re.sub(r"\(anonymous namespace\)::|czc::|void ", "", hit[0]["Name"]).split("(")[0]
+        out.append(f"| `{name}` | {role} | {calls // batches} | {ns / calls / 1e3:.0f} | {100 * ns / total_ns:.1f} % | {ach} | {bound} |")
+        shown += ns
+    out.append(f"| everything else ({len(rows)} kernel names in all) | | | | {100 * (total_ns - shown) / total_ns:.1f} % | | |")
+    out.append("")
+    out.append(f"GPU time of one caption batch on one stream: {total_ns / batches / 1e6:.0f} ms over {sum(int(r['Calls']) for r in rows) // batches} launches; "
+               f"{R / 1e6:.1f} M packed rows x 12 layers (the reference would run {S * 15 / 1e6:.1f} M).")
+    return "\n".join(out)
+
+
 def block_header(f):
     """The measured figures of the precision comments in include/conzic_hip.h (C comment lines)."""
     lines = [
@@ -171,6 +238,7 @@ def block_header(f):
 TARGETS = [
     ("README.md", "status", block_status, "<!-- {} GENERATED {} -->"),
     ("DESIGN.md", "status", block_status, "<!-- {} GENERATED {} -->"),
+    ("DESIGN.md", "kernels", block_kernels, "<!-- {} GENERATED {} -->"),
     ("include/conzic_hip.h", "measured", block_header, " * {} GENERATED {}"),
 ]
 
