@@ -422,6 +422,9 @@ CASES = dict(
     # POS control on full-size towers (control_gen_utils.py:136-195), the template demo.py:40-45 ships
     full_senti_ctx=dict(tiny=False, B=2, L=12, K=200, I=1, order="sequential", image="synthetic", gamma=5.0, style="positive",
                         ctx=True),
+    # sentiment_shuffle_generation (control_gen_utils.py:82-134) at full size, negative style, the reference's own scorer
+    full_senti_shuffle_neg_ctx=dict(tiny=False, B=2, L=12, K=200, I=1, order="shuffle", image="synthetic", gamma=5.0, style="negative",
+                                    ctx=True),
     full_pos_ctx=dict(tiny=False, B=2, L=10, K=200, I=1, order="sequential", image="synthetic", gamma=5.0, ctx=True,
                       pos=[["DET"], ["ADJ", "NOUN"], ["NOUN"], ["VERB"], ["VERB"], ["ADV"], ["ADP"], ["DET", "NOUN"], ["NOUN"],
                            ["NOUN", "."], [".", "NOUN"], [".", "NOUN"]]),

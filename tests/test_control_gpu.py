@@ -28,7 +28,7 @@ pytestmark = pytest.mark.gpu
 SEED_LEN = 4
 F32 = native.PREC_F32
 CTX_TINY = ["tiny_senti_ctx", "tiny_senti_ctx_neg", "tiny_pos_ctx"]
-CTX_FULL = ["full_senti_ctx", "full_pos_ctx"]
+CTX_FULL = ["full_senti_ctx", "full_pos_ctx", "full_senti_shuffle_neg_ctx"]
 FLIPS = []  # (case, mode, flipped winners, image-steps): printed by conftest at the end of the run
 OVERLAP = []  # (step ms, scorer cost ms per step, wall-time ratio against the free scorer)
 
@@ -76,8 +76,7 @@ def _call_like_demo_py(meta, lm, clip, tok, imgs, mask):
     return control_generate_caption(names, lm, clip, tok, imgs, mask, logging.getLogger("control-test"), **kw)
 
 
-@pytest.mark.parametrize("mode", [None, "exact"])
-@pytest.mark.parametrize("name", CTX_TINY)
+@pytest.mark.parametrize("mode,name", [(m_, n_) for n_ in CTX_TINY for m_ in (None, "exact")] + [(None, "full_senti_shuffle_neg_ctx")])
 def test_default_mode_reproduces_the_reference_captions(name, mode, standin, monkeypatch):
     """control_generate_caption called as demo.py calls it, nothing configured (CZC_CONTROL unset = auto) or
     CZC_CONTROL=exact: the captions and scores the reference produced with its own nltk scorers (context-dependent

@@ -448,7 +448,8 @@ def test_visiting_orders_and_partitions_hold_their_invariants():
     parts()
 
 
-@pytest.mark.parametrize("name", ["tiny_senti_ctx", "tiny_senti_ctx_neg", "tiny_pos_ctx", "full_senti_ctx", "full_pos_ctx"])
+@pytest.mark.parametrize("name", ["tiny_senti_ctx", "tiny_senti_ctx_neg", "tiny_pos_ctx", "full_senti_ctx", "full_pos_ctx",
+                                  "full_senti_shuffle_neg_ctx"])
 def test_host_control_scorer_reproduces_the_reference_scores(name):
     """The product's exact-mode scorer (conzic_amd/control.py: what `czc_set_control_callback` calls once per step) on the
     candidate rows of the `*_ctx` goldens: the raw control score of every candidate equals what the reference's UNCHANGED

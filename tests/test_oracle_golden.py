@@ -110,7 +110,8 @@ def test_oracle_imageproc_matches_reference_processor(label, S):
 
 
 @pytest.mark.parametrize("name,step", [("full_scale100", 6), ("full_senti", 7), ("full_shuffle_k512", 3), ("full_pos", 5),
-                                       ("full_senti_ctx", 6), ("full_pos_ctx", 4), ("full_span", 4), ("full_random", 5)])
+                                       ("full_senti_ctx", 6), ("full_pos_ctx", 4), ("full_span", 4), ("full_random", 5),
+                                       ("full_senti_shuffle_neg_ctx", 5)])
 def test_oracle_full_size_mid_trajectory_step(name, step):
     """The oracle on the full-size goldens added for the published logit scale (x100, clip/clip.py:95-98), the
     sentiment control path at configs[4] shape (gamma=5, L=12; control_gen_utils.py:53-63) and configs[3] shape
