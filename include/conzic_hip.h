@@ -340,8 +340,10 @@ int czc_refine_guard(czc_engine* e, int reset, float* max_dev, int64_t* tripped)
  * "refine_gate_x1e6" * 1e-6, default 400 = 2x the largest deviation measured over 256 k candidates; the check is the
  * adversarial one: winner's logit down, challenger's up, the rest both ways) needs no second pass for its id; at a snapshot
  * step its winner alone is re-encoded, for the cosine the call returns.  Image-steps that fail the gate take the full selection,
- * and so does every image at the snapshot step of every fourth sweep (the first included): the audit steps on which the guard
- * above keeps measuring the screening tower.
+ * and so does every image at the snapshot step of every fourth sweep (the first included) -- whether or not the caller passes
+ * out_cos -- and, in a call too short to reach a snapshot step, at its last step: the audit steps on which the guard above keeps
+ * measuring the screening tower.  The gate is the guard's dependant: with "refine_guard_x1e6" = 0 nothing polices the bound the
+ * gate rests on and nothing is gated.
  * czc_step never gates: all K scores are its output and all of them are refined.  *gated of *image_steps since
  * czc_profile_reset. */
 int czc_refine_gate_stats(czc_engine* e, int64_t* gated, int64_t* image_steps);
