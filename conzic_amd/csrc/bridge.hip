@@ -280,6 +280,7 @@ __global__ __launch_bounds__(256) void prefix_plan_kernel(const int* cids, const
                                                           int* max_len_out, int* img_max, int* rep, int* n_dup_out) {
   __shared__ int s_p, s_max, s_keys, s_dup;
   __shared__ unsigned long long s_hash[1024];  // K <= CZC_MAX_TOPK
+  __shared__ short s_len[1024];                 // sequence lengths (<= 77)
   const int b = blockIdx.x, tid = threadIdx.x;
   if (tid == 0) { s_p = 1 << 30; s_max = 0; s_keys = 0; s_dup = 0; }
   __syncthreads();
@@ -297,7 +298,8 @@ __global__ __launch_bounds__(256) void prefix_plan_kernel(const int* cids, const
     if (rep) {
       unsigned long long h = 1469598103934665603ull ^ (unsigned)lk;
       for (int c2 = 0; c2 < lk; ++c2) { h ^= (unsigned)rk[c2]; h *= 1099511628211ull; }
-      s_hash[k] = h;
+      s_hash[k] = h;   // (the length is part of the hash: equal hashes of unequal lengths are caught by the id compare below)
+      s_len[k] = (short)lk;
     }
   }
   atomicMin(&s_p, p);
@@ -314,16 +316,16 @@ __global__ __launch_bounds__(256) void prefix_plan_kernel(const int* cids, const
   int dups = 0;
   for (int k = tid; k < K; k += blockDim.x) {
     const int s = B + b * K + k;
-    int own = clen[b * K + k] - pb;
+    const int lk = clen[b * K + k];
+    int own = lk - pb;
     if (rep) {
       int r = k;
       const unsigned long long hk = s_hash[k];
-      const int lk = clen[b * K + k];
       const int* rk = r0 + (long)k * BR_LEN;
-      for (int j = 0; j < k; ++j) {
-        if (s_hash[j] != hk || clen[b * K + j] != lk) continue;
+      for (int j = 0; j < k; ++j) {          // LDS only until a hash matches (K^2 / 512 compares per thread)
+        if (s_hash[j] != hk || s_len[j] != lk) continue;
         const int* rj = r0 + (long)j * BR_LEN;
-        int c = 0;
+        int c = pb;                            // the first pb ids are the image's common prefix: equal by construction
         while (c < lk && rj[c] == rk[c]) ++c;
         if (c == lk) { r = j; break; }  // the lowest identical candidate is the representative (it is its own: rep[j] == j)
       }
