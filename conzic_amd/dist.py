@@ -61,11 +61,13 @@ def gpu_numa_node(device_index: int, sysfs: str = "/sys") -> Optional[int]:
 
 
 def rank_cpu_share(local_rank: int, local_world: int, node: Optional[int] = None, sysfs: str = "/sys",
-                   allowed: Optional[List[int]] = None) -> List[int]:
+                   allowed: Optional[List[int]] = None, peers_on_node: Optional[List[int]] = None) -> List[int]:
     """CPUs rank `local_rank` of `local_world` ranks on this host should run on.  With the NUMA node of its GPU known: the
-    CPUs of that node, cut into ceil(local_world / nodes) slices and indexed by local_rank modulo that count (GPUs are spread
-    evenly over the nodes on the 8-GPU boxes: 4 per socket).  Without NUMA information: slice local_rank of local_world equal
-    slices of the allowed CPUs.  Always at least one CPU; always a subset of `allowed` (the current affinity mask)."""
+    CPUs of that node, cut into one slice per rank whose GPU sits on the same node -- `peers_on_node` (the local ranks on that
+    node, in order; `pin_rank` reads it from sysfs for every visible GPU) or, when that is not known, ceil(local_world / nodes)
+    slices indexed by local_rank modulo that count (GPUs spread evenly and in order over the nodes: 4 per socket on the 8-GPU
+    boxes).  Without NUMA information: slice local_rank of local_world equal slices of the allowed CPUs.  Always at least one
+    CPU; always a subset of `allowed` (the current affinity mask)."""
     if allowed is None:
         try:
             allowed = sorted(os.sched_getaffinity(0))
@@ -80,8 +82,11 @@ def rank_cpu_share(local_rank: int, local_world: int, node: Optional[int] = None
             mine = [c for c in allowed if c in on_node]
             if mine:
                 cpus = mine
-                per_node = max(1, -(-local_world // max(1, nodes)))   # ranks per node, rounded up
-                slices, idx = per_node, local_rank % per_node
+                if peers_on_node and local_rank in peers_on_node:
+                    slices, idx = len(peers_on_node), peers_on_node.index(local_rank)
+                else:
+                    per_node = max(1, -(-local_world // max(1, nodes)))   # ranks per node, rounded up
+                    slices, idx = per_node, local_rank % per_node
         except OSError:
             pass
     q, r = divmod(len(cpus), slices)
@@ -99,8 +104,14 @@ def pin_rank(local_rank: int, device_index: Optional[int] = None, set_torch_thre
     info: Dict[str, object] = dict(local_world=lw, pinned=False)
     if lw <= 1 or os.environ.get("CZC_PIN", "1") == "0":
         return info
-    node = gpu_numa_node(local_rank if device_index is None else device_index)
-    cpus = rank_cpu_share(local_rank, lw, node)
+    dev = local_rank if device_index is None else device_index
+    node = gpu_numa_node(dev)
+    peers = None
+    if node is not None and dev == local_rank:   # rank r <-> GPU r (one process per GPU): which local ranks share this node
+        nodes_of = [gpu_numa_node(i) for i in range(lw)]
+        if all(n is not None for n in nodes_of):
+            peers = [i for i in range(lw) if nodes_of[i] == node]
+    cpus = rank_cpu_share(local_rank, lw, node, peers_on_node=peers)
     try:
         os.sched_setaffinity(0, cpus)
         info.update(pinned=True)

@@ -146,6 +146,12 @@ def test_rank_cpu_shares_partition_the_numa_nodes(tmp_path):
     assert len(set(flat)) == 256                                    # disjoint and complete
     n0 = set(czd._parse_cpulist("0-63,128-191"))
     assert all(set(shares[r]) <= n0 for r in range(4)) and all(not (set(shares[r]) & n0) for r in range(4, 8))
+    # GPUs interleaved over the sockets (0, 1, 4, 5 on node 0): the slice index comes from the rank's place among its node's ranks
+    on0, on1 = [0, 1, 4, 5], [2, 3, 6, 7]
+    inter = [czd.rank_cpu_share(r, 8, node=0 if r in on0 else 1, sysfs=str(tmp_path), allowed=allowed,
+                                peers_on_node=on0 if r in on0 else on1) for r in range(8)]
+    assert len({c for s_ in inter for c in s_}) == 256 and all(len(s_) == 32 for s_ in inter)
+    assert all(set(inter[r]) <= n0 for r in on0) and all(not (set(inter[r]) & n0) for r in on1)
     plain = [czd.rank_cpu_share(r, 8, node=None, allowed=list(range(20))) for r in range(8)]
     assert sorted(c for s in plain for c in s) == list(range(20)) and max(map(len, plain)) - min(map(len, plain)) <= 1
     assert czd.rank_cpu_share(5, 8, node=None, allowed=[3, 4]) in ([3], [4])    # fewer CPUs than ranks: still one each
