@@ -75,25 +75,9 @@ __global__ __launch_bounds__(TK_THREADS) void softmax_mask_topk_kernel(const flo
     for (int i = tid; i < 256; i += TK_THREADS) hist[i] = 0;
     __syncthreads();
     const unsigned himask = shift == 24 ? 0u : (0xFFFFFFFFu << (shift + 8));
-    // One LDS atomic per element serialises on the hot bin: in the first pass nearly every probability has the same top
-    // byte (30 k atomics on one address = most of this kernel's time at one image).  A wave whose matching lanes all fall
-    // into ONE bin adds their count with a single atomic; mixed waves take the per-lane path.  Counts are integers: the
-    // histogram, and with it every output, is what the per-element form produces.
-    for (int base = 0; base < V; base += TK_THREADS) {
-      const int i = base + tid;
-      const unsigned u = i < V ? pu[i] : 0u;
-      const bool match = i < V && (u & himask) == prefix;
-      const unsigned bin = (u >> shift) & 255u;
-      const unsigned long long m = __ballot(match);
-      if (m == 0ull) continue;  // uniform over the wave
-      const int first = __ffsll((long long)m) - 1;
-      const unsigned b0 = (unsigned)__shfl((int)bin, first, 64);
-      const unsigned long long same = __ballot(match && bin == b0);
-      if (same == m) {
-        if ((threadIdx.x & 63) == first) atomicAdd(&hist[b0], (unsigned)__popcll(m));
-      } else if (match) {
-        atomicAdd(&hist[bin], 1u);
-      }
+    for (int i = tid; i < V; i += TK_THREADS) {
+      const unsigned u = pu[i];
+      if ((u & himask) == prefix) atomicAdd(&hist[(u >> shift) & 255u], 1u);
     }
     __syncthreads();
     if (tid == 0) {
