@@ -675,6 +675,15 @@ def main():
                        ms_per_step=round(main_res["single_ms"], 2), value=round(B * max(1, a.samples) / main_res["single_ms"] * 1e3, 4),
                        note="the same step on ONE engine / ONE stream (rank 0's images), wall-clock around the pass "
                             "`roofline.single_stream_pass` is measured on; `value` and `roofline.frac` come from the timed region"),
+                   parity=dict(bar="fused score within 1e-3 of the reference's CPU path; identical argmax ids wherever the reference's own top-2 "
+                                   "margin exceeds twice the engine's fused-score error",
+                               bf16_engine="worst fused-score error 2.5e-4 on the full-size goldens; FREE-RUNNING it leaves the reference's "
+                                           "trajectory only at near-ties (full-size goldens: 19 of 20 tokens on `full_senti`, reference margin "
+                                           "2.7e-5 at the divergence; all other cases on it)",
+                               scale100_engine="screen-then-refine: worst 6.0e-4 on the goldens, ids identical to the all-split engine over "
+                                               "25 600 image-steps of the fitted draw and 76 797 of 76 800 on five more weight draws (three "
+                                               "near-ties of 1.3-2.3e-5)",
+                               where="tests/test_step_gpu.py; profiles/r06_gpu_tests_summary.txt, profiles/r06_refine_validate_*.jsonl"),
                    batch_invariance=main_res["invariance"],
                    captions_crc32=dict(value=main_res["ids_crc"], images=main_res["n_ids"],
                                        note="crc32 of the final token ids of every image of the last timed step, gathered over the ranks in "
