@@ -121,6 +121,7 @@ struct czc_engine {
   int last_BT = 0, last_B = 0, last_T = 0;  // shape of the forward whose rows b_x / b_xg hold (n_mask = 0 re-use needs the same B AND T)
   int bert_prune = 1;       // last BERT layer behind the attention on the one row per sequence the MLM head reads (n_mask == 1 steps)
   int bert_pruned_idx = -1; // row the previous forward kept (-1: all rows of b_x are valid)
+  int bert_fuse_splitk_ln = 1;  // BERT fc2: the LayerNorm kernel sums the split-K slabs itself (no reduce kernel); 0 = two kernels
   int share_prefix = 1;  // encode the candidates' common causal prefix once per image
   int dedup = 1;         // candidates of one image with identical CLIP id rows are encoded once (bridge.hip prefix_plan_kernel; exact)
   float* d_staged = nullptr; int staged_cap = 0, staged_n = 0;  // czc_preprocess_u8 output slots [cap][3][S][S]
@@ -476,6 +477,21 @@ int bert_forward(czc_engine* e, const int* d_inp, int B, int T, int keep_idx = -
     E_CHECK(launch_bert_embed(P, d_inp, B, T, H, word, pos, typ, g, b, c.bert_eps, xa, x, e->st)); }
   const float scale = 1.0f / sqrtf(64.0f);
   e->bert_pruned_idx = -1;
+  // fc2 + residual + LayerNorm (HF:bert/modeling_bert.py:488-496): xr <- LN(xr + h.W2^T + b), xa <- the same in the operand type.
+  // Where the launcher splits K (fc2's K = 3072 at every row count above the skinny kernel's 32) the slice sums stay in its slab
+  // workspace and the LayerNorm kernel sums them itself (GemmArgs::splitk_pending): one launch less per layer, no fp32 round trip
+  auto fc2_ln = [&](const void* h, LayerW& l, float* xr, int rows) -> int {
+    SplitkPending pend;
+    GemmArgs g;
+    g.A = h; g.lda = I; g.W = l.fc2_w; g.ldw = I; g.bias = l.fc2_b; g.resid = xr; g.ldr = H; g.out_act = nullptr; g.out_f32 = tmp; g.ldc = H;
+    g.M = rows; g.N = H; g.K = I; g.act = ACT_NONE;
+    g.splitk_pending = e->bert_fuse_splitk_ln ? &pend : nullptr;
+    E_CHECK(gemm_ex(e, P, "gemm_bert", g));
+    ProfScope ps(e, "rowops", 0);
+    if (pend.nslab > 0) E_CHECK(launch_layernorm_splitk(P, pend, l.fc2_b, xr, H, l.ln2_g, l.ln2_b, c.bert_eps, rows, H, xa, xr, e->st));
+    else E_CHECK(launch_layernorm(P, tmp, nullptr, l.ln2_g, l.ln2_b, c.bert_eps, rows, H, xa, xr, e->st));
+    return 0;
+  };
   for (int n = 0; n < c.bert_layers; ++n) {
     LayerW& l = e->bert[n];
     E_CHECK(gemm(e, P, "gemm_bert", xa, H, l.qkv_w, H, l.qkv_b, nullptr, 0, qkv, nullptr, 3 * H, M, 3 * H, H, ACT_NONE));
@@ -495,16 +511,14 @@ int bert_forward(czc_engine* e, const int* d_inp, int B, int T, int keep_idx = -
       E_CHECK(gemm(e, P, "gemm_bert", ctx_g, H, l.o_w, H, l.o_b, x_g, H, nullptr, tmp, H, B, H, H, ACT_NONE));
       { ProfScope ps(e, "rowops", 0); E_CHECK(launch_layernorm(P, tmp, nullptr, l.ln1_g, l.ln1_b, c.bert_eps, B, H, xa, x_g, e->st)); }
       E_CHECK(gemm(e, P, "gemm_bert", xa, H, l.fc1_w, H, l.fc1_b, nullptr, 0, hbuf, nullptr, I, B, I, H, ACT_GELU_ERF));
-      E_CHECK(gemm(e, P, "gemm_bert", hbuf, I, l.fc2_w, I, l.fc2_b, x_g, H, nullptr, tmp, H, B, H, I, ACT_NONE));
-      { ProfScope ps(e, "rowops", 0); E_CHECK(launch_layernorm(P, tmp, nullptr, l.ln2_g, l.ln2_b, c.bert_eps, B, H, xa, x_g, e->st)); }
+      E_CHECK(fc2_ln(hbuf, l, x_g, B));
       e->bert_pruned_idx = keep_idx;
       break;
     }
     E_CHECK(gemm(e, P, "gemm_bert", ctx, H, l.o_w, H, l.o_b, x, H, nullptr, tmp, H, M, H, H, ACT_NONE));
     { ProfScope ps(e, "rowops", 0); E_CHECK(launch_layernorm(P, tmp, nullptr, l.ln1_g, l.ln1_b, c.bert_eps, M, H, xa, x, e->st)); }
     E_CHECK(gemm(e, P, "gemm_bert", xa, H, l.fc1_w, H, l.fc1_b, nullptr, 0, hbuf, nullptr, I, M, I, H, ACT_GELU_ERF));
-    E_CHECK(gemm(e, P, "gemm_bert", hbuf, I, l.fc2_w, I, l.fc2_b, x, H, nullptr, tmp, H, M, H, I, ACT_NONE));
-    { ProfScope ps(e, "rowops", 0); E_CHECK(launch_layernorm(P, tmp, nullptr, l.ln2_g, l.ln2_b, c.bert_eps, M, H, xa, x, e->st)); }
+    E_CHECK(fc2_ln(hbuf, l, x, M));
   }
   return 0;
 }
@@ -980,7 +994,7 @@ int czc_replicate(czc_engine* p, czc_engine** out) {
   e->patch_w = p->patch_w; e->tproj_wx = p->tproj_wx;
   e->logit_scale_exp = p->logit_scale_exp;
   e->share_prefix = p->share_prefix; e->dedup = p->dedup; e->pack_branches = p->pack_branches; e->pool_last_layer = p->pool_last_layer;
-  e->fuse_ln = p->fuse_ln; e->bert_prune = p->bert_prune; e->resid16 = p->resid16; e->fold_ln = p->fold_ln;
+  e->fuse_ln = p->fuse_ln; e->bert_prune = p->bert_prune; e->bert_fuse_splitk_ln = p->bert_fuse_splitk_ln; e->resid16 = p->resid16; e->fold_ln = p->fold_ln;
   memset(&e->bd, 0, sizeof(e->bd));
   if (hipSetDevice(e->dev) != hipSuccess || hipStreamCreate(&e->st) != hipSuccess ||
       hipHostMalloc((void**)&e->h_totals, 256) != hipSuccess) {
@@ -1460,6 +1474,7 @@ int czc_set_option(czc_engine* e, const char* name, int value) {
   if (!strcmp(name, "share_prefix")) { e->share_prefix = value ? 1 : 0; return CZC_OK; }
   if (!strcmp(name, "dedup")) { e->dedup = value ? 1 : 0; return CZC_OK; }
   if (!strcmp(name, "bert_prune")) { e->bert_prune = value ? 1 : 0; return CZC_OK; }
+  if (!strcmp(name, "bert_fuse_splitk_ln")) { e->bert_fuse_splitk_ln = value ? 1 : 0; return CZC_OK; }
   if (!strcmp(name, "pack_branches")) { e->pack_branches = value ? 1 : 0; return CZC_OK; }
   if (!strcmp(name, "pool_last_layer")) { e->pool_last_layer = value ? 1 : 0; return CZC_OK; }
   if (!strcmp(name, "fuse_ln")) { e->fuse_ln = value; return CZC_OK; }  // 0 off, 1 out-proj -> LN2, 2 also fc2 -> next LN1
@@ -1486,7 +1501,7 @@ int czc_get_option(czc_engine* e, const char* name, int* value) {
   const float f16x = r16 ? e->refine_rows16_factor : 1.f;
   struct { const char* n; int v; } tab[] = {
       {"share_prefix", e->share_prefix}, {"bert_prune", e->bert_prune}, {"pack_branches", e->pack_branches},
-      {"dedup", e->dedup}, {"pool_last_layer", e->pool_last_layer}, {"fuse_ln", e->fuse_ln}, {"resid16", e->resid16}, {"fold_ln", e->fold_ln},
+      {"dedup", e->dedup}, {"pool_last_layer", e->pool_last_layer}, {"bert_fuse_splitk_ln", e->bert_fuse_splitk_ln}, {"fuse_ln", e->fuse_ln}, {"resid16", e->resid16}, {"fold_ln", e->fold_ln},
       {"refine_samples", e->refine_samples}, {"refine_theta_x1000", (int)lrintf(e->refine_theta_x * 1000.f)},
       {"refine_theta_gen_x1000", (int)lrintf(e->refine_theta_gen * 1000.f)},
       {"refine_guard_x1e6", (int)lrintf(e->refine_guard_dev * 1e6f)}, {"refine_gate_x1e6", (int)lrintf(e->refine_gate_delta * 1e6f)},

@@ -570,8 +570,12 @@ static int try_splitk(const GemmArgs& g, int tiles_m, int tiles_n, hipStream_t s
     ws = w.p;
   }
   GemmArgs p = g;
-  p.bias = nullptr; p.resid = nullptr; p.out_f32 = ws;
+  p.bias = nullptr; p.resid = nullptr; p.out_f32 = ws; p.splitk_pending = nullptr;
   launch_t<T>(p, tiles_m, tiles_n, true, st, ks, split_small);
+  if (g.splitk_pending) {  // the caller's next kernel sums the slabs itself (launch_layernorm_splitk)
+    g.splitk_pending->slabs = ws; g.splitk_pending->nslab = ks; g.splitk_pending->slab_stride = (long)g.M * g.ldc; g.splitk_pending->ld = g.ldc;
+    return ks;
+  }
   const long n4 = (long)g.M * (g.N >> 2);
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv(n4, 256)), dim3(256), 0, st, ws, ks, (long)g.M * g.ldc,
                      g.bias, g.resid, g.ldr, g.out_f32, g.ldc, g.M, g.N);
@@ -583,6 +587,7 @@ int g_use_gemm256 = 1;  // 0: 128x128 only; 1: the 256x256 ring kernels of gemm2
 int launch_gemm(int prec, const GemmArgs& g_in, hipStream_t st) {
   GemmArgs g = g_in;
   g.f16 = prec == PREC_F16;
+  if (g.splitk_pending) *g.splitk_pending = SplitkPending();
   if (g.M <= 0) return 0;
   const int kpt = prec_is_half(prec) ? Mma<bf16_t>::KPT : Mma<float>::KPT;  // split_t: 32 like float
   if (g.K % kpt != 0 || g.N <= 0) {

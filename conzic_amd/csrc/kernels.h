@@ -42,7 +42,13 @@ struct GemmArgs {
   const float* ln_gamma = nullptr;
   const float* ln_beta = nullptr;
   float ln_eps = 0.f;
+  // Deferred split-K reduce (round 6; BERT fc2 -> LayerNorm): when the launcher splits K, it leaves the slice sums in its slab
+  // workspace and describes them here INSTEAD of launching splitk_reduce_kernel -- the caller's next kernel
+  // (launch_layernorm_splitk) sums the slabs, adds bias and residual in the reduce kernel's order and normalises the row in one
+  // pass.  pending->nslab == 0 after the call: the launch was not split, out_f32 holds the finished rows as usual.
+  struct SplitkPending* splitk_pending = nullptr;
 };
+struct SplitkPending { const float* slabs = nullptr; int nslab = 0; long slab_stride = 0; int ld = 0; };
 int launch_gemm(int prec, const GemmArgs& g, hipStream_t st);
 bool gemm256_eligible(const GemmArgs& g);
 int launch_gemm256(const GemmArgs& g, hipStream_t st);  // gemm256.hip: 256x256 LDS-DMA ring kernels (bf16 / fp16 operands)
@@ -78,6 +84,10 @@ int launch_clip_preprocess(const unsigned char* rgb_dev, int H, int W, int S, co
 
 // ---- rowops.hip -------------------------------------------------------------------------
 // y = LN(x[row_idx ? row_idx[m] : m]) ; x fp32 [*,H]; outputs optional
+// LayerNorm of rows that are still split-K slabs: v = slab_0 + slab_1 + ... (+ bias) (+ resid), in splitk_reduce_kernel's order, then
+// launch_layernorm's arithmetic on v: bit-identical to the reduce kernel followed by the LayerNorm kernel (split-fp16 / f32 towers)
+int launch_layernorm_splitk(int prec, const SplitkPending& sk, const float* bias, const float* resid, int ldr, const float* gamma,
+                            const float* beta, float eps, int M, int H, void* y_act, float* y_f32, hipStream_t st);
 int launch_layernorm(int prec, const float* x, const int* row_idx, const float* gamma, const float* beta, float eps,
                      int M, int H, void* y_act, float* y_f32, hipStream_t st);
 // the same on a 2-byte residual stream: x16 = fp16 rows [*,512] (H must be 512, half-precision engines), y_act only

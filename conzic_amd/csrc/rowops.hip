@@ -345,6 +345,62 @@ int launch_layernorm(int prec, const float* x, const int* row_idx, const float* 
   return 0;
 }
 
+// LayerNorm of rows that still are split-K slabs (GemmArgs::splitk_pending; BERT fc2 -> LayerNorm): the row is the sum of the
+// slice slabs in slice order, + bias, + residual -- splitk_reduce_kernel's arithmetic, element for element -- and is normalised
+// in the same pass (layernorm_kernel's ln_row): one launch and no fp32 round trip of the row through HBM instead of two launches.
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_splitk_kernel(const float* slabs, int nslab, long slab_stride, int ld, const float* bias,
+                                                               const float* resid, int ldr, const float* gamma, const float* beta,
+                                                               float eps, int M, int H, T* y_act, float* y_f32) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  float4 v[LN_MAXV];
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < H) {
+      float4 a = *(const float4*)(slabs + (long)m * ld + c);
+      for (int z = 1; z < nslab; ++z) {
+        const float4 p = *(const float4*)(slabs + z * slab_stride + (long)m * ld + c);
+        a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
+      }
+      if (bias) { const float4 b = *(const float4*)(bias + c); a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+      if (resid) { const float4 r = *(const float4*)(resid + (long)m * ldr + c); a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w; }
+      v[i] = a;
+    } else {
+      v[i] = make_float4(0, 0, 0, 0);
+    }
+  }
+  ln_row<LN_MAXV>(v, H, lane, gamma, beta, eps);
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < H) {
+      if (y_f32) *(float4*)(y_f32 + (long)m * H + c) = v[i];
+      if (y_act) Act<T>::st4(y_act, (long)m * H + c, v[i].x, v[i].y, v[i].z, v[i].w);
+    }
+  }
+}
+
+int launch_layernorm_splitk(int prec, const SplitkPending& sk, const float* bias, const float* resid, int ldr, const float* gamma,
+                            const float* beta, float eps, int M, int H, void* y_act, float* y_f32, hipStream_t st) {
+  if (M <= 0) return 0;
+  if (H % 4 || H > LN_MAXV * 256 || sk.nslab <= 0 || !sk.slabs || sk.ld % 4 || (resid && ldr % 4) || (prec != PREC_F16X3 && prec != PREC_F32)) {
+    snprintf(g_err, sizeof(g_err), "layernorm_splitk: unsupported shape / precision (H=%d, slabs=%d)", H, sk.nslab);
+    return 1;
+  }
+  dim3 grid(cdiv(M, 4)), block(256);
+  if (prec == PREC_F16X3)
+    hipLaunchKernelGGL(layernorm_splitk_kernel<split_t>, grid, block, 0, st, sk.slabs, sk.nslab, sk.slab_stride, sk.ld, bias, resid, ldr, gamma,
+                       beta, eps, M, H, (split_t*)y_act, y_f32);
+  else
+    hipLaunchKernelGGL(layernorm_splitk_kernel<float>, grid, block, 0, st, sk.slabs, sk.nslab, sk.slab_stride, sk.ld, bias, resid, ldr, gamma,
+                       beta, eps, M, H, (float*)y_act, y_f32);
+  CZC_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
 // ---- BERT embeddings + LN ------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void bert_embed_kernel(const int* ids, int M, int T_, int H, const float* word,

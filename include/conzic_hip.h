@@ -266,6 +266,8 @@ int czc_generate(czc_engine* e, int B, int T, int L, int seed_len, const int32_t
  *                         (czc_dedup_stats)
  *   "bert_prune"      (1) n_mask == 1 steps: the last BERT layer behind its attention (out-projection, LayerNorms, MLP) on the
  *                         masked row of every sequence only -- the one row the MLM head reads (gen_utils.py:69)
+ *   "bert_fuse_splitk_ln" (1) BERT fc2 (split along K at every row count above 32): the LayerNorm kernel behind it sums the slice slabs,
+ *                         bias and residual itself instead of a reduce kernel followed by the LayerNorm kernel; bit-identical
  *   "pack_branches"   (1) attention of the branch rows with G candidates packed per 32-query MFMA tile
  *   "pool_last_layer" (1) last CLIP-text layer: out-projection + MLP on the EOS rows only
  *   "fold_ln"         (1) with "resid16": the LayerNorms inside the CLIP-text stack folded into the q/k/v and fc1 GEMMs (they

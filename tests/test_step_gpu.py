@@ -1105,6 +1105,42 @@ def test_dedup_leaves_the_flat_softmax_goldens_alone():
         eng.set_option("dedup", 1)
 
 
+@pytest.mark.parametrize("prec,B", [(BF16, 8), (BF16, 64), (F32, 8)])
+def test_bert_fc2_layernorm_sums_the_split_k_slabs_itself(prec, B):
+    """BERT's fc2 (K = 3072) is split along K at every row count above 32; the slice sums used to be reduced by one kernel and
+    normalised by the next.  Now the LayerNorm kernel sums the slabs itself (option bert_fuse_splitk_ln, GemmArgs::splitk_pending):
+    same additions in the same order, same ln_row -- the masked-row logits and everything behind them are bit-identical to the
+    two-kernel form (the f32 engine's fc2 is not split: the option is a no-op there)."""
+    L, K = 10, 50
+    su = harness.build_synthetic(False, prec, regular_only=True)
+    eng = su.engine
+    try:
+        rng = np.random.default_rng(B)
+        eng.set_image_embeds(rng.standard_normal((B, 512)).astype(np.float32))
+        hp = Engine.hyper(0.02, 2.0, 0.1)
+        inp0 = np.array([su.bert_tok.encode("Image of a" + su.bert_tok.mask_token * L)] * B, dtype=np.int32)
+        regular = np.nonzero(su.token_mask[0] > 0)[0]
+        inp0[:, SEED_LEN:SEED_LEN + L] = rng.choice(regular, size=(B, L))
+        outs = []
+        for on in (1, 0):
+            eng.set_option("bert_fuse_splitk_ln", on)
+            assert eng.get_option("bert_fuse_splitk_ln") == on
+            for prune in (1, 0):   # the pruned last layer (B rows) and the full one (B * T rows) both take the fused form
+                eng.set_option("bert_prune", prune)
+                inp = inp0.copy()
+                r = eng.step(inp, SEED_LEN + 3, K, hp, want=("logits", "probs", "idxs", "final_score", "best"))
+                outs.append((on, prune, r, inp))
+        for (_, p1, a, ia), (_, p0, b, ib) in zip(outs[:2], outs[2:]):
+            assert p1 == p0
+            for k in ("logits", "probs", "idxs", "final_score", "best"):
+                np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+            np.testing.assert_array_equal(ia, ib)
+    finally:
+        eng.set_option("bert_fuse_splitk_ln", 1)
+        eng.set_option("bert_prune", 1)
+        eng.close()
+
+
 @pytest.mark.parametrize("prec", [F32, BF16])
 @pytest.mark.parametrize("name", ["tiny_shuffle", "full_synth_b2", "full_senti"])
 def test_last_bert_layer_on_the_masked_row_only_is_exact(prec, name):
