@@ -168,11 +168,12 @@ KERNELS = [
     (r"gemm_kernel<czc::split_t, 0, true, true, 64>", "BERT out-projection (64-wide tiles), pruned last layer", "latency", None),
     (r"attention_mfma_split_kernel", "BERT attention (split-fp16)", "latency", None),
     (r"ln_finalize_kernel", "(mean, rstd) per row from the producers' 16 partial sums", "HBM: 136 B per row", ("bytes", 136, "all2")),
-    (r"layernorm_kernel<czc::split_t>", "BERT residual + LayerNorm", "HBM", None),
+    (r"layernorm_kernel<czc::split_t>", "BERT residual + LayerNorm (behind the out-projection)", "HBM", None),
+    (r"layernorm_splitk_kernel", "BERT fc2: sum of the K slices + bias + residual -> LayerNorm in one pass", "HBM", None),
     (r"clip_embed_kernel", "token + position embedding -> fp16 rows + LayerNorm statistics of layer 0", "HBM (fp32 table rows in, fp16 rows out)", None),
     (r"bridge_kernel", "WordPiece decode -> CLIP BPE ids, control scores (`bridge.hip`)", "latency", None),
     (r"attention_mfma_kernel", "trunk attention (one wave per image and head)", "latency", None),
-    (r"splitk_reduce_kernel", "BERT fc2: sum of the K slices + bias + residual", "HBM", None),
+    (r"splitk_reduce_kernel", "sum of split-K slices + bias + residual (layers without a LayerNorm behind them)", "HBM", None),
     (r"softmax_mask_topk_kernel", "softmax(logits / tau) * mask -> top-K (`topk.hip`)", "HBM: 122 KB per image", None),
     (r"scan_kernel", "exclusive scan of the segment lengths", "latency (one work-group)", None),
     (r"gemm_kernel<czc::split_t, 0, false, false, 128>", "MLM decoder 768->30522 on the masked rows", "weight streaming", None),
