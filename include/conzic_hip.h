@@ -77,7 +77,7 @@ extern "C" {
  *   CZC_PREC_SPLIT 4.2e-06, CZC_PREC_F32 7.3e-06 (bar 1e-3);
  *   CZC_PREC_REFINE against CZC_PREC_SPLIT over 2560 more image-steps: worst 4.85e-04, 99.9th percentile 1.4e-04, winners identical
  *   2560 / 2560; guard sample maximum 1.54e-04 against 2.36e-04 over all candidates;
- *   BASELINE configs[2]: 81.5 captions/s (CZC_PREC_BF16), 68.7 (CZC_PREC_REFINE through czc_generate, 76 % of the image-steps gated).
+ *   BASELINE configs[2]: 79.4 captions/s (CZC_PREC_BF16), 67.1 (CZC_PREC_REFINE through czc_generate, 76 % of the image-steps gated).
  * END GENERATED measured
  */
 #define CZC_MAX_TOPK 1024

@@ -1450,6 +1450,50 @@ def test_batch16_step_vs_oracle(prec):
         su.engine.close()
 
 
+@pytest.mark.parametrize("prec", [BF16, SPLIT])
+def test_maximum_topk_step_vs_oracle(prec):
+    """The largest K the boundary accepts (CZC_MAX_TOPK = 1024: the top-K sort buffer, the per-image LDS arrays of the plan /
+    de-duplication / combine kernels all sit at their limit) on full-size towers, two images, against the ORACLE; K + 1 is
+    refused loudly."""
+    from oracle import models as M, step as S, text as T
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    su = harness.build_synthetic(False, prec, logit_scale=4.6052 if prec == SPLIT else 2.6592)
+    try:
+        ccfg = synth.clip_b32()
+        ccfg.logit_scale = su.clip_cfg.logit_scale
+        o = S.Oracle(M.to_torch(synth.make_bert_weights(su.bert_cfg, 11)), su.bert_cfg,
+                     M.to_torch(synth.make_clip_weights(ccfg, 12)), ccfg, su.sv.bert_tokens,
+                     T.ClipBpe(su.sv.clip_vocab, su.sv.clip_merges))
+        B, L, K = 2, 10, 1024
+        rng = np.random.default_rng(1024)
+        inp = np.array(o.init_text("Image of a", L, B), dtype=np.int32)
+        regular = np.nonzero(su.token_mask[0] > 0)[0]
+        inp[:, SEED_LEN:SEED_LEN + L] = rng.choice(regular, size=(B, L))
+        gen_idx = SEED_LEN + 6
+        emb = rng.standard_normal((B, su.clip_cfg.proj)).astype(np.float32)
+        su.engine.set_image_embeds(emb)
+        res = su.engine.step(inp.copy(), gen_idx, K, Engine.hyper(0.02, 2.0, 0.1))
+        tmask = torch.from_numpy(su.token_mask.copy())
+        o.update_token_mask(tmask, L, 6)
+        ref_inp = torch.from_numpy(inp.astype(np.int64))
+        ref_inp[:, gen_idx] = o.mask_id
+        r = S.polish_step(o, ref_inp, torch.from_numpy(emb), tmask, gen_idx, K, 0.1, 0.02, 2.0)
+        same = res["idxs"] == r["idxs"].numpy()
+        assert same.mean() > 0.99
+        tol = 1e-3 if prec == BF16 else 1e-4
+        err = np.abs(res["final_score"] - r["final"].numpy())[same]
+        assert err.max() < tol, err.max()
+        fin = r["final"].numpy()
+        srt = np.sort(fin, axis=1)[:, ::-1]
+        clear = (srt[:, 0] - srt[:, 1]) > 2 * tol
+        assert (res["best"][clear] == r["best"].numpy()[clear]).all()
+        with pytest.raises(native.NativeError) as ei:
+            su.engine.step(inp.copy(), gen_idx, K + 1, Engine.hyper(0.02, 2.0, 0.1))
+        assert ei.value.code == native.ERR_ARG
+    finally:
+        su.engine.close()
+
+
 def test_large_batch_kernel_families_agree():
     """B = 64 images x K = 200 candidates (78 k packed CLIP rows, ~58 blocks per work-group of the weight-stationary
     GEMM, the per-image attention kernel selected by the engine itself): the exact-count vmcnt pipelines of
