@@ -105,7 +105,7 @@ def facts():
             f["rv_max_dfinal"], f["rv_p999"], f["rv_winners"], f["rv_image_steps"] = r["max_abs_dfinal"], r["p999"], r["winners_identical"], r["image_steps"]
             f["rv_guard_max_dev"], f["rv_true_max_dev"] = r.get("guard_max_dev"), r.get("true_max_dev")
     # round 6: the further weight draws of the refine validation, and what the de-duplication removes on a trained-like head
-    draws = [r for r in jlines(f"{ROUND}_refine_validate_draws_128x10.jsonl")]
+    draws = [r for r in jlines(f"{ROUND}_refine_validate_draws_128x10.jsonl")] + [r for r in jlines(f"{ROUND}_refine_validate_draws2_256x10.jsonl")]
     gen = [r for r in draws if r.get("mode") == "generate"]
     stp = [r for r in draws if "max_abs_dfinal" in r and (r.get("draw") or {}).get("outlier_gain", 1.0) != 12.0]
     if gen:
@@ -116,7 +116,8 @@ def facts():
         f["draws_tripped"] = sum(1 for r in gen if r["guard_tripped_image_steps"] > 0)
     if stp:
         f["draws_worst_dfinal"] = max(r["max_abs_dfinal"] for r in stp)
-    div = [d_ for r in jlines(f"{ROUND}_refine_validate_divergences_128x10.jsonl") if r.get("mode") == "generate" for d_ in r.get("divergences", [])]
+    div = [d_ for name in (f"{ROUND}_refine_validate_divergences_128x10.jsonl", f"{ROUND}_refine_validate_draws2_256x10.jsonl")
+           for r in jlines(name) if r.get("mode") == "generate" for d_ in r.get("divergences", [])]
     if div:
         f["div_n"] = len(div)
         f["div_max_gap"] = max(d_["gap_to_other_engines_choice"] for d_ in div)
@@ -146,7 +147,7 @@ def block_status(f):
         f"| headline, BASELINE configs[2] (`profiles/{ROUND}_bench_driver_cmd.json` = the driver's `--gpus 1 --steps 20 --warmup 5`) | **{fmt(f.get('value'), '.1f')} captions/s** bf16 engine (HF-init logit scale), **{fmt(f.get('value_scale100'), '.1f')}** screen-then-refine (published checkpoints' logit scale); one stream {fmt(f.get('single_stream_value'), '.1f')}; this box ran the vendor library's dense bf16 8192^3 matmul at {fmt(f.get('calib'), '.0f')} TFLOP/s (`box_calibration`: the pool's boxes differ by several per cent on identical code, `profiles/r05_tower_ab.txt` holds the same-box A/Bs) |",
         f"| roofline of the CLIP-text GEMM family (dense bf16 peak 2.5 PFLOP/s) | {fmt(f.get('frac'), '.3f')} over the timed two-stream region, {fmt(f.get('frac_1s'), '.3f')} on one stream; `clip_text_mfma_util` (GEMM + attention FLOPs over all CLIP-text kernel time) {fmt(f.get('tower_util'), '.3f')} |",
         f"| screen-then-refine in `czc_generate` | {fmt(None if f.get('gated_frac') is None else 100 * f['gated_frac'], '.0f')} % of the image-steps pass the margin gate, {fmt(None if f.get('re_encoded_frac') is None else 100 * f['re_encoded_frac'], '.1f')} % of the candidates re-encoded; against the all-split engine: ids identical = {f.get('rv_gen_ids_identical', 'n/a')} over {fmt(f.get('rv_gen_steps'), 'd')} image-steps, `czc_step` worst fused-score difference {fmt(f.get('rv_max_dfinal'), '.2e')} over {fmt(f.get('rv_image_steps'), 'd')} image-steps |",
-        f"| the same engine on {fmt(f.get('draws_n'), 'd')} further weight draws (`profiles/{ROUND}_refine_validate_draws_128x10.jsonl`: four other seed pairs, a x12 and a x6 outlier tower) | `czc_step` worst fused-score difference {fmt(f.get('draws_worst_dfinal'), '.2e')} on the draws that do not trip the guard; free-running 10 sweeps: {fmt(f.get('draws_identical'), 'd')} of {fmt(f.get('draws_images'), 'd')} images ({fmt(f.get('draws_image_steps'), 'd')} image-steps) keep the all-split engine's ids, the {fmt(f.get('div_n'), 'd')} that leave do so where the split engine's own winner and runner-up are {fmt(f.get('div_max_gap'), '.1e')} or less apart (`..._divergences_...`); the x12 tower trips the guard |",
+        f"| the same engine on {fmt(f.get('draws_n'), 'd')} further weight draws (`profiles/{ROUND}_refine_validate_draws_128x10.jsonl`, `..._draws2_256x10.jsonl`: eight other seed pairs, x12 / x6 / x3 outlier towers) | `czc_step` worst fused-score difference {fmt(f.get('draws_worst_dfinal'), '.2e')} on the draws that do not trip the guard; free-running 10 sweeps: {fmt(f.get('draws_identical'), 'd')} of {fmt(f.get('draws_images'), 'd')} images ({fmt(f.get('draws_image_steps'), 'd')} image-steps) keep the all-split engine's ids, the {fmt(f.get('div_n'), 'd')} that leave do so where the split engine's own winner and runner-up are {fmt(f.get('div_max_gap'), '.1e')} or less apart (`..._divergences_...`); the x12 tower trips the guard |",
         f"| exact de-duplication on a trained-like MLM head (`test_dedup_is_exact`, 64 images) | {fmt(None if f.get('dedup_seq_frac') is None else 100 * f['dedup_seq_frac'], '.0f')} % of the candidates ride on an identical one, text-tower rows x{fmt(f.get('dedup_row_frac'), '.2f')}; nothing to remove on the flat-softmax synthetic headline |",
         f"| 8 ranks on one shared GPU (`profiles/{ROUND}_bench_8ranks_shared_gpu.json`, gloo rendezvous, test flag) | n_gpus {fmt(f.get('r8_n'), 'd')}, {fmt(f.get('r8_backend_ranks'), 'd')} ranks reported by the backend, weight broadcast {fmt(f.get('r8_broadcast_s'), '.2f')} s, gather {fmt(f.get('r8_gather_s'), '.3f')} s; the multi-GPU curve itself is unmeasured (no node) |",
         f"| other BASELINE shapes (`profiles/{ROUND}_bench_cfg*.json`) | single image {fmt(f.get('cfg1'), '.2f')} captions/s; configs[3] shard (256 images, shuffle, L=15, K=512) {fmt(f.get('cfg3'), '.1f')}; configs[4] shard (64 images, sentiment, L=12): table mode {fmt(f.get('cfg4_table'), '.1f')}, exact host scorer {fmt(f.get('cfg4_exact'), '.1f')} ({fmt(f.get('cfg4_exact_workers'), 'd')} worker interpreters, stand-in tagger at {fmt(f.get('cfg4_exact_cost_us'), '.0f')} us per 12-word sentence) |",
