@@ -78,7 +78,13 @@ struct czc_engine {
   // carriers to re-encode; winners identical to the all-split engine on every validated image-step), the bound above is czc_step's
   float refine_theta_gen = 4.0f;
   bool in_generate = false;
-  int refine_samples = 12;      // strata of the sample among the candidates below the threshold
+  int refine_samples = 12;      // strata of the sample among the candidates below the threshold, inside czc_generate
+  // czc_step (all K fused scores are its output): twice the strata.  The sample's job is the mass-weighted MEAN screening error of
+  // the candidates that keep their screening cosine; what is left of it after the correction scales the softmax denominator, and
+  // through it the score of every re-encoded candidate by beta * p_k * exp(logit_scale) * (kept mass) * (error of the mean) -- the
+  // largest term of czc_step's error on peaky images, and one the guard does not see.  Round 6, eleven weight draws x 2560
+  // image-steps: worst fused-score difference 4.5e-4 .. 9.2e-4 with 12 strata, 2.8e-4 .. 5.4e-4 with 24 (profiles/r06_refine_samples_sweep.jsonl)
+  int refine_samples_step = 24;
   // guard: the ~20 candidates an image re-encodes show their own |screening error - mean|; the candidates that keep their
   // screening cosine reach at most GUARD_RATIO = 2 times that sample maximum (fitted: 1.75 worst over 1280 image-steps), so
   // theta_x * 2 * sample_dev <= 1e-3 holds while sample_dev <= 2.5e-4 at theta_x = 2; trip point 0.8 of that
@@ -809,7 +815,7 @@ int step_phase_b(czc_engine* e, const StepArgs& a, int M, int max_len, int max_b
     ca.inp = nullptr;
     E_CHECK(launch_combine(ca, e->st));
     const float gate_h = e->gate_now ? e->refine_gate_delta * (refine_rows16_now(e) ? e->refine_rows16_factor : 1.f) * e->logit_scale_exp : 0.f;
-    E_CHECK(launch_refine_select(cscore, fin, a.B, a.K, theta, e->refine_samples, gate_h, hp->beta, e->gate_need_cos ? 1 : 0,
+    E_CHECK(launch_refine_select(cscore, fin, a.B, a.K, theta, e->in_generate ? e->refine_samples : e->refine_samples_step, gate_h, hp->beta, e->gate_need_cos ? 1 : 0,
                                  ca.nonfinite + 4, kind, list, count, e->st)); }
   { ProfScope ps(e, "bridge", 0);
     E_HIP(hipMemsetAsync(rtot, 0, 64, e->st));
@@ -986,7 +992,7 @@ int czc_replicate(czc_engine* p, czc_engine** out) {
   czc_engine* e = new czc_engine();
   e->cfg = p->cfg; e->dev = p->dev; e->finalized = true; e->shares_weights = true;
   e->esz = p->esz; e->pb = p->pb; e->pc = p->pc; e->pv = p->pv; e->eb = p->eb;
-  e->refine = p->refine; e->refine_theta_x = p->refine_theta_x; e->refine_samples = p->refine_samples;
+  e->refine = p->refine; e->refine_theta_x = p->refine_theta_x; e->refine_samples = p->refine_samples; e->refine_samples_step = p->refine_samples_step;
   e->refine_guard_dev = p->refine_guard_dev; e->refine_gate_delta = p->refine_gate_delta; e->refine_theta_gen = p->refine_theta_gen;
   e->refine_rows16 = p->refine_rows16; e->refine_rows16_factor = p->refine_rows16_factor;
   e->w = p->w; e->bert = p->bert; e->ctext = p->ctext; e->cvis = p->cvis; e->ctext_x = p->ctext_x;
@@ -1486,6 +1492,7 @@ int czc_set_option(czc_engine* e, const char* name, int value) {
   if (!strcmp(name, "resid16")) { const int old = e->resid16; e->resid16 = value < 0 ? 0 : value; const int rc = fold_ready(); if (rc) e->resid16 = old; return rc; }
   if (!strcmp(name, "fold_ln")) { const int old = e->fold_ln; e->fold_ln = value ? 1 : 0; const int rc = fold_ready(); if (rc) e->fold_ln = old; return rc; }
   if (!strcmp(name, "refine_samples")) { e->refine_samples = value < 0 ? 0 : value; return CZC_OK; }
+  if (!strcmp(name, "refine_samples_step")) { e->refine_samples_step = value < 0 ? 0 : value; return CZC_OK; }
   if (!strcmp(name, "refine_theta_x1000")) { e->refine_theta_x = (float)value / 1000.f; return CZC_OK; }
   if (!strcmp(name, "refine_theta_gen_x1000")) { e->refine_theta_gen = (float)value / 1000.f; return CZC_OK; }
   if (!strcmp(name, "refine_guard_x1e6")) { e->refine_guard_dev = (float)value * 1e-6f; return CZC_OK; }
@@ -1502,7 +1509,7 @@ int czc_get_option(czc_engine* e, const char* name, int* value) {
   struct { const char* n; int v; } tab[] = {
       {"share_prefix", e->share_prefix}, {"bert_prune", e->bert_prune}, {"pack_branches", e->pack_branches},
       {"dedup", e->dedup}, {"pool_last_layer", e->pool_last_layer}, {"bert_fuse_splitk_ln", e->bert_fuse_splitk_ln}, {"fuse_ln", e->fuse_ln}, {"resid16", e->resid16}, {"fold_ln", e->fold_ln},
-      {"refine_samples", e->refine_samples}, {"refine_theta_x1000", (int)lrintf(e->refine_theta_x * 1000.f)},
+      {"refine_samples", e->refine_samples}, {"refine_samples_step", e->refine_samples_step}, {"refine_theta_x1000", (int)lrintf(e->refine_theta_x * 1000.f)},
       {"refine_theta_gen_x1000", (int)lrintf(e->refine_theta_gen * 1000.f)},
       {"refine_guard_x1e6", (int)lrintf(e->refine_guard_dev * 1e6f)}, {"refine_gate_x1e6", (int)lrintf(e->refine_gate_delta * 1e6f)},
       {"refine_rows16", e->refine_rows16}, {"refine_rows16_x1000", (int)lrintf(e->refine_rows16_factor * 1000.f)},

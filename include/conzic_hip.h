@@ -75,8 +75,8 @@ extern "C" {
  * Measured on one MI355X, round 6 (generated by tools/refresh_docs.py from profiles/r06_*):
  *   fused score vs the reference, worst over the full-size goldens: CZC_PREC_BF16 2.46e-04, CZC_PREC_REFINE 6.03e-04,
  *   CZC_PREC_SPLIT 4.2e-06, CZC_PREC_F32 7.3e-06 (bar 1e-3);
- *   CZC_PREC_REFINE against CZC_PREC_SPLIT over 2560 more image-steps: worst 4.85e-04, 99.9th percentile 1.4e-04, winners identical
- *   2560 / 2560; guard sample maximum 1.54e-04 against 2.36e-04 over all candidates;
+ *   CZC_PREC_REFINE against CZC_PREC_SPLIT over 2560 more image-steps: worst 3.80e-04, 99.9th percentile 1.3e-04, winners identical
+ *   2560 / 2560; guard sample maximum 1.74e-04 against 2.33e-04 over all candidates;
  *   BASELINE configs[2]: 79.4 captions/s (CZC_PREC_BF16), 67.1 (CZC_PREC_REFINE through czc_generate, 76 % of the image-steps gated).
  * END GENERATED measured
  */
@@ -282,8 +282,9 @@ int czc_generate(czc_engine* e, int B, int T, int L, int seed_len, const int32_t
  *                         (outside its validated error budget: experiments), 0 = fp32 rows everywhere.  With it the
  *                         out-projection runs on the weight-stationary kernel ("fuse_ln" then has nothing to fuse)
  *   "refine_theta_gen_x1000" (4000): the same threshold inside czc_generate (ids and winner cosines are its output, not the K scores)
- *   "refine_samples" (12), "refine_theta_x1000" (2000): CZC_PREC_REFINE selection -- strata of the mass-stratified sample
- *                         and the softmax_K mass threshold theta = value / 1000 / (beta * exp(logit_scale))
+ *   "refine_samples" (12) / "refine_samples_step" (24), "refine_theta_x1000" (2000): CZC_PREC_REFINE selection -- strata of the
+ *                         mass-stratified sample inside czc_generate / in czc_step, and the softmax_K mass threshold
+ *                         theta = value / 1000 / (beta * exp(logit_scale))
  *   "refine_guard_x1e6" (200): trip point of czc_refine_guard, in units of 1e-6 of cosine
  *   "refine_gate_x1e6" (400): cosine-error bound delta of the margin gate of czc_generate (czc_refine_gate_stats), 0 = off
  *   "refine_rows16"   (1) CZC_PREC_REFINE inside czc_generate: the screening pass on the 2-byte residual stream with the folded
@@ -331,8 +332,14 @@ int czc_refine_stats(czc_engine* e, int64_t* refine_seqs, int64_t* refine_rows);
  * that runs the full selection records, over the ~20 candidates per image it re-encodes exactly, the largest
  * |screening error - mean| (*max_dev, since the last reset) and counts the image-steps where it exceeds option
  * "refine_guard_x1e6" * 1e-6 (default 200) in *tripped.  The candidates that are NOT re-encoded reach at most twice the sample
- * maximum on the validated towers (tools/refine_validate.py prints the ratio), so below the trip point the bound is
- * theta_x * 2 * 2.0e-4 = 8e-4 < 1e-3; a checkpoint whose activations the fp16 tower carries worse trips the guard, and
+ * maximum on the validated towers (tools/refine_validate.py prints the ratio: 1.15-1.54 on ten plain weight draws, 2.02 on a x6
+ * outlier tower), so below the trip point a KEPT candidate moves its own score by at most theta_x * 2 * 2.0e-4 = 8e-4.  That is
+ * not the whole error of czc_step: the sample's estimate of the mean screening error is itself uncertain, what is left of the
+ * mean scales the softmax denominator, and every RE-ENCODED candidate moves by beta * p_k * exp(logit_scale) * (kept mass) *
+ * (error of the mean) -- the largest term on peaky images, measured not bounded: worst |d final_score| against the all-split
+ * engine over eleven weight draws 4.5e-4 .. 9.2e-4 with 12 strata, 2.8e-4 .. 5.4e-4 with the 24 czc_step uses since round 6
+ * ("refine_samples_step"; czc_generate keeps 12: only the winner matters there).  A checkpoint whose activations the fp16 tower
+ * carries worse trips the guard, and
  * conzic_amd/runtime.py then repeats the call on the all-split engine (CZC_REFINE_GUARD=rerun | warn | off).  Inside czc_generate
  * gated image-steps re-encode nothing and are not measured: the audit steps (czc_refine_gate_stats) are. */
 int czc_refine_guard(czc_engine* e, int reset, float* max_dev, int64_t* tripped);

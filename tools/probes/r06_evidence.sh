@@ -18,8 +18,8 @@ if [ "$1" != "kernels" ]; then
 python bench.py --config 3 --total-images 256 --steps 1 --warmup 1 --no-cpu-baseline > $O/bench_cfg3.json 2> $O/bench_cfg3.err
 python bench.py --gpus 8 --share-gpu --total-images 16 --steps 1 --warmup 0 --iters 1 --no-cpu-baseline --no-invariance --no-profile --no-alt > $O/bench_8ranks_shared_gpu.json 2> $O/bench_8ranks_shared_gpu.err
 python bench.py --config 4 --total-images 64 --control both --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_cfg4.json 2> $O/bench_cfg4.err
-python tools/refine_validate.py 128 10 12 2000 > $O/refine_validate_128x10.jsonl 2> $O/refine_validate.err
-if [ "$1" != "quick" ]; then GEN_SWEEPS=10 python tools/refine_validate.py 256 10 12 2000 > $O/refine_validate_256x10_fullcaptions.jsonl 2>> $O/refine_validate.err; fi
+python tools/refine_validate.py 128 10 24 2000 > $O/refine_validate_128x10.jsonl 2> $O/refine_validate.err
+if [ "$1" != "quick" ]; then GEN_SWEEPS=10 python tools/refine_validate.py 256 10 24 2000 > $O/refine_validate_256x10_fullcaptions.jsonl 2>> $O/refine_validate.err; fi
 # (the further weight draws -- profiles/r06_refine_validate_draws_128x10.jsonl / _divergences_ -- were run on their own:
 #  for d in "21 22 1" "31 32 1" "41 42 1" "51 52 1" "11 12 12" "61 62 6"; do set -- $d; BSEED=$1 CSEED=$2 OUTLIER=$3 EMB_SEED=$((3000+$1)) GEN_SWEEPS=10 GATES=400 python tools/refine_validate.py 128 10; done)
 fi

@@ -30,7 +30,7 @@ from conzic_amd.engine import Engine  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 P = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-SAMPLES = [int(v) for v in (sys.argv[3] if len(sys.argv) > 3 else "12").split(",")]
+SAMPLES = [int(v) for v in (sys.argv[3] if len(sys.argv) > 3 else "24").split(",")]   # strata of czc_step's sample (engine default 24)
 THETAS = [int(v) for v in (sys.argv[4] if len(sys.argv) > 4 else "2000").split(",")]
 L, K, SEED_LEN, SCALE = 10, 200, 4, 4.6052
 hp = Engine.hyper(0.02, 2.0, 0.1)
@@ -73,7 +73,7 @@ for kv in filter(None, os.environ.get("CZC_OPTS", "").split(",")):  # engine opt
 su.engine.set_image_embeds(emb)
 for th in THETAS:
     for m in SAMPLES:
-        su.engine.set_option("refine_samples", m)
+        su.engine.set_option("refine_samples_step", m)   # czc_step's strata (czc_generate's stay at the engine default)
         su.engine.set_option("refine_theta_x1000", th)
         su.engine.profile_reset()
         su.engine.refine_guard(reset=True)
@@ -101,7 +101,7 @@ for th in THETAS:
                               image_steps=n, winners_identical=agree, reference_margin_at_flips=margins,
                               re_encoded_seq_frac=round(st["refine_seqs"] / max(st["clip_seqs"], 1), 4),
                               re_encoded_row_frac=round(st["refine_rows"] / max(st["clip_rows"], 1), 4))), flush=True)
-su.engine.set_option("refine_samples", 12)
+su.engine.set_option("refine_samples_step", 24)
 su.engine.set_option("refine_theta_x1000", 2000)
 for gate in [int(v) for v in os.environ.get("GATES", "400,0").split(",")]:
     su.engine.set_option("refine_gate_x1e6", gate)
