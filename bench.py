@@ -680,9 +680,9 @@ def main():
                                bf16_engine="worst fused-score error 2.5e-4 on the full-size goldens; FREE-RUNNING it leaves the reference's "
                                            "trajectory only at near-ties (full-size goldens: 19 of 20 tokens on `full_senti`, reference margin "
                                            "2.7e-5 at the divergence; all other cases on it)",
-                               scale100_engine="screen-then-refine: worst 6.0e-4 on the goldens, ids identical to the all-split engine over "
-                                               "25 600 image-steps of the fitted draw; on six more weight draws 765 of 768 images keep its ids over 10 "
-                                               "sweeps, three leave at near-ties of 1.3-2.3e-5",
+                               scale100_engine="screen-then-refine: worst 2.8e-4 on the goldens (czc_step, 24 sample strata), ids identical to the all-split engine over "
+                                               "25 600 image-steps of the fitted draw; on eleven more weight draws 2038 of 2048 images keep its ids over 10 "
+                                               "sweeps, ten leave at near-ties of 2.3e-5 or less",
                                where="tests/test_step_gpu.py; profiles/r06_gpu_tests_summary.txt, profiles/r06_refine_validate_*.jsonl"),
                    batch_invariance=main_res["invariance"],
                    captions_crc32=dict(value=main_res["ids_crc"], images=main_res["n_ids"],

@@ -73,7 +73,7 @@ extern "C" {
 /*
  * BEGIN GENERATED measured
  * Measured on one MI355X, round 6 (generated by tools/refresh_docs.py from profiles/r06_*):
- *   fused score vs the reference, worst over the full-size goldens: CZC_PREC_BF16 2.46e-04, CZC_PREC_REFINE 6.03e-04,
+ *   fused score vs the reference, worst over the full-size goldens: CZC_PREC_BF16 2.46e-04, CZC_PREC_REFINE 2.78e-04,
  *   CZC_PREC_SPLIT 4.2e-06, CZC_PREC_F32 7.3e-06 (bar 1e-3);
  *   CZC_PREC_REFINE against CZC_PREC_SPLIT over 2560 more image-steps: worst 3.80e-04, 99.9th percentile 1.3e-04, winners identical
  *   2560 / 2560; guard sample maximum 1.74e-04 against 2.33e-04 over all candidates;
